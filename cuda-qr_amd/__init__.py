@@ -1,0 +1,317 @@
+"""cuda-qr_amd: thin ctypes binding over the C-ABI library libmi355xqr.so (include/mi355x_qr.h).
+
+This Python layer is plumbing for tests and bench.py -- the product is the C library (C host layer
++ hand-written gfx950 HIP kernels).  There is NO CPU fallback: importing works anywhere the shared
+library loads, but every compute entry point needs an MI355X and fails loudly otherwise.
+
+The directory name has a hyphen (it mirrors the reference repo's name), so import it through the
+root-level shim:  `import cuda_qr_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi355xqr.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "mi355x_qr.h")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {HERE}` (or python -c 'import __graft_entry__ as g; "
+        "g.build()').  The HIP extension is mandatory; there is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+QR_PROF_CLASSES = 4
+PROF_NAMES = ("update_nn", "vta_tn", "panel", "vt_misc")
+
+
+class QRError(RuntimeError):
+    pass
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * QR_PROF_CLASSES), ("flops", C.c_double * QR_PROF_CLASSES),
+                ("bytes", C.c_double * QR_PROF_CLASSES), ("launches", C.c_longlong * QR_PROF_CLASSES)]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_sig("getPanelDims", None, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int))
+_sig("mmqr_status", C.c_int, _dp, C.POINTER(_dp), C.c_int, C.c_int)
+_sig("mmqr", None, _dp, C.POINTER(_dp), C.c_int, C.c_int)
+_sig("explicitQR_status", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int)
+_sig("explicitQR", None, _dp, _dp, _dp, _dp, C.c_int, C.c_int)
+_sig("dgemm_status", C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int)
+_sig("dgemm", None, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int)
+_sig("identity", None, _dp, C.c_int)
+_sig("printMat", None, _dp, C.c_int, C.c_int)
+_sig("qr_strerror", C.c_char_p, C.c_int)
+_sig("qr_set_block_size", C.c_int, C.c_int, C.c_int)
+_sig("qr_get_block_size", None, C.POINTER(C.c_int), C.POINTER(C.c_int))
+_sig("qr_thin", C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int)
+_sig("qr_plan_create", C.c_int, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("qr_plan_destroy", C.c_int, _vp)
+_sig("qr_geqrf_dev", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp)
+_sig("qr_applyq_dev", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int)
+_sig("qr_extract_r_dev", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int)
+_sig("qr_gemm_dev", C.c_int, _vp, C.c_char, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, C.c_int,
+     C.c_double, _vp, C.c_int)
+_sig("qr_fill_uniform_dev", C.c_int, _vp, _vp, C.c_int, C.c_longlong, C.c_int, C.c_longlong, C.c_longlong,
+     C.c_ulonglong)
+_sig("qr_uniform_at", C.c_double, C.c_ulonglong, C.c_ulonglong)
+_sig("qr_diffnorm_dev", C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, C.c_longlong,
+     C.c_longlong, C.c_ulonglong, C.c_int, _dp)
+_sig("qr_plan_sync", C.c_int, _vp)
+_sig("qr_plan_stream", _vp, _vp)
+_sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)
+_sig("qr_plan_get_profile", C.c_int, _vp, C.POINTER(Profile))
+_sig("qr_device_info", C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t))
+_sig("qr_probe_mfma_f64_tflops", C.c_int, _dp)
+_sig("qr_probe_copy_gbps", C.c_int, _dp)
+# internal launch layer (kernel unit tests only)
+_sig("qrd_gemm_nn", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, C.c_int, C.c_double,
+     _vp, C.c_int)
+_sig("qrd_gemm_tn", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, C.c_int, C.c_double,
+     _vp, C.c_int, _vp, C.c_size_t, _vp, C.c_int)
+_sig("qrd_leaf_panel", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp)
+_sig("qrd_larft", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int)
+_sig("qrd_init", C.c_int)
+_sig("qrd_device_sync", C.c_int)
+
+
+def strerror(rc):
+    return lib.qr_strerror(rc).decode()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise QRError(f"{what or 'mi355xqr'} failed: {strerror(rc)} ({rc})")
+
+
+def exported_symbols():
+    """Names declared in include/mi355x_qr.h (parsed), for the 'library exports its header' test."""
+    import re
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|double|char\*|void\*|const char\*)\s*\*?\s*(\w+)\s*\(", txt, flags=re.M)
+    return sorted(set(names))
+
+
+# ------------------------------------------------------------------------------------------------
+# host-pointer drop-in calls (numpy in / numpy out)
+# ------------------------------------------------------------------------------------------------
+def _f(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def get_panel_dims(m, n):
+    rp, cp = C.c_int(), C.c_int()
+    lib.getPanelDims(m, n, C.byref(rp), C.byref(cp))
+    return rp.value, cp.value
+
+
+def get_block_size():
+    nb, ib = C.c_int(), C.c_int()
+    lib.qr_get_block_size(C.byref(nb), C.byref(ib))
+    return nb.value, ib.value
+
+
+def set_block_size(nb, ib):
+    check(lib.qr_set_block_size(nb, ib), "qr_set_block_size")
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def mmqr(A):
+    """reference mmqr (qr.c:55): returns (factored copy, tau array of colPanels*nb entries)."""
+    F = np.array(A, dtype=np.float64, order="F", copy=True)
+    m, n = F.shape
+    tptr = _dp()
+    check(lib.mmqr_status(_p(F), C.byref(tptr), m, n), "mmqr")
+    rp, cp = get_panel_dims(m, n)
+    nb, _ = get_block_size()
+    tau = np.ctypeslib.as_array(tptr, shape=(rp * cp * nb,)).copy()
+    _libc.free(C.cast(tptr, C.c_void_p))
+    return F, tau
+
+
+def explicit_qr(F, tau):
+    """reference explicitQR (qr.c:330): Q (m x m), R (m x n)."""
+    F = _f(F)
+    m, n = F.shape
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    Q = np.empty((m, m), order="F")
+    R = np.empty((m, n), order="F")
+    check(lib.explicitQR_status(_p(F), _p(tau), _p(Q), _p(R), m, n), "explicitQR")
+    return Q, R
+
+
+def dgemm(A, B):
+    """reference dgemm (qr.c:443): C (k x n) = A (k x m) B (m x n)."""
+    A, B = _f(A), _f(B)
+    k, m = A.shape
+    m2, n = B.shape
+    assert m == m2
+    Cm = np.empty((k, n), order="F")
+    check(lib.dgemm_status(_p(A), _p(B), _p(Cm), k, m, n), "dgemm")
+    return Cm
+
+
+def identity(m):
+    A = np.empty((m, m), order="F")
+    lib.identity(_p(A), m)
+    return A
+
+
+def qr_thin(A, nb=0, nshards=1):
+    A = _f(A)
+    m, n = A.shape
+    Q = np.empty((m, n), order="F")
+    R = np.empty((n, n), order="F")
+    check(lib.qr_thin(_p(A), m, n, _p(Q), _p(R), nb, nshards), "qr_thin")
+    return Q, R
+
+
+def device_info():
+    name = C.create_string_buffer(64)
+    cus, clk, mem = C.c_int(), C.c_int(), C.c_size_t()
+    check(lib.qr_device_info(name, 64, C.byref(cus), C.byref(clk), C.byref(mem)), "qr_device_info")
+    return {"arch": name.value.decode(), "compute_units": cus.value, "clock_khz": clk.value, "hbm_bytes": mem.value}
+
+
+def probe_mfma_f64_tflops():
+    v = C.c_double()
+    check(lib.qr_probe_mfma_f64_tflops(C.byref(v)), "probe")
+    return v.value
+
+
+def probe_copy_gbps():
+    v = C.c_double()
+    check(lib.qr_probe_copy_gbps(C.byref(v)), "probe")
+    return v.value
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident API.  Device buffers are anything with .data_ptr() (torch tensors) or raw ints.
+# A column-major m x n matrix with leading dimension ld is a flat float64 buffer of ld*n elements;
+# `colmajor(m, n)` makes one as a torch tensor of shape (n, m) whose .T is the matrix.
+# ------------------------------------------------------------------------------------------------
+def _dptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+def colmajor(m, n, device="cuda"):
+    import torch
+    return torch.empty((n, m), dtype=torch.float64, device=device)
+
+
+def to_device_colmajor(A, device="cuda"):
+    """numpy (m x n) -> torch (n, m) buffer holding A column-major."""
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(A, dtype=np.float64).T)).to(device)
+
+
+def from_device_colmajor(t):
+    return np.asfortranarray(t.detach().cpu().numpy().T)
+
+
+class Plan:
+    """qr_plan wrapper.  The plan's HIP stream is independent of torch's current stream: call
+    torch.cuda.synchronize() (or Plan.sync) at the hand-over points."""
+
+    def __init__(self, m, n, nb=0, ib=0):
+        self.h = None
+        h = _vp()
+        check(lib.qr_plan_create(C.byref(h), m, n, nb, ib), "qr_plan_create")
+        self.h, self.m, self.n = h, m, n
+
+    def close(self):
+        if self.h:
+            lib.qr_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sync(self):
+        check(lib.qr_plan_sync(self.h), "qr_plan_sync")
+
+    @property
+    def stream(self):
+        return lib.qr_plan_stream(self.h)
+
+    def geqrf(self, dA, m, n, lda, dtau):
+        check(lib.qr_geqrf_dev(self.h, _dptr(dA), m, n, lda, _dptr(dtau)), "qr_geqrf_dev")
+
+    def applyq(self, dA, m, n, lda, dtau, dC, ccols, ldc, identity_start):
+        check(lib.qr_applyq_dev(self.h, _dptr(dA), m, n, lda, _dptr(dtau), _dptr(dC), ccols, ldc,
+                                int(identity_start)), "qr_applyq_dev")
+
+    def extract_r(self, dA, m, n, lda, dR, rrows, ldr):
+        check(lib.qr_extract_r_dev(self.h, _dptr(dA), m, n, lda, _dptr(dR), rrows, ldr), "qr_extract_r_dev")
+
+    def gemm(self, trans, M, N, K, alpha, dA, lda, dB, ldb, beta, dC, ldc):
+        check(lib.qr_gemm_dev(self.h, trans.encode(), M, N, K, alpha, _dptr(dA), lda, _dptr(dB), ldb, beta,
+                              _dptr(dC), ldc), "qr_gemm_dev")
+
+    def fill_uniform(self, dA, lda, rows, cols, row_off=0, total_rows=None, seed=12):
+        check(lib.qr_fill_uniform_dev(self.h, _dptr(dA), lda, rows, cols, row_off,
+                                      rows if total_rows is None else total_rows, seed), "qr_fill_uniform_dev")
+
+    def diffnorm(self, dX, ldx, rows, cols, dY=None, ldy=0, row_off=0, total_rows=None, seed=12, mode=0):
+        out = (C.c_double * 2)()
+        check(lib.qr_diffnorm_dev(self.h, _dptr(dX), ldx, _dptr(dY), ldy, rows, cols, row_off,
+                                  rows if total_rows is None else total_rows, seed, mode, out), "qr_diffnorm_dev")
+        return out[0], out[1]
+
+    def set_profile(self, on):
+        check(lib.qr_plan_set_profile(self.h, int(on)), "qr_plan_set_profile")
+
+    def get_profile(self):
+        pr = Profile()
+        check(lib.qr_plan_get_profile(self.h, C.byref(pr)), "qr_plan_get_profile")
+        return {PROF_NAMES[c]: {"ms": pr.ms[c], "flops": pr.flops[c], "bytes": pr.bytes[c],
+                                "launches": pr.launches[c]} for c in range(QR_PROF_CLASSES)}
+
+
+def uniform_at(seed, idx):
+    return lib.qr_uniform_at(seed, idx)
+
+
+def uniform_matrix_host(rows, cols, row_off=0, total_rows=None, seed=12):
+    """Host evaluation of the device generator (same hash): numpy (rows x cols)."""
+    total = rows if total_rows is None else total_rows
+    c = np.arange(cols, dtype=np.uint64)[None, :]
+    i = (np.arange(rows, dtype=np.uint64) + np.uint64(row_off))[:, None]
+    idx = c * np.uint64(total) + i
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + (idx + np.uint64(1)) * np.uint64(0xD1B54A32D192ED03)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def flops(m, n):
+    """Householder QR factorisation flops, 2mn^2 - 2n^3/3."""
+    return 2.0 * m * n * n - 2.0 * n ** 3 / 3.0

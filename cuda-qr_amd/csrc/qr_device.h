@@ -1,0 +1,64 @@
+/* qr_device.h -- internal C interface between the C host layer (qr_host.c) and the HIP launch
+ * layer (qr_kernels.hip).  Plain C types only: the host layer never includes a HIP header.
+ * All functions return 0 on success or a hipError_t / negative library code. */
+#ifndef QR_DEVICE_H
+#define QR_DEVICE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int qrd_init(void);
+int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                int ldb, double beta, double* C, int ldc);
+int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
+                int ldt);
+int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
+                   int ldv, double* scratch);
+int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,
+              double* Tt, int build_diag);
+int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols);
+int qrd_extract_v(void* stream, const double* P, int ld, int mk, int w, double* V, int ldv);
+int qrd_extract_r(void* stream, const double* A, int lda, int m, int n, double* R, int ldr, int rrows);
+int qrd_set_identity(void* stream, double* C, int ld, int rows, int cols, int row_off);
+int qrd_copy_block(void* stream, const double* S, int lds, double* D, int ldd, int rows, int cols);
+int qrd_fill_uniform(void* stream, double* A, int ld, long long rows, int cols, long long row_off,
+                     long long total_rows, unsigned long long seed);
+double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx);
+int qrd_diff_norm(void* stream, const double* X, int ldx, const double* Y, int ldy, long long rows, int cols,
+                  long long row_off, long long total_rows, unsigned long long seed, int sub_identity, double* out);
+
+int qrd_malloc(void** p, size_t bytes);
+int qrd_free(void* p);
+int qrd_memset(void* stream, void* p, int v, size_t bytes);
+int qrd_h2d(void* stream, void* d, const void* h, size_t bytes);
+int qrd_d2h(void* stream, void* h, const void* d, size_t bytes);
+int qrd_d2d(void* stream, void* dst, const void* src, size_t bytes);
+int qrd_h2d_2d(void* stream, void* d, size_t dpitch, const void* h, size_t hpitch, size_t width, size_t height);
+int qrd_d2h_2d(void* stream, void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, size_t height);
+int qrd_stream_create(void** s, int high_priority);
+int qrd_stream_destroy(void* s);
+int qrd_stream_sync(void* s);
+int qrd_device_sync(void);
+int qrd_event_create(void** e);
+int qrd_event_create_notiming(void** e);
+int qrd_event_destroy(void* e);
+int qrd_event_record(void* e, void* s);
+int qrd_event_sync(void* e);
+int qrd_stream_wait_event(void* s, void* e);
+int qrd_event_elapsed_ms(void* a, void* b, float* ms);
+int qrd_device_count(int* n);
+int qrd_set_device(int d);
+const char* qrd_error_string(int e);
+int qrd_device_info(char* name, int name_len, int* cus, int* clock_khz, size_t* mem_bytes);
+int qrd_probe_mfma_f64(double* tflops);
+int qrd_probe_copy(double* gbps);
+
+#define QRD_LEAFW 32
+#define QRD_LEAF_SCRATCH (2 * (256 * QRD_LEAFW + QRD_LEAFW))
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,501 @@
+/* qr_host.c -- C host layer of libmi355xqr.so.
+ *
+ * Plain C99 (the reference's host language, qr.c); it owns the algorithm schedule -- which panel,
+ * which leaf, which contraction, on which stream -- and reaches the GPU only through the extern "C"
+ * launch layer declared in qr_device.h.  No HIP headers here, no exit(), no CPU compute fallback:
+ * without a HIP device every entry point fails with QR_E_NODEVICE.
+ *
+ * Algorithm (replaces the reference's sliding-window "MMQR", qr.c:55-313, on purpose -- see DESIGN.md):
+ * right-looking blocked Householder QR with compact-WY accumulation.
+ *   for each outer panel k (nb columns, full remaining height mk = m-k):
+ *     for each leaf (ib <= 32 columns): leaf_panel  -> v, tau, R, leaf T        [qr.c:109-235]
+ *                                       W_l = T_l^T V_l^T A_rest ; A_rest -= V_l W_l   (rest of panel)
+ *     G = V^T V ; T = larft(G, leaf T's) ; VT = V T                             [qr.c:170-213]
+ *     W = VT^T A2 ; A2 -= V W                                                   [qr.c:255-293]
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/mi355x_qr.h"
+#include "qr_device.h"
+
+#define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct qr_plan {
+    int m, n, nb, ib, ldv, ldt;
+    void* stream;
+    double *Vw, *VT, *W, *T, *Tt, *G, *slabs, *leaf_scratch;
+    size_t slab_cap, w_cap;
+    /* profiling */
+    int prof_on, prof_count, prof_cap, prof_open;
+    void** prof_ev;             /* 2 events per record */
+    int* prof_cls;
+    double *prof_flops, *prof_bytes;
+};
+
+/* ---------------------------------------------------------------------------------------------- */
+static int g_nb = 0, g_ib = 0, g_inited = 0;
+
+static void defaults_from_env(void)
+{
+    if (g_nb == 0) {
+        const char* e = getenv("MI355XQR_NB");
+        g_nb = e ? atoi(e) : 128;
+        e = getenv("MI355XQR_IB");
+        g_ib = e ? atoi(e) : 32;
+        if (g_ib < 1 || g_ib > QRD_LEAFW) g_ib = 32;
+        if (g_nb < g_ib || g_nb > 256 || g_nb % g_ib) g_nb = 128;
+    }
+}
+
+int qr_set_block_size(int nb, int ib)
+{
+    if (ib < 1 || ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
+    g_nb = nb; g_ib = ib;
+    return 0;
+}
+
+void qr_get_block_size(int* nb, int* ib)
+{
+    defaults_from_env();
+    if (nb) *nb = g_nb;
+    if (ib) *ib = g_ib;
+}
+
+static int ensure_device(void)
+{
+    if (g_inited) return 0;
+    int n = 0;
+    if (qrd_device_count(&n) != 0 || n < 1) return QR_E_NODEVICE;
+    CHECK(qrd_init());
+    g_inited = 1;
+    return 0;
+}
+
+const char* qr_strerror(int status)
+{
+    switch (status) {
+    case 0: return "success";
+    case QR_E_ARG: return "invalid argument";
+    case QR_E_ALLOC: return "host allocation failed";
+    case QR_E_NODEVICE: return "no HIP device (this library has no CPU fallback)";
+    case QR_E_INTERNAL: return "internal error";
+    default: return status > 0 ? qrd_error_string(status) : "kernel launch argument error";
+    }
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+
+/* ---------------------------------------------------------------------------------------------- */
+int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
+{
+    if (!out || m < 1 || n < 1 || m < n) return QR_E_ARG;
+    CHECK(ensure_device());
+    defaults_from_env();
+    if (nb <= 0) nb = g_nb;
+    if (ib <= 0) ib = g_ib;
+    if (ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
+    qr_plan* p = (qr_plan*) calloc(1, sizeof(qr_plan));
+    if (!p) return QR_E_ALLOC;
+    p->m = m; p->n = n; p->nb = nb; p->ib = ib;
+    p->ldv = (m + 15) & ~15;
+    p->ldt = nb;
+    int rc = qrd_stream_create(&p->stream, 0);
+    size_t cap = (size_t) 256 * nb * (size_t) n;
+    if (cap > ((size_t) 16 << 20)) cap = (size_t) 16 << 20;
+    if (cap < ((size_t) 1 << 16)) cap = (size_t) 1 << 16;
+    p->slab_cap = cap;
+    p->w_cap = (size_t) nb * n;
+    if (!rc) rc = qrd_malloc((void**) &p->Vw, sizeof(double) * (size_t) p->ldv * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->VT, sizeof(double) * (size_t) p->ldv * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->W, sizeof(double) * p->w_cap);
+    if (!rc) rc = qrd_malloc((void**) &p->T, sizeof(double) * (size_t) nb * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->Tt, sizeof(double) * (size_t) nb * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->G, sizeof(double) * (size_t) nb * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->slabs, sizeof(double) * p->slab_cap);
+    if (!rc) rc = qrd_malloc((void**) &p->leaf_scratch, sizeof(double) * QRD_LEAF_SCRATCH);
+    if (!rc) rc = qrd_memset(p->stream, p->T, 0, sizeof(double) * (size_t) nb * nb);
+    if (!rc) rc = qrd_memset(p->stream, p->Vw, 0, sizeof(double) * (size_t) p->ldv * nb);
+    if (rc) { qr_plan_destroy(p); return rc; }
+    *out = p;
+    return 0;
+}
+
+int qr_plan_destroy(qr_plan* p)
+{
+    if (!p) return 0;
+    if (p->stream) qrd_stream_sync(p->stream);
+    for (int i = 0; i < 2 * p->prof_cap; ++i)
+        if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
+    free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
+    qrd_free(p->Vw); qrd_free(p->VT); qrd_free(p->W); qrd_free(p->T); qrd_free(p->Tt); qrd_free(p->G);
+    qrd_free(p->slabs); qrd_free(p->leaf_scratch);
+    if (p->stream) qrd_stream_destroy(p->stream);
+    free(p);
+    return 0;
+}
+
+int qr_plan_sync(qr_plan* p) { return p ? qrd_stream_sync(p->stream) : QR_E_ARG; }
+void* qr_plan_stream(qr_plan* p) { return p ? p->stream : NULL; }
+
+static int ensure_w(qr_plan* p, size_t elems)
+{
+    if (elems <= p->w_cap) return 0;
+    CHECK(qrd_stream_sync(p->stream));
+    qrd_free(p->W);
+    p->W = NULL; p->w_cap = 0;
+    CHECK(qrd_malloc((void**) &p->W, sizeof(double) * elems));
+    p->w_cap = elems;
+    return 0;
+}
+
+/* ---- profiling (HIP events on the plan's stream) ---------------------------------------------- */
+int qr_plan_set_profile(qr_plan* p, int on)
+{
+    if (!p) return QR_E_ARG;
+    p->prof_on = on ? 1 : 0;
+    p->prof_count = 0;
+    p->prof_open = 0;
+    return 0;
+}
+
+static int prof_begin(qr_plan* p, int cls)
+{
+    if (!p->prof_on) return 0;
+    if (p->prof_count == p->prof_cap) {
+        const int ncap = p->prof_cap ? 2 * p->prof_cap : 1024;
+        void** ev = (void**) realloc(p->prof_ev, sizeof(void*) * 2 * ncap);
+        if (!ev) return QR_E_ALLOC;
+        p->prof_ev = ev;
+        int* cl = (int*) realloc(p->prof_cls, sizeof(int) * ncap);
+        if (!cl) return QR_E_ALLOC;
+        p->prof_cls = cl;
+        double* fl = (double*) realloc(p->prof_flops, sizeof(double) * ncap);
+        if (!fl) return QR_E_ALLOC;
+        p->prof_flops = fl;
+        double* by = (double*) realloc(p->prof_bytes, sizeof(double) * ncap);
+        if (!by) return QR_E_ALLOC;
+        p->prof_bytes = by;
+        for (int i = 2 * p->prof_cap; i < 2 * ncap; ++i) p->prof_ev[i] = NULL;
+        p->prof_cap = ncap;
+    }
+    const int r = p->prof_count;
+    for (int e = 0; e < 2; ++e)
+        if (!p->prof_ev[2 * r + e]) CHECK(qrd_event_create(&p->prof_ev[2 * r + e]));
+    p->prof_cls[r] = cls;
+    p->prof_open = 1;
+    return qrd_event_record(p->prof_ev[2 * r], p->stream);
+}
+
+static int prof_end(qr_plan* p, double flops, double bytes)
+{
+    if (!p->prof_on || !p->prof_open) return 0;
+    const int r = p->prof_count++;
+    p->prof_flops[r] = flops;
+    p->prof_bytes[r] = bytes;
+    p->prof_open = 0;
+    return qrd_event_record(p->prof_ev[2 * r + 1], p->stream);
+}
+
+int qr_plan_get_profile(qr_plan* p, qr_profile* out)
+{
+    if (!p || !out) return QR_E_ARG;
+    memset(out, 0, sizeof(*out));
+    CHECK(qrd_stream_sync(p->stream));
+    for (int r = 0; r < p->prof_count; ++r) {
+        float ms = 0.f;
+        CHECK(qrd_event_elapsed_ms(p->prof_ev[2 * r], p->prof_ev[2 * r + 1], &ms));
+        const int c = p->prof_cls[r];
+        out->ms[c] += ms;
+        out->flops[c] += p->prof_flops[r];
+        out->bytes[c] += p->prof_bytes[r];
+        out->launches[c] += 1;
+    }
+    p->prof_count = 0;
+    return 0;
+}
+
+/* ---- thin wrappers --------------------------------------------------------------------------- */
+static int tn(qr_plan* p, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C,
+              int ldc, const double* Tm)
+{
+    return qrd_gemm_tn(p->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, p->slabs, p->slab_cap, Tm, p->ldt);
+}
+
+int qr_gemm_dev(qr_plan* p, char transa, int M, int N, int K, double alpha, const double* dA, int lda,
+                const double* dB, int ldb, double beta, double* dC, int ldc)
+{
+    if (!p || !dA || !dB || !dC) return QR_E_ARG;
+    if (transa == 'N' || transa == 'n') return qrd_gemm_nn(p->stream, M, N, K, alpha, dA, lda, dB, ldb, beta, dC, ldc);
+    if (transa == 'T' || transa == 't')
+        return qrd_gemm_tn(p->stream, M, N, K, alpha, dA, lda, dB, ldb, beta, dC, ldc, p->slabs, p->slab_cap, NULL, 0);
+    return QR_E_ARG;
+}
+
+/* ---- factorisation --------------------------------------------------------------------------- */
+/* One outer panel: columns [k, k+wout) over rows [k, m).  Leaves V (explicit, unit lower trapezoid)
+ * in p->Vw, the panel's compact-WY T in p->T and V*T in p->VT (the last two only if want_t). */
+static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t)
+{
+    const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt;
+    double* Ak = dA + (size_t) k * lda + k;
+    CHECK(qrd_zero_block(p->stream, p->Vw, ldv, wout, wout));
+    for (int c = 0; c < wout; c += ib) {
+        const int w = imin(ib, wout - c), mkl = mk - c;
+        double* P = Ak + (size_t) c * lda + c;
+        double* Vl = p->Vw + (size_t) c * ldv + c;
+        double* Tl = p->T + (size_t) c * ldt + c;
+        CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
+        const int nrest = wout - (c + w);
+        if (nrest > 0) {
+            double* Arest = P + (size_t) w * lda;
+            CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->W, w, Tl));                   /* T_l^T V_l^T A_rest */
+            CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->W, w, 1.0, Arest, lda));
+        }
+    }
+    if (want_t) {
+        if (wout > ib) {
+            CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, p->nb, NULL));          /* Gram */
+            CHECK(qrd_larft(p->stream, wout, ib, p->G, p->nb, dtau + k, p->T, ldt, NULL, 0));
+        }
+        CHECK(qrd_gemm_nn(p->stream, mk, wout, wout, 1.0, p->Vw, ldv, p->T, ldt, 0.0, p->VT, ldv));
+    }
+    return 0;
+}
+
+int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
+{
+    if (!p || !dA || !dtau || n < 1 || m < n || m > p->m || n > p->n || lda < m) return QR_E_ARG;
+    const int nb = p->nb, ldv = p->ldv;
+    for (int k = 0; k < n; k += nb) {
+        const int wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
+        CHECK(prof_begin(p, 2));
+        CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0));
+        CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+        if (nt > 0) {
+            double* A2 = dA + (size_t) (k + wout) * lda + k;
+            CHECK(prof_begin(p, 1));
+            CHECK(tn(p, wout, nt, mk, p->VT, ldv, A2, lda, p->W, wout, NULL));                /* W = (V T)^T A2 */
+            CHECK(prof_end(p, 2.0 * mk * (double) nt * wout, 8.0 * mk * ((double) nt + wout)));
+            CHECK(prof_begin(p, 0));
+            CHECK(qrd_gemm_nn(p->stream, mk, nt, wout, -1.0, p->Vw, ldv, p->W, wout, 1.0, A2, lda));   /* A2 -= V W */
+            CHECK(prof_end(p, 2.0 * mk * (double) nt * wout, 16.0 * mk * (double) nt + 8.0 * mk * wout));
+        }
+    }
+    return 0;
+}
+
+int qr_applyq_dev(qr_plan* p, const double* dA, int m, int n, int lda, const double* dtau, double* dC, int ccols,
+                  int ldc, int identity_start)
+{
+    if (!p || !dA || !dtau || !dC || n < 1 || m < n || m > p->m || n > p->n || ccols < 1 || ldc < m) return QR_E_ARG;
+    const int nb = p->nb, ib = p->ib, ldv = p->ldv, ldt = p->ldt;
+    CHECK(ensure_w(p, (size_t) nb * ccols));
+    if (identity_start) CHECK(qrd_set_identity(p->stream, dC, ldc, m, ccols, 0));
+    const int npan = (n + nb - 1) / nb;
+    for (int pi = npan - 1; pi >= 0; --pi) {
+        const int k = pi * nb, wout = imin(nb, n - k), mk = m - k;
+        const int c0 = identity_start ? k : 0, nc = ccols - c0;
+        if (nc <= 0) continue;
+        const double* Ak = dA + (size_t) k * lda + k;
+        CHECK(qrd_extract_v(p->stream, Ak, lda, mk, wout, p->Vw, ldv));
+        CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, nb, NULL));
+        CHECK(qrd_larft(p->stream, wout, ib, p->G, nb, dtau + k, p->T, ldt, p->Tt, 1));
+        CHECK(qrd_gemm_nn(p->stream, mk, wout, wout, 1.0, p->Vw, ldv, p->Tt, ldt, 0.0, p->VT, ldv));   /* V T^T */
+        double* Cs = dC + (size_t) c0 * ldc + k;
+        CHECK(tn(p, wout, nc, mk, p->VT, ldv, Cs, ldc, p->W, wout, NULL));                              /* T V^T C */
+        CHECK(qrd_gemm_nn(p->stream, mk, nc, wout, -1.0, p->Vw, ldv, p->W, wout, 1.0, Cs, ldc));
+    }
+    return 0;
+}
+
+int qr_extract_r_dev(qr_plan* p, const double* dA, int m, int n, int lda, double* dR, int rrows, int ldr)
+{
+    if (!p || !dA || !dR || rrows < 1 || ldr < rrows) return QR_E_ARG;
+    return qrd_extract_r(p->stream, dA, lda, m, n, dR, ldr, rrows);
+}
+
+int qr_fill_uniform_dev(qr_plan* p, double* dA, int lda, long long rows, int cols, long long row_off,
+                        long long total_rows, unsigned long long seed)
+{
+    if (!p || !dA) return QR_E_ARG;
+    return qrd_fill_uniform(p->stream, dA, lda, rows, cols, row_off, total_rows, seed);
+}
+
+double qr_uniform_at(unsigned long long seed, unsigned long long idx) { return qrd_hash_uniform_host(seed, idx); }
+
+int qr_diffnorm_dev(qr_plan* p, const double* dX, int ldx, const double* dY, int ldy, long long rows, int cols,
+                    long long row_off, long long total_rows, unsigned long long seed, int mode, double* sums)
+{
+    if (!p || !dX || !sums) return QR_E_ARG;
+    return qrd_diff_norm(p->stream, dX, ldx, dY, ldy, rows, cols, row_off, total_rows, seed, mode == 1, sums);
+}
+
+int qr_device_info(char* arch, int arch_len, int* cus, int* clock_khz, size_t* hbm)
+{
+    CHECK(ensure_device());
+    return qrd_device_info(arch, arch_len, cus, clock_khz, hbm);
+}
+int qr_probe_mfma_f64_tflops(double* t) { CHECK(ensure_device()); return qrd_probe_mfma_f64(t); }
+int qr_probe_copy_gbps(double* g) { CHECK(ensure_device()); return qrd_probe_copy(g); }
+
+/* ---------------------------------------------------------------------------------------------- *
+ * Host-pointer entry points (drop-in for the reference's qr.c)
+ * ---------------------------------------------------------------------------------------------- */
+void getPanelDims(int m, int n, int* rowPanels, int* colPanels)
+{
+    (void) m;
+    defaults_from_env();
+    if (colPanels) *colPanels = n / g_nb + (n % g_nb != 0);
+    if (rowPanels) *rowPanels = 1;
+}
+
+int mmqr_status(double* mat, double** tau, int m, int n)
+{
+    if (!mat || !tau || n < 1 || m < n) return QR_E_ARG;
+    int rp, cp;
+    getPanelDims(m, n, &rp, &cp);
+    const size_t ntau = (size_t) rp * cp * g_nb;
+    double* htau = (double*) calloc(ntau, sizeof(double));          /* zero-filled like qr.c:61-62 */
+    if (!htau) return QR_E_ALLOC;
+    qr_plan* p = NULL;
+    double *dA = NULL, *dtau = NULL;
+    int rc = qr_plan_create(&p, m, n, 0, 0);
+    const size_t bytes = sizeof(double) * (size_t) m * n;
+    if (!rc) rc = qrd_malloc((void**) &dA, bytes);
+    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * n);
+    if (!rc) rc = qrd_h2d(p->stream, dA, mat, bytes);
+    if (!rc) rc = qr_geqrf_dev(p, dA, m, n, m, dtau);
+    if (!rc) rc = qrd_d2h(p->stream, mat, dA, bytes);
+    if (!rc) rc = qrd_d2h(p->stream, htau, dtau, sizeof(double) * n);
+    if (!rc) rc = qrd_stream_sync(p->stream);
+    qrd_free(dA); qrd_free(dtau);
+    qr_plan_destroy(p);
+    if (rc) { free(htau); return rc; }
+    *tau = htau;
+    return 0;
+}
+
+int explicitQR_status(double* A, double* tau, double* Q, double* R, int m, int n)
+{
+    if (!A || !tau || !Q || !R || n < 1 || m < n) return QR_E_ARG;
+    qr_plan* p = NULL;
+    double *dA = NULL, *dtau = NULL, *dQ = NULL, *dR = NULL;
+    const size_t abytes = sizeof(double) * (size_t) m * n, qbytes = sizeof(double) * (size_t) m * m;
+    int rc = qr_plan_create(&p, m, n, 0, 0);
+    if (!rc) rc = qrd_malloc((void**) &dA, abytes);
+    if (!rc) rc = qrd_malloc((void**) &dR, abytes);
+    if (!rc) rc = qrd_malloc((void**) &dQ, qbytes);
+    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * n);
+    if (!rc) rc = qrd_h2d(p->stream, dA, A, abytes);
+    if (!rc) rc = qrd_h2d(p->stream, dtau, tau, sizeof(double) * n);
+    if (!rc) rc = qr_extract_r_dev(p, dA, m, n, m, dR, m, m);
+    if (!rc) rc = qr_applyq_dev(p, dA, m, n, m, dtau, dQ, m, m, 1);
+    if (!rc) rc = qrd_d2h(p->stream, R, dR, abytes);
+    if (!rc) rc = qrd_d2h(p->stream, Q, dQ, qbytes);
+    if (!rc) rc = qrd_stream_sync(p->stream);
+    qrd_free(dA); qrd_free(dR); qrd_free(dQ); qrd_free(dtau);
+    qr_plan_destroy(p);
+    return rc;
+}
+
+int dgemm_status(double* A, double* B, double* C, int k, int m, int n)
+{
+    if (!A || !B || !C || k < 1 || m < 1 || n < 1) return QR_E_ARG;
+    CHECK(ensure_device());
+    void* s = NULL;
+    double *dA = NULL, *dB = NULL, *dC = NULL;
+    int rc = qrd_stream_create(&s, 0);
+    if (!rc) rc = qrd_malloc((void**) &dA, sizeof(double) * (size_t) k * m);
+    if (!rc) rc = qrd_malloc((void**) &dB, sizeof(double) * (size_t) m * n);
+    if (!rc) rc = qrd_malloc((void**) &dC, sizeof(double) * (size_t) k * n);
+    if (!rc) rc = qrd_h2d(s, dA, A, sizeof(double) * (size_t) k * m);
+    if (!rc) rc = qrd_h2d(s, dB, B, sizeof(double) * (size_t) m * n);
+    if (!rc) rc = qrd_gemm_nn(s, k, n, m, 1.0, dA, k, dB, m, 0.0, dC, k);
+    if (!rc) rc = qrd_d2h(s, C, dC, sizeof(double) * (size_t) k * n);
+    if (!rc) rc = qrd_stream_sync(s);
+    qrd_free(dA); qrd_free(dB); qrd_free(dC);
+    if (s) qrd_stream_destroy(s);
+    return rc;
+}
+
+static void complain(const char* fn, int rc)
+{
+    if (rc) fprintf(stderr, "mi355xqr: %s failed: %s (%d)\n", fn, qr_strerror(rc), rc);
+}
+
+void mmqr(double* mat, double** tau, int m, int n) { complain("mmqr", mmqr_status(mat, tau, m, n)); }
+void explicitQR(double* A, double* tau, double* Q, double* R, int m, int n)
+{ complain("explicitQR", explicitQR_status(A, tau, Q, R, m, n)); }
+void dgemm(double* A, double* B, double* C, int k, int m, int n) { complain("dgemm", dgemm_status(A, B, C, k, m, n)); }
+
+void identity(double* A, int m)
+{
+    if (!A || m < 1) return;
+    memset(A, 0, sizeof(double) * (size_t) m * m);
+    for (int i = 0; i < m; ++i) A[(size_t) i * m + i] = 1.0;
+}
+
+void printMat(double* mat, int m, int n)
+{
+    if (!mat) return;
+    printf("Matrix %d x %d, row by row:\n", m, n);
+    for (int r = 0; r < m; ++r) {
+        for (int c = 0; c < n; ++c) printf("%9f ", mat[(size_t) c * m + r]);
+        putchar('\n');
+    }
+    putchar('\n');
+}
+
+/* ---- thin QR / single-device TSQR over row shards -------------------------------------------- */
+int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nshards)
+{
+    if (!A || !Q || !R || n < 1 || m < n || nshards < 1) return QR_E_ARG;
+    const int ms = (m + nshards - 1) / nshards;
+    if (nshards > 1 && (m - (nshards - 1) * ms) < n) return QR_E_ARG;   /* every shard needs >= n rows */
+    qr_plan *p = NULL, *p2 = NULL;
+    double *dA = NULL, *dQ = NULL, *dtau = NULL, *dR = NULL, *dS = NULL, *dQt = NULL, *dtau2 = NULL;
+    const size_t abytes = sizeof(double) * (size_t) m * n;
+    const int sm = nshards * n;
+    int rc = qr_plan_create(&p, nshards > 1 ? ms : m, n, nb, 0);
+    if (!rc) rc = qrd_malloc((void**) &dA, abytes);
+    if (!rc) rc = qrd_malloc((void**) &dQ, abytes);
+    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * (size_t) n * nshards);
+    if (!rc) rc = qrd_malloc((void**) &dR, sizeof(double) * (size_t) n * n);
+    if (!rc) rc = qrd_h2d(p->stream, dA, A, abytes);
+    if (!rc && nshards == 1) {
+        rc = qr_geqrf_dev(p, dA, m, n, m, dtau);
+        if (!rc) rc = qr_extract_r_dev(p, dA, m, n, m, dR, n, n);
+        if (!rc) rc = qr_applyq_dev(p, dA, m, n, m, dtau, dQ, n, m, 1);
+    } else if (!rc) {
+        rc = qr_plan_create(&p2, sm, n, nb, 0);
+        if (!rc) rc = qrd_malloc((void**) &dS, sizeof(double) * (size_t) sm * n);
+        if (!rc) rc = qrd_malloc((void**) &dQt, sizeof(double) * (size_t) sm * n);
+        if (!rc) rc = qrd_malloc((void**) &dtau2, sizeof(double) * n);
+        for (int s = 0; s < nshards && !rc; ++s) {            /* step 1: independent local QRs */
+            const int r0 = s * ms, rows = imin(ms, m - r0);
+            rc = qr_geqrf_dev(p, dA + r0, rows, n, m, dtau + (size_t) s * n);
+            if (!rc) rc = qr_extract_r_dev(p, dA + r0, rows, n, m, dS + (size_t) s * n, n, sm);
+        }
+        if (!rc) rc = qrd_stream_sync(p->stream);
+        /* step 2: QR of the stacked R factors (what every rank does after the all-gather) */
+        if (!rc) rc = qr_geqrf_dev(p2, dS, sm, n, sm, dtau2);
+        if (!rc) rc = qr_extract_r_dev(p2, dS, sm, n, sm, dR, n, n);
+        if (!rc) rc = qr_applyq_dev(p2, dS, sm, n, sm, dtau2, dQt, n, sm, 1);
+        if (!rc) rc = qrd_stream_sync(p2->stream);
+        /* step 3: Q_s = Q_local_s * [Qtree_s ; 0] */
+        if (!rc) rc = qrd_memset(p->stream, dQ, 0, abytes);
+        for (int s = 0; s < nshards && !rc; ++s) {
+            const int r0 = s * ms, rows = imin(ms, m - r0);
+            rc = qrd_copy_block(p->stream, dQt + (size_t) s * n, sm, dQ + r0, m, n, n);
+            if (!rc) rc = qr_applyq_dev(p, dA + r0, rows, n, m, dtau + (size_t) s * n, dQ + r0, n, m, 0);
+        }
+    }
+    if (!rc) rc = qrd_d2h(p->stream, Q, dQ, abytes);
+    if (!rc) rc = qrd_d2h(p->stream, R, dR, sizeof(double) * (size_t) n * n);
+    if (!rc) rc = qrd_stream_sync(p->stream);
+    qrd_free(dA); qrd_free(dQ); qrd_free(dtau); qrd_free(dR); qrd_free(dS); qrd_free(dQt); qrd_free(dtau2);
+    qr_plan_destroy(p); qr_plan_destroy(p2);
+    return rc;
+}

@@ -1,0 +1,144 @@
+/* mi355x_qr.h -- public C ABI of libmi355xqr.so: MI355X-native (gfx950) fp64 blocked Householder QR.
+ *
+ * The library is a drop-in for the host entry points of brian-kelley/CUDA-QR's qr.c built with
+ * Scalar = double ("double* A, m, n -> Q, R"), plus a device-resident API for callers that keep the
+ * matrix in HBM (bench, TSQR over several GPUs).  Plain pointers and sizes only; no HIP, C++ or torch
+ * types cross this boundary.  All matrices are column-major with leading dimension = row count unless
+ * an ld argument says otherwise (reference layout, qr.c:35,85).
+ *
+ * Every entry point cites the reference interface it replaces as file:line into the reference repo.
+ */
+#ifndef MI355X_QR_H
+#define MI355X_QR_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Drop-in symbols (same names, argument order and meaning as the reference, Scalar = double)
+ * ------------------------------------------------------------------------------------------- */
+
+/* replaces qr.c:47-53 getPanelDims.  The reference's sliding PR x PC window does not exist here: a
+ * column panel of width nb (the library block size, default 128) is factored over its full height,
+ * so rowPanels = 1 and colPanels = ceil(n/nb).  tau therefore holds rowPanels*colPanels*nb >= n
+ * entries, which keeps the reference caller's tau[i*rowPanels + j] indexing (qr.c:483-490) in bounds. */
+void getPanelDims(int m, int n, int* rowPanels, int* colPanels);
+
+/* replaces qr.c:55-313 mmqr (and its GPU twin qr.cu:475-553).  In-place Householder QR of the m x n
+ * (m >= n) host matrix `mat`: on return the upper triangle holds R and the sub-diagonal of column j
+ * holds the tail of reflector v_j (v_j(j) = 1 implicit).  *tau is malloc'ed here (caller frees, as
+ * qr.c:61,521) with colPanels*nb entries: tau[j] = Householder scalar of column j, zero padded.
+ * tau is an opaque array consumed by this library's own explicitQR: the reference's
+ * window-indexed layout (qr.c:300-304) depends on its compile-time PR, PC and is not reproduced.
+ * Convention: LAPACK dlarfg (H = I - tau v v^T, R diagonal = -sign(x0)*||x||, same as qr.c:144-158),
+ * except that an exactly-zero column tail gives tau = 0 where the reference yields NaN (qr.c:152). */
+void mmqr(double* mat, double** tau, int m, int n);
+
+/* replaces qr.c:330-438 explicitQR.  From mmqr's output builds R (m x n: upper triangle of A, zero
+ * below, qr.c:334-343) and the dense m x m orthogonal Q = H_0 H_1 ... H_{n-1} (the reference forms it
+ * with an m^3 product per reflector, qr.c:415-429; here: blocked backward accumulation on MFMA tiles).
+ * Q and R are caller-allocated (qr.c:492-493). */
+void explicitQR(double* A, double* tau, double* Q, double* R, int m, int n);
+
+/* replaces qr.c:443-459 dgemm: C (k x n) = A (k x m) * B (m x n), column-major. Runs on the GPU. */
+void dgemm(double* A, double* B, double* C, int k, int m, int n);
+
+/* replaces qr.c:316-324 identity: A = I(m). */
+void identity(double* A, int m);
+
+/* replaces qr.c:21-33 printMat (row-by-row debug print to stdout, "%9f "). */
+void printMat(double* mat, int m, int n);
+
+/* The reference returns nothing and exits/asserts on error (qr.c:465, qr.cu:467-471).  The void
+ * shims above print a diagnostic to stderr and return; these variants return a status instead
+ * (0 = ok, >0 = hipError_t, <0 = QR_E_*).  The library never calls exit(). */
+int mmqr_status(double* mat, double** tau, int m, int n);
+int explicitQR_status(double* A, double* tau, double* Q, double* R, int m, int n);
+int dgemm_status(double* A, double* B, double* C, int k, int m, int n);
+
+#define QR_E_ARG      (-101)  /* bad argument (null pointer, m < n, non-positive size) */
+#define QR_E_ALLOC    (-102)  /* host allocation failed */
+#define QR_E_NODEVICE (-103)  /* no HIP device visible: there is NO CPU fallback */
+#define QR_E_INTERNAL (-104)
+const char* qr_strerror(int status);
+
+/* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 256;
+ * leaf width ib <= 32).  Defaults 128 / 32; env MI355XQR_NB / MI355XQR_IB override the defaults. */
+int qr_set_block_size(int nb, int ib);
+void qr_get_block_size(int* nb, int* ib);
+
+/* Thin QR for shapes whose m x m Q cannot exist (no reference counterpart: the
+ * reference's explicitQR is m x m only).  A (m x n, host) is not modified; Q is m x n, R is n x n
+ * (upper triangular, diag of any sign).  nshards > 1 factors `nshards` contiguous row blocks
+ * independently and combines their R factors (TSQR on one device; the multi-GPU form of the same
+ * steps is driven through the device API below with an RCCL all-gather between steps 1 and 2). */
+int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nshards);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. Device-resident API (all d* pointers are device memory of the current HIP device)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct qr_plan qr_plan;
+
+/* Workspace + streams for factoring matrices up to m x n with outer block nb and leaf width ib
+ * (nb = 0 / ib = 0 select the library defaults). */
+int qr_plan_create(qr_plan** plan, int m, int n, int nb, int ib);
+int qr_plan_destroy(qr_plan* plan);
+
+/* In-place blocked Householder QR of dA (m x n, lda), m <= plan m, n <= plan n; dtau: n doubles.
+ * Device-side counterpart of mmqr (qr.c:55) with input already resident in HBM; asynchronous on the
+ * plan's stream -- call qr_plan_sync before reading results on another stream. */
+int qr_geqrf_dev(qr_plan* plan, double* dA, int m, int n, int lda, double* dtau);
+
+/* dC (m x ccols, ldc) <- Q * dC where Q = H_0..H_{n-1} comes from qr_geqrf_dev's factors.
+ * identity_start != 0 first sets dC = I(m, ccols) and skips the structurally-zero part, i.e. forms
+ * the leading ccols columns of Q (ccols = n: thin Q; ccols = m: the reference's m x m Q, qr.c:330). */
+int qr_applyq_dev(qr_plan* plan, const double* dA, int m, int n, int lda, const double* dtau, double* dC,
+                  int ccols, int ldc, int identity_start);
+
+/* dR (rrows x n, ldr) = upper triangle of the factored dA, zero elsewhere (qr.c:334-343). */
+int qr_extract_r_dev(qr_plan* plan, const double* dA, int m, int n, int lda, double* dR, int rrows, int ldr);
+
+/* C = beta*C + alpha*op(A)*B with op = none ('N') or transpose ('T'); MFMA f64 tiles. */
+int qr_gemm_dev(qr_plan* plan, char transa, int M, int N, int K, double alpha, const double* dA, int lda,
+                const double* dB, int ldb, double beta, double* dC, int ldc);
+
+/* Synthetic input: uniform[0,1) by a counter-based hash of the global element index, so any row
+ * shard (rows [row_off, row_off+rows) of a total_rows x cols matrix) of the same seed is the same
+ * data regardless of how many GPUs hold it.  Same distribution as the reference's
+ * generator (qr.c:468-474), which is serial glibc rand() and kept for the small CPU-parity cases. */
+int qr_fill_uniform_dev(qr_plan* plan, double* dA, int lda, long long rows, int cols, long long row_off,
+                        long long total_rows, unsigned long long seed);
+double qr_uniform_at(unsigned long long seed, unsigned long long linear_index);
+
+/* sums[0] = ||X - Y||_F^2, sums[1] = ||Y||_F^2 over an rows x cols block.  Y is dY (ldy) if non-null,
+ * else the generator above (row_off/total_rows/seed), else (mode 1) the identity.  Synchronous. */
+int qr_diffnorm_dev(qr_plan* plan, const double* dX, int ldx, const double* dY, int ldy, long long rows,
+                    int cols, long long row_off, long long total_rows, unsigned long long seed, int mode,
+                    double* sums);
+
+int qr_plan_sync(qr_plan* plan);
+void* qr_plan_stream(qr_plan* plan);          /* the hipStream_t work is queued on */
+
+/* Per-kernel-class timing with HIP events recorded on the plan's stream inside the timed region.
+ * class 0 = trailing update A2 -= V*W (gemm_nn), 1 = W = (V T)^T A2 (gemm_tn + slab reduce),
+ * 2 = panel factorisation (leaf kernels + in-panel updates + T), 3 = V*T and misc. */
+#define QR_PROF_CLASSES 4
+typedef struct qr_profile {
+    double ms[QR_PROF_CLASSES];      /* summed event-to-event time */
+    double flops[QR_PROF_CLASSES];   /* algorithmic flops issued */
+    double bytes[QR_PROF_CLASSES];   /* algorithmic HBM bytes (compulsory traffic) */
+    long long launches[QR_PROF_CLASSES];
+} qr_profile;
+int qr_plan_set_profile(qr_plan* plan, int on);
+int qr_plan_get_profile(qr_plan* plan, qr_profile* out);   /* synchronises, sums, resets */
+
+/* Device facts + micro-probes used by bench.py / DESIGN.md (measured, not datasheet). */
+int qr_device_info(char* arch, int arch_len, int* compute_units, int* clock_khz, size_t* hbm_bytes);
+int qr_probe_mfma_f64_tflops(double* tflops);
+int qr_probe_copy_gbps(double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

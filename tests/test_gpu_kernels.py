@@ -1,0 +1,216 @@
+"""-m gpu: each hand-written HIP kernel against a numpy restatement of the same operation
+(fp64; tolerance stated per test).  Calls go through the library's launch layer."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, host, rel, zeros
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def q(qr):
+    qr.check(qr.lib.qrd_init(), "qrd_init")
+    return qr
+
+
+def _sync(q):
+    q.check(q.lib.qrd_device_sync(), "sync")
+
+
+NN_SHAPES = [(16, 16, 4), (128, 128, 16), (256, 384, 128), (130, 70, 33), (1000, 40, 32), (37, 300, 7),
+             (4096, 128, 128), (2048, 2048, 64), (6, 4, 2), (515, 515, 515), (12800, 32, 32), (64, 1, 64)]
+
+
+@pytest.mark.parametrize("M,N,K", NN_SHAPES)
+def test_gemm_nn(q, M, N, K):
+    """C = beta*C + alpha*A*B on f64 MFMA tiles; asymmetric random data catches any row/col swap."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A, B, C0 = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((M, N))
+    for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.5, -2.0)):
+        dA, dB, dC = dev(A), dev(B), dev(C0)
+        torch.cuda.synchronize()
+        q.check(q.lib.qrd_gemm_nn(None, M, N, K, alpha, dA.data_ptr(), M, dB.data_ptr(), K, beta, dC.data_ptr(), M))
+        _sync(q)
+        ref = alpha * (A @ B) + beta * C0
+        assert rel(host(dC), ref) < 1e-13, (M, N, K, alpha, beta)
+
+
+def test_gemm_nn_with_leading_dimensions(q):
+    rng = np.random.default_rng(5)
+    M, N, K, lda, ldb, ldc = 200, 96, 48, 260, 50, 333     # ldc odd -> scalar path for C only
+    A, B, C0 = rng.standard_normal((lda, K)), rng.standard_normal((ldb, N)), rng.standard_normal((ldc, N))
+    dA, dB, dC = dev(A), dev(B), dev(C0)
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_gemm_nn(None, M, N, K, -1.0, dA.data_ptr(), lda, dB.data_ptr(), ldb, 1.0, dC.data_ptr(), ldc))
+    _sync(q)
+    out = host(dC)
+    ref = C0.copy()
+    ref[:M] -= A[:M] @ B[:K]
+    assert rel(out, ref) < 1e-13
+    assert np.array_equal(out[M:], C0[M:])             # rows beyond M untouched
+
+
+TN_SHAPES = [(16, 16, 64), (128, 128, 4096), (128, 1000, 5000), (32, 96, 16384), (32, 224, 777), (64, 64, 100),
+             (128, 16384, 1024), (5, 3, 11), (256, 256, 3000), (130, 67, 129), (1, 1, 1), (32, 20, 100000)]
+
+
+@pytest.mark.parametrize("M,N,K", TN_SHAPES)
+def test_gemm_tn_splitk(q, M, N, K):
+    """C = A^T B with the long K dimension split over workgroups + deterministic slab reduction."""
+    rng = np.random.default_rng(M + 13 * N + K)
+    A, B = rng.standard_normal((K, M)), rng.standard_normal((K, N))
+    dA, dB, dC = dev(A), dev(B), zeros(M, N)
+    cap = 4 << 20
+    slabs = torch.empty(cap, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(2):
+        q.check(q.lib.qrd_gemm_tn(None, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), K, 0.0, dC.data_ptr(), M,
+                                  slabs.data_ptr(), cap, None, 0))
+        _sync(q)
+        outs.append(host(dC))
+    ref = A.T @ B
+    assert np.abs(outs[0] - ref).max() < 1e-13 * np.sqrt(K) * max(1.0, np.abs(ref).max())
+    assert np.array_equal(outs[0], outs[1]), "split-K reduction must be bitwise reproducible"
+
+
+def test_gemm_tn_without_slabs_and_beta(q):
+    rng = np.random.default_rng(9)
+    M, N, K = 96, 80, 500
+    A, B, C0 = rng.standard_normal((K, M)), rng.standard_normal((K, N)), rng.standard_normal((M, N))
+    dA, dB, dC = dev(A), dev(B), dev(C0)
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_gemm_tn(None, M, N, K, 2.0, dA.data_ptr(), K, dB.data_ptr(), K, -1.0, dC.data_ptr(), M,
+                              None, 0, None, 0))
+    _sync(q)
+    assert rel(host(dC), 2.0 * A.T @ B - C0) < 1e-13
+
+
+@pytest.mark.parametrize("w,N,K", [(32, 96, 4000), (16, 224, 333), (32, 7, 64), (8, 100, 20000)])
+def test_gemm_tn_fused_Tt(q, w, N, K):
+    """leaf-level fold: C = T^T (A^T B) with T upper triangular (w <= 32)."""
+    rng = np.random.default_rng(w + N + K)
+    A, B = rng.standard_normal((K, w)), rng.standard_normal((K, N))
+    T = np.triu(rng.standard_normal((w, w)))
+    ldt = 40
+    Tpad = np.zeros((ldt, w)); Tpad[:w] = T
+    dA, dB, dT, dC = dev(A), dev(B), dev(Tpad), zeros(w, N)
+    cap = 1 << 20
+    slabs = torch.empty(cap, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_gemm_tn(None, w, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), K, 0.0, dC.data_ptr(), w,
+                              slabs.data_ptr(), cap, dT.data_ptr(), ldt))
+    _sync(q)
+    ref = T.T @ (A.T @ B)
+    assert np.abs(host(dC) - ref).max() < 1e-12 * np.sqrt(K) * max(1.0, np.abs(ref).max())
+
+
+LEAF_SHAPES = [(32, 32), (64, 32), (256, 32), (1000, 32), (4096, 16), (16384, 32), (70000, 32), (300, 7), (5, 5),
+               (2, 1), (200000, 24)]
+
+
+@pytest.mark.parametrize("mk,w", LEAF_SHAPES)
+def test_leaf_panel(q, oracle, mk, w):
+    """Householder panel kernel vs unblocked numpy geqr2 (LAPACK convention): R, v tails, tau, T, explicit V."""
+    rng = np.random.default_rng(mk + w)
+    P = rng.random((mk, w))
+    ld, ldv, ldt = mk + 6, mk + 2, w + 3
+    buf = np.full((ld, w), 7.0); buf[:mk] = P
+    dP = dev(buf)
+    dtau, dT, dV = zeros(w, 1), zeros(ldt, w), dev(np.full((ldv, w), np.nan))
+    scratch = torch.zeros(2 * (256 * 32 + 32), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_leaf_panel(None, dP.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), ldt,
+                                 dV.data_ptr(), ldv, scratch.data_ptr()))
+    _sync(q)
+    F, tau = oracle.np_geqr2(P)
+    out = host(dP)
+    assert np.array_equal(out[mk:], buf[mk:])                                   # padding rows untouched
+    scale = np.abs(F).max()
+    assert np.abs(out[:mk] - F).max() < 2e-13 * scale * np.sqrt(mk), "R / reflector tails"
+    assert np.abs(host(dtau)[:, 0] - tau).max() < 1e-13
+    V = oracle.np_unit_lower(F)
+    assert np.abs(host(dV)[:mk] - V).max() < 2e-13 * np.sqrt(mk)
+    T = oracle.np_larft(V, tau)
+    assert np.abs(host(dT)[:w] - T).max() < 1e-12
+    # the factorisation property itself: (I - V T V^T)^T P = [R; 0]
+    Vd, Td = host(dV)[:mk], host(dT)[:w]
+    QtP = P - Vd @ (Td.T @ (Vd.T @ P))
+    assert np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-12 * np.sqrt(mk)
+    assert np.abs(QtP[w:]).max() < 1e-12 * np.sqrt(mk) and np.abs(np.tril(QtP[:w], -1)).max() < 1e-12 * np.sqrt(mk)
+
+
+def test_leaf_panel_zero_column_gives_tau_zero(q):
+    """Deviation from the reference stated in include/mi355x_qr.h: zero tail -> tau = 0 (reference: NaN)."""
+    mk, w = 300, 8
+    P = np.random.default_rng(1).random((mk, w))
+    P[:, 3] = 0.0
+    P[4:, 5] = 0.0
+    dP, dtau, dT, dV = dev(P), zeros(w, 1), zeros(w, w), zeros(mk, w)
+    scratch = torch.zeros(2 * (256 * 32 + 32), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_leaf_panel(None, dP.data_ptr(), mk, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(),
+                                 mk, scratch.data_ptr()))
+    _sync(q)
+    out, tau = host(dP), host(dtau)[:, 0]
+    assert np.isfinite(out).all() and np.isfinite(tau).all()
+    V, T = host(dV), host(dT)
+    QtP = P - V @ (T.T @ (V.T @ P))
+    assert np.abs(np.tril(QtP, -1)).max() < 1e-12
+
+
+@pytest.mark.parametrize("nbp,ib,build_diag", [(128, 32, 1), (128, 32, 0), (256, 32, 1), (96, 16, 1), (64, 32, 0),
+                                               (40, 32, 1), (32, 32, 1), (8, 8, 1), (72, 8, 0)])
+def test_larft(q, oracle, nbp, ib, build_diag):
+    rng = np.random.default_rng(nbp + ib)
+    mk = 3 * nbp + 17
+    V = np.tril(rng.standard_normal((mk, nbp)), -1) * 0.3
+    V[np.arange(nbp), np.arange(nbp)] = 1.0
+    tau = 2.0 / (V * V).sum(axis=0)                    # genuine Householder scalars
+    G = V.T @ V
+    Tref = oracle.np_larft(V, tau)
+    T0 = np.full((nbp, nbp), np.nan)
+    for cb in range(0, nbp, ib):                       # diagonal blocks as the leaf kernels would leave them
+        wb = min(ib, nbp - cb)
+        T0[cb:cb + wb, cb:cb + wb] = Tref[cb:cb + wb, cb:cb + wb] if not build_diag else np.nan
+    dG, dtau, dT, dTt = dev(G), dev(tau[:, None]), dev(T0), zeros(nbp, nbp)
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_larft(None, nbp, ib, dG.data_ptr(), nbp, dtau.data_ptr(), dT.data_ptr(), nbp, dTt.data_ptr(),
+                            build_diag))
+    _sync(q)
+    T = host(dT)
+    assert np.abs(T - Tref).max() < 1e-12 * max(1.0, np.abs(Tref).max())
+    assert np.array_equal(host(dTt), T.T)
+    H = np.eye(mk) - V @ T @ V.T
+    assert np.abs(H.T @ H - np.eye(mk)).max() < 1e-11
+
+
+def test_fill_uniform_matches_host_hash(q):
+    p = q.Plan(64, 32)
+    rows, cols, ld, off, total = 1000, 7, 1003, 12345, 99999
+    d = zeros(ld, cols)
+    torch.cuda.synchronize()
+    p.fill_uniform(d, ld, rows, cols, row_off=off, total_rows=total, seed=12)
+    p.sync()
+    out = host(d)
+    assert np.array_equal(out[:rows], q.uniform_matrix_host(rows, cols, off, total, 12))
+    assert np.array_equal(out[rows:], np.zeros((ld - rows, cols)))
+    p.close()
+
+
+def test_diffnorm(q):
+    p = q.Plan(64, 32)
+    rng = np.random.default_rng(0)
+    X, Y = rng.standard_normal((777, 13)), rng.standard_normal((777, 13))
+    dX, dY = dev(X), dev(Y)
+    torch.cuda.synchronize()
+    a, b = p.diffnorm(dX, 777, 777, 13, dY=dY, ldy=777)
+    assert abs(a - ((X - Y) ** 2).sum()) < 1e-9 and abs(b - (Y ** 2).sum()) < 1e-9
+    G = q.uniform_matrix_host(777, 13, 5, 1000, 12)
+    a, b = p.diffnorm(dX, 777, 777, 13, row_off=5, total_rows=1000, seed=12)
+    assert abs(a - ((X - G) ** 2).sum()) < 1e-9 and abs(b - (G ** 2).sum()) < 1e-9
+    a, b = p.diffnorm(dX, 777, 13, 13, mode=1)
+    assert abs(a - ((X[:13] - np.eye(13)) ** 2).sum()) < 1e-9 and abs(b - 13.0) < 1e-12
+    p.close()

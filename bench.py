@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- the round benchmark contract.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one full fp64 Householder QR factorisation of a synthetic dense matrix that is already
+resident in HBM when the timed region starts (uniform[0,1) from the library's counter-based
+generator, seed-indexed per step; no regeneration, copy or PCIe traffic inside the timed region).
+
+  N = 1   BASELINE config C3: 16384 x 16384 on one MI355X (--workload c2 for 4096 x 4096, nb 64;
+          --workload tsqr for one 262144 x 512 shard)
+  N > 1   TSQR, weak scaling: every rank owns a 262144 x 512 row shard of a (N*262144) x 512 matrix
+          (N = 8 is exactly BASELINE config C5, 2097152 x 512); local QR + ONE RCCL all-gather of the
+          R factors + redundant stacked QR.  --workload c4 runs 262144 x 256 split over the ranks instead.
+
+Prints ONE JSON line on rank 0: metric fp64 GFLOP/s (F = 2mn^2 - 2n^3/3 per factorisation, whole job),
+plus `roofline` for the dominant kernel (the trailing-update MFMA GEMM; for TSQR the panel kernels),
+`cpu_baseline` (the REAL reference qr.c, or the oracle port of it, on one host core over a bounded
+sample) and the accuracy figures of the north-star (||A-QR||_F/||A||_F, ||Q^T Q - I||_F).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet, fp64 matrix (= 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz);
+                                 # /opt/skills/guides/MI355X_MICROARCH.md lists no fp64 MFMA row
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tsqr", "c4"])
+    ap.add_argument("--nb", type=int, default=0)
+    ap.add_argument("--ib", type=int, default=0)
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run residual/orthogonality check")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="1184x640", help="m x n of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def flops(m, n):
+    return 2.0 * m * n * n - 2.0 * n ** 3 / 3.0
+
+
+def cpu_baseline(sample):
+    """The reference qr.c (oracle/_ref, PR=64 PC=8, double) on ONE host core -- the reference has no
+    threading anywhere -- over a bounded sample of the same kind of input (dense uniform[0,1))."""
+    import numpy as np
+    from oracle import oracle as O
+    m, n = (int(x) for x in sample.split("x"))
+    PR, PC = 64, 8
+    O.check_shape(m, n, PR, PC)
+    A = O.fill_rand(m, n, 12, np.float64)
+    kind = "reference" if O.ref_path(np.float64, PR, PC) else "port"
+    t0 = time.perf_counter()
+    if kind == "reference":
+        O.ref_mmqr(A, PR, PC)            # real qr.c mmqr; its printf chatter goes to /dev/null
+    else:
+        O.mmqr(A, PR, PC)                # oracle restatement (bitwise-equal arithmetic, no prints)
+    dt = time.perf_counter() - t0
+    return {"value": flops(m, n) / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": kind,
+            "host_cores_available": os.cpu_count(), "seconds": dt,
+            "sample": f"reference qr.c mmqr (Scalar=double, PR=64, PC=8) on a {m}x{n} uniform[0,1) matrix "
+                      f"(srand(12) generator, qr.c:468-474), stdout to /dev/null, 1 thread; "
+                      f"useful flops 2mn^2-2n^3/3"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    import cuda_qr_amd as qr
+    from cuda_qr_amd import tsqr as T
+
+    wl = args.workload
+    if wl == "auto":
+        wl = "c3" if world == 1 else "tsqr"
+    if wl == "c2":
+        m_local, n, nb, desc = 4096, 4096, args.nb or 64, "C2: 4096x4096 square fp64 QR, block size 64"
+    elif wl == "c3":
+        m_local, n, nb = 16384, 16384, args.nb or 128
+        desc = f"C3: 16384x16384 square fp64 QR on 1 MI355X, nb={nb}"
+    elif wl == "c4":
+        m_local, n, nb = 262144 // world, 256, args.nb or 128
+        desc = f"C4: tall-skinny 262144x256 fp64 TSQR, row-block sharded over {world} GPU(s)"
+    else:
+        m_local, n, nb = 262144, 512, args.nb or 128
+        desc = (f"TSQR weak scaling: {world} x (262144x512) row shards = {262144 * world}x512 fp64"
+                + (" (= C5)" if world == 8 else ""))
+    m_total = m_local * world
+    if wl in ("c2", "c3") and world > 1:
+        raise SystemExit("square configs do not shard (replicas only, DESIGN.md); use --workload tsqr")
+
+    be = T.HipBackend(qr, m_local, n, world, nb, args.ib)
+    ts = T.TSQR(be, n, world, rank)
+    K, W = args.steps, args.warmup
+    bytes_per = 8 * m_local * n
+    nbuf = min(K + W, max(1, int(160e9 // bytes_per)))
+    bufs = [be.new_matrix(m_local, n) for _ in range(nbuf)]
+    seeds = [12 + i for i in range(nbuf)]
+    for A, s in zip(bufs, seeds):
+        be.fill(A, m_local, n, rank * m_local, m_total, s)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        A = bufs[i % nbuf]
+        if i >= nbuf:                       # only when K+W exceeds the buffer pool: regenerate (stated in config)
+            be.fill(A, m_local, n, rank * m_local, m_total, seeds[i % nbuf])
+        return ts.factor(A)
+
+    for i in range(W):
+        step(i)
+    barrier()
+    be.plan.set_profile(True)               # HIP events on the plan's own streams, inside the timed region
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = be.plan.get_profile()
+    be.plan.set_profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_flops = K * flops(m_total, n)
+    value = total_flops / dt / 1e9
+
+    # ---- accuracy (outside the timed region): last factored matrix, thin Q, on-device norms
+    acc = {}
+    if not args.no_check:
+        last = (W + K - 1) % nbuf
+        A = bufs[last]
+        R = ts.R
+        Q = ts.form_q(A)
+        QR = be.new_matrix(m_local, n)
+        G = be.new_matrix(n, n)
+        be.plan.gemm("N", m_local, n, n, 1.0, Q, m_local, R, n, 0.0, QR, m_local)
+        be.plan.gemm("T", n, n, m_local, 1.0, Q, m_local, Q, m_local, 0.0, G, n)
+        be.plan.sync()
+        d, a = be.plan.diffnorm(QR, m_local, m_local, n, row_off=rank * m_local, total_rows=m_total,
+                                seed=seeds[last])
+        sums = torch.tensor([d, a], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(sums)
+            dist.all_reduce(G)                                  # Q^T Q = sum over shards
+        o, _ = be.plan.diffnorm(G, n, n, n, mode=1)
+        acc = {"resid": float((sums[0] / sums[1]).sqrt().item()), "orth": float(o ** 0.5)}
+        del Q, QR, G
+
+    # ---- roofline of the dominant kernel
+    upd, tn, pan = prof["update_nn"], prof["vta_tn"], prof["panel"]
+    if wl in ("c2", "c3") and upd["launches"]:
+        ach = upd["flops"] / (upd["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nn_kernel<4,4,true> (trailing update A2 -= V*W)",
+                "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],
+                "algorithmic_flops_per_launch": upd["flops"] / upd["launches"],
+                "companion_tn": {"kernel": "gemm_tn_kernel<4,4,true> + slab_reduce (W = (V T)^T A2)",
+                                 "achieved": tn["flops"] / (tn["ms"] * 1e-3) / 1e12 if tn["ms"] else None,
+                                 "launches": tn["launches"]},
+                "panel_ms_per_step": pan["ms"] / K}
+    else:
+        # tall-skinny: the panel (leaf Householder kernels + in-panel updates) is the dominant cost and is
+        # bounded by HBM traffic: compulsory bytes = 16 * mk * w per panel (read + write once)
+        ach = pan["bytes"] / (pan["ms"] * 1e-3) / 1e9 if pan["ms"] else 0.0
+        roof = {"bound": "hbm", "kernel": "leaf_step_kernel<J> chain + in-panel gemm_tn/gemm_nn (panel factorisation)",
+                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "traffic": None, "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),
+                "algorithmic_bytes_per_launch": pan["bytes"] / max(pan["launches"], 1),
+                "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None}
+
+    line = None
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_sample)
+        info = qr.device_info()
+        line = {
+            "metric": "fp64 GFLOP/s (% of roofline) + ||A-QR||_F/||A||_F, m x n QR at 1/2/4/8 GPUs",
+            "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "m": m_total, "n": n, "m_per_gpu": m_local, "nb": nb,
+                       "ib": args.ib or qr.get_block_size()[1],
+                       "flops_per_step": flops(m_total, n), "input_buffers": nbuf,
+                       "input": "uniform[0,1) counter-hash generator, seed 12+i, resident in HBM",
+                       "collective": "none" if world == 1 else "1 all_gather of n*n doubles per rank (RCCL)"},
+            "frac_of_fp64_matrix_peak": value / 1e3 / (FP64_MATRIX_PEAK_TFLOPS * world),
+            "accuracy": acc,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "device": info,
+        }
+        print(json.dumps(line), flush=True)
+    be.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
 int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
                    int ldv, double* scratch);
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,
-              double* Tt, int build_diag);
+              double* Tt, int build_diag, double* X, int ldx);
 int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols);
 int qrd_extract_v(void* stream, const double* P, int ld, int mk, int w, double* V, int ldv);
 int qrd_extract_r(void* stream, const double* A, int lda, int m, int n, double* R, int ldr, int rrows);
@@ -56,7 +56,7 @@ int qrd_probe_mfma_f64(double* tflops);
 int qrd_probe_copy(double* gbps);
 
 #define QRD_LEAFW 32
-#define QRD_LEAF_SCRATCH (2 * (256 * QRD_LEAFW + QRD_LEAFW))
+#define QRD_LEAF_SCRATCH (2 * (256 * QRD_LEAFW + QRD_LEAFW) + QRD_LEAFW * QRD_LEAFW)
 
 #ifdef __cplusplus
 }

@@ -24,12 +24,19 @@
 
 struct qr_plan {
     int m, n, nb, ib, ldv, ldt;
-    void* stream;
-    double *Vw, *VT, *W, *T, *Tt, *G, *slabs, *leaf_scratch;
+    int lookahead;              /* 1: panel k+1 is factored on `stream` while `stream_u` updates the rest */
+    void* stream;               /* panel / critical-path stream (high priority); the plan's public stream */
+    void* stream_u;             /* wide trailing-update stream */
+    void* ev_panel[2];          /* panel set s ready (V, T, VT) */
+    void* ev_wide[2];           /* wide update that read panel set s finished */
+    double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
+    double *Vw2[2], *VT2[2], *T2[2];
+    double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *leaf_scratch;
     size_t slab_cap, w_cap;
     /* profiling */
     int prof_on, prof_count, prof_cap, prof_open;
     void** prof_ev;             /* 2 events per record */
+    void* prof_stream;          /* stream of the open record */
     int* prof_cls;
     double *prof_flops, *prof_bytes;
 };
@@ -101,22 +108,35 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     p->m = m; p->n = n; p->nb = nb; p->ib = ib;
     p->ldv = (m + 15) & ~15;
     p->ldt = nb;
-    int rc = qrd_stream_create(&p->stream, 0);
+    const char* la = getenv("MI355XQR_LOOKAHEAD");
+    p->lookahead = la ? atoi(la) != 0 : 1;
+    int rc = qrd_stream_create(&p->stream, 1);
+    if (!rc) rc = qrd_stream_create(&p->stream_u, 0);
+    for (int e = 0; e < 2 && !rc; ++e) {
+        rc = qrd_event_create_notiming(&p->ev_panel[e]);
+        if (!rc) rc = qrd_event_create_notiming(&p->ev_wide[e]);
+    }
     size_t cap = (size_t) 256 * nb * (size_t) n;
     if (cap > ((size_t) 16 << 20)) cap = (size_t) 16 << 20;
     if (cap < ((size_t) 1 << 16)) cap = (size_t) 1 << 16;
     p->slab_cap = cap;
     p->w_cap = (size_t) nb * n;
-    if (!rc) rc = qrd_malloc((void**) &p->Vw, sizeof(double) * (size_t) p->ldv * nb);
-    if (!rc) rc = qrd_malloc((void**) &p->VT, sizeof(double) * (size_t) p->ldv * nb);
+    for (int e = 0; e < 2 && !rc; ++e) {
+        rc = qrd_malloc((void**) &p->Vw2[e], sizeof(double) * (size_t) p->ldv * nb);
+        if (!rc) rc = qrd_malloc((void**) &p->VT2[e], sizeof(double) * (size_t) p->ldv * nb);
+        if (!rc) rc = qrd_malloc((void**) &p->T2[e], sizeof(double) * (size_t) nb * nb);
+        if (!rc) rc = qrd_memset(p->stream, p->T2[e], 0, sizeof(double) * (size_t) nb * nb);
+        if (!rc) rc = qrd_memset(p->stream, p->Vw2[e], 0, sizeof(double) * (size_t) p->ldv * nb);
+    }
+    p->Vw = p->Vw2[0]; p->VT = p->VT2[0]; p->T = p->T2[0];
     if (!rc) rc = qrd_malloc((void**) &p->W, sizeof(double) * p->w_cap);
-    if (!rc) rc = qrd_malloc((void**) &p->T, sizeof(double) * (size_t) nb * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->Wn, sizeof(double) * (size_t) nb * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->slabs_u, sizeof(double) * p->slab_cap);
     if (!rc) rc = qrd_malloc((void**) &p->Tt, sizeof(double) * (size_t) nb * nb);
     if (!rc) rc = qrd_malloc((void**) &p->G, sizeof(double) * (size_t) nb * nb);
+    if (!rc) rc = qrd_malloc((void**) &p->X, sizeof(double) * (size_t) nb * QRD_LEAFW);
     if (!rc) rc = qrd_malloc((void**) &p->slabs, sizeof(double) * p->slab_cap);
     if (!rc) rc = qrd_malloc((void**) &p->leaf_scratch, sizeof(double) * QRD_LEAF_SCRATCH);
-    if (!rc) rc = qrd_memset(p->stream, p->T, 0, sizeof(double) * (size_t) nb * nb);
-    if (!rc) rc = qrd_memset(p->stream, p->Vw, 0, sizeof(double) * (size_t) p->ldv * nb);
     if (rc) { qr_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -126,23 +146,36 @@ int qr_plan_destroy(qr_plan* p)
 {
     if (!p) return 0;
     if (p->stream) qrd_stream_sync(p->stream);
+    if (p->stream_u) qrd_stream_sync(p->stream_u);
+    for (int e = 0; e < 2; ++e) {
+        if (p->ev_panel[e]) qrd_event_destroy(p->ev_panel[e]);
+        if (p->ev_wide[e]) qrd_event_destroy(p->ev_wide[e]);
+        qrd_free(p->Vw2[e]); qrd_free(p->VT2[e]); qrd_free(p->T2[e]);
+    }
+    qrd_free(p->Wn); qrd_free(p->slabs_u);
+    if (p->stream_u) qrd_stream_destroy(p->stream_u);
     for (int i = 0; i < 2 * p->prof_cap; ++i)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
-    qrd_free(p->Vw); qrd_free(p->VT); qrd_free(p->W); qrd_free(p->T); qrd_free(p->Tt); qrd_free(p->G);
+    qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
     qrd_free(p->slabs); qrd_free(p->leaf_scratch);
     if (p->stream) qrd_stream_destroy(p->stream);
     free(p);
     return 0;
 }
 
-int qr_plan_sync(qr_plan* p) { return p ? qrd_stream_sync(p->stream) : QR_E_ARG; }
+int qr_plan_sync(qr_plan* p)
+{
+    if (!p) return QR_E_ARG;
+    CHECK(qrd_stream_sync(p->stream_u));
+    return qrd_stream_sync(p->stream);
+}
 void* qr_plan_stream(qr_plan* p) { return p ? p->stream : NULL; }
 
 static int ensure_w(qr_plan* p, size_t elems)
 {
     if (elems <= p->w_cap) return 0;
-    CHECK(qrd_stream_sync(p->stream));
+    CHECK(qr_plan_sync(p));
     qrd_free(p->W);
     p->W = NULL; p->w_cap = 0;
     CHECK(qrd_malloc((void**) &p->W, sizeof(double) * elems));
@@ -160,7 +193,7 @@ int qr_plan_set_profile(qr_plan* p, int on)
     return 0;
 }
 
-static int prof_begin(qr_plan* p, int cls)
+static int prof_begin_on(qr_plan* p, int cls, void* stream)
 {
     if (!p->prof_on) return 0;
     if (p->prof_count == p->prof_cap) {
@@ -185,8 +218,11 @@ static int prof_begin(qr_plan* p, int cls)
         if (!p->prof_ev[2 * r + e]) CHECK(qrd_event_create(&p->prof_ev[2 * r + e]));
     p->prof_cls[r] = cls;
     p->prof_open = 1;
-    return qrd_event_record(p->prof_ev[2 * r], p->stream);
+    p->prof_stream = stream;
+    return qrd_event_record(p->prof_ev[2 * r], stream);
 }
+
+static int prof_begin(qr_plan* p, int cls) { return prof_begin_on(p, cls, p->stream); }
 
 static int prof_end(qr_plan* p, double flops, double bytes)
 {
@@ -195,14 +231,14 @@ static int prof_end(qr_plan* p, double flops, double bytes)
     p->prof_flops[r] = flops;
     p->prof_bytes[r] = bytes;
     p->prof_open = 0;
-    return qrd_event_record(p->prof_ev[2 * r + 1], p->stream);
+    return qrd_event_record(p->prof_ev[2 * r + 1], p->prof_stream);
 }
 
 int qr_plan_get_profile(qr_plan* p, qr_profile* out)
 {
     if (!p || !out) return QR_E_ARG;
     memset(out, 0, sizeof(*out));
-    CHECK(qrd_stream_sync(p->stream));
+    CHECK(qr_plan_sync(p));
     for (int r = 0; r < p->prof_count; ++r) {
         float ms = 0.f;
         CHECK(qrd_event_elapsed_ms(p->prof_ev[2 * r], p->prof_ev[2 * r + 1], &ms));
@@ -250,39 +286,94 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
         const int nrest = wout - (c + w);
         if (nrest > 0) {
             double* Arest = P + (size_t) w * lda;
-            CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->W, w, Tl));                   /* T_l^T V_l^T A_rest */
-            CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->W, w, 1.0, Arest, lda));
+            /* Wn, not W: with look-ahead the wide update on stream_u owns p->W while this panel runs */
+            CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->Wn, w, Tl));                  /* T_l^T V_l^T A_rest */
+            CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
         }
     }
     if (want_t) {
         if (wout > ib) {
             CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, p->nb, NULL));          /* Gram */
-            CHECK(qrd_larft(p->stream, wout, ib, p->G, p->nb, dtau + k, p->T, ldt, NULL, 0));
+            CHECK(qrd_larft(p->stream, wout, ib, p->G, p->nb, dtau + k, p->T, ldt, NULL, 0, p->X, p->nb));
         }
         CHECK(qrd_gemm_nn(p->stream, mk, wout, wout, 1.0, p->Vw, ldv, p->T, ldt, 0.0, p->VT, ldv));
     }
     return 0;
 }
 
+static void use_set(qr_plan* p, int e) { p->Vw = p->Vw2[e]; p->VT = p->VT2[e]; p->T = p->T2[e]; }
+
+/* trailing update of columns [c0, c0+nc) with the reflectors of panel set e: W = (V T)^T A ; A -= V W */
+static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int k, int mk, int wout, int c0, int nc,
+                       double* Wbuf, double* slabs, int profile)
+{
+    double* A2 = dA + (size_t) c0 * lda + k;
+    const int ldv = p->ldv;
+    if (profile) CHECK(prof_begin_on(p, 1, stream));
+    CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap, NULL, 0));
+    if (profile) CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 8.0 * mk * ((double) nc + wout)));
+    if (profile) CHECK(prof_begin_on(p, 0, stream));
+    CHECK(qrd_gemm_nn(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
+    if (profile) CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 16.0 * mk * (double) nc + 8.0 * mk * wout));
+    return 0;
+}
+
 int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     if (!p || !dA || !dtau || n < 1 || m < n || m > p->m || n > p->n || lda < m) return QR_E_ARG;
-    const int nb = p->nb, ldv = p->ldv;
-    for (int k = 0; k < n; k += nb) {
-        const int wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
-        CHECK(prof_begin(p, 2));
-        CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0));
-        CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
-        if (nt > 0) {
-            double* A2 = dA + (size_t) (k + wout) * lda + k;
-            CHECK(prof_begin(p, 1));
-            CHECK(tn(p, wout, nt, mk, p->VT, ldv, A2, lda, p->W, wout, NULL));                /* W = (V T)^T A2 */
-            CHECK(prof_end(p, 2.0 * mk * (double) nt * wout, 8.0 * mk * ((double) nt + wout)));
-            CHECK(prof_begin(p, 0));
-            CHECK(qrd_gemm_nn(p->stream, mk, nt, wout, -1.0, p->Vw, ldv, p->W, wout, 1.0, A2, lda));   /* A2 -= V W */
-            CHECK(prof_end(p, 2.0 * mk * (double) nt * wout, 16.0 * mk * (double) nt + 8.0 * mk * wout));
+    const int nb = p->nb;
+    if (!p->lookahead) {
+        use_set(p, 0);
+        for (int k = 0; k < n; k += nb) {
+            const int wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
+            CHECK(prof_begin(p, 2));
+            CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0));
+            CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+            if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, p->slabs, 1));
         }
+        return 0;
     }
+    /* Look-ahead (depth 1).  Step s: P(s) factor panel s, N(s) update only the next panel's columns,
+     * W(s) update everything to the right of that.  Critical chain P(s) -> N(s) -> P(s+1) runs on
+     * p->stream (high priority); W(s) runs on p->stream_u concurrently with P(s+1).
+     *   N(s)  needs P(s) (stream order) and W(s-1) (ev_wide[(s-1)&1]);
+     *   W(s)  needs P(s) (ev_panel[s&1]) and W(s-1) (stream order);
+     *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
+    int wide_pending[2] = {0, 0};
+    {
+        const int w0 = imin(nb, n);
+        use_set(p, 0);
+        CHECK(prof_begin(p, 2));
+        CHECK(factor_panel(p, dA, m, lda, 0, w0, dtau, n > w0));
+        CHECK(prof_end(p, 2.0 * m * (double) w0 * w0, 16.0 * m * w0));
+        CHECK(qrd_event_record(p->ev_panel[0], p->stream));
+    }
+    int s = 0;
+    for (int k = 0; k < n; k += nb, ++s) {
+        const int e = s & 1, wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
+        if (nt <= 0) break;
+        const int wnext = imin(nb, nt), nwide = nt - wnext;
+        if (s > 0 && wide_pending[e ^ 1]) {
+            CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e ^ 1]));
+            wide_pending[e ^ 1] = 0;
+        }
+        CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout, wnext, p->Wn, p->slabs, 0));   /* N(s) */
+        if (nwide > 0) {                                                                                      /* W(s) */
+            CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
+            CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout + wnext, nwide, p->W, p->slabs_u, 1));
+            CHECK(qrd_event_record(p->ev_wide[e], p->stream_u));
+            wide_pending[e] = 1;
+        }
+        const int k1 = k + wout, mk1 = m - k1, nt1 = n - (k1 + wnext);                                        /* P(s+1) */
+        use_set(p, e ^ 1);
+        CHECK(prof_begin(p, 2));
+        CHECK(factor_panel(p, dA, m, lda, k1, wnext, dtau, nt1 > 0));
+        CHECK(prof_end(p, 2.0 * mk1 * (double) wnext * wnext, 16.0 * mk1 * wnext));
+        CHECK(qrd_event_record(p->ev_panel[e ^ 1], p->stream));
+    }
+    for (int e = 0; e < 2; ++e)
+        if (wide_pending[e]) CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e]));
+    use_set(p, 0);
     return 0;
 }
 
@@ -292,6 +383,7 @@ int qr_applyq_dev(qr_plan* p, const double* dA, int m, int n, int lda, const dou
     if (!p || !dA || !dtau || !dC || n < 1 || m < n || m > p->m || n > p->n || ccols < 1 || ldc < m) return QR_E_ARG;
     const int nb = p->nb, ib = p->ib, ldv = p->ldv, ldt = p->ldt;
     CHECK(ensure_w(p, (size_t) nb * ccols));
+    use_set(p, 0);
     if (identity_start) CHECK(qrd_set_identity(p->stream, dC, ldc, m, ccols, 0));
     const int npan = (n + nb - 1) / nb;
     for (int pi = npan - 1; pi >= 0; --pi) {
@@ -301,7 +393,7 @@ int qr_applyq_dev(qr_plan* p, const double* dA, int m, int n, int lda, const dou
         const double* Ak = dA + (size_t) k * lda + k;
         CHECK(qrd_extract_v(p->stream, Ak, lda, mk, wout, p->Vw, ldv));
         CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, nb, NULL));
-        CHECK(qrd_larft(p->stream, wout, ib, p->G, nb, dtau + k, p->T, ldt, p->Tt, 1));
+        CHECK(qrd_larft(p->stream, wout, ib, p->G, nb, dtau + k, p->T, ldt, p->Tt, 1, p->X, nb));
         CHECK(qrd_gemm_nn(p->stream, mk, wout, wout, 1.0, p->Vw, ldv, p->Tt, ldt, 0.0, p->VT, ldv));   /* V T^T */
         double* Cs = dC + (size_t) c0 * ldc + k;
         CHECK(tn(p, wout, nc, mk, p->VT, ldv, Cs, ldc, p->W, wout, NULL));                              /* T V^T C */

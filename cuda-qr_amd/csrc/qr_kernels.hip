@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#include <utility>
 #include "qr_device.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -39,24 +40,30 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define BK 16
 #define LDKF (BK + 2)
 
+// Tile loaders.  `fast` is block-uniform (whole tile in range, 16-byte aligned): the fast path is
+// straight-line 16-byte loads.  The edge path uses clamped addresses + selects, never a branch per
+// element: hipcc waits (s_waitcnt vmcnt(0)) inside every divergent branch that consumes a load, which
+// would turn one tile fetch into dozens of serial HBM round trips.
 template <int TR>   // TR = tile extent / 32 (rows of the row-fast image)
 __device__ __forceinline__ void load_rowfast(v2d (&reg)[TR], const double* __restrict__ A, int lda,
-                                             int i0, int k0, int M, int kend, bool vec, int tid)
+                                             int i0, int k0, int M, int kend, bool fast, int tid)
 {
     constexpr int HALF = 16 * TR;          // double2 per column
+    if (fast) {
 #pragma unroll
-    for (int q = 0; q < TR; ++q) {
-        const int idx = tid + 256 * q;
-        const int col = idx / HALF, r2 = idx % HALF;
-        const int i = i0 + 2 * r2, k = k0 + col;
-        v2d v = {0.0, 0.0};
-        if (vec && i + 1 < M && k < kend) {
-            v = *reinterpret_cast<const v2d*>(A + (size_t) k * lda + i);
-        } else if (k < kend) {
-            if (i < M) v.x = A[(size_t) k * lda + i];
-            if (i + 1 < M) v.y = A[(size_t) k * lda + i + 1];
+        for (int q = 0; q < TR; ++q) {
+            const int idx = tid + 256 * q;
+            reg[q] = *reinterpret_cast<const v2d*>(A + (size_t) (k0 + idx / HALF) * lda + i0 + 2 * (idx % HALF));
         }
-        reg[q] = v;
+    } else {
+#pragma unroll
+        for (int q = 0; q < TR; ++q) {
+            const int idx = tid + 256 * q;
+            const int i = i0 + 2 * (idx % HALF), k = k0 + idx / HALF;
+            const double* col = A + (size_t) min(k, kend - 1) * lda;
+            const double a = col[min(i, M - 1)], b = col[min(i + 1, M - 1)];
+            reg[q] = (v2d){(k < kend && i < M) ? a : 0.0, (k < kend && i + 1 < M) ? b : 0.0};
+        }
     }
 }
 
@@ -74,22 +81,23 @@ __device__ __forceinline__ void store_rowfast(const v2d (&reg)[TR], double* __re
 
 template <int TC>   // TC = tile extent / 32 (columns of the k-fast image)
 __device__ __forceinline__ void load_kfast(v2d (&reg)[TC], const double* __restrict__ B, int ldb,
-                                           int j0, int k0, int N, int kend, bool vec, int tid)
+                                           int j0, int k0, int N, int kend, bool fast, int tid)
 {
+    if (fast) {
 #pragma unroll
-    for (int q = 0; q < TC; ++q) {
-        const int idx = tid + 256 * q;
-        const int j = j0 + idx / 8, k = k0 + 2 * (idx % 8);
-        v2d v = {0.0, 0.0};
-        if (j < N) {
-            if (vec && k + 1 < kend) {
-                v = *reinterpret_cast<const v2d*>(B + (size_t) j * ldb + k);
-            } else {
-                if (k < kend) v.x = B[(size_t) j * ldb + k];
-                if (k + 1 < kend) v.y = B[(size_t) j * ldb + k + 1];
-            }
+        for (int q = 0; q < TC; ++q) {
+            const int idx = tid + 256 * q;
+            reg[q] = *reinterpret_cast<const v2d*>(B + (size_t) (j0 + idx / 8) * ldb + k0 + 2 * (idx % 8));
         }
-        reg[q] = v;
+    } else {
+#pragma unroll
+        for (int q = 0; q < TC; ++q) {
+            const int idx = tid + 256 * q;
+            const int j = j0 + idx / 8, k = k0 + 2 * (idx % 8);
+            const double* col = B + (size_t) min(j, N - 1) * ldb;
+            const double a = col[min(k, kend - 1)], b = col[min(k + 1, kend - 1)];
+            reg[q] = (v2d){(j < N && k < kend) ? a : 0.0, (j < N && k + 1 < kend) ? b : 0.0};
+        }
     }
 }
 
@@ -103,14 +111,102 @@ __device__ __forceinline__ void store_kfast(const v2d (&reg)[TC], double* __rest
     }
 }
 
+// ---- shared GEMM pieces -----------------------------------------------------------------------
+// One BK-deep step of the wave tile from LDS.  AROW: the row operand comes from a row-fast image
+// (NN kernel), else from a k-fast image (TN kernel).  The column operand image is always k-fast.
+template <int TI, int TJ, bool AROW>
+__device__ __forceinline__ void mma_tile(v4d (&acc)[TJ][TI], const double* __restrict__ as,
+                                         const double* __restrict__ bs, int wi, int wj, int l15, int l4)
+{
+    constexpr int LA = 32 * TI + 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int kk = 4 * ks + l4;
+        double rowv[TI], colv[TJ];
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+            rowv[b] = AROW ? as[kk * LA + wi * 16 * TI + 16 * b + l15] : as[(wi * 16 * TI + 16 * b + l15) * LDKF + kk];
+#pragma unroll
+        for (int a = 0; a < TJ; ++a) colv[a] = bs[(wj * 16 * TJ + 16 * a + l15) * LDKF + kk];
+#pragma unroll
+        for (int a = 0; a < TJ; ++a)
+#pragma unroll
+            for (int b = 0; b < TI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[a], rowv[b], acc[a][b], 0, 0, 0);
+    }
+}
+
+// Double-buffered K loop over [kbeg, kend).  FAST is a compile-time copy of the block-uniform "every
+// tile of this block is fully in range and 16-byte aligned" flag, so the hot instantiation has no
+// branch (and therefore no compiler-inserted wait) between issuing the next tile's global loads and
+// starting this tile's MFMAs: the loads fly under 64 MFMAs (~4k cycles) and are only waited for at
+// the ds_write that follows them.
+template <int TI, int TJ, bool AROW, bool FAST>
+__device__ __forceinline__ void gemm_kloop(v4d (&acc)[TJ][TI], const double* __restrict__ A, int lda,
+                                           const double* __restrict__ B, int ldb, int i0, int j0, int M, int N,
+                                           int kbeg, int kend, double* __restrict__ As, double* __restrict__ Bs,
+                                           int tid, int wi, int wj, int l15, int l4)
+{
+    constexpr int BM = 32 * TI, BN = 32 * TJ;
+    constexpr int ASZ = AROW ? BK * (BM + 16) : BM * LDKF, BSZ = BN * LDKF;
+    v2d ra[TI], rb[TJ];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        if (AROW) load_rowfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
+        else load_kfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
+        load_kfast<TJ>(rb, B, ldb, j0, kbeg, N, kend, FAST, tid);
+        if (AROW) store_rowfast<TI>(ra, As, tid); else store_kfast<TI>(ra, As, tid);
+        store_kfast<TJ>(rb, Bs, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            if (AROW) load_rowfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
+            else load_kfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
+            load_kfast<TJ>(rb, B, ldb, j0, k0, N, kend, FAST, tid);
+        }
+        mma_tile<TI, TJ, AROW>(acc, As + buf * ASZ, Bs + buf * BSZ, wi, wj, l15, l4);
+        if (kt + 1 < nk) {
+            if (AROW) store_rowfast<TI>(ra, As + (buf ^ 1) * ASZ, tid); else store_kfast<TI>(ra, As + (buf ^ 1) * ASZ, tid);
+            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BSZ, tid);
+        }
+        __syncthreads();
+    }
+}
+
+// C = alpha*acc (+ beta*C on the generic path).  STORE_ONLY: no load sits between the stores (a load
+// there makes every store wait for the previous one: vmcnt is in-order and counts stores).
+template <int TI, int TJ, bool STORE_ONLY>
+__device__ __forceinline__ void gemm_epilogue(const v4d (&acc)[TJ][TI], double* __restrict__ C, int ldc, int M, int N,
+                                              int i0, int j0, double alpha, double beta, int wi, int wj, int l15, int l4)
+{
+#pragma unroll
+    for (int a = 0; a < TJ; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + wj * 16 * TJ + 16 * a + l4 + 4 * r;
+#pragma unroll
+            for (int b = 0; b < TI; ++b) {
+                const int i = i0 + wi * 16 * TI + 16 * b + l15;
+                if (i < M && j < N) {
+                    double* cp = C + (size_t) j * ldc + i;
+                    double v = alpha * acc[a][b][r];
+                    if (!STORE_ONLY) v += beta * (*cp);
+                    *cp = v;
+                }
+            }
+        }
+}
+
 // C = beta*C + alpha*A*B     A: M x K (lda), B: K x N (ldb), C: M x N (ldc), all column-major.
-// Used for: trailing update A2 -= V*W (K = nb), VT = V*T, Q*R products, Q_local*Q_tree.
-template <int TI, int TJ>
+// Used for: trailing update A2 -= V*W (K = nb), VT = V*T, T merges, Q*R products, Q_local*Q_tree.
+template <int TI, int TJ, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, double alpha,
                                                          const double* __restrict__ A, int lda,
                                                          const double* __restrict__ B, int ldb,
-                                                         double beta, double* __restrict__ C, int ldc,
-                                                         int vecA, int vecB)
+                                                         double beta, double* __restrict__ C, int ldc)
 {
     constexpr int BM = 32 * TI, BN = 32 * TJ, LA = BM + 16;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -121,77 +217,48 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, do
     const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
     const int l15 = lane & 15, l4 = lane >> 4;
 
+    // beta == 1 (the trailing update C -= V*W): C enters through the accumulators, acc = C/alpha, so the
+    // epilogue is stores only.  alpha = +-1 there, so the scaling is exact.
+    const bool cinit = (beta == 1.0);
+    const double inv_alpha = 1.0 / alpha;
     v4d acc[TJ][TI];
+    if (cinit) {          // one uniform branch, straight-line body: all TI*TJ*4 loads in flight together
 #pragma unroll
-    for (int a = 0; a < TJ; ++a)
+        for (int a = 0; a < TJ; ++a)
 #pragma unroll
-        for (int b = 0; b < TI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-    v2d ra[TI], rb[TJ];
-    const int nk = (K + BK - 1) / BK;
-    load_rowfast<TI>(ra, A, lda, i0, 0, M, K, vecA != 0, tid);
-    load_kfast<TJ>(rb, B, ldb, j0, 0, N, K, vecB != 0, tid);
-    store_rowfast<TI>(ra, As, tid);
-    store_kfast<TJ>(rb, Bs, tid);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            load_rowfast<TI>(ra, A, lda, i0, (kt + 1) * BK, M, K, vecA != 0, tid);
-            load_kfast<TJ>(rb, B, ldb, j0, (kt + 1) * BK, N, K, vecB != 0, tid);
-        }
-        const double* as = As + buf * BK * LA;
-        const double* bs = Bs + buf * BN * LDKF;
+            for (int b = 0; b < TI; ++b) {
+                const int i = i0 + wi * 16 * TI + 16 * b + l15;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = 4 * ks + l4;
-            double rowv[TI], colv[TJ];
-#pragma unroll
-            for (int b = 0; b < TI; ++b) rowv[b] = as[kk * LA + wi * 16 * TI + 16 * b + l15];
-#pragma unroll
-            for (int a = 0; a < TJ; ++a) colv[a] = bs[(wj * 16 * TJ + 16 * a + l15) * LDKF + kk];
-#pragma unroll
-            for (int a = 0; a < TJ; ++a)
-#pragma unroll
-                for (int b = 0; b < TI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[a], rowv[b], acc[a][b], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            store_rowfast<TI>(ra, As + (buf ^ 1) * BK * LA, tid);
-            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BN * LDKF, tid);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < TJ; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + wj * 16 * TJ + 16 * a + l4 + 4 * r;
-            if (j < N) {
-#pragma unroll
-                for (int b = 0; b < TI; ++b) {
-                    const int i = i0 + wi * 16 * TI + 16 * b + l15;
-                    if (i < M) {
-                        double* cp = C + (size_t) j * ldc + i;
-                        double v = alpha * acc[a][b][r];
-                        if (beta != 0.0) v += beta * (*cp);
-                        *cp = v;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + wj * 16 * TJ + 16 * a + l4 + 4 * r;
+                    const double cv = C[(size_t) min(j, N - 1) * ldc + min(i, M - 1)];    // clamped, unconditional
+                    acc[a][b][r] = (i < M && j < N) ? cv * inv_alpha : 0.0;
                 }
             }
-        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < TJ; ++a)
+#pragma unroll
+            for (int b = 0; b < TI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+
+    // FAST (host-checked): every tile of this launch is fully in range, K % BK == 0, operands 16-B aligned
+    gemm_kloop<TI, TJ, true, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, 0, K, As, Bs, tid, wi, wj, l15, l4);
+
+    if (cinit || beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
+    else gemm_epilogue<TI, TJ, false>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
 }
 
 // C = alpha * A^T * B (+ beta*C when not split)   A: K x M (lda), B: K x N (ldb), C: M x N (ldc).
 // K is the long dimension (panel height): gridDim.z K-slices each write their own slab
 // (slab z at C + z*slab_stride, ld = ldc) and slab_reduce_kernel sums them in a fixed order
 // (deterministic; no float atomics).  Used for W = (V T)^T A2, Gram = V^T V, Q^T Q.
-template <int TI, int TJ>
+template <int TI, int TJ, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, int kchunk, double alpha,
                                                          const double* __restrict__ A, int lda,
                                                          const double* __restrict__ B, int ldb,
                                                          double beta, double* __restrict__ C, int ldc,
-                                                         size_t slab_stride, int vecA, int vecB)
+                                                         size_t slab_stride)
 {
     constexpr int BM = 32 * TI, BN = 32 * TJ;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -211,61 +278,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 #pragma unroll
         for (int b = 0; b < TI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    v2d ra[TI], rb[TJ];
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        load_kfast<TI>(ra, A, lda, i0, kbeg, M, kend, vecA != 0, tid);
-        load_kfast<TJ>(rb, B, ldb, j0, kbeg, N, kend, vecB != 0, tid);
-        store_kfast<TI>(ra, As, tid);
-        store_kfast<TJ>(rb, Bs, tid);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            load_kfast<TI>(ra, A, lda, i0, kbeg + (kt + 1) * BK, M, kend, vecA != 0, tid);
-            load_kfast<TJ>(rb, B, ldb, j0, kbeg + (kt + 1) * BK, N, kend, vecB != 0, tid);
-        }
-        const double* as = As + buf * BM * LDKF;
-        const double* bs = Bs + buf * BN * LDKF;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = 4 * ks + l4;
-            double rowv[TI], colv[TJ];
-#pragma unroll
-            for (int b = 0; b < TI; ++b) rowv[b] = as[(wi * 16 * TI + 16 * b + l15) * LDKF + kk];
-#pragma unroll
-            for (int a = 0; a < TJ; ++a) colv[a] = bs[(wj * 16 * TJ + 16 * a + l15) * LDKF + kk];
-#pragma unroll
-            for (int a = 0; a < TJ; ++a)
-#pragma unroll
-                for (int b = 0; b < TI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[a], rowv[b], acc[a][b], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            store_kfast<TI>(ra, As + (buf ^ 1) * BM * LDKF, tid);
-            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BN * LDKF, tid);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < TJ; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + wj * 16 * TJ + 16 * a + l4 + 4 * r;
-            if (j < N) {
-#pragma unroll
-                for (int b = 0; b < TI; ++b) {
-                    const int i = i0 + wi * 16 * TI + 16 * b + l15;
-                    if (i < M) {
-                        double* cp = C + (size_t) j * ldc + i;
-                        double v = alpha * acc[a][b][r];
-                        if (beta != 0.0) v += beta * (*cp);
-                        *cp = v;
-                    }
-                }
-            }
-        }
+    gemm_kloop<TI, TJ, false, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+
+    if (beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
+    else gemm_epilogue<TI, TJ, false>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
 }
 
 // out(:,j) = beta*out(:,j) + Tm^T * sum_z slab_z(:,j)   (Tm optional, upper triangular M x M, M <= 256)
@@ -300,54 +316,115 @@ __global__ void slab_reduce_kernel(int M, int N, int nslab, const double* __rest
 // ------------------------------------------------------------------------------------------------
 // Leaf panel factorisation: one launch per column (the kernel boundary is the grid-wide
 // dependency of Householder QR: ~1.5 us, cheaper than an in-kernel grid barrier on 8 XCDs).
-// Launch j (j = -1 .. w-1):
+// Launch j (j = -1 .. w-1), every global round trip issued up front so the launch costs ONE load
+// latency + ONE store latency:
+//   0. every thread issues the loads of its row of the panel (registers, one row per thread:
+//      each access is 64 consecutive doubles of one column -> coalesced);
 //   1. every block sums the per-block partial dot products left by launch j-1
-//        d[c] = sum_{i>j} P(i,j) P(i,c)   (c = 0..w-1: c==j -> ||x||^2 tail, c>j -> x^T a_c, c<j -> v_c^T x)
+//        d[c] = sum_{i>j} P(i,j) P(i,c)   (c==j: ||x||^2 tail, c>j: x^T a_c, c<j: v_c^T x)
 //      in a fixed order (bitwise identical in all blocks, deterministic run to run);
 //   2. forms beta, tau, 1/u (LAPACK dlarfg convention; tau = 0 when the tail is exactly zero -- the
-//      reference divides by norm = 0 there and produces NaN, qr.c:152) and s_c = v^T a_c;
-//   3. block 0 appends column j of the leaf's T (T(0:j,j) = -tau T(0:j,0:j) V^T v);
-//   4. every thread scales its row of v, applies the reflector to its row of the remaining
-//      columns (registers only), stores, and accumulates the dot products of column j+1;
-//   5. wave-shuffle + LDS reduction of the w partial sums -> part_out[block][c].
-// Rows are one-per-thread: every global access is 64 consecutive doubles of one column (coalesced).
+//      reference divides by norm = 0 there and produces NaN, qr.c:152) and s_c = v^T a_c; block 0
+//      records tau_j and Z(0:j, j) = V(:,0:j)^T v_j (the Gram column leaf_t_kernel turns into T);
+//   3. scales its row of v, applies the reflector to its row of the remaining columns, stores,
+//      and accumulates the dot products of column j+1;
+//   4. transposing wave butterfly (32 shuffles for 32 sums) + LDS across waves -> part_out[block][c].
 // ------------------------------------------------------------------------------------------------
 #define LEAFW 32
 
-__global__ __launch_bounds__(256) void leaf_step_kernel(double* __restrict__ P, int ld, int mk, int w,
-                                                        int j, int rpt,
+// in: a[c], c < 32, per lane.  out (every lane): sum over the 64 lanes of a[lane >> 1].
+__device__ __forceinline__ double wave_reduce32(const double (&a)[LEAFW], int lane)
+{
+    double b16[16], b8[8], b4[4], b2[2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double send = up ? a[q] : a[q + 16], keep = up ? a[q + 16] : a[q];
+            b16[q] = keep + __shfl_xor(send, 32);
+        }
+    }
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double send = up ? b16[q] : b16[q + 8], keep = up ? b16[q + 8] : b16[q];
+            b8[q] = keep + __shfl_xor(send, 16);
+        }
+    }
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double send = up ? b8[q] : b8[q + 4], keep = up ? b8[q + 4] : b8[q];
+            b4[q] = keep + __shfl_xor(send, 8);
+        }
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double send = up ? b4[q] : b4[q + 2], keep = up ? b4[q + 2] : b4[q];
+            b2[q] = keep + __shfl_xor(send, 4);
+        }
+    }
+    const bool up = (lane & 2) != 0;
+    double v = (up ? b2[1] : b2[0]) + __shfl_xor(up ? b2[0] : b2[1], 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+// J is a template parameter (-1 .. 31): with the column index known at compile time the row update is
+// straight-line code on exactly the live columns (no per-column predicate masks: the runtime-j version
+// of this kernel executed ~3000 instructions per wave, most of them selects and SGPR spill traffic, and
+// took 12 us; this one is a few hundred).
+template <int J>
+__global__ __launch_bounds__(256) void leaf_step_kernel(double* __restrict__ P, int ld, int mk, int w, int rpt,
                                                         const double* __restrict__ part_in, int nblk_in,
                                                         const double* __restrict__ row_in,
                                                         double* __restrict__ part_out,
                                                         double* __restrict__ row_out,
-                                                        double* __restrict__ tau, double* __restrict__ T,
-                                                        int ldt, double* __restrict__ Vw, int ldv)
+                                                        double* __restrict__ tau, double* __restrict__ Z,
+                                                        double* __restrict__ Vw, int ldv)
 {
     __shared__ double s_red[8][LEAFW];
-    __shared__ double s_d[LEAFW];
     __shared__ double s_s[LEAFW];
     __shared__ double s_scal[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int JN = J + 1;
+
+    // 0. row loads first: independent of everything below.  Columns >= w read as zero and stay zero.
+    double x[LEAFW];
+    int i = blockIdx.x * rpt * 256 + tid;
+    {
+        const double* src = P + min(i, mk - 1);
+#pragma unroll
+        for (int c = 0; c < LEAFW; ++c) x[c] = (c < w) ? src[(size_t) c * ld] : 0.0;   // c < w is wave-uniform
+    }
 
     double tj = 0.0, beta = 0.0, inv_u = 0.0;
-    if (j >= 0) {
+    if (J >= 0) {
         {
             const int c = tid & 31, part = tid >> 5;
             double sum = 0.0;
-            for (int g = part; g < nblk_in; g += 8) sum += part_in[g * LEAFW + c];
+            for (int g0 = part; g0 < nblk_in; g0 += 64) {
+                double pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)           // unconditional (clamped) loads: one round trip for all 8
+                    pv[u] = part_in[min(g0 + 8 * u, nblk_in - 1) * LEAFW + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += (g0 + 8 * u < nblk_in) ? pv[u] : 0.0;
+            }
             s_red[part][c] = sum;
         }
+        const double alpha = row_in[J >= 0 ? J : 0];
+        const double rowc = row_in[tid & (LEAFW - 1)];
         __syncthreads();
         if (tid < LEAFW) {
             double d = 0.0;
 #pragma unroll
             for (int p = 0; p < 8; ++p) d += s_red[p][tid];
-            s_d[tid] = d;
-        }
-        __syncthreads();
-        if (tid < LEAFW) {
-            const double alpha = row_in[j];
-            const double sigma = s_d[j];
+            const double sigma = __shfl(d, J >= 0 ? J : 0);
             double t, b, iu;
             if (sigma == 0.0) { t = 0.0; b = alpha; iu = 0.0; }
             else {
@@ -356,165 +433,127 @@ __global__ __launch_bounds__(256) void leaf_step_kernel(double* __restrict__ P, 
                 t = (b - alpha) / b;
                 iu = 1.0 / (alpha - b);
             }
-            s_s[tid] = (tid < w) ? row_in[tid] + s_d[tid] * iu : 0.0;
+            const double sc = (tid < w) ? rowc + d * iu : 0.0;
+            s_s[tid] = sc;
             if (tid == 0) { s_scal[0] = t; s_scal[1] = b; s_scal[2] = iu; }
+            if (blockIdx.x == 0) {
+                if (tid < J) Z[J * LEAFW + tid] = sc;
+                else if (tid == J) tau[J] = t;
+            }
         }
         __syncthreads();
         tj = s_scal[0]; beta = s_scal[1]; inv_u = s_scal[2];
-        if (blockIdx.x == 0 && tid < w) {
-            if (tid < j) {
-                double t = 0.0;
-                for (int q = tid; q < j; ++q) t += T[(size_t) q * ldt + tid] * s_s[q];
-                T[(size_t) j * ldt + tid] = -tj * t;
-            } else if (tid == j) {
-                T[(size_t) j * ldt + j] = tj;
-                tau[j] = tj;
-            } else {
-                T[(size_t) j * ldt + tid] = 0.0;
-            }
-        }
     }
 
-    const int jn = j + 1;
     double acc[LEAFW];
 #pragma unroll
     for (int c = 0; c < LEAFW; ++c) acc[c] = 0.0;
 
     for (int r = 0; r < rpt; ++r) {
-        const int i = (blockIdx.x * rpt + r) * 256 + tid;
-        if (i >= mk) continue;
-        double x[LEAFW];
+        if (r > 0) {
+            i = (blockIdx.x * rpt + r) * 256 + tid;
+            const double* src = P + min(i, mk - 1);
 #pragma unroll
-        for (int c = 0; c < LEAFW; ++c) x[c] = (c < w) ? P[(size_t) c * ld + i] : 0.0;
-        if (j >= 0) {
-            if (i > j) {
-                double xj = 0.0;
+            for (int c = 0; c < LEAFW; ++c) x[c] = (c < w) ? src[(size_t) c * ld] : 0.0;
+        }
+        const bool live = (i < mk);
+        if (J >= 0) {
+            constexpr int JJ = J >= 0 ? J : 0;
+            const bool below = live && (i > J), diag = live && (i == J);
+            // compute phase (every load consumed here, before the first store: vmcnt counts stores too)
+            const double vi = below ? x[JJ] * inv_u : (diag ? 1.0 : 0.0);       // component i of v_J
+            const double coef = tj * vi;                                        // 0 above the diagonal
+            x[JJ] = below ? vi : (diag ? beta : x[JJ]);
 #pragma unroll
-                for (int c = 0; c < LEAFW; ++c) if (c == j) xj = x[c];
-                const double vi = xj * inv_u;
-                const double tv = tj * vi;
+            for (int c = JJ + 1; c < LEAFW; ++c) x[c] -= coef * s_s[c];
+            // store phase
+            if (live) {
+                Vw[(size_t) JJ * ldv + i] = vi;
+                if (i >= J) {
 #pragma unroll
-                for (int c = 0; c < LEAFW; ++c) {
-                    if (c == j) { x[c] = vi; P[(size_t) c * ld + i] = vi; Vw[(size_t) c * ldv + i] = vi; }
-                    else if (c > j && c < w) { x[c] -= tv * s_s[c]; P[(size_t) c * ld + i] = x[c]; }
+                    for (int c = JJ; c < LEAFW; ++c)
+                        if (c < w) P[(size_t) c * ld + i] = x[c];
                 }
-            } else if (i == j) {
-#pragma unroll
-                for (int c = 0; c < LEAFW; ++c) {
-                    if (c == j) { x[c] = beta; P[(size_t) c * ld + i] = beta; Vw[(size_t) c * ldv + i] = 1.0; }
-                    else if (c > j && c < w) { x[c] -= tj * s_s[c]; P[(size_t) c * ld + i] = x[c]; }
-                }
-            } else {
-                Vw[(size_t) j * ldv + i] = 0.0;
             }
         }
-        if (jn < w) {
-            if (i == jn) {
+        if (JN < LEAFW) {
+            constexpr int JC = JN < LEAFW ? JN : 0;
+            if (JN < w) {
+                if (live && i == JN) {
 #pragma unroll
-                for (int c = 0; c < LEAFW; ++c) if (c < w) row_out[c] = x[c];
-            } else if (i > jn) {
-                double xn = 0.0;
-#pragma unroll
-                for (int c = 0; c < LEAFW; ++c) if (c == jn) xn = x[c];
+                    for (int c = 0; c < LEAFW; ++c) if (c < w) row_out[c] = x[c];
+                }
+                const double xn = (live && i > JN) ? x[JC] : 0.0;
 #pragma unroll
                 for (int c = 0; c < LEAFW; ++c) acc[c] += xn * x[c];
             }
         }
     }
-    if (jn < w) {
-#pragma unroll
-        for (int c = 0; c < LEAFW; ++c) {
-            double v = acc[c];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) s_red[wave][c] = v;
-        }
+    if (JN < LEAFW && JN < w) {
+        const double v = wave_reduce32(acc, lane);
+        if ((lane & 1) == 0) s_red[wave][lane >> 1] = v;
         __syncthreads();
         if (tid < LEAFW)
             part_out[blockIdx.x * LEAFW + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Compact-WY T for an outer panel of nbp columns made of leaves of width ib, from the Gram matrix
-// G = V^T V (one gemm_tn) -- the compact-WY counterpart of the reference's W accumulation
-// (qr.c:170-213).  I - V T V^T = H_0 H_1 ... H_{nbp-1}.
-//   build_diag != 0 : diagonal blocks are (re)built from G and tau by the column recurrence
-//                     T(0:j,j) = -tau_j T(0:j,0:j) G(0:j,j); row p of a block depends only on row p,
-//                     so one thread per row needs no synchronisation at all.
-//   then block column b is merged: T(0:cb, cb:cb+wb) = -T(0:cb,0:cb) * (G(0:cb, cb:cb+wb) * T_bb).
-// Also writes Tt = T^T (used when applying Q instead of Q^T).  Single block of 256 threads.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void larft_kernel(int nbp, int ib, const double* __restrict__ G, int ldg,
-                                                    const double* __restrict__ tau, double* __restrict__ T,
-                                                    int ldt, double* __restrict__ Tt, int build_diag)
+typedef void (*leaf_step_fn)(double*, int, int, int, int, const double*, int, const double*, double*, double*,
+                             double*, double*, double*, int);
+template <int... Js>
+static const leaf_step_fn* leaf_step_table_impl(std::integer_sequence<int, Js...>)
 {
-    extern __shared__ __attribute__((aligned(16))) double X[];   // [cb][LEAFW]
-    const int tid = threadIdx.x;
-    if (build_diag) {
-        for (int p = tid; p < nbp; p += 256) {
-            const int cb = (p / ib) * ib, wb = min(ib, nbp - cb), pl = p - cb;
-            double trow[LEAFW];
-#pragma unroll
-            for (int q = 0; q < LEAFW; ++q) trow[q] = 0.0;
-#pragma unroll
-            for (int jj = 0; jj < LEAFW; ++jj) {
-                if (jj < wb) {
-                    const double tj = tau[cb + jj];
-                    if (pl == jj) trow[jj] = tj;
-                    else if (pl < jj) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int q = 0; q < LEAFW; ++q)
-                            if (q >= pl && q < jj) s += trow[q] * G[(size_t) (cb + jj) * ldg + cb + q];
-                        trow[jj] = -tj * s;
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < LEAFW; ++q)
-                if (q < wb) T[(size_t) (cb + q) * ldt + p] = trow[q];
-        }
-        __syncthreads();
+    static const leaf_step_fn table[] = {leaf_step_kernel<Js - 1>...};
+    return table;
+}
+static const leaf_step_fn* leaf_step_table() { return leaf_step_table_impl(std::make_integer_sequence<int, LEAFW + 1>{}); }
+
+// ------------------------------------------------------------------------------------------------
+// Compact-WY T, the counterpart of the reference's W accumulation (qr.c:170-213):
+// I - V T V^T = H_0 H_1 ... H_{nbp-1}.
+// leaf_t_kernel: diagonal blocks (one block of threads per leaf) from the Gram entries
+//   G(q,j) = v_q^T v_j and tau by the column recurrence T(0:j,j) = -tau_j T(0:j,0:j) G(0:j,j);
+//   row p of a block depends only on row p, so one thread per row needs no synchronisation.
+// The off-diagonal blocks T(0:cb, cb:cb+wb) = -T(0:cb,0:cb) (G(0:cb,cb:cb+wb) T_bb) are two small
+// MFMA GEMMs per leaf (qrd_larft below).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void leaf_t_kernel(int nbp, int ib, const double* __restrict__ G, int ldg,
+                                                   const double* __restrict__ tau, double* __restrict__ T, int ldt)
+{
+    __shared__ double sg[LEAFW][LEAFW + 1];
+    __shared__ double st[LEAFW];
+    const int cb = blockIdx.x * ib, wb = min(ib, nbp - cb), pl = threadIdx.x;
+    const double* Gb = G + (size_t) cb * ldg + cb;
+    double* Tb = T + (size_t) cb * ldt + cb;
+    for (int e = pl; e < wb * wb; e += 64) {
+        const int q = e % wb, jj = e / wb;
+        sg[jj][q] = (q < jj) ? Gb[(size_t) jj * ldg + q] : 0.0;
     }
-    // zero the strictly-lower block part (leaf kernels only write their own diagonal blocks)
-    for (int e = tid; e < nbp * nbp; e += 256) {
-        const int p = e % nbp, c = e / nbp;
-        if (p / ib > c / ib) T[(size_t) c * ldt + p] = 0.0;
-    }
+    if (pl < wb) st[pl] = tau[cb + pl];
     __syncthreads();
-    for (int cb = ib; cb < nbp; cb += ib) {
-        const int wb = min(ib, nbp - cb);
-        // X(q,c) = sum_{r<=c} G(q, cb+r) * T_bb(r, c)
-        for (int e = tid; e < cb * wb; e += 256) {
-            const int q = e % cb, c = e / cb;
-            double s = 0.0;
-            for (int r = 0; r <= c; ++r) s += G[(size_t) (cb + r) * ldg + q] * T[(size_t) (cb + c) * ldt + cb + r];
-            X[q * LEAFW + c] = s;
+    if (pl >= wb) return;
+    double trow[LEAFW];
+#pragma unroll
+    for (int q = 0; q < LEAFW; ++q) trow[q] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < LEAFW; ++jj) {
+        if (jj < wb) {
+            const double tj = st[jj];
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < jj; ++q) sacc += trow[q] * sg[jj][q];      // trow[q] == 0 for q < pl
+            trow[jj] = (pl == jj) ? tj : ((pl < jj) ? -tj * sacc : 0.0);
         }
-        __syncthreads();
-        // T(p, cb+c) = - sum_{q>=p} T(p,q) X(q,c)
-        for (int p = tid; p < cb; p += 256) {
-            double a[LEAFW];
-#pragma unroll
-            for (int c = 0; c < LEAFW; ++c) a[c] = 0.0;
-            for (int q = p; q < cb; ++q) {
-                const double t = T[(size_t) q * ldt + p];
-                const double* xr = X + q * LEAFW;
-#pragma unroll
-                for (int c = 0; c < LEAFW; ++c) a[c] += t * xr[c];
-            }
-#pragma unroll
-            for (int c = 0; c < LEAFW; ++c)
-                if (c < wb) T[(size_t) (cb + c) * ldt + p] = -a[c];
-        }
-        __syncthreads();
     }
-    if (Tt)
-        for (int e = tid; e < nbp * nbp; e += 256) {
-            const int p = e % nbp, c = e / nbp;
-            Tt[(size_t) p * ldt + c] = T[(size_t) c * ldt + p];
-        }
+#pragma unroll
+    for (int q = 0; q < LEAFW; ++q)
+        if (q < wb) Tb[(size_t) q * ldt + pl] = trow[q];
+}
+
+__global__ void transpose_kernel(int n, const double* __restrict__ S, int lds, double* __restrict__ D, int ldd)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * n) { const int p = e % n, c = e / n; D[(size_t) p * ldd + c] = S[(size_t) c * lds + p]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,15 +673,49 @@ __global__ void stream_copy_kernel(const v2d* __restrict__ src, v2d* __restrict_
 // ================================================================================================
 static inline int vec_ok(const void* p, int ld) { return (((uintptr_t) p) % 16 == 0) && (ld % 2 == 0); }
 
+// Launch helpers.  The FAST instantiation runs on the largest tile-aligned interior of the problem; the
+// ragged right / bottom strips (and everything, when operands are not 16-byte aligned or K % 16 != 0)
+// go to the guarded instantiation as separate launches.
+template <int TI, int TJ, bool FAST>
+static int launch_nn1(hipStream_t s, int M, int N, int K, double alpha, const double* A, int lda,
+                      const double* B, int ldb, double beta, double* C, int ldc)
+{
+    constexpr int BM = 32 * TI, BN = 32 * TJ;
+    if (M <= 0 || N <= 0) return 0;
+    const size_t shm = sizeof(double) * (2 * BK * (BM + 16) + 2 * BN * LDKF);
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_nn_kernel<TI, TJ, FAST>), grid, dim3(256), shm, s, M, N, K, alpha, A, lda, B, ldb, beta,
+                       C, ldc);
+    return (int) hipGetLastError();
+}
+
 template <int TI, int TJ>
 static int launch_nn(hipStream_t s, int M, int N, int K, double alpha, const double* A, int lda,
                      const double* B, int ldb, double beta, double* C, int ldc)
 {
     constexpr int BM = 32 * TI, BN = 32 * TJ;
-    const size_t shm = sizeof(double) * (2 * BK * (BM + 16) + 2 * BN * LDKF);
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_nn_kernel<TI, TJ>), grid, dim3(256), shm, s, M, N, K, alpha, A, lda, B, ldb, beta,
-                       C, ldc, vec_ok(A, lda), vec_ok(B, ldb));
+    const bool al = vec_ok(A, lda) && vec_ok(B, ldb) && (K % BK) == 0;
+    const int Mi = al ? (M / BM) * BM : 0, Ni = al ? (N / BN) * BN : 0;
+    if (!(Mi > 0 && Ni > 0)) return launch_nn1<TI, TJ, false>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    int rc = launch_nn1<TI, TJ, true>(s, Mi, Ni, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    if (!rc && Ni < N)      /* right strip: all rows, columns [Ni, N) */
+        rc = launch_nn1<TI, TJ, false>(s, M, N - Ni, K, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta,
+                                       C + (size_t) Ni * ldc, ldc);
+    if (!rc && Mi < M)      /* bottom strip: rows [Mi, M), columns [0, Ni) */
+        rc = launch_nn1<TI, TJ, false>(s, M - Mi, Ni, K, alpha, A + Mi, lda, B, ldb, beta, C + Mi, ldc);
+    return rc;
+}
+
+template <int TI, int TJ, bool FAST>
+static int launch_tn1(hipStream_t s, int M, int N, int K, int ksplit, int kchunk, double alpha, const double* A,
+                      int lda, const double* B, int ldb, double beta, double* C, int ldc, size_t slab_stride)
+{
+    constexpr int BM = 32 * TI, BN = 32 * TJ;
+    if (M <= 0 || N <= 0) return 0;
+    const size_t shm = sizeof(double) * (2 * BM * LDKF + 2 * BN * LDKF);
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, ksplit);
+    hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, FAST>), grid, dim3(256), shm, s, M, N, K, kchunk, alpha, A, lda, B, ldb,
+                       beta, C, ldc, slab_stride);
     return (int) hipGetLastError();
 }
 
@@ -651,11 +724,18 @@ static int launch_tn(hipStream_t s, int M, int N, int K, int ksplit, int kchunk,
                      int lda, const double* B, int ldb, double beta, double* C, int ldc, size_t slab_stride)
 {
     constexpr int BM = 32 * TI, BN = 32 * TJ;
-    const size_t shm = sizeof(double) * (2 * BM * LDKF + 2 * BN * LDKF);
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, ksplit);
-    hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ>), grid, dim3(256), shm, s, M, N, K, kchunk, alpha, A, lda, B, ldb,
-                       beta, C, ldc, slab_stride, vec_ok(A, lda), vec_ok(B, ldb));
-    return (int) hipGetLastError();
+    const bool al = vec_ok(A, lda) && vec_ok(B, ldb) && (K % BK) == 0;
+    const int Mi = al ? (M / BM) * BM : 0, Ni = al ? (N / BN) * BN : 0;
+    if (!(Mi > 0 && Ni > 0))
+        return launch_tn1<TI, TJ, false>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, beta, C, ldc, slab_stride);
+    int rc = launch_tn1<TI, TJ, true>(s, Mi, Ni, K, ksplit, kchunk, alpha, A, lda, B, ldb, beta, C, ldc, slab_stride);
+    if (!rc && Ni < N)
+        rc = launch_tn1<TI, TJ, false>(s, M, N - Ni, K, ksplit, kchunk, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta,
+                                       C + (size_t) Ni * ldc, ldc, slab_stride);
+    if (!rc && Mi < M)
+        rc = launch_tn1<TI, TJ, false>(s, M - Mi, Ni, K, ksplit, kchunk, alpha, A + (size_t) Mi * lda, lda, B, ldb, beta,
+                                       C + Mi, ldc, slab_stride);
+    return rc;
 }
 
 template <typename K>
@@ -670,8 +750,10 @@ extern "C" {
 int qrd_init(void)
 {
     int rc = 0;
-    rc |= allow_lds(gemm_nn_kernel<4, 4>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
-    rc |= allow_lds(gemm_tn_kernel<4, 4>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_nn_kernel<4, 4, true>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
+    rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, false>, sizeof(double) * (4 * 128 * LDKF));
     return rc;
 }
 
@@ -744,8 +826,8 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
     return rc;
 }
 
-// One leaf: factor the mk x w panel at P (ld) in place; tau[0..w), T (w x w at T, ldt), explicit V into Vw.
-// scratch: 2*(256*LEAFW + LEAFW) doubles.
+// One leaf: factor the mk x w panel at P (ld) in place; tau[0..w), leaf T (w x w at T, ldt), explicit V into Vw.
+// scratch: QRD_LEAF_SCRATCH doubles.
 int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
                    int ldv, double* scratch)
 {
@@ -756,22 +838,41 @@ int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, 
     const int nblk = (mk + 256 * rpt - 1) / (256 * rpt);
     double* part[2] = {scratch, scratch + 256 * LEAFW + LEAFW};
     double* rowb[2] = {part[0] + 256 * LEAFW, part[1] + 256 * LEAFW};
+    double* Z = scratch + 2 * (256 * LEAFW + LEAFW);
+    const leaf_step_fn* table = leaf_step_table();
     for (int j = -1; j < w; ++j) {
         const int in = (j + 2) & 1, out = (j + 1) & 1;
-        hipLaunchKernelGGL(leaf_step_kernel, dim3(nblk), dim3(256), 0, s, P, ld, mk, w, j, rpt, part[in], nblk,
-                           rowb[in], part[out], rowb[out], tau, T, ldt, Vw, ldv);
+        hipLaunchKernelGGL(table[j + 1], dim3(nblk), dim3(256), 0, s, P, ld, mk, w, rpt, part[in], nblk,
+                           rowb[in], part[out], rowb[out], tau, Z, Vw, ldv);
     }
+    hipLaunchKernelGGL(leaf_t_kernel, dim3(1), dim3(64), 0, s, w, w, Z, LEAFW, tau, T, ldt);
     return (int) hipGetLastError();
 }
 
+// Outer-panel T (nbp x nbp, leaves of width ib) from G = V^T V.  build_diag: diagonal blocks are rebuilt
+// from G and tau (otherwise the leaf kernels already left them in T).  X: nbp x ib scratch (ldx >= nbp).
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,
-              double* Tt, int build_diag)
+              double* Tt, int build_diag, double* X, int ldx)
 {
+    hipStream_t s = (hipStream_t) stream;
     if (ib > LEAFW || nbp < 1) return -5;
-    const size_t shm = sizeof(double) * (size_t) (nbp > ib ? nbp : ib) * LEAFW;
-    hipLaunchKernelGGL(larft_kernel, dim3(1), dim3(256), shm, (hipStream_t) stream, nbp, ib, G, ldg, tau, T, ldt,
-                       Tt, build_diag);
-    return (int) hipGetLastError();
+    if (build_diag) {
+        hipLaunchKernelGGL(leaf_t_kernel, dim3((nbp + ib - 1) / ib), dim3(64), 0, s, nbp, ib, G, ldg, tau, T, ldt);
+        int rc = (int) hipGetLastError();
+        if (rc) return rc;
+    }
+    for (int cb = ib; cb < nbp; cb += ib) {
+        const int wb = (ib < nbp - cb) ? ib : nbp - cb;
+        int rc = qrd_gemm_nn(stream, cb, wb, wb, 1.0, G + (size_t) cb * ldg, ldg, T + (size_t) cb * ldt + cb, ldt, 0.0, X, ldx);
+        if (rc) return rc;
+        rc = qrd_gemm_nn(stream, cb, wb, cb, -1.0, T, ldt, X, ldx, 0.0, T + (size_t) cb * ldt, ldt);
+        if (rc) return rc;
+    }
+    if (Tt) {
+        hipLaunchKernelGGL(transpose_kernel, dim3((nbp * nbp + 255) / 256), dim3(256), 0, s, nbp, T, ldt, Tt, ldt);
+        return (int) hipGetLastError();
+    }
+    return 0;
 }
 
 int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols)

@@ -120,7 +120,7 @@ def test_leaf_panel(q, oracle, mk, w):
     buf = np.full((ld, w), 7.0); buf[:mk] = P
     dP = dev(buf)
     dtau, dT, dV = zeros(w, 1), zeros(ldt, w), dev(np.full((ldv, w), np.nan))
-    scratch = torch.zeros(2 * (256 * 32 + 32), dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(q.LEAF_SCRATCH, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     q.check(q.lib.qrd_leaf_panel(None, dP.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), ldt,
                                  dV.data_ptr(), ldv, scratch.data_ptr()))
@@ -139,7 +139,8 @@ def test_leaf_panel(q, oracle, mk, w):
     Vd, Td = host(dV)[:mk], host(dT)[:w]
     QtP = P - Vd @ (Td.T @ (Vd.T @ P))
     assert np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-12 * np.sqrt(mk)
-    assert np.abs(QtP[w:]).max() < 1e-12 * np.sqrt(mk) and np.abs(np.tril(QtP[:w], -1)).max() < 1e-12 * np.sqrt(mk)
+    assert np.abs(np.tril(QtP[:w], -1)).max(initial=0.0) < 1e-12 * np.sqrt(mk)
+    assert np.abs(QtP[w:]).max(initial=0.0) < 1e-12 * np.sqrt(mk)
 
 
 def test_leaf_panel_zero_column_gives_tau_zero(q):
@@ -149,7 +150,7 @@ def test_leaf_panel_zero_column_gives_tau_zero(q):
     P[:, 3] = 0.0
     P[4:, 5] = 0.0
     dP, dtau, dT, dV = dev(P), zeros(w, 1), zeros(w, w), zeros(mk, w)
-    scratch = torch.zeros(2 * (256 * 32 + 32), dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(q.LEAF_SCRATCH, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     q.check(q.lib.qrd_leaf_panel(None, dP.data_ptr(), mk, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(),
                                  mk, scratch.data_ptr()))
@@ -175,10 +176,13 @@ def test_larft(q, oracle, nbp, ib, build_diag):
     for cb in range(0, nbp, ib):                       # diagonal blocks as the leaf kernels would leave them
         wb = min(ib, nbp - cb)
         T0[cb:cb + wb, cb:cb + wb] = Tref[cb:cb + wb, cb:cb + wb] if not build_diag else np.nan
-    dG, dtau, dT, dTt = dev(G), dev(tau[:, None]), dev(T0), zeros(nbp, nbp)
+    T0[np.tril_indices(nbp, -1)] = np.where(np.isnan(T0[np.tril_indices(nbp, -1)]), 0.0, T0[np.tril_indices(nbp, -1)])
+    for cb in range(0, nbp, ib):                       # sub-diagonal blocks are zero in the plan's T buffer
+        T0[cb + ib:, cb:cb + ib] = 0.0
+    dG, dtau, dT, dTt, dX = dev(G), dev(tau[:, None]), dev(T0), zeros(nbp, nbp), zeros(nbp, 32)
     torch.cuda.synchronize()
     q.check(q.lib.qrd_larft(None, nbp, ib, dG.data_ptr(), nbp, dtau.data_ptr(), dT.data_ptr(), nbp, dTt.data_ptr(),
-                            build_diag))
+                            build_diag, dX.data_ptr(), nbp))
     _sync(q)
     T = host(dT)
     assert np.abs(T - Tref).max() < 1e-12 * max(1.0, np.abs(Tref).max())

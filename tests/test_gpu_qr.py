@@ -172,6 +172,37 @@ def test_c2_4096_square_nb64_properties(qr):
     p.close()
 
 
+@pytest.mark.parametrize("nb", [128, 256])
+def test_c3_16384_square_properties(qr, nb):
+    """BASELINE config C3 at full size (16384 x 16384): residual < 1e-12 (north-star), orthogonality.
+    Also the regression test for the look-ahead race fixed in round 1 (panel and wide update sharing
+    one W buffer only went wrong once the wide GEMM outlasted the next panel, i.e. at this size)."""
+    m = n = 16384
+    p = qr.Plan(m, n, nb, 32)
+    dA = zeros(m, n)
+    p.fill_uniform(dA, m, m, n, seed=12)
+    p.sync()
+    resid, orth, _ = _device_metrics(qr, p, dA, m, n, 12)
+    assert resid < 1e-12 and orth < 1e-10
+    p.close()
+
+
+def test_lookahead_matches_sequential_schedule(qr, oracle):
+    """Same matrix through the two-stream look-ahead schedule and the single-stream schedule."""
+    import subprocess, sys, os, json
+    code = ("import sys, json, numpy as np, torch; sys.path.insert(0, %r); import cuda_qr_amd as q;"
+            "m,n=6144,3072; p=q.Plan(m,n,128,32); A=torch.empty((n,m),dtype=torch.float64,device='cuda');"
+            "t=torch.empty(n,dtype=torch.float64,device='cuda'); p.fill_uniform(A,m,m,n,seed=5); p.geqrf(A,m,n,m,t); p.sync();"
+            "R=np.triu(A.cpu().numpy().T[:n]); np.save(sys.argv[1], R)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for la in ("1", "0"):
+        path = f"/tmp/la_{la}.npy"
+        env = dict(os.environ, MI355XQR_LOOKAHEAD=la)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+        outs.append(np.load(path))
+    assert rel(oracle.sign_normalise(outs[0]), oracle.sign_normalise(outs[1])) < 1e-13
+
+
 def test_tall_skinny_65536x256_properties(qr):
     """One C4 shard (262144 x 256 over 4 GPUs -> 65536 x 256 per GPU)."""
     m, n = 65536, 256
@@ -207,8 +238,7 @@ def test_profile_hooks(qr):
     p.geqrf(dA, m, n, m, dtau)
     prof = p.get_profile()
     nb = qr.get_block_size()[0]
-    assert prof["update_nn"]["launches"] == n // nb - 1 and prof["panel"]["launches"] == n // nb
+    assert 1 <= prof["update_nn"]["launches"] <= n // nb - 1 and prof["panel"]["launches"] == n // nb
     assert prof["update_nn"]["ms"] > 0 and prof["update_nn"]["flops"] > 0
-    tot = sum(v["flops"] for v in prof.values() if v["flops"])
-    assert abs(prof["update_nn"]["flops"] + prof["vta_tn"]["flops"] - (tot - prof["panel"]["flops"])) < 1
+    assert prof["update_nn"]["flops"] == prof["vta_tn"]["flops"]
     p.close()

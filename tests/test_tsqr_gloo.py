@@ -1,0 +1,118 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of the TSQR orchestration (cuda-qr_amd/tsqr.py).
+
+The collective, the stacking order of the gathered R factors, the redundant stacked QR and the
+Q_p = Q_local [Qtree_p; 0] combine are exercised exactly as on GPUs; only the local factorisation
+backend is swapped for the numpy mirror from the test oracle (injected here, by the test -- the
+product has no CPU backend of its own)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class NumpyBackend:
+    """TEST-ONLY local-step backend (oracle.np_geqrf / np_orgqr) with the HipBackend interface."""
+
+    def __init__(self, oracle, m_local, n, world):
+        self.O, self.m, self.n, self.world = oracle, m_local, n, world
+        self.f_local = self.f_stack = None
+
+    def new_matrix(self, rows, cols):
+        return torch.zeros((cols, rows), dtype=torch.float64)
+
+    @staticmethod
+    def _np(t):
+        return t.numpy().T          # (rows x cols) view of a column-major buffer
+
+    def local_factor(self, A, R_out):
+        F, tau, _ = self.O.np_geqrf(self._np(A), 8)
+        self._np(A)[:] = F
+        self.f_local = (F, tau)
+        self._np(R_out)[:] = np.triu(F[:self.n])
+
+    def stack_factor(self, S, R_out):
+        F, tau, _ = self.O.np_geqrf(self._np(S), 8)
+        self._np(S)[:] = F
+        self.f_stack = (F, tau)
+        self._np(R_out)[:] = np.triu(F[:self.n])
+
+    def tree_q(self, S, Qt):
+        self._np(Qt)[:] = self.O.np_orgqr(self.f_stack[0], self.f_stack[1], self.n, 8)
+
+    def thin_q(self, A):
+        Q = self.new_matrix(self.m, self.n)
+        self._np(Q)[:] = self.O.np_orgqr(self.f_local[0], self.f_local[1], self.n, 8)
+        return Q
+
+    def local_q(self, A, C):
+        F, tau = self.f_local
+        Qfull = self.O.np_orgqr(F, tau, self.m, 8)
+        self._np(C)[:] = Qfull @ self._np(C)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, m_local, n, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cuda_qr_amd as qr
+    from cuda_qr_amd import tsqr as T
+    from oracle import oracle as O
+    m = m_local * world
+    shard = qr.uniform_matrix_host(m_local, n, row_off=rank * m_local, total_rows=m, seed=12)
+    be = NumpyBackend(O, m_local, n, world)
+    ts = T.TSQR(be, n, world, rank)
+    A = be.new_matrix(m_local, n)
+    A.numpy().T[:] = shard
+    R = ts.factor(A)
+    Q = ts.form_q(A)
+    np.save(os.path.join(outdir, f"R{rank}.npy"), R.numpy().T.copy())
+    np.save(os.path.join(outdir, f"Q{rank}.npy"), Q.numpy().T.copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tsqr_orchestration_gloo(tmp_path, oracle, world):
+    import cuda_qr_amd as qr
+    m_local, n = 96, 24
+    mp.spawn(_worker, args=(world, _free_port(), m_local, n, str(tmp_path)), nprocs=world, join=True)
+    m = m_local * world
+    A = qr.uniform_matrix_host(m, n, seed=12)
+    Rs = [np.load(tmp_path / f"R{r}.npy") for r in range(world)]
+    Q = np.vstack([np.load(tmp_path / f"Q{r}.npy") for r in range(world)])
+    for r in range(1, world):
+        assert np.array_equal(Rs[0], Rs[r]), "every rank must hold the identical final R"
+    R = Rs[0]
+    ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert np.linalg.norm(oracle.sign_normalise(R) - ref) / np.linalg.norm(ref) < 1e-13
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+
+
+def test_tsqr_single_rank_path(oracle):
+    import cuda_qr_amd as qr
+    from cuda_qr_amd import tsqr as T
+    m, n = 120, 16
+    A0 = qr.uniform_matrix_host(m, n, seed=3)
+    be = NumpyBackend(oracle, m, n, 1)
+    ts = T.TSQR(be, n, 1, 0)
+    A = be.new_matrix(m, n)
+    A.numpy().T[:] = A0
+    R = ts.factor(A).numpy().T
+    Q = ts.form_q(A).numpy().T
+    assert np.linalg.norm(A0 - Q @ R) / np.linalg.norm(A0) < 1e-14

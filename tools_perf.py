@@ -1,0 +1,33 @@
+"""ad-hoc perf exploration (not the bench contract): time geqrf with per-class event profile."""
+import sys, time, json
+import torch
+import cuda_qr_amd as q
+
+def run(m, n, nb, ib=32, reps=2):
+    p = q.Plan(m, n, nb, ib)
+    dA = torch.empty((n, m), dtype=torch.float64, device="cuda")
+    dtau = torch.empty(n, dtype=torch.float64, device="cuda")
+    best = None
+    for r in range(reps + 1):
+        p.fill_uniform(dA, m, m, n, seed=12)
+        p.sync()
+        p.set_profile(r == reps)
+        t0 = time.perf_counter()
+        p.geqrf(dA, m, n, m, dtau)
+        p.sync()
+        dt = time.perf_counter() - t0
+        if r > 0 and (best is None or dt < best) and r < reps: best = dt
+        if r == reps:
+            prof = p.get_profile(); tprof = dt
+    fl = q.flops(m, n)
+    line = {"m": m, "n": n, "nb": nb, "ib": ib, "ms": best * 1e3, "tflops": fl / best / 1e12, "ms_profiled": tprof*1e3}
+    for k, v in prof.items():
+        if v["launches"]:
+            line[k] = {"ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "n": v["launches"]}
+    print(json.dumps(line), flush=True)
+    p.close()
+
+if __name__ == "__main__":
+    cfgs = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
+    for c in cfgs:
+        run(*c)

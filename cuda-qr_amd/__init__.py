@@ -198,9 +198,10 @@ def device_info():
 
 
 def probe_mfma_f64_tflops():
-    v = C.c_double()
-    check(lib.qr_probe_mfma_f64_tflops(C.byref(v)), "probe")
-    return v.value
+    """{mfma_tflops, mfma_clock_ghz, valu_tflops}: sustained fp64 rates measured on this device."""
+    v = (C.c_double * 3)()
+    check(lib.qr_probe_mfma_f64_tflops(v), "probe")
+    return {"mfma_f64_tflops": v[0], "mfma_clock_ghz": v[1], "valu_f64_tflops": v[2]}
 
 
 def probe_copy_gbps():

@@ -38,6 +38,7 @@ int qrd_d2d(void* stream, void* dst, const void* src, size_t bytes);
 int qrd_h2d_2d(void* stream, void* d, size_t dpitch, const void* h, size_t hpitch, size_t width, size_t height);
 int qrd_d2h_2d(void* stream, void* h, size_t hpitch, const void* d, size_t dpitch, size_t width, size_t height);
 int qrd_stream_create(void** s, int high_priority);
+int qrd_stream_create_cumask(void** s, int first, int count);
 int qrd_stream_destroy(void* s);
 int qrd_stream_sync(void* s);
 int qrd_device_sync(void);
@@ -52,7 +53,7 @@ int qrd_device_count(int* n);
 int qrd_set_device(int d);
 const char* qrd_error_string(int e);
 int qrd_device_info(char* name, int name_len, int* cus, int* clock_khz, size_t* mem_bytes);
-int qrd_probe_mfma_f64(double* tflops);
+int qrd_probe_mfma_f64(double* out3);
 int qrd_probe_copy(double* gbps);
 
 #define QRD_LEAFW 32

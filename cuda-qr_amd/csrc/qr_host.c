@@ -110,8 +110,22 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
     p->lookahead = la ? atoi(la) != 0 : 1;
-    int rc = qrd_stream_create(&p->stream, 1);
-    if (!rc) rc = qrd_stream_create(&p->stream_u, 0);
+    /* MI355XQR_PANEL_CUS = c > 0: the panel chain runs on its own c compute units and the wide update on the
+     * other 256-c, so a leaf kernel never queues behind resident GEMM workgroups (0: shared, priority only). */
+    const char* pc = getenv("MI355XQR_PANEL_CUS");
+    /* default: 64 CUs for the panel chain when there is a wide update worth overlapping with (n >= 2048);
+     * tall-skinny problems are all panel, so they keep the whole chip on one stream set */
+    const int panel_cus = pc ? atoi(pc) : (n >= 2048 ? 64 : 0);
+    int rc;
+    if (p->lookahead && panel_cus > 0 && panel_cus < 224) {
+        int cus = 256;
+        qrd_device_info(NULL, 0, &cus, NULL, NULL);
+        rc = qrd_stream_create_cumask(&p->stream, 0, panel_cus);
+        if (!rc) rc = qrd_stream_create_cumask(&p->stream_u, panel_cus, cus - panel_cus);
+    } else {
+        rc = qrd_stream_create(&p->stream, 1);
+        if (!rc) rc = qrd_stream_create(&p->stream_u, 0);
+    }
     for (int e = 0; e < 2 && !rc; ++e) {
         rc = qrd_event_create_notiming(&p->ev_panel[e]);
         if (!rc) rc = qrd_event_create_notiming(&p->ev_wide[e]);
@@ -429,7 +443,7 @@ int qr_device_info(char* arch, int arch_len, int* cus, int* clock_khz, size_t* h
     CHECK(ensure_device());
     return qrd_device_info(arch, arch_len, cus, clock_khz, hbm);
 }
-int qr_probe_mfma_f64_tflops(double* t) { CHECK(ensure_device()); return qrd_probe_mfma_f64(t); }
+int qr_probe_mfma_f64_tflops(double* t3) { CHECK(ensure_device()); return qrd_probe_mfma_f64(t3); }
 int qr_probe_copy_gbps(double* g) { CHECK(ensure_device()); return qrd_probe_copy(g); }
 
 /* ---------------------------------------------------------------------------------------------- *

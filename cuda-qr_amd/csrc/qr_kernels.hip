@@ -645,20 +645,43 @@ __global__ __launch_bounds__(256) void diff_norm_kernel(const double* __restrict
     }
 }
 
-// MFMA fp64 issue-rate probe: each wave runs `iters` x 8 independent accumulators back to back.
-__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters, double seed)
+// MFMA fp64 issue-rate probe: each wave runs `iters` x NACC independent accumulators back to back and
+// stamps shader clock (s_memtime) and the 100 MHz wall counter (s_memrealtime) around the loop, so the
+// sustained in-kernel clock is known next to the rate (DVFS: MI355X_MICROARCH.md 'DVFS give-back').
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, unsigned long long* stamps, int iters, double seed)
 {
-    v4d acc[8];
+    v4d acc[NACC];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) acc[a] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < NACC; ++a) acc[a] = (v4d){0.0, 0.0, 0.0, 0.0};
     double x = seed + threadIdx.x * 1e-3, y = 1.0 - threadIdx.x * 1e-4;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int a = 0; a < 8; ++a) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[a], 0, 0, 0);
+        for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[a], 0, 0, 0);
     }
     double s = 0.0;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+    for (int a = 0; a < NACC; ++a) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[(size_t) blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && stamps) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+// f64 VALU FMA probe (the vector pipe has the same datasheet rate as the matrix pipe on CDNA4)
+__global__ __launch_bounds__(256) void valu_peak_kernel(double* out, int iters, double seed)
+{
+    double a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = seed + q + threadIdx.x * 1e-3;
+    const double m = 1.0 - 1e-9, c = 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = a[q] * m + c;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += a[q];
     out[(size_t) blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -973,6 +996,21 @@ int qrd_stream_create(void** s, int high_priority)
     *s = (void*) st;
     return (int) e;
 }
+// Stream restricted to CUs [first, first+count) of the device (count = 0: no restriction).  Used to give
+// the latency-critical panel chain its own compute units while the wide update saturates the rest.
+int qrd_stream_create_cumask(void** s, int first, int count)
+{
+    hipStream_t st;
+    if (count <= 0) { hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); *s = (void*) st; return (int) e; }
+    uint32_t mask[16] = {0};
+    for (int c = first; c < first + count && c < 512; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipDeviceProp_t p; int dev = 0;
+    HIPCHK(hipGetDevice(&dev)); HIPCHK(hipGetDeviceProperties(&p, dev));
+    const uint32_t words = (uint32_t) ((p.multiProcessorCount + 31) / 32);
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, words, mask);
+    *s = (void*) st;
+    return (int) e;
+}
 int qrd_stream_destroy(void* s) { return (int) hipStreamDestroy((hipStream_t) s); }
 int qrd_stream_sync(void* s) { return (int) hipStreamSynchronize((hipStream_t) s); }
 int qrd_device_sync(void) { return (int) hipDeviceSynchronize(); }
@@ -999,23 +1037,59 @@ int qrd_device_info(char* name, int name_len, int* cus, int* clock_khz, size_t* 
     return 0;
 }
 
-// microbenchmarks (DESIGN.md "measured peaks"): returns TFLOP/s of back-to-back f64 MFMA and GB/s of a 16-B copy
-int qrd_probe_mfma_f64(double* tflops)
+// microbenchmarks (DESIGN.md "measured peaks").  out[0] = best TFLOP/s of back-to-back f64 MFMA over
+// {1,2,4 workgroups per CU} x {4,8 accumulators}; out[1] = in-kernel shader clock (GHz) of that best run;
+// out[2] = f64 VALU FMA TFLOP/s.
+}   // extern "C" (templates need C++ linkage)
+template <int NACC>
+static int probe_one(int blocks, int iters, double* tflops, double* ghz)
 {
-    int cus = 256;
-    hipDeviceProp_t p; int dev = 0;
-    HIPCHK(hipGetDevice(&dev)); HIPCHK(hipGetDeviceProperties(&p, dev)); cus = p.multiProcessorCount;
-    const int blocks = cus * 2, iters = 4000;
-    double* out; HIPCHK(hipMalloc(&out, sizeof(double) * blocks * 256));
+    double* out; unsigned long long* st;
+    HIPCHK(hipMalloc(&out, sizeof(double) * blocks * 256));
+    HIPCHK(hipMalloc(&st, sizeof(unsigned long long) * 2 * blocks));
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, 100, 0.5);
+    hipLaunchKernelGGL(mfma_peak_kernel<NACC>, dim3(blocks), dim3(256), 0, 0, out, st, iters / 8, 0.5);   // warm
     HIPCHK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0.5);
+    hipLaunchKernelGGL(mfma_peak_kernel<NACC>, dim3(blocks), dim3(256), 0, 0, out, st, iters, 0.5);
     HIPCHK(hipEventRecord(b, 0)); HIPCHK(hipEventSynchronize(b));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
-    const double fl = (double) blocks * 4 * iters * 8 * 2048.0;
-    *tflops = fl / (ms * 1e-3) / 1e12;
-    hipEventDestroy(a); hipEventDestroy(b); hipFree(out);
+    *tflops = (double) blocks * 4 * iters * NACC * 2048.0 / (ms * 1e-3) / 1e12;
+    unsigned long long h[2];
+    HIPCHK(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+    *ghz = h[1] ? (double) h[0] / (double) h[1] * 0.1 : 0.0;      // shader cycles per 10 ns tick
+    hipEventDestroy(a); hipEventDestroy(b); hipFree(out); hipFree(st);
+    return 0;
+}
+extern "C" {
+
+int qrd_probe_mfma_f64(double* out3)
+{
+    hipDeviceProp_t p; int dev = 0;
+    HIPCHK(hipGetDevice(&dev)); HIPCHK(hipGetDeviceProperties(&p, dev));
+    const int cus = p.multiProcessorCount;
+    double best = 0.0, best_ghz = 0.0;
+    for (int bpc = 1; bpc <= 4; bpc *= 2) {
+        double t, g;
+        int rc = probe_one<4>(cus * bpc, 16000 / bpc, &t, &g);
+        if (rc) return rc;
+        if (t > best) { best = t; best_ghz = g; }
+        rc = probe_one<8>(cus * bpc, 8000 / bpc, &t, &g);
+        if (rc) return rc;
+        if (t > best) { best = t; best_ghz = g; }
+    }
+    out3[0] = best; out3[1] = best_ghz;
+    {
+        const int blocks = cus * 8, iters = 20000;
+        double* o; HIPCHK(hipMalloc(&o, sizeof(double) * blocks * 256));
+        hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, 0, o, 1000, 0.5);
+        HIPCHK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, 0, o, iters, 0.5);
+        HIPCHK(hipEventRecord(b, 0)); HIPCHK(hipEventSynchronize(b));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+        out3[2] = (double) blocks * 256 * iters * 16 * 2.0 / (ms * 1e-3) / 1e12;
+        hipEventDestroy(a); hipEventDestroy(b); hipFree(o);
+    }
     return 0;
 }
 

@@ -135,7 +135,9 @@ int qr_plan_get_profile(qr_plan* plan, qr_profile* out);   /* synchronises, sums
 
 /* Device facts + micro-probes used by bench.py / DESIGN.md (measured, not datasheet). */
 int qr_device_info(char* arch, int arch_len, int* compute_units, int* clock_khz, size_t* hbm_bytes);
-int qr_probe_mfma_f64_tflops(double* tflops);
+/* out3[0] = sustained back-to-back v_mfma_f64_16x16x4_f64 TFLOP/s (best over 1/2/4 workgroups per CU),
+ * out3[1] = in-kernel shader clock (GHz) during that run, out3[2] = f64 VALU FMA TFLOP/s */
+int qr_probe_mfma_f64_tflops(double* out3);
 int qr_probe_copy_gbps(double* gbps);
 
 #ifdef __cplusplus

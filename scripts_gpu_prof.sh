@@ -1,8 +1,12 @@
 #!/bin/bash
-mkdir -p gpurun_out/prof3
+R=gpurun_out/pmc_try
+mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-export MI355XQR_PANEL_CUS=32
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof3 -o p -- python3 tools_perf.py 16384x16384x128 > gpurun_out/prof3/run.log 2>&1
-python3 tools_trace_summary.py gpurun_out/prof3/p_kernel_trace.csv | sed 's/void //' | awk '{ if ($1 ~ /leaf_step/) { c+=$3; b+=$5 } else print } END { print "leaf_step_kernel<*> calls", c, "busy", b, "ms avg", b/c*1000, "us" }'
-rm -f gpurun_out/prof3/p_kernel_trace.csv
+for sz in 4096 8192 16384; do
+  MI355XQR_PANEL_CUS=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/d$sz -o pmc -- python3 tools_pmc_driver.py $sz 128 > $R/d$sz.log 2>&1
+  echo "driver $sz rc=$? sigsegv=$(grep -c SIGSEGV $R/d$sz.log) $(grep -c . $R/d$sz/pmc_counter_collection.csv 2>/dev/null)"
+  f=$R/d$sz/pmc_counter_collection.csv
+  [ -f $f ] && python3 tools_pmc_summary.py $f FETCH_SIZE | head -8
+  rm -f $f
+done

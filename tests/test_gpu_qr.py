@@ -242,3 +242,21 @@ def test_profile_hooks(qr):
     assert prof["update_nn"]["ms"] > 0 and prof["update_nn"]["flops"] > 0
     assert prof["update_nn"]["flops"] == prof["vta_tn"]["flops"]
     p.close()
+
+
+@pytest.mark.parametrize("m,n", [(6, 4), (512, 128)])
+def test_c_caller_links_the_drop_in_symbols(qr, tmp_path, m, n):
+    """A plain C program written like the reference's main() (qr.c:461-523), compiled with gcc against
+    include/mi355x_qr.h and linked to the shared library -- the drop-in boundary exercised from C."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "selfcheck")
+    libdir = os.path.join(root, "cuda-qr_amd")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "selfcheck.c"),
+                    "-o", exe, "-L", libdir, "-lmi355xqr", "-lm", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([exe, str(m), str(n)], check=True, capture_output=True, text=True).stdout
+    resid = float(re.search(r"L2 norm of residual QR-A: (\S+)", out).group(1))
+    rel_resid = float(re.search(r"relative residual: (\S+)", out).group(1))
+    assert rel_resid < 1e-12 and resid < 1e-12 * (m * n) ** 0.5 * 4
+    if (m, n) == (6, 4):
+        assert "Matrix 6 x 4, row by row:" in out          # printMat, qr.c:21-33

@@ -16,6 +16,9 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
                 int ldt);
 int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
                    int ldv, double* scratch);
+size_t qrd_panel_ws_size(int m);
+int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                   double* ws, int m_cap);
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,
               double* Tt, int build_diag, double* X, int ldx);
 int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols);
@@ -40,6 +43,10 @@ int qrd_d2h_2d(void* stream, void* h, size_t hpitch, const void* d, size_t dpitc
 int qrd_stream_create(void** s, int high_priority);
 int qrd_stream_create_cumask(void** s, int first, int count);
 int qrd_stream_destroy(void* s);
+int qrd_capture_begin(void* s);
+int qrd_capture_end(void* s, void** exec);
+int qrd_graph_launch(void* exec, void* s);
+int qrd_graph_destroy(void* exec);
 int qrd_stream_sync(void* s);
 int qrd_device_sync(void);
 int qrd_event_create(void** e);

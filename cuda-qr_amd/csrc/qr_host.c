@@ -24,6 +24,9 @@
 
 struct qr_plan {
     int m, n, nb, ib, ldv, ldt;
+    int use_graph;              /* 1: qr_geqrf_dev is captured into a hipGraph once per argument set and replayed */
+    void* graph_exec;
+    double *g_dA, *g_dtau; int g_m, g_n, g_lda;
     int lookahead;              /* 1: panel k+1 is factored on `stream` while `stream_u` updates the rest */
     void* stream;               /* panel / critical-path stream (high priority); the plan's public stream */
     void* stream_u;             /* wide trailing-update stream */
@@ -31,7 +34,9 @@ struct qr_plan {
     void* ev_wide[2];           /* wide update that read panel set s finished */
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
     double *Vw2[2], *VT2[2], *T2[2];
-    double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *leaf_scratch;
+    double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *leaf_scratch, *panel_ws;
+    int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height */
+    int tsqr_min_rows;
     size_t slab_cap, w_cap;
     /* profiling */
     int prof_on, prof_count, prof_cap, prof_open;
@@ -110,6 +115,8 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
     p->lookahead = la ? atoi(la) != 0 : 1;
+    const char* gr = getenv("MI355XQR_GRAPH");
+    p->use_graph = gr ? atoi(gr) != 0 : 0;
     /* MI355XQR_PANEL_CUS = c > 0: the panel chain runs on its own c compute units and the wide update on the
      * other 256-c, so a leaf kernel never queues behind resident GEMM workgroups (0: shared, priority only). */
     const char* pc = getenv("MI355XQR_PANEL_CUS");
@@ -151,6 +158,13 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     if (!rc) rc = qrd_malloc((void**) &p->X, sizeof(double) * (size_t) nb * QRD_LEAFW);
     if (!rc) rc = qrd_malloc((void**) &p->slabs, sizeof(double) * p->slab_cap);
     if (!rc) rc = qrd_malloc((void**) &p->leaf_scratch, sizeof(double) * QRD_LEAF_SCRATCH);
+    {
+        const char* pa = getenv("MI355XQR_PANEL");
+        p->panel_tsqr = !pa ? 2 : (strcmp(pa, "col") == 0 ? 0 : (strcmp(pa, "tsqr") == 0 ? 1 : 2));
+        const char* tm = getenv("MI355XQR_TSQR_MIN_ROWS");
+        p->tsqr_min_rows = tm ? atoi(tm) : 100000;
+    }
+    if (!rc && p->panel_tsqr) rc = qrd_malloc((void**) &p->panel_ws, sizeof(double) * qrd_panel_ws_size(m));
     if (rc) { qr_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -161,6 +175,7 @@ int qr_plan_destroy(qr_plan* p)
     if (!p) return 0;
     if (p->stream) qrd_stream_sync(p->stream);
     if (p->stream_u) qrd_stream_sync(p->stream_u);
+    qrd_graph_destroy(p->graph_exec);
     for (int e = 0; e < 2; ++e) {
         if (p->ev_panel[e]) qrd_event_destroy(p->ev_panel[e]);
         if (p->ev_wide[e]) qrd_event_destroy(p->ev_wide[e]);
@@ -172,7 +187,7 @@ int qr_plan_destroy(qr_plan* p)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
-    qrd_free(p->slabs); qrd_free(p->leaf_scratch);
+    qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws);
     if (p->stream) qrd_stream_destroy(p->stream);
     free(p);
     return 0;
@@ -296,7 +311,12 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
         double* P = Ak + (size_t) c * lda + c;
         double* Vl = p->Vw + (size_t) c * ldv + c;
         double* Tl = p->T + (size_t) c * ldt + c;
-        CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
+        /* leaf algorithm: the TSQR + Householder-reconstruction leaf reads the leaf ~3 times whatever its
+         * height, the one-launch-per-column leaf ~25 times: measured crossover is around 10^5 rows */
+        if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
+            CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
+        else
+            CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
         const int nrest = wout - (c + w);
         if (nrest > 0) {
             double* Arest = P + (size_t) w * lda;
@@ -332,9 +352,29 @@ static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int
     return 0;
 }
 
+static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau);
+
 int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     if (!p || !dA || !dtau || n < 1 || m < n || m > p->m || n > p->n || lda < m) return QR_E_ARG;
+    if (!p->use_graph || p->prof_on) return geqrf_issue(p, dA, m, n, lda, dtau);
+    if (!(p->graph_exec && p->g_dA == dA && p->g_dtau == dtau && p->g_m == m && p->g_n == n && p->g_lda == lda)) {
+        CHECK(qr_plan_sync(p));
+        qrd_graph_destroy(p->graph_exec);
+        p->graph_exec = NULL;
+        CHECK(qrd_capture_begin(p->stream));
+        int rc = geqrf_issue(p, dA, m, n, lda, dtau);
+        void* exec = NULL;
+        int rc2 = qrd_capture_end(p->stream, &exec);
+        if (rc || rc2) { qrd_graph_destroy(exec); return rc ? rc : rc2; }
+        p->graph_exec = exec;
+        p->g_dA = dA; p->g_dtau = dtau; p->g_m = m; p->g_n = n; p->g_lda = lda;
+    }
+    return qrd_graph_launch(p->graph_exec, p->stream);
+}
+
+static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
+{
     const int nb = p->nb;
     if (!p->lookahead) {
         use_set(p, 0);

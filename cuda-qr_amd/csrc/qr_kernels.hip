@@ -22,9 +22,7 @@
 #include <stdlib.h>
 #include <utility>
 #include "qr_device.h"
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
+#include "qr_common.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int) e_; } while (0)
 
@@ -285,31 +283,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 }
 
 // out(:,j) = beta*out(:,j) + Tm^T * sum_z slab_z(:,j)   (Tm optional, upper triangular M x M, M <= 256)
-// One block per output column; blockDim.x >= M.
-__global__ void slab_reduce_kernel(int M, int N, int nslab, const double* __restrict__ slabs, int lds,
-                                   size_t slab_stride, const double* __restrict__ Tm, int ldt,
-                                   double beta, double* __restrict__ out, int ldo)
+// One 256-thread block per output column.  The slab index is spread over 256/Mp thread groups (Mp = M rounded up
+// to 32), each summing its slabs in a fixed order, then the groups are added in a fixed order: deterministic and
+// short dependency chains even for hundreds of slabs.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(int M, int N, int nslab, const double* __restrict__ slabs, int lds,
+                                                          size_t slab_stride, const double* __restrict__ Tm, int ldt,
+                                                          double beta, double* __restrict__ out, int ldo)
 {
+    __shared__ double red[256];
     __shared__ double col[256];
-    const int j = blockIdx.x, i = threadIdx.x;
-    if (j >= N) return;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int Mp = (M + 31) & ~31, nz = 256 / Mp;
+    const int i = tid % Mp, zp = tid / Mp;
     double s = 0.0;
-    if (i < M) {
+    if (i < M && zp < nz) {
         const double* p = slabs + (size_t) j * lds + i;
-        for (int z = 0; z < nslab; ++z) s += p[(size_t) z * slab_stride];
-    }
-    if (Tm) {
-        col[i] = s;
-        __syncthreads();
-        if (i < M) {
-            double t = 0.0;
-            for (int p = 0; p <= i; ++p) t += Tm[(size_t) i * ldt + p] * col[p];   // (T^T)(i,p) = T(p,i)
-            s = t;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int z = zp;
+        for (; z + 3 * nz < nslab; z += 4 * nz) {
+            s0 += p[(size_t) z * slab_stride];
+            s1 += p[(size_t) (z + nz) * slab_stride];
+            s2 += p[(size_t) (z + 2 * nz) * slab_stride];
+            s3 += p[(size_t) (z + 3 * nz) * slab_stride];
         }
+        for (; z < nslab; z += nz) s0 += p[(size_t) z * slab_stride];
+        s = (s0 + s1) + (s2 + s3);
     }
-    if (i < M) {
-        double* o = out + (size_t) j * ldo + i;
-        *o = (beta != 0.0) ? beta * (*o) + s : s;
+    red[tid] = s;
+    __syncthreads();
+    if (tid < Mp) {
+        double t = 0.0;
+        for (int g = 0; g < nz; ++g) t += red[g * Mp + tid];
+        col[tid] = t;
+    }
+    __syncthreads();
+    if (tid < M) {
+        double v = col[tid];
+        if (Tm) {
+            double t = 0.0;
+            for (int p2 = 0; p2 <= tid; ++p2) t += Tm[(size_t) tid * ldt + p2] * col[p2];   // (T^T)(i,p) = T(p,i)
+            v = t;
+        }
+        double* o = out + (size_t) j * ldo + tid;
+        *o = (beta != 0.0) ? beta * (*o) + v : v;
     }
 }
 
@@ -330,50 +346,6 @@ __global__ void slab_reduce_kernel(int M, int N, int nslab, const double* __rest
 //      and accumulates the dot products of column j+1;
 //   4. transposing wave butterfly (32 shuffles for 32 sums) + LDS across waves -> part_out[block][c].
 // ------------------------------------------------------------------------------------------------
-#define LEAFW 32
-
-// in: a[c], c < 32, per lane.  out (every lane): sum over the 64 lanes of a[lane >> 1].
-__device__ __forceinline__ double wave_reduce32(const double (&a)[LEAFW], int lane)
-{
-    double b16[16], b8[8], b4[4], b2[2];
-    {
-        const bool up = (lane & 32) != 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const double send = up ? a[q] : a[q + 16], keep = up ? a[q + 16] : a[q];
-            b16[q] = keep + __shfl_xor(send, 32);
-        }
-    }
-    {
-        const bool up = (lane & 16) != 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double send = up ? b16[q] : b16[q + 8], keep = up ? b16[q + 8] : b16[q];
-            b8[q] = keep + __shfl_xor(send, 16);
-        }
-    }
-    {
-        const bool up = (lane & 8) != 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double send = up ? b8[q] : b8[q + 4], keep = up ? b8[q + 4] : b8[q];
-            b4[q] = keep + __shfl_xor(send, 8);
-        }
-    }
-    {
-        const bool up = (lane & 4) != 0;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const double send = up ? b4[q] : b4[q + 2], keep = up ? b4[q + 2] : b4[q];
-            b2[q] = keep + __shfl_xor(send, 4);
-        }
-    }
-    const bool up = (lane & 2) != 0;
-    double v = (up ? b2[1] : b2[0]) + __shfl_xor(up ? b2[0] : b2[1], 2);
-    v += __shfl_xor(v, 1);
-    return v;
-}
-
 // J is a template parameter (-1 .. 31): with the column index known at compile time the row update is
 // straight-line code on exactly the live columns (no per-column predicate masks: the runtime-j version
 // of this kernel executed ~3000 instructions per wave, most of them selects and SGPR spill traffic, and
@@ -811,7 +783,7 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
     if (M <= 0 || N <= 0) return 0;
     if (Tm && M > 256) return -2;
     int ti, tj;
-    if (M <= 32) { ti = 1; tj = (N > 64) ? 4 : 1; }
+    if (M <= 32) { ti = 1; tj = (N >= 128 && N % 128 == 0) ? 4 : 1; }   // keep the FAST (unguarded) instantiation
     else if (M <= 64 || N <= 64) { ti = 2; tj = 2; }
     else { ti = 4; tj = 4; }
     const int BM = 32 * ti, BN = 32 * tj;
@@ -824,7 +796,7 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
     const size_t per = (size_t) M * N;
     if (slabs == nullptr || slab_cap < per) want = 1;
     else if ((size_t) want * per > slab_cap) want = (long long) (slab_cap / per);
-    if (want > 1024) want = 1024;
+    if (want > 256) want = 256;
     int ksplit = (int) want;
     int kchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (K + kchunk - 1) / kchunk;
@@ -841,8 +813,7 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
     else rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     if (rc) return rc;
     if (!direct) {
-        const int threads = (M + 63) / 64 * 64;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(N), dim3(threads), 0, s, M, N, ksplit, slabs, M, per, Tm, ldt,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(N), dim3(256), 0, s, M, N, ksplit, slabs, M, per, Tm, ldt,
                            beta, C, ldc);
         rc = (int) hipGetLastError();
     }
@@ -1012,6 +983,21 @@ int qrd_stream_create_cumask(void** s, int first, int count)
     return (int) e;
 }
 int qrd_stream_destroy(void* s) { return (int) hipStreamDestroy((hipStream_t) s); }
+// hipGraph capture of a whole factorisation (thousands of dependent launches replayed by one call)
+int qrd_capture_begin(void* s) { return (int) hipStreamBeginCapture((hipStream_t) s, hipStreamCaptureModeRelaxed); }
+int qrd_capture_end(void* s, void** exec)
+{
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t) s, &g);
+    if (e != hipSuccess) return (int) e;
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    *exec = (void*) x;
+    return (int) e;
+}
+int qrd_graph_launch(void* exec, void* s) { return (int) hipGraphLaunch((hipGraphExec_t) exec, (hipStream_t) s); }
+int qrd_graph_destroy(void* exec) { return exec ? (int) hipGraphExecDestroy((hipGraphExec_t) exec) : 0; }
 int qrd_stream_sync(void* s) { return (int) hipStreamSynchronize((hipStream_t) s); }
 int qrd_device_sync(void) { return (int) hipDeviceSynchronize(); }
 int qrd_event_create(void** e) { hipEvent_t ev; hipError_t r = hipEventCreate(&ev); *e = (void*) ev; return (int) r; }

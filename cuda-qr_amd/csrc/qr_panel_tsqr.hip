@@ -1,0 +1,505 @@
+// qr_panel_tsqr.hip -- leaf panel factorisation as an intra-GPU TSQR with Householder reconstruction.
+//
+// Replaces the reference's one-block serial panel kernel (panelHouseholderKernel, qr.cu:60-333; host loop
+// qr.c:109-235) for a leaf of w <= 32 columns over mk rows.  Instead of one grid-wide dependency per
+// Householder column (one kernel launch per column: 33 launches and ~49 passes over the leaf), the leaf is
+// cut into row blocks of <= 512 rows; each workgroup holds its block in registers (one row per thread) and
+// runs all w Householder columns with workgroup-local synchronisation only:
+//
+//   F  tsqr_factor_kernel   every block: local Householder QR -> R_b (w x w), local reflectors
+//      (repeated on the stacked R_b while the stack is taller than 512 rows)
+//   T  tsqr_top_kernel      one block: QR of the last stack -> R~, and its explicit Q applied to [I;0]
+//   A  tsqr_apply_kernel    down the tree: Q1_b = Q_local_b [C_b ; 0]  -> explicit Q1 (mk x w)
+//   H1 hr_top_kernel        Householder reconstruction (Ballard/Demmel/Grigori/Jacquelin/Nguyen/Solomonik):
+//                           sign matrix S, LU(Q1_top - S) = L1 U, T = -U S L1^-T, R = S R~, tau = diag(T)
+//   H2 hr_rows_kernel       V(w:mk, :) = Q1(w:mk, :) U^-1   (row-parallel)
+//
+// The result is an ordinary compact-WY panel (unit-lower V in place below R, tau, T), identical in form to what
+// the per-column kernels produce, so everything downstream is unchanged; I - V T V^T has first w columns Q1 S.
+// 5 launches (mk <= 8192), 7 (mk <= 131072), ~3 passes over the leaf.  mk <= 512: panel_single_kernel, 1 launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "qr_device.h"
+#include "qr_common.h"
+
+#define PW LEAFW          // max leaf width
+#define PT 512            // threads per workgroup = rows per block
+#define PWAVES (PT / 64)
+
+struct PanelShared {
+    double part[PWAVES][PW];
+    double row[PW];
+    double s[PW];
+    double tau[PW];
+    double scal[4];
+};
+
+// rows [start, start+rows) of block b: even split when chunk == 0 (level 1), fixed chunks otherwise
+__device__ __forceinline__ void block_range(int rows_total, int chunk, int b, int nb, int& start, int& rows)
+{
+    if (chunk > 0) {
+        start = b * chunk;
+        rows = min(chunk, rows_total - start);
+    } else {
+        start = (int) ((long long) b * rows_total / nb);
+        rows = (int) ((long long) (b + 1) * rows_total / nb) - start;
+    }
+}
+
+// One Householder column on a workgroup-resident block (row r of the block in x[], one row per thread).
+// Same arithmetic as leaf_step_kernel (dlarfg convention; tau = 0 for an exactly-zero tail; qr.c:144-167 for the
+// reference's form).  ZCAP: also record Z(c, J) = v_c^T v_J for c < J (needed only when T is built from Z).
+template <int J, bool ZCAP>
+__device__ __forceinline__ void house_step(double (&x)[PW], int r, int rows, int w, PanelShared& sh, double (*Z)[PW + 1],
+                                           int tid, int lane, int wave)
+{
+    if (J >= w) return;                              // wave-uniform
+    const bool below = (r > J) && (r < rows);
+    {
+        const double xj = below ? x[J] : 0.0;
+        double prod[PW];
+#pragma unroll
+        for (int c = 0; c < PW; ++c) prod[c] = xj * x[c];
+        if (tid == J) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c) sh.row[c] = x[c];
+        }
+        const double v = wave_reduce32(prod, lane);
+        if ((lane & 1) == 0) sh.part[wave][lane >> 1] = v;
+    }
+    __syncthreads();
+    if (tid < PW) {
+        double d = 0.0;
+#pragma unroll
+        for (int p = 0; p < PWAVES; ++p) d += sh.part[p][tid];
+        const double alpha = sh.row[J];
+        const double sigma = __shfl(d, J);
+        double t, b, iu;
+        if (sigma == 0.0) { t = 0.0; b = alpha; iu = 0.0; }
+        else {
+            const double nrm = sqrt(alpha * alpha + sigma);
+            b = -copysign(nrm, alpha);
+            t = (b - alpha) / b;
+            iu = 1.0 / (alpha - b);
+        }
+        const double sc = sh.row[tid] + d * iu;
+        sh.s[tid] = sc;
+        if (ZCAP && tid < J) Z[J][tid] = sc;
+        if (tid == 0) { sh.scal[0] = t; sh.scal[1] = b; sh.scal[2] = iu; sh.tau[J] = t; }
+    }
+    __syncthreads();
+    const double tj = sh.scal[0], beta = sh.scal[1], iu = sh.scal[2];
+    const bool diag = (r == J);
+    const double vi = below ? x[J] * iu : (diag ? 1.0 : 0.0);
+    const double coef = tj * vi;
+    x[J] = below ? vi : (diag ? beta : x[J]);
+#pragma unroll
+    for (int c = J + 1; c < PW; ++c) x[c] -= coef * sh.s[c];
+}
+
+template <int J, bool ZCAP>
+__device__ __forceinline__ void factor_all(double (&x)[PW], int r, int rows, int w, PanelShared& sh, double (*Z)[PW + 1],
+                                           int tid, int lane, int wave)
+{
+    house_step<J, ZCAP>(x, r, rows, w, sh, Z, tid, lane, wave);
+    if constexpr (J + 1 < PW) factor_all<J + 1, ZCAP>(x, r, rows, w, sh, Z, tid, lane, wave);
+}
+
+// T (w x w upper triangular, into Tl[PW][PW+1] in LDS) of the block's reflectors from the captured Gram
+// columns Z(q, j) = v_q^T v_j and tau:  T(0:j,j) = -tau_j T(0:j,0:j) Z(0:j,j).  Row p depends only on row p:
+// thread tid < PW computes row tid with no synchronisation.
+__device__ __forceinline__ void build_t_rows(double (*Tl)[PW + 1], double (*Z)[PW + 1], const PanelShared& sh, int w, int tid)
+{
+    if (tid < PW) {
+        double trow[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) trow[q] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < PW; ++jj) {
+            if (jj < w) {
+                const double tj = sh.tau[jj];
+                double sacc = 0.0;
+#pragma unroll
+                for (int q = 0; q < jj; ++q) sacc += trow[q] * Z[jj][q];
+                trow[jj] = (tid == jj) ? tj : ((tid < jj) ? -tj * sacc : 0.0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PW; ++q) Tl[tid][q] = (tid < w && q < w) ? trow[q] : 0.0;
+    }
+}
+
+// Compact-WY application of a block's Q to [Cin; 0]:  out(r,:) = Cin(r,:) - V(r,:) M,  M = T (V1^T Cin)
+// (V1 = unit-lower top w x w of the block).  No reductions over rows: M is w x w and every row is independent,
+// so the tree is walked down at GEMM speed instead of one workgroup-wide reduction per reflector.
+// Ml must hold V1^T Cin on entry in Wl... see callers; here: given M in LDS, compute this thread's row.
+__device__ __forceinline__ void wy_row(const double (&x)[PW], double (&out)[PW], int r, int w, double (*Ml)[PW + 1])
+{
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        if (k < w) {
+            const double vk = (k < r) ? x[k] : (k == r ? 1.0 : 0.0);
+#pragma unroll
+            for (int q = 0; q < PW; ++q) out[q] -= vk * Ml[k][q];
+        }
+        __builtin_amdgcn_sched_barrier(0);        // keep the 1024 LDS reads from being hoisted (VGPR blow-up)
+    }
+}
+
+// M = T (V1^T C) for one block without ever forming T:  T^-1 = striu(Z) + diag(1/tau)  (Z(i,k) = v_i^T v_k), so
+// M solves  T^-1 M = V1^T C  by back substitution; column q of M lives in the registers of thread q (no
+// synchronisation inside the solve).  tau_i = 0 (H_i = I) makes row i of T zero: M(i,:) = 0.
+// LDS operands: V1 (unit-lower top of the block), Cl (w x w input), Zl[k][i] = Z(i,k) for i < k, tl[i] = tau_i.
+__device__ __forceinline__ void small_m(double (*V1)[PW + 1], double (*Cl)[PW + 1], double (*Zl)[PW + 1], const double* tl,
+                                        double (*Wl)[PW + 1], double (*Ml)[PW + 1], int w, int tid)
+{
+    for (int e = tid; e < PW * PW; e += PT) {           // Wl = V1^T Cl   (V1 unit lower: V1(k, i) for k >= i)
+        const int i = e / PW, q = e % PW;
+        double acc = 0.0;
+        for (int k = i; k < w; ++k) acc += V1[k][i] * Cl[k][q];
+        Wl[i][q] = acc;
+    }
+    __syncthreads();
+    if (tid < PW) {
+        double mcol[PW];
+#pragma unroll
+        for (int i = PW - 1; i >= 0; --i) {
+            double acc = 0.0;
+            if (i < w) {
+                acc = Wl[i][tid];
+#pragma unroll
+                for (int k = i + 1; k < PW; ++k) acc -= Zl[k][i] * mcol[k];      // Zl[k][i] = 0 for k >= w
+                acc *= tl[i];                                                     // (1/tau_i)^-1; 0 when tau_i = 0
+            }
+            mcol[i] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) Ml[i][tid] = mcol[i];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_block(double (&x)[PW], const double* __restrict__ src, int ld, int start, int r,
+                                           int rows, int w)
+{
+    const double* p = src + start + min(r, rows - 1);
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+        const double v = (c < w) ? p[(size_t) c * ld] : 0.0;     // c < w is wave-uniform; the row index is clamped
+        x[c] = (r < rows) ? v : 0.0;
+    }
+}
+
+// F: local QR of every block of `src` (rows_total x w).  Leaves the factored block (R on top, reflector tails
+// below) in Vloc, its tau in tauloc[b*PW..], the Gram entries Z(i,k) = v_i^T v_k (the strict upper triangle of T^-1)
+// in Tloc[b*PW*PW + k*PW + i], and its R (w x w, zeros below the diagonal) in rows [b*w, b*w+w) of Rstack.
+__global__ __launch_bounds__(PT) void tsqr_factor_kernel(const double* __restrict__ src, int lds, int rows_total, int chunk,
+                                                         int w, double* __restrict__ Vloc, int ldv,
+                                                         double* __restrict__ tauloc, double* __restrict__ Tloc,
+                                                         double* __restrict__ Rstack, int ldr)
+{
+    __shared__ PanelShared sh;
+    __shared__ double Z[PW][PW + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    int start, rows;
+    block_range(rows_total, chunk, b, gridDim.x, start, rows);
+    double x[PW];
+    load_block(x, src, lds, start, tid, rows, w);
+    factor_all<0, true>(x, tid, rows, w, sh, Z, tid, lane, wave);
+    __syncthreads();
+    if (tid < rows) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+            if (c < w) Vloc[(size_t) c * ldv + start + tid] = x[c];
+    }
+    if (tid < w) {
+        tauloc[b * PW + tid] = sh.tau[tid];
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+            if (c < w) Rstack[(size_t) c * ldr + b * w + tid] = (c >= tid && tid < rows) ? x[c] : 0.0;
+    }
+    for (int e = tid; e < PW * PW; e += PT) {           // Zloc[b][k][i] = Z(i, k) = v_i^T v_k (i < k < w), else 0
+        const int i = e % PW, k = e / PW;
+        Tloc[(size_t) b * PW * PW + e] = (i < k && k < w) ? Z[k][i] : 0.0;
+    }
+}
+
+// T: the last stack (rows <= 512): R~ -> Rt (ld PW), explicit Q_top [I;0] -> Cout (rows x w) in compact-WY form:
+// Q_top [I;0] = [I;0] - V (T V1^T)
+__global__ __launch_bounds__(PT) void tsqr_top_kernel(const double* __restrict__ stack, int lds, int rows, int w,
+                                                      double* __restrict__ Rt, double* __restrict__ Cout, int ldc)
+{
+    __shared__ PanelShared sh;
+    __shared__ double Z[PW][PW + 1];
+    __shared__ double V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
+    __shared__ double tl[PW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double x[PW];
+    load_block(x, stack, lds, 0, tid, rows, w);
+    factor_all<0, true>(x, tid, rows, w, sh, Z, tid, lane, wave);
+    __syncthreads();
+    if (tid < PW) {
+        tl[tid] = (tid < w) ? sh.tau[tid] : 0.0;
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+            if (tid < w && c < w) Rt[c * PW + tid] = (c >= tid) ? x[c] : 0.0;
+            V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[c] : (c == tid ? 1.0 : 0.0)) : 0.0;
+            Cl[tid][c] = (tid == c && tid < w) ? 1.0 : 0.0;
+            if (!(c < tid && tid < w)) Z[tid][c] = 0.0;          // keep only Z(k = tid, i = c < k)
+        }
+    }
+    __syncthreads();
+    small_m(V1, Cl, Z, tl, Wl, Ml, w, tid);
+    double out[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q) out[q] = (tid == q && tid < w) ? 1.0 : 0.0;
+    wy_row(x, out, tid, w, Ml);
+    if (tid < rows) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q)
+            if (q < w) Cout[(size_t) q * ldc + tid] = out[q];
+    }
+}
+
+// A: Cout(block rows, :) = Q_local_b [Cin_b ; 0] = [Cin_b; 0] - V_b (T_b V_b1^T Cin_b),
+// Cin_b = rows [b*w, b*w+w) of the parent's output
+__global__ __launch_bounds__(PT) void tsqr_apply_kernel(const double* __restrict__ Vloc, int ldv,
+                                                        const double* __restrict__ tauloc,
+                                                        const double* __restrict__ Tloc, int rows_total, int chunk, int w,
+                                                        const double* __restrict__ Cin, int ldci,
+                                                        double* __restrict__ Cout, int ldco)
+{
+    __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
+    __shared__ double tl[PW];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    int start, rows;
+    block_range(rows_total, chunk, b, gridDim.x, start, rows);
+    double x[PW];
+    load_block(x, Vloc, ldv, start, tid, rows, w);
+    for (int e = tid; e < PW * PW; e += PT) {
+        const int i = e % PW, c = e / PW;
+        Zl[c][i] = Tloc[(size_t) b * PW * PW + e];                           // Zl[k][i] = Z(i, k)
+        Cl[i][c] = (i < w && c < w) ? Cin[(size_t) c * ldci + b * w + i] : 0.0;
+    }
+    if (tid < PW) {
+        tl[tid] = (tid < w) ? tauloc[b * PW + tid] : 0.0;
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+            V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[c] : (c == tid ? 1.0 : 0.0)) : 0.0;
+    }
+    __syncthreads();
+    small_m(V1, Cl, Zl, tl, Wl, Ml, w, tid);
+    double out[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q) out[q] = (tid < w) ? Cl[min(tid, PW - 1)][q] : 0.0;
+    wy_row(x, out, tid, w, Ml);
+    if (tid < rows) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q)
+            if (q < w) Cout[(size_t) q * ldco + start + tid] = out[q];
+    }
+}
+
+// H1: Householder reconstruction on the top w x w block of Q1.  One 1024-thread workgroup, thread (r, c) owns
+// element (r, c); both phases are right-looking with one barrier per step (ping-pong broadcast rows in LDS):
+//   modified LU without pivoting:  S_j = -sign(pivot), pivot -= S_j (|pivot| >= 1 afterwards),  Q1_top - S = L1 U
+//   T = -U S L1^-T  as the forward substitution  L1 X = -S U^T,  X = T^T
+// Outputs: R = S R~ and L1 into the top of the panel, tau = diag(T), T, the unit-lower top of Vw, and
+// Umat = U^-1 (w x w upper triangular, ld PW) for hr_rows_kernel.
+__global__ __launch_bounds__(1024) void hr_top_kernel(const double* __restrict__ Q1, int ldq, const double* __restrict__ Rt,
+                                                      int w, double* __restrict__ A, int lda, double* __restrict__ tau,
+                                                      double* __restrict__ T, int ldt, double* __restrict__ Vw, int ldv,
+                                                      double* __restrict__ Umat)
+{
+    __shared__ double Bs[PW][PW + 1];
+    __shared__ double rowb[2][PW], colb[2][PW];
+    __shared__ double Ss[PW];
+    const int r = threadIdx.x & (PW - 1), c = threadIdx.x >> 5;
+    const bool act = (r < w) && (c < w);
+    double b = act ? Q1[(size_t) c * ldq + r] : 0.0;
+    for (int j = 0; j < w; ++j) {
+        const int pp = j & 1;
+        if (r == j) rowb[pp][c] = b;            // row j (U row incl. the pivot before its shift)
+        if (c == j) colb[pp][r] = b;            // column j
+        __syncthreads();
+        const double p = rowb[pp][j];
+        const double S = (p >= 0.0) ? -1.0 : 1.0;
+        const double piv = p - S;
+        if (r > j && act) {
+            const double l = colb[pp][r] / piv;
+            if (c == j) b = l;
+            else if (c > j) b -= l * rowb[pp][c];
+        } else if (r == j && c == j) {
+            b = piv;
+            Ss[j] = S;
+        }
+    }
+    Bs[r][c] = b;
+    __syncthreads();
+    // X = T^T (lower triangular): L1 X = -S U^T
+    double x = (act && c <= r) ? -Ss[r] * Bs[c][r] : 0.0;
+    for (int k = 0; k < w; ++k) {
+        const int pp = k & 1;
+        if (r == k) rowb[pp][c] = x;            // row k of X is final
+        __syncthreads();
+        if (r > k && act) x -= Bs[r][k] * rowb[pp][c];
+    }
+    // Uinv = U^-1 (upper triangular) by right-looking back substitution: row k final, then eliminate it from rows < k
+    double ui = (act && r == c) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int k = w - 1; k >= 0; --k) {
+        const int pp = k & 1;
+        if (r == k) { ui /= Bs[k][k]; rowb[pp][c] = ui; }
+        __syncthreads();
+        if (r < k && act) ui -= Bs[r][k] * rowb[pp][c];
+    }
+    if (!act) return;
+    T[(size_t) r * ldt + c] = x;                                           // T(c, r) = X(r, c)
+    A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * Rt[c * PW + r] : b;
+    Vw[(size_t) c * ldv + r] = (c < r) ? b : (c == r ? 1.0 : 0.0);
+    Umat[c * PW + r] = (c >= r) ? ui : 0.0;                                // Umat := U^-1 (w x w, ld PW)
+    if (c == r) tau[r] = x;
+}
+
+// H2: V(r, :) = Q1(r, :) U^-1 for rows r >= w (thread per row), U^-1 broadcast from LDS: a 32 x 32 product per
+// row with no dependency between the output columns.
+__global__ __launch_bounds__(256) void hr_rows_kernel(const double* __restrict__ Q1, int ldq, const double* __restrict__ Umat,
+                                                      int mk, int w, double* __restrict__ A, int lda,
+                                                      double* __restrict__ Vw, int ldv)
+{
+    __shared__ double Ui[PW][PW + 1];        // Ui[k][c] = Uinv(k, c)
+    const int r = w + blockIdx.x * 256 + threadIdx.x;
+    double q[PW], y[PW];
+    {
+        const double* p = Q1 + min(r, mk - 1);
+#pragma unroll
+        for (int c = 0; c < PW; ++c) { q[c] = (c < w) ? p[(size_t) c * ldq] : 0.0; y[c] = 0.0; }
+    }
+    for (int e = threadIdx.x; e < PW * PW; e += 256) {
+        const int k = e % PW, c = e / PW;
+        Ui[k][c] = (k <= c && c < w) ? Umat[c * PW + k] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        if (k < w) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c) y[c] += q[k] * Ui[k][c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (r < mk) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+            if (c < w) { A[(size_t) c * lda + r] = y[c]; Vw[(size_t) c * ldv + r] = y[c]; }
+    }
+}
+
+// mk <= 512: the whole leaf in one workgroup -- V, R, tau and T in a single launch.
+__global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P, int ld, int mk, int w,
+                                                          double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                          double* __restrict__ Vw, int ldv)
+{
+    __shared__ PanelShared sh;
+    __shared__ double Z[PW][PW + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double x[PW];
+    load_block(x, P, ld, 0, tid, mk, w);
+    factor_all<0, true>(x, tid, mk, w, sh, Z, tid, lane, wave);
+    __syncthreads();
+    if (tid < mk) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+            if (c < w) {
+                P[(size_t) c * ld + tid] = x[c];
+                Vw[(size_t) c * ldv + tid] = (tid > c) ? x[c] : (tid == c ? 1.0 : 0.0);
+            }
+    }
+    __shared__ double Tl[PW][PW + 1];
+    build_t_rows(Tl, Z, sh, w, tid);
+    if (tid < w) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q)
+            if (q < w) T[(size_t) q * ldt + tid] = Tl[tid][q];
+        tau[tid] = sh.tau[tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+// workspace (doubles) for leaves of up to m rows
+size_t qrd_panel_ws_size(int m)
+{
+    const size_t nblk1 = (size_t) (m + PT - 1) / PT;
+    const size_t up = 2 * nblk1 * PW + 4 * PT;                 // all upper-level stacks together (geometric)
+    return 2 * (size_t) m * PW      /* Vloc1, Q1 */
+         + 3 * up * PW              /* stacks, upper Vloc, upper C */
+         + (nblk1 + up / PW + 64) * (PW + PW * PW)   /* tau and T per block, all levels */
+         + 2 * PW * PW + PW + 64;   /* Rt, Umat + reciprocal diagonal */
+}
+
+int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                   double* ws, int m_cap)
+{
+    hipStream_t s = (hipStream_t) stream;
+    if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
+    if (mk <= PT) {
+        hipLaunchKernelGGL(panel_single_kernel, dim3(1), dim3(PT), 0, s, P, ld, mk, w, tau, T, ldt, Vw, ldv);
+        return (int) hipGetLastError();
+    }
+    // carve the workspace
+    const size_t nblk1cap = (size_t) (m_cap + PT - 1) / PT;
+    const size_t up = 2 * nblk1cap * PW + 4 * PT;
+    double* Vloc1 = ws;                        // ld = mk
+    double* Q1 = Vloc1 + (size_t) m_cap * PW;  // ld = mk
+    double* stacks = Q1 + (size_t) m_cap * PW;
+    double* Vup = stacks + up * PW;
+    double* Cup = Vup + up * PW;
+    double* taus = Cup + up * PW;
+    double* Ts = taus + (nblk1cap + up / PW + 64) * PW;
+    double* Rt = Ts + (nblk1cap + up / PW + 64) * PW * PW;
+    double* Umat = Rt + PW * PW;
+
+    // ---- up the tree
+    const int MAXL = 8;
+    int lv_rows[MAXL], lv_nblk[MAXL], lv_chunk[MAXL];
+    size_t lv_off[MAXL], lv_tau[MAXL];        // offsets of level l's input stack / Vloc / C (l >= 1) and tau
+    int L = 0;
+    lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + PT - 1) / PT; lv_off[0] = 0; lv_tau[0] = 0;
+    size_t off = 0, toff = (size_t) lv_nblk[0] * PW;
+    hipLaunchKernelGGL(tsqr_factor_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, P, ld, mk, 0, w, Vloc1, mk, taus, Ts,
+                       stacks, lv_nblk[0] * w);
+    int cur_rows = lv_nblk[0] * w;
+    const int gchunk = (PT / w) * w;
+    while (cur_rows > PT) {
+        if (L + 2 >= MAXL) return -6;
+        ++L;
+        lv_rows[L] = cur_rows; lv_chunk[L] = gchunk; lv_nblk[L] = (cur_rows + gchunk - 1) / gchunk;
+        lv_off[L] = off; lv_tau[L] = toff;
+        const size_t next_off = off + (size_t) cur_rows * PW;
+        hipLaunchKernelGGL(tsqr_factor_kernel, dim3(lv_nblk[L]), dim3(PT), 0, s, stacks + off, cur_rows, cur_rows, gchunk, w,
+                           Vup + off, cur_rows, taus + toff, Ts + toff * PW, stacks + next_off, lv_nblk[L] * w);
+        off = next_off; toff += (size_t) lv_nblk[L] * PW;
+        cur_rows = lv_nblk[L] * w;
+    }
+    // ---- top: factor + explicit Q of the last stack; its output is the coefficient input of the level below
+    hipLaunchKernelGGL(tsqr_top_kernel, dim3(1), dim3(PT), 0, s, stacks + off, cur_rows, cur_rows, w, Rt, Cup + off, cur_rows);
+    // ---- down the tree
+    const double* Cin = Cup + off;
+    int ldci = cur_rows;
+    for (int l = L; l >= 1; --l) {
+        hipLaunchKernelGGL(tsqr_apply_kernel, dim3(lv_nblk[l]), dim3(PT), 0, s, Vup + lv_off[l], lv_rows[l], taus + lv_tau[l], Ts + lv_tau[l] * PW,
+                           lv_rows[l], lv_chunk[l], w, Cin, ldci, Cup + lv_off[l], lv_rows[l]);
+        Cin = Cup + lv_off[l];
+        ldci = lv_rows[l];
+    }
+    hipLaunchKernelGGL(tsqr_apply_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, 0, w, Cin, ldci, Q1, mk);
+    // ---- Householder reconstruction
+    hipLaunchKernelGGL(hr_top_kernel, dim3(1), dim3(1024), 0, s, Q1, mk, Rt, w, P, ld, tau, T, ldt, Vw, ldv, Umat);
+    hipLaunchKernelGGL(hr_rows_kernel, dim3((mk - w + 255) / 256), dim3(256), 0, s, Q1, mk, Umat, mk, w, P, ld, Vw, ldv);
+    return (int) hipGetLastError();
+}
+
+}   // extern "C"

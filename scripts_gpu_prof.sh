@@ -1,12 +1,7 @@
 #!/bin/bash
-R=gpurun_out/pmc_try
-mkdir -p $R
+mkdir -p gpurun_out/prof5
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for sz in 4096 8192 16384; do
-  MI355XQR_PANEL_CUS=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/d$sz -o pmc -- python3 tools_pmc_driver.py $sz 128 > $R/d$sz.log 2>&1
-  echo "driver $sz rc=$? sigsegv=$(grep -c SIGSEGV $R/d$sz.log) $(grep -c . $R/d$sz/pmc_counter_collection.csv 2>/dev/null)"
-  f=$R/d$sz/pmc_counter_collection.csv
-  [ -f $f ] && python3 tools_pmc_summary.py $f FETCH_SIZE | head -8
-  rm -f $f
-done
+MI355XQR_PANEL=tsqr rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof5 -o p -- python3 tools_perf.py 262144x512x128 > gpurun_out/prof5/run.log 2>&1
+python3 tools_trace_summary.py gpurun_out/prof5/p_kernel_trace.csv | sed 's/void //' | head -24
+rm -f gpurun_out/prof5/p_kernel_trace.csv

@@ -143,6 +143,64 @@ def test_leaf_panel(q, oracle, mk, w):
     assert np.abs(QtP[w:]).max(initial=0.0) < 1e-12 * np.sqrt(mk)
 
 
+TSQR_SHAPES = [(32, 32), (33, 32), (512, 32), (513, 32), (1000, 32), (4096, 32), (8192, 32), (8193, 32), (16384, 32),
+               (70000, 32), (200000, 32), (262144, 16), (300, 7), (5, 5), (2, 1), (600, 1), (5000, 24), (20000, 8)]
+
+
+@pytest.mark.parametrize("mk,w", TSQR_SHAPES)
+def test_panel_tsqr_householder_reconstruction(q, oracle, mk, w):
+    """Leaf panel by intra-GPU TSQR + Householder reconstruction: the output must be an ordinary compact-WY
+    panel -- unit-lower V in place below R, tau = diag(T) = 2/(v^T v), T upper triangular with
+    (I - V T V^T)^T P = [R; 0] -- and R must equal LAPACK's up to row signs."""
+    rng = np.random.default_rng(mk * 3 + w)
+    P = rng.random((mk, w))
+    ld, ldv, ldt = mk + 6, mk + 2, w + 3
+    buf = np.full((ld, w), 7.0); buf[:mk] = P
+    dP = dev(buf)
+    dtau, dT, dV = zeros(w, 1), dev(np.full((ldt, w), np.nan)), dev(np.full((ldv, w), np.nan))
+    ws = torch.zeros(int(q.lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_panel_tsqr(None, dP.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), ldt, dV.data_ptr(),
+                                 ldv, ws.data_ptr(), mk))
+    _sync(q)
+    out, tau, T, V = host(dP), host(dtau)[:, 0], host(dT)[:w], host(dV)[:mk]
+    assert np.array_equal(out[mk:], buf[mk:])                                   # padding rows untouched
+    assert np.isfinite(out).all() and np.isfinite(T).all() and np.isfinite(V).all()
+    R = np.triu(out[:w])
+    assert np.array_equal(np.triu(V[:w], 1), np.zeros((w, w))) and np.array_equal(np.diag(V[:w]), np.ones(w))
+    assert np.array_equal(np.tril(V, -1), np.tril(out[:mk], -1)), "explicit V and in-place tails must agree"
+    assert np.abs(np.tril(T, -1)).max(initial=0.0) == 0.0
+    assert np.abs(np.diag(T) - tau).max() == 0.0
+    vv = (V * V).sum(axis=0)
+    live = vv > 1.0                    # an empty tail (last column of a square block) gives tau = 0, H = I
+    assert np.abs(tau[live] - 2.0 / vv[live]).max(initial=0.0) < 1e-12 and np.all(tau[~live] == 0.0)
+    QtP = P - V @ (T.T @ (V.T @ P))
+    tol = 2e-13 * np.sqrt(mk) * max(1.0, np.abs(R).max())
+    assert np.abs(QtP[:w] - R).max() < tol and np.abs(QtP[w:]).max(initial=0.0) < tol
+    ref = oracle.sign_normalise(np.linalg.qr(P, mode="r"))
+    assert np.linalg.norm(oracle.sign_normalise(R) - ref) / np.linalg.norm(ref) < 1e-13 * max(1.0, np.sqrt(mk) / 30)
+    if mk <= 4096:
+        H = np.eye(mk) - V @ T @ V.T
+        assert np.abs(H.T @ H - np.eye(mk)).max() < 1e-12
+
+
+def test_panel_tsqr_zero_and_dependent_columns(q):
+    mk, w = 3000, 16
+    P = np.random.default_rng(1).random((mk, w))
+    P[:, 3] = 0.0
+    P[:, 9] = P[:, 2]
+    dP, dtau, dT, dV = dev(P), zeros(w, 1), zeros(w, w), zeros(mk, w)
+    ws = torch.zeros(int(q.lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_panel_tsqr(None, dP.data_ptr(), mk, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), mk,
+                                 ws.data_ptr(), mk))
+    _sync(q)
+    out, T, V = host(dP), host(dT), host(dV)
+    assert np.isfinite(out).all() and np.isfinite(T).all()
+    QtP = P - V @ (T.T @ (V.T @ P))
+    assert np.abs(np.tril(QtP, -1)).max() < 1e-11 and np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-11
+
+
 def test_leaf_panel_zero_column_gives_tau_zero(q):
     """Deviation from the reference stated in include/mi355x_qr.h: zero tail -> tau = 0 (reference: NaN)."""
     mk, w = 300, 8

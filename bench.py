@@ -101,7 +101,7 @@ def main():
     if wl == "c2":
         m_local, n, nb, desc = 4096, 4096, args.nb or 64, "C2: 4096x4096 square fp64 QR, block size 64"
     elif wl == "c3":
-        m_local, n, nb = 16384, 16384, args.nb or 128
+        m_local, n, nb = 16384, 16384, args.nb or 256
         desc = f"C3: 16384x16384 square fp64 QR on 1 MI355X, nb={nb}"
     elif wl == "c4":
         m_local, n, nb = 262144 // world, 256, args.nb or 128
@@ -179,26 +179,50 @@ def main():
 
     # ---- roofline of the dominant kernel
     upd, tn, pan = prof["update_nn"], prof["vta_tn"], prof["panel"]
+    measured = None
+    if rank == 0:
+        try:
+            measured = qr.probe_mfma_f64_tflops()       # sustained v_mfma_f64_16x16x4_f64 issue rate of THIS device
+        except Exception:
+            measured = None
+    traffic = None
+    try:                                                 # PMC pass of the same kernels/shapes, see profiles/README.md
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except Exception:
+        tj = None
     if wl in ("c2", "c3") and upd["launches"]:
         ach = upd["flops"] / (upd["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nn_kernel<4,4,true> (trailing update A2 -= V*W)",
+        if tj and wl == "c3" and nb == 256:
+            traffic = tj["gemm_nn_kernel<4,4,true>"]["hbm_bytes_per_launch"]
+        roof = {"bound": "mfma",
+                "kernel": "gemm_nn_kernel<4, 4, true, 1> (trailing update A2 -= V*W, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_note": ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction) from a separate "
+                                 "rocprofv3 --pmc pass of the same kernel at every 8th C3 step, profiles/r01_pmc_traffic.json"
+                                 if traffic else None),
+                "peak_source": "AMD MI355X datasheet fp64 matrix 78.6 TFLOP/s (MI355X_MICROARCH.md has no fp64 MFMA row)",
+                "measured_mfma_f64_issue_limit_tflops": measured["mfma_f64_tflops"] if measured else None,
+                "frac_of_measured_issue_limit": ach / measured["mfma_f64_tflops"] if measured else None,
+                "measured_probe": measured,
                 "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],
                 "algorithmic_flops_per_launch": upd["flops"] / upd["launches"],
-                "companion_tn": {"kernel": "gemm_tn_kernel<4,4,true> + slab_reduce (W = (V T)^T A2)",
+                "algorithmic_bytes_per_launch": upd["bytes"] / upd["launches"],
+                "companion_tn": {"kernel": "gemm_tn_kernel<4, 4, true, 1> + slab_reduce_kernel (W = (V T)^T A2)",
                                  "achieved": tn["flops"] / (tn["ms"] * 1e-3) / 1e12 if tn["ms"] else None,
                                  "launches": tn["launches"]},
                 "panel_ms_per_step": pan["ms"] / K}
     else:
-        # tall-skinny: the panel (leaf Householder kernels + in-panel updates) is the dominant cost and is
-        # bounded by HBM traffic: compulsory bytes = 16 * mk * w per panel (read + write once)
+        # tall-skinny: the panel (TSQR leaf kernels + in-panel updates) is the dominant cost; its compulsory HBM
+        # traffic is 16 * mk * w bytes per panel (read + write once)
         ach = pan["bytes"] / (pan["ms"] * 1e-3) / 1e9 if pan["ms"] else 0.0
-        roof = {"bound": "hbm", "kernel": "leaf_step_kernel<J> chain + in-panel gemm_tn/gemm_nn (panel factorisation)",
+        roof = {"bound": "hbm", "kernel": "panel factorisation (tsqr_factor/top/apply/final + hr_top kernels, in-panel gemm_tn/gemm_nn)",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": None, "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),
                 "algorithmic_bytes_per_launch": pan["bytes"] / max(pan["launches"], 1),
-                "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None}
+                "note": "the panel is latency/instruction-bound, far from the HBM roof (DESIGN.md section 3.1)",
+                "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None,
+                "measured_probe": measured}
 
     line = None
     if rank == 0:

@@ -14,6 +14,10 @@ int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A
 int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                 int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
                 int ldt);
+int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                       int ldb, double beta, double* C, int ldc);
+int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                       int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap);
 int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
                    int ldv, double* scratch);
 size_t qrd_panel_ws_size(int m);

@@ -160,7 +160,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     if (!rc) rc = qrd_malloc((void**) &p->leaf_scratch, sizeof(double) * QRD_LEAF_SCRATCH);
     {
         const char* pa = getenv("MI355XQR_PANEL");
-        p->panel_tsqr = !pa ? 2 : (strcmp(pa, "col") == 0 ? 0 : (strcmp(pa, "tsqr") == 0 ? 1 : 2));
+        p->panel_tsqr = !pa ? 1 : (strcmp(pa, "col") == 0 ? 0 : (strcmp(pa, "tsqr") == 0 ? 1 : 2));
         const char* tm = getenv("MI355XQR_TSQR_MIN_ROWS");
         p->tsqr_min_rows = tm ? atoi(tm) : 100000;
     }
@@ -311,8 +311,9 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
         double* P = Ak + (size_t) c * lda + c;
         double* Vl = p->Vw + (size_t) c * ldv + c;
         double* Tl = p->T + (size_t) c * ldt + c;
-        /* leaf algorithm: the TSQR + Householder-reconstruction leaf reads the leaf ~3 times whatever its
-         * height, the one-launch-per-column leaf ~25 times: measured crossover is around 10^5 rows */
+        /* leaf algorithm (MI355XQR_PANEL = tsqr [default] | col | auto): the TSQR + Householder-reconstruction leaf
+         * reads the leaf twice whatever its height and needs 4-6 launches; the one-launch-per-column leaf needs 34
+         * launches and ~25 passes */
         if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
             CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
         else
@@ -344,10 +345,16 @@ static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int
     double* A2 = dA + (size_t) c0 * lda + k;
     const int ldv = p->ldv;
     if (profile) CHECK(prof_begin_on(p, 1, stream));
-    CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap, NULL, 0));
+    if (profile && wout >= 128 && nc >= 128)   /* the wide update: same kernels under their own profiler names */
+        CHECK(qrd_gemm_tn_update(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap));
+    else
+        CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap, NULL, 0));
     if (profile) CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 8.0 * mk * ((double) nc + wout)));
     if (profile) CHECK(prof_begin_on(p, 0, stream));
-    CHECK(qrd_gemm_nn(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
+    if (profile && wout >= 128 && nc >= 128)
+        CHECK(qrd_gemm_nn_update(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
+    else
+        CHECK(qrd_gemm_nn(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
     if (profile) CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 16.0 * mk * (double) nc + 8.0 * mk * wout));
     return 0;
 }

@@ -200,7 +200,8 @@ __device__ __forceinline__ void gemm_epilogue(const v4d (&acc)[TJ][TI], double* 
 
 // C = beta*C + alpha*A*B     A: M x K (lda), B: K x N (ldb), C: M x N (ldc), all column-major.
 // Used for: trailing update A2 -= V*W (K = nb), VT = V*T, T merges, Q*R products, Q_local*Q_tree.
-template <int TI, int TJ, bool FAST>
+// TAG only gives the wide trailing-update launches their own kernel name in profiler output (TAG = 1).
+template <int TI, int TJ, bool FAST, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, double alpha,
                                                          const double* __restrict__ A, int lda,
                                                          const double* __restrict__ B, int ldb,
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, do
 // K is the long dimension (panel height): gridDim.z K-slices each write their own slab
 // (slab z at C + z*slab_stride, ld = ldc) and slab_reduce_kernel sums them in a fixed order
 // (deterministic; no float atomics).  Used for W = (V T)^T A2, Gram = V^T V, Q^T Q.
-template <int TI, int TJ, bool FAST>
+template <int TI, int TJ, bool FAST, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, int kchunk, double alpha,
                                                          const double* __restrict__ A, int lda,
                                                          const double* __restrict__ B, int ldb,
@@ -293,11 +294,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int M, int N, int nsla
     __shared__ double red[256];
     __shared__ double col[256];
     const int j = blockIdx.x, tid = threadIdx.x;
-    const int Mp = (M + 31) & ~31, nz = 256 / Mp;
+    // rows [i0, i0 + Mc) of the column: one 256-row chunk per blockIdx.y when M > 256 (then nz = 1, no Tm)
+    const int i0 = blockIdx.y * 256, Mc = min(256, M - i0);
+    const int Mp = (Mc + 31) & ~31, nz = 256 / Mp;
     const int i = tid % Mp, zp = tid / Mp;
     double s = 0.0;
-    if (i < M && zp < nz) {
-        const double* p = slabs + (size_t) j * lds + i;
+    if (i < Mc && zp < nz) {
+        const double* p = slabs + (size_t) j * lds + i0 + i;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int z = zp;
         for (; z + 3 * nz < nslab; z += 4 * nz) {
@@ -317,14 +320,14 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int M, int N, int nsla
         col[tid] = t;
     }
     __syncthreads();
-    if (tid < M) {
+    if (tid < Mc) {
         double v = col[tid];
         if (Tm) {
             double t = 0.0;
             for (int p2 = 0; p2 <= tid; ++p2) t += Tm[(size_t) tid * ldt + p2] * col[p2];   // (T^T)(i,p) = T(p,i)
             v = t;
         }
-        double* o = out + (size_t) j * ldo + tid;
+        double* o = out + (size_t) j * ldo + i0 + tid;
         *o = (beta != 0.0) ? beta * (*o) + v : v;
     }
 }
@@ -671,7 +674,7 @@ static inline int vec_ok(const void* p, int ld) { return (((uintptr_t) p) % 16 =
 // Launch helpers.  The FAST instantiation runs on the largest tile-aligned interior of the problem; the
 // ragged right / bottom strips (and everything, when operands are not 16-byte aligned or K % 16 != 0)
 // go to the guarded instantiation as separate launches.
-template <int TI, int TJ, bool FAST>
+template <int TI, int TJ, bool FAST, int TAG = 0>
 static int launch_nn1(hipStream_t s, int M, int N, int K, double alpha, const double* A, int lda,
                       const double* B, int ldb, double beta, double* C, int ldc)
 {
@@ -679,12 +682,12 @@ static int launch_nn1(hipStream_t s, int M, int N, int K, double alpha, const do
     if (M <= 0 || N <= 0) return 0;
     const size_t shm = sizeof(double) * (2 * BK * (BM + 16) + 2 * BN * LDKF);
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_nn_kernel<TI, TJ, FAST>), grid, dim3(256), shm, s, M, N, K, alpha, A, lda, B, ldb, beta,
+    hipLaunchKernelGGL((gemm_nn_kernel<TI, TJ, FAST, TAG>), grid, dim3(256), shm, s, M, N, K, alpha, A, lda, B, ldb, beta,
                        C, ldc);
     return (int) hipGetLastError();
 }
 
-template <int TI, int TJ>
+template <int TI, int TJ, int TAG = 0>
 static int launch_nn(hipStream_t s, int M, int N, int K, double alpha, const double* A, int lda,
                      const double* B, int ldb, double beta, double* C, int ldc)
 {
@@ -692,7 +695,7 @@ static int launch_nn(hipStream_t s, int M, int N, int K, double alpha, const dou
     const bool al = vec_ok(A, lda) && vec_ok(B, ldb) && (K % BK) == 0;
     const int Mi = al ? (M / BM) * BM : 0, Ni = al ? (N / BN) * BN : 0;
     if (!(Mi > 0 && Ni > 0)) return launch_nn1<TI, TJ, false>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-    int rc = launch_nn1<TI, TJ, true>(s, Mi, Ni, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    int rc = launch_nn1<TI, TJ, true, TAG>(s, Mi, Ni, K, alpha, A, lda, B, ldb, beta, C, ldc);
     if (!rc && Ni < N)      /* right strip: all rows, columns [Ni, N) */
         rc = launch_nn1<TI, TJ, false>(s, M, N - Ni, K, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta,
                                        C + (size_t) Ni * ldc, ldc);
@@ -701,7 +704,7 @@ static int launch_nn(hipStream_t s, int M, int N, int K, double alpha, const dou
     return rc;
 }
 
-template <int TI, int TJ, bool FAST>
+template <int TI, int TJ, bool FAST, int TAG = 0>
 static int launch_tn1(hipStream_t s, int M, int N, int K, int ksplit, int kchunk, double alpha, const double* A,
                       int lda, const double* B, int ldb, double beta, double* C, int ldc, size_t slab_stride)
 {
@@ -709,12 +712,12 @@ static int launch_tn1(hipStream_t s, int M, int N, int K, int ksplit, int kchunk
     if (M <= 0 || N <= 0) return 0;
     const size_t shm = sizeof(double) * (2 * BM * LDKF + 2 * BN * LDKF);
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, ksplit);
-    hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, FAST>), grid, dim3(256), shm, s, M, N, K, kchunk, alpha, A, lda, B, ldb,
+    hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, FAST, TAG>), grid, dim3(256), shm, s, M, N, K, kchunk, alpha, A, lda, B, ldb,
                        beta, C, ldc, slab_stride);
     return (int) hipGetLastError();
 }
 
-template <int TI, int TJ>
+template <int TI, int TJ, int TAG = 0>
 static int launch_tn(hipStream_t s, int M, int N, int K, int ksplit, int kchunk, double alpha, const double* A,
                      int lda, const double* B, int ldb, double beta, double* C, int ldc, size_t slab_stride)
 {
@@ -723,7 +726,7 @@ static int launch_tn(hipStream_t s, int M, int N, int K, int ksplit, int kchunk,
     const int Mi = al ? (M / BM) * BM : 0, Ni = al ? (N / BN) * BN : 0;
     if (!(Mi > 0 && Ni > 0))
         return launch_tn1<TI, TJ, false>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, beta, C, ldc, slab_stride);
-    int rc = launch_tn1<TI, TJ, true>(s, Mi, Ni, K, ksplit, kchunk, alpha, A, lda, B, ldb, beta, C, ldc, slab_stride);
+    int rc = launch_tn1<TI, TJ, true, TAG>(s, Mi, Ni, K, ksplit, kchunk, alpha, A, lda, B, ldb, beta, C, ldc, slab_stride);
     if (!rc && Ni < N)
         rc = launch_tn1<TI, TJ, false>(s, M, N - Ni, K, ksplit, kchunk, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta,
                                        C + (size_t) Ni * ldc, ldc, slab_stride);
@@ -746,10 +749,20 @@ int qrd_init(void)
 {
     int rc = 0;
     rc |= allow_lds(gemm_nn_kernel<4, 4, true>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
+    rc |= allow_lds(gemm_nn_kernel<4, 4, true, 1>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, false>, sizeof(double) * (4 * 128 * LDKF));
     return rc;
+}
+
+// the wide trailing update A2 -= V*W: always the 128x128 tile, its own kernel name (TAG = 1) for the profiler
+int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                       int ldb, double beta, double* C, int ldc)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return launch_nn<4, 4, 1>((hipStream_t) stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
 int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
@@ -775,9 +788,27 @@ int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A
 
 // C = alpha*A^T*B + beta*C with split-K through `slabs` (capacity slab_cap doubles).
 // Tm (optional, M <= 256): C = beta*C + Tm^T * (alpha*A^T*B)   [leaf-level T^T fold].
+static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                        int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
+                        int ldt, int tag);
+
 int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                 int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
                 int ldt)
+{
+    return gemm_tn_impl(stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, slabs, slab_cap, Tm, ldt, 0);
+}
+
+// the wide W = (V T)^T A2 of the trailing update: same kernel under its own profiler name (TAG = 1)
+int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                       int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap)
+{
+    return gemm_tn_impl(stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, slabs, slab_cap, nullptr, 0, 1);
+}
+
+static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                        int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
+                        int ldt, int tag)
 {
     hipStream_t s = (hipStream_t) stream;
     if (M <= 0 || N <= 0) return 0;
@@ -810,10 +841,11 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
     if (ti == 1 && tj == 4) rc = launch_tn<1, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else if (ti == 1) rc = launch_tn<1, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else if (ti == 2) rc = launch_tn<2, 2>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (tag == 1) rc = launch_tn<4, 4, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     if (rc) return rc;
     if (!direct) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(N), dim3(256), 0, s, M, N, ksplit, slabs, M, per, Tm, ldt,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, (M + 255) / 256), dim3(256), 0, s, M, N, ksplit, slabs, M, per, Tm, ldt,
                            beta, C, ldc);
         rc = (int) hipGetLastError();
     }

@@ -16,7 +16,7 @@
 //
 // The result is an ordinary compact-WY panel (unit-lower V in place below R, tau, T), identical in form to what
 // the per-column kernels produce, so everything downstream is unchanged; I - V T V^T has first w columns Q1 S.
-// 5 launches (mk <= 8192), 7 (mk <= 131072), ~3 passes over the leaf.  mk <= 512: panel_single_kernel, 1 launch.
+// 4 launches (mk <= 8192), 6 (mk <= 131072), 2 passes over the leaf.  mk <= 512: panel_single_kernel, 1 launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "qr_device.h"
@@ -301,98 +301,208 @@ __global__ __launch_bounds__(PT) void tsqr_apply_kernel(const double* __restrict
     }
 }
 
-// H1: Householder reconstruction on the top w x w block of Q1.  One 1024-thread workgroup, thread (r, c) owns
-// element (r, c); both phases are right-looking with one barrier per step (ping-pong broadcast rows in LDS):
+// H1: Householder reconstruction on the top w x w block of Q1 = Q_local_0 [C_0; 0].  One 16-wave workgroup; lane
+// r < 32 of wave g owns row r of the columns c = g + 16 q (q < 2).  Rows are broadcast inside a wave with
+// v_readlane (the row a step needs always lives in a lane of the same wave), the multipliers come from LDS, so
+// only the LU needs a barrier per step; the three substitutions run without any synchronisation:
+//   M_0 = T_0 V_01^T C_0 by back substitution with T_0^-1 = striu(Z_0) + diag(1/tau_0);  Q1_top = C_0 - V_01 M_0
 //   modified LU without pivoting:  S_j = -sign(pivot), pivot -= S_j (|pivot| >= 1 afterwards),  Q1_top - S = L1 U
-//   T = -U S L1^-T  as the forward substitution  L1 X = -S U^T,  X = T^T
-// Outputs: R = S R~ and L1 into the top of the panel, tau = diag(T), T, the unit-lower top of Vw, and
-// Umat = U^-1 (w x w upper triangular, ld PW) for hr_rows_kernel.
-__global__ __launch_bounds__(1024) void hr_top_kernel(const double* __restrict__ Q1, int ldq, const double* __restrict__ Rt,
-                                                      int w, double* __restrict__ A, int lda, double* __restrict__ tau,
-                                                      double* __restrict__ T, int ldt, double* __restrict__ Vw, int ldv,
-                                                      double* __restrict__ Umat)
+//   T = -U S L1^-T  as the forward substitution  L1 X = -S U^T,  X = T^T ;   Uinv = U^-1
+// Outputs: R = S R~ and L1 into the top of the panel, tau = diag(T), T, the unit-lower top of Vw, Umat = U^-1.
+#define HQ 2
+#define HG (PW / HQ)      /* waves in hr_top_kernel: wave g owns columns g + HG q */
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-    __shared__ double Bs[PW][PW + 1];
-    __shared__ double rowb[2][PW], colb[2][PW];
-    __shared__ double Ss[PW];
-    const int r = threadIdx.x & (PW - 1), c = threadIdx.x >> 5;
-    const bool act = (r < w) && (c < w);
-    double b = act ? Q1[(size_t) c * ldq + r] : 0.0;
-    for (int j = 0; j < w; ++j) {
-        const int pp = j & 1;
-        if (r == j) rowb[pp][c] = b;            // row j (U row incl. the pivot before its shift)
-        if (c == j) colb[pp][r] = b;            // column j
-        __syncthreads();
-        const double p = rowb[pp][j];
-        const double S = (p >= 0.0) ? -1.0 : 1.0;
-        const double piv = p - S;
-        if (r > j && act) {
-            const double l = colb[pp][r] / piv;
-            if (c == j) b = l;
-            else if (c > j) b -= l * rowb[pp][c];
-        } else if (r == j && c == j) {
-            b = piv;
-            Ss[j] = S;
-        }
-    }
-    Bs[r][c] = b;
-    __syncthreads();
-    // X = T^T (lower triangular): L1 X = -S U^T
-    double x = (act && c <= r) ? -Ss[r] * Bs[c][r] : 0.0;
-    for (int k = 0; k < w; ++k) {
-        const int pp = k & 1;
-        if (r == k) rowb[pp][c] = x;            // row k of X is final
-        __syncthreads();
-        if (r > k && act) x -= Bs[r][k] * rowb[pp][c];
-    }
-    // Uinv = U^-1 (upper triangular) by right-looking back substitution: row k final, then eliminate it from rows < k
-    double ui = (act && r == c) ? 1.0 : 0.0;
-    __syncthreads();
-    for (int k = w - 1; k >= 0; --k) {
-        const int pp = k & 1;
-        if (r == k) { ui /= Bs[k][k]; rowb[pp][c] = ui; }
-        __syncthreads();
-        if (r < k && act) ui -= Bs[r][k] * rowb[pp][c];
-    }
-    if (!act) return;
-    T[(size_t) r * ldt + c] = x;                                           // T(c, r) = X(r, c)
-    A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * Rt[c * PW + r] : b;
-    Vw[(size_t) c * ldv + r] = (c < r) ? b : (c == r ? 1.0 : 0.0);
-    Umat[c * PW + r] = (c >= r) ? ui : 0.0;                                // Umat := U^-1 (w x w, ld PW)
-    if (c == r) tau[r] = x;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-// H2: V(r, :) = Q1(r, :) U^-1 for rows r >= w (thread per row), U^-1 broadcast from LDS: a 32 x 32 product per
-// row with no dependency between the output columns.
-__global__ __launch_bounds__(256) void hr_rows_kernel(const double* __restrict__ Q1, int ldq, const double* __restrict__ Umat,
-                                                      int mk, int w, double* __restrict__ A, int lda,
-                                                      double* __restrict__ Vw, int ldv)
-{
-    __shared__ double Ui[PW][PW + 1];        // Ui[k][c] = Uinv(k, c)
-    const int r = w + blockIdx.x * 256 + threadIdx.x;
-    double q[PW], y[PW];
+template <int I> struct HrStep {
+    // back substitution step i (descending): row I of M is final; eliminate it from rows < I
+    static __device__ __forceinline__ void msolve(double (&e)[HQ], int r, int w, const double* t0, double (*Zs)[PW + 1])
     {
-        const double* p = Q1 + min(r, mk - 1);
+        if (I < w) {
+            const double ti = t0[I];
+            const double z = (r < I) ? Zs[r][I] : 0.0;
 #pragma unroll
-        for (int c = 0; c < PW; ++c) { q[c] = (c < w) ? p[(size_t) c * ldq] : 0.0; y[c] = 0.0; }
+            for (int q = 0; q < HQ; ++q) {
+                e[q] = (r == I) ? e[q] * ti : e[q];
+                e[q] -= z * readlane_f64(e[q], I);
+            }
+        }
+        if constexpr (I > 0) HrStep<I - 1>::msolve(e, r, w, t0, Zs);
     }
-    for (int e = threadIdx.x; e < PW * PW; e += 256) {
-        const int k = e % PW, c = e / PW;
-        Ui[k][c] = (k <= c && c < w) ? Umat[c * PW + k] : 0.0;
+    // Q1_top(r, :) -= V1(r, k) M(k, :), k ascending
+    static __device__ __forceinline__ void q1top(double (&b)[HQ], const double (&e)[HQ], int r, int w, double (*V1)[PW + 1])
+    {
+        if (I < w) {
+            const double v = (I <= r) ? V1[r][I] : 0.0;
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) b[q] -= v * readlane_f64(e[q], I);
+        }
+        if constexpr (I + 1 < PW) HrStep<I + 1>::q1top(b, e, r, w, V1);
+    }
+    // modified LU step j = I (ascending); column j multipliers go through LDS (one barrier per step)
+    static __device__ __forceinline__ void lu(double (&b)[HQ], int r, int g, int w, double (*colb)[PW], double* Ss)
+    {
+        if (I < w) {
+            constexpr int pp = I & 1, qj = I / HG, gj = I % HG;
+            if (g == gj && r < PW) colb[pp][r] = b[qj];
+            __syncthreads();
+            const double p = colb[pp][I];
+            const double S = (p >= 0.0) ? -1.0 : 1.0;
+            const double piv = p - S;
+            const double l = (r > I && r < w) ? colb[pp][r] / piv : 0.0;
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const int c = g + HG * q;
+                const double u = readlane_f64(b[q], I);
+                if (c > I) b[q] -= l * u;
+            }
+            if (g == gj) {
+                b[qj] = (r > I) ? l : ((r == I) ? piv : b[qj]);
+                if (r == I) Ss[I] = S;
+            }
+        }
+        if constexpr (I + 1 < PW) HrStep<I + 1>::lu(b, r, g, w, colb, Ss);
+    }
+    // forward substitution L1 X = RHS, step k = I (ascending): row I of X is final
+    static __device__ __forceinline__ void xsolve(double (&x)[HQ], int r, int w, double (*Bs)[PW + 1])
+    {
+        if (I < w) {
+            const double l = (r > I && r < w) ? Bs[r][I] : 0.0;
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) x[q] -= l * readlane_f64(x[q], I);
+        }
+        if constexpr (I + 1 < PW) HrStep<I + 1>::xsolve(x, r, w, Bs);
+    }
+    // back substitution U Uinv = I, step k = I (descending)
+    static __device__ __forceinline__ void uinv(double (&ui)[HQ], int r, int w, double (*Bs)[PW + 1])
+    {
+        if (I < w) {
+            const double d = 1.0 / Bs[I][I];
+            const double u = (r < I) ? Bs[r][I] : 0.0;
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                ui[q] = (r == I) ? ui[q] * d : ui[q];
+                ui[q] -= u * readlane_f64(ui[q], I);
+            }
+        }
+        if constexpr (I > 0) HrStep<I - 1>::uinv(ui, r, w, Bs);
+    }
+};
+
+__global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restrict__ Vloc, int ldvl, const double* __restrict__ tau0,
+                                                     const double* __restrict__ Z0, const double* __restrict__ C0, int ldc0,
+                                                     const double* __restrict__ Rt, int w, double* __restrict__ A, int lda,
+                                                     double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                     double* __restrict__ Vw, int ldv, double* __restrict__ Umat)
+{
+    __shared__ double Bs[PW][PW + 1], V1[PW][PW + 1], Cs[PW][PW + 1];
+    __shared__ double colb[2][PW];
+    __shared__ double Ss[PW], t0[PW];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r = lane;                          // lanes >= 32 carry zeros and write nothing
+    const bool ra = r < w;
+    for (int el = threadIdx.x; el < PW * PW; el += 64 * HG) {
+        const int i = el % PW, c = el / PW;
+        const bool in = (i < w && c < w);
+        const double v = in ? Vloc[(size_t) c * ldvl + i] : 0.0;
+        V1[i][c] = in ? ((c < i) ? v : (c == i ? 1.0 : 0.0)) : 0.0;
+        Cs[i][c] = in ? C0[(size_t) c * ldc0 + i] : 0.0;
+        Bs[i][c] = (in && i < c) ? Z0[c * PW + i] : 0.0;          // Z(i, c), i < c
+    }
+    if (threadIdx.x < PW) t0[threadIdx.x] = (threadIdx.x < w) ? tau0[threadIdx.x] : 0.0;
+    __syncthreads();
+    double e[HQ], b[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {               // W = V1^T C0
+        const int c = g + HG * q;
+        double acc = 0.0;
+        if (r < PW)
+            for (int k = r; k < w; ++k) acc += V1[k][r] * Cs[k][c];
+        e[q] = acc;
+        b[q] = (ra && c < w) ? Cs[r][c] : 0.0;
+    }
+    HrStep<PW - 1>::msolve(e, r, w, t0, Bs);     // e := M_0 rows
+    HrStep<0>::q1top(b, e, ra ? r : -1, w, V1);  // b := Q1_top rows (inactive lanes: no update)
+    __syncthreads();                             // everyone is done with Bs as Z
+    HrStep<0>::lu(b, r, g, w, colb, Ss);
+    __syncthreads();
+    if (r < PW) {
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) Bs[r][g + HG * q] = b[q];
     }
     __syncthreads();
+    double x[HQ], ui[HQ];
 #pragma unroll
-    for (int k = 0; k < PW; ++k) {
-        if (k < w) {
-#pragma unroll
-            for (int c = 0; c < PW; ++c) y[c] += q[k] * Ui[k][c];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int q = 0; q < HQ; ++q) {
+        const int c = g + HG * q;
+        x[q] = (ra && c <= r) ? -Ss[r] * Bs[c][r] : 0.0;          // -S U^T
+        ui[q] = (ra && r == c) ? 1.0 : 0.0;
     }
-    if (r < mk) {
+    HrStep<0>::xsolve(x, r, w, Bs);
+    HrStep<PW - 1>::uinv(ui, r, w, Bs);
+    if (!ra) return;
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const int c = g + HG * q;
+        if (c < w) {
+            T[(size_t) r * ldt + c] = x[q];                                        // T(c, r) = X(r, c)
+            A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * Rt[c * PW + r] : b[q];
+            Vw[(size_t) c * ldv + r] = (c < r) ? b[q] : (c == r ? 1.0 : 0.0);
+            Umat[c * PW + r] = (c >= r) ? ui[q] : 0.0;                             // Umat := U^-1 (ld PW)
+            if (c == r) tau[r] = x[q];
+        }
+    }
+}
+
+// A1 + H2 fused (level 1, last launch of the leaf): V(rows, :) = Q1(rows, :) U^-1 with Q1 = [C_b; 0] - V_b M_b, i.e.
+// V(r, :) = [C_b U^-1; 0](r, :) - V_b(r, :) (M_b U^-1), written straight into the panel and Vw for global rows >= w
+// (the top w rows were written by hr_top_kernel).  No explicit Q1 round trip through memory.
+__global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict__ Vloc, int ldvl,
+                                                        const double* __restrict__ tauloc, const double* __restrict__ Tloc,
+                                                        int rows_total, int w, const double* __restrict__ Cin, int ldci,
+                                                        const double* __restrict__ Umat, double* __restrict__ A, int lda,
+                                                        double* __restrict__ Vw, int ldv)
+{
+    __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1], Ui[PW][PW + 1];
+    __shared__ double tl[PW];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    int start, rows;
+    block_range(rows_total, 0, b, gridDim.x, start, rows);
+    double x[PW];
+    load_block(x, Vloc, ldvl, start, tid, rows, w);
+    for (int e = tid; e < PW * PW; e += PT) {
+        const int i = e % PW, c = e / PW;
+        Zl[c][i] = Tloc[(size_t) b * PW * PW + e];                           // Zl[k][i] = Z(i, k)
+        Cl[i][c] = (i < w && c < w) ? Cin[(size_t) c * ldci + b * w + i] : 0.0;
+        Ui[i][c] = (i <= c && c < w) ? Umat[c * PW + i] : 0.0;
+    }
+    if (tid < PW) {
+        tl[tid] = (tid < w) ? tauloc[b * PW + tid] : 0.0;
 #pragma unroll
         for (int c = 0; c < PW; ++c)
-            if (c < w) { A[(size_t) c * lda + r] = y[c]; Vw[(size_t) c * ldv + r] = y[c]; }
+            V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[c] : (c == tid ? 1.0 : 0.0)) : 0.0;
+    }
+    __syncthreads();
+    small_m(V1, Cl, Zl, tl, Wl, Ml, w, tid);
+    for (int e = tid; e < PW * PW; e += PT) {           // Wl = Ml Ui ;  Zl (reused) = Cl Ui     (Ui upper triangular)
+        const int i = e / PW, q = e % PW;
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k <= q && k < w; ++k) { a1 += Ml[i][k] * Ui[k][q]; a2 += Cl[i][k] * Ui[k][q]; }
+        Wl[i][q] = a1;
+        Zl[i][q] = a2;
+    }
+    __syncthreads();
+    double out[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q) out[q] = (tid < w) ? Zl[min(tid, PW - 1)][q] : 0.0;
+    wy_row(x, out, tid, w, Wl);
+    if (tid < rows && start + tid >= w) {
+        const size_t rg = (size_t) start + tid;
+#pragma unroll
+        for (int q = 0; q < PW; ++q)
+            if (q < w) { A[(size_t) q * lda + rg] = out[q]; Vw[(size_t) q * ldv + rg] = out[q]; }
     }
 }
 
@@ -495,10 +605,12 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
         Cin = Cup + lv_off[l];
         ldci = lv_rows[l];
     }
-    hipLaunchKernelGGL(tsqr_apply_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, 0, w, Cin, ldci, Q1, mk);
-    // ---- Householder reconstruction
-    hipLaunchKernelGGL(hr_top_kernel, dim3(1), dim3(1024), 0, s, Q1, mk, Rt, w, P, ld, tau, T, ldt, Vw, ldv, Umat);
-    hipLaunchKernelGGL(hr_rows_kernel, dim3((mk - w + 255) / 256), dim3(256), 0, s, Q1, mk, Umat, mk, w, P, ld, Vw, ldv);
+    // ---- Householder reconstruction on the top block, then every level-1 block writes its rows of V directly
+    hipLaunchKernelGGL(hr_top_kernel, dim3(1), dim3(1024), 0, s, Vloc1, mk, taus, Ts, Cin, ldci, Rt, w, P, ld, tau, T, ldt, Vw,
+                       ldv, Umat);
+    hipLaunchKernelGGL(tsqr_final_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, w, Cin, ldci, Umat, P, ld,
+                       Vw, ldv);
+    (void) Q1;
     return (int) hipGetLastError();
 }
 

@@ -1,7 +1,19 @@
 #!/bin/bash
-mkdir -p gpurun_out/prof5
+R=gpurun_out/prof_r01
+rm -rf $R; mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-MI355XQR_PANEL=tsqr rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof5 -o p -- python3 tools_perf.py 262144x512x128 > gpurun_out/prof5/run.log 2>&1
-python3 tools_trace_summary.py gpurun_out/prof5/p_kernel_trace.csv | sed 's/void //' | head -24
-rm -f gpurun_out/prof5/p_kernel_trace.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_c3 -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/bench_c3.json 2> $R/bench_c3.err
+python3 tools_trace_summary.py $R/bench_c3/bench_kernel_trace.csv > $R/bench_c3_trace_summary.txt; rm -f $R/bench_c3/bench_kernel_trace.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_tsqr -o bench -- python3 bench.py --workload tsqr --steps 3 --warmup 1 --no-cpu-baseline > $R/bench_tsqr.json 2> $R/bench_tsqr.err
+rm -f $R/bench_tsqr/bench_kernel_trace.csv
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  MI355XQR_PANEL_CUS=0 rocprofv3 --pmc $ctr --output-format csv -d $R/pmc_$ctr -o pmc -- python3 tools_pmc_driver.py 256 > $R/pmc_${ctr}_driver.json 2> $R/pmc_$ctr.err
+  f=$(find $R/pmc_$ctr -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 tools_pmc_summary.py $f $ctr > $R/pmc_${ctr}_summary.txt && rm -f $f
+  head -8 $R/pmc_${ctr}_summary.txt
+done
+python -c "
+import json; d=json.load(open('$R/bench_c3.json')); print('C3', d['value'], d['ms_per_step'], d['accuracy'], d['roofline']['achieved'], d['roofline']['companion_tn']['achieved'])
+d=json.load(open('$R/bench_tsqr.json')); print('TSQR', d['value'], d['ms_per_step'], d['accuracy'])"
+head -12 $R/bench_c3/bench_kernel_stats.csv | cut -c1-150

@@ -1,18 +1,35 @@
-"""Workload for the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): calibration kernels with known
-byte counts in the access widths the GEMMs use, then one C3 factorisation (profiles/README.md)."""
+"""Workload for the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), profiles/README.md.
+
+rocprofv3 counter collection crashes on this pool beyond ~16k dispatches per process and on CU-masked
+streams, so the counters are taken on (a) calibration kernels with known byte counts in the access widths
+the GEMMs use and (b) the trailing-update GEMM pair at the exact C3 shapes of every 8th outer step
+(mk = nt + nb = 16384 - k, K = nb), launched through qr_gemm_dev -- the same kernels, tiles and split-K
+the factorisation uses -- instead of all ~17k dispatches of a full factorisation."""
+import json
 import sys
+
 import torch
+
 import cuda_qr_amd as q
 
-m = n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-nb = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+m = n = 16384
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 p = q.Plan(m, n, nb, 32)
 A = torch.empty((n, m), dtype=torch.float64, device="cuda")
-tau = torch.empty(n, dtype=torch.float64, device="cuda")
-q.probe_copy_gbps()                                   # stream_copy_kernel: 6 launches x (1 GiB read + 1 GiB write), 16 B/lane
-p.fill_uniform(A, m, m, n, seed=12)                   # fill_uniform_kernel: m*n*8 bytes written, 8 B/lane
+V = torch.empty((nb, m), dtype=torch.float64, device="cuda")
+W = torch.empty((n, nb), dtype=torch.float64, device="cuda")
+q.probe_copy_gbps()                                   # stream_copy_kernel: 6 x (1 GiB read + 1 GiB write), 16 B/lane
+p.fill_uniform(A, m, m, n, seed=12)                   # fill_uniform_kernel: m*n*8 B written, 8 B/lane
+p.fill_uniform(V, m, m, nb, seed=13)
 p.sync()
-p.diffnorm(A, m, m, n, seed=12)                       # diff_norm_kernel: m*n*8 bytes read, 8 B/lane
-p.geqrf(A, m, n, m, tau)
+p.diffnorm(A, m, m, n, seed=12)                       # diff_norm_kernel: m*n*8 B read, 8 B/lane
+shapes = []
+for k in range(0, n - nb, 8 * nb):
+    mk, nt = m - k, n - k - nb
+    a2 = A.data_ptr() + 8 * ((k + nb) * m + k)
+    p.gemm("T", nb, nt, mk, 1.0, V.data_ptr() + 8 * k, m, a2, m, 0.0, W, nb)          # W = (V T)^T A2
+    p.gemm("N", mk, nt, nb, -1.0, V.data_ptr() + 8 * k, m, W, nb, 1.0, a2, m)          # A2 -= V W
+    shapes.append({"k": k, "mk": mk, "nt": nt, "nb": nb, "nn_alg_bytes": 16 * mk * nt + 8 * mk * nb + 8 * nb * nt,
+                   "tn_alg_bytes": 8 * mk * (nt + nb), "flops_each": 2 * mk * nt * nb})
 p.sync()
-print("done", m, n, nb)
+print(json.dumps({"nb": nb, "steps": shapes}))

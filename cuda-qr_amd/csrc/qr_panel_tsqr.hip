@@ -26,13 +26,15 @@
 #define PT 512            // threads per workgroup = rows per block
 #define PWAVES (PT / 64)
 
-struct PanelShared {
-    double part[PWAVES][PW];
+template <int NW>
+struct PanelSharedT {
+    double part[NW][PW];
     double row[PW];
     double s[PW];
     double tau[PW];
     double scal[4];
 };
+typedef PanelSharedT<PWAVES> PanelShared;
 
 // rows [start, start+rows) of block b: even split when chunk == 0 (level 1), fixed chunks otherwise
 __device__ __forceinline__ void block_range(int rows_total, int chunk, int b, int nb, int& start, int& rows)
@@ -49,8 +51,8 @@ __device__ __forceinline__ void block_range(int rows_total, int chunk, int b, in
 // One Householder column on a workgroup-resident block (row r of the block in x[], one row per thread).
 // Same arithmetic as leaf_step_kernel (dlarfg convention; tau = 0 for an exactly-zero tail; qr.c:144-167 for the
 // reference's form).  ZCAP: also record Z(c, J) = v_c^T v_J for c < J (needed only when T is built from Z).
-template <int J, bool ZCAP>
-__device__ __forceinline__ void house_step(double (&x)[PW], int r, int rows, int w, PanelShared& sh, double (*Z)[PW + 1],
+template <int J, bool ZCAP, int NT>
+__device__ __forceinline__ void house_step(double (&x)[PW], int r, int rows, int w, PanelSharedT<NT / 64>& sh, double (*Z)[PW + 1],
                                            int tid, int lane, int wave)
 {
     if (J >= w) return;                              // wave-uniform
@@ -71,7 +73,7 @@ __device__ __forceinline__ void house_step(double (&x)[PW], int r, int rows, int
     if (tid < PW) {
         double d = 0.0;
 #pragma unroll
-        for (int p = 0; p < PWAVES; ++p) d += sh.part[p][tid];
+        for (int p = 0; p < NT / 64; ++p) d += sh.part[p][tid];
         const double alpha = sh.row[J];
         const double sigma = __shfl(d, J);
         double t, b, iu;
@@ -97,18 +99,19 @@ __device__ __forceinline__ void house_step(double (&x)[PW], int r, int rows, int
     for (int c = J + 1; c < PW; ++c) x[c] -= coef * sh.s[c];
 }
 
-template <int J, bool ZCAP>
-__device__ __forceinline__ void factor_all(double (&x)[PW], int r, int rows, int w, PanelShared& sh, double (*Z)[PW + 1],
+template <int J, bool ZCAP, int NT>
+__device__ __forceinline__ void factor_all(double (&x)[PW], int r, int rows, int w, PanelSharedT<NT / 64>& sh, double (*Z)[PW + 1],
                                            int tid, int lane, int wave)
 {
-    house_step<J, ZCAP>(x, r, rows, w, sh, Z, tid, lane, wave);
-    if constexpr (J + 1 < PW) factor_all<J + 1, ZCAP>(x, r, rows, w, sh, Z, tid, lane, wave);
+    house_step<J, ZCAP, NT>(x, r, rows, w, sh, Z, tid, lane, wave);
+    if constexpr (J + 1 < PW) factor_all<J + 1, ZCAP, NT>(x, r, rows, w, sh, Z, tid, lane, wave);
 }
 
 // T (w x w upper triangular, into Tl[PW][PW+1] in LDS) of the block's reflectors from the captured Gram
 // columns Z(q, j) = v_q^T v_j and tau:  T(0:j,j) = -tau_j T(0:j,0:j) Z(0:j,j).  Row p depends only on row p:
 // thread tid < PW computes row tid with no synchronisation.
-__device__ __forceinline__ void build_t_rows(double (*Tl)[PW + 1], double (*Z)[PW + 1], const PanelShared& sh, int w, int tid)
+template <class SH>
+__device__ __forceinline__ void build_t_rows(double (*Tl)[PW + 1], double (*Z)[PW + 1], const SH& sh, int w, int tid)
 {
     if (tid < PW) {
         double trow[PW];
@@ -150,10 +153,11 @@ __device__ __forceinline__ void wy_row(const double (&x)[PW], double (&out)[PW],
 // M solves  T^-1 M = V1^T C  by back substitution; column q of M lives in the registers of thread q (no
 // synchronisation inside the solve).  tau_i = 0 (H_i = I) makes row i of T zero: M(i,:) = 0.
 // LDS operands: V1 (unit-lower top of the block), Cl (w x w input), Zl[k][i] = Z(i,k) for i < k, tl[i] = tau_i.
+template <int NT>
 __device__ __forceinline__ void small_m(double (*V1)[PW + 1], double (*Cl)[PW + 1], double (*Zl)[PW + 1], const double* tl,
                                         double (*Wl)[PW + 1], double (*Ml)[PW + 1], int w, int tid)
 {
-    for (int e = tid; e < PW * PW; e += PT) {           // Wl = V1^T Cl   (V1 unit lower: V1(k, i) for k >= i)
+    for (int e = tid; e < PW * PW; e += NT) {           // Wl = V1^T Cl   (V1 unit lower: V1(k, i) for k >= i)
         const int i = e / PW, q = e % PW;
         double acc = 0.0;
         for (int k = i; k < w; ++k) acc += V1[k][i] * Cl[k][q];
@@ -194,19 +198,20 @@ __device__ __forceinline__ void load_block(double (&x)[PW], const double* __rest
 // F: local QR of every block of `src` (rows_total x w).  Leaves the factored block (R on top, reflector tails
 // below) in Vloc, its tau in tauloc[b*PW..], the Gram entries Z(i,k) = v_i^T v_k (the strict upper triangle of T^-1)
 // in Tloc[b*PW*PW + k*PW + i], and its R (w x w, zeros below the diagonal) in rows [b*w, b*w+w) of Rstack.
-__global__ __launch_bounds__(PT) void tsqr_factor_kernel(const double* __restrict__ src, int lds, int rows_total, int chunk,
+template <int NT>
+__global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restrict__ src, int lds, int rows_total, int chunk,
                                                          int w, double* __restrict__ Vloc, int ldv,
                                                          double* __restrict__ tauloc, double* __restrict__ Tloc,
                                                          double* __restrict__ Rstack, int ldr)
 {
-    __shared__ PanelShared sh;
+    __shared__ PanelSharedT<NT / 64> sh;
     __shared__ double Z[PW][PW + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     int start, rows;
     block_range(rows_total, chunk, b, gridDim.x, start, rows);
     double x[PW];
     load_block(x, src, lds, start, tid, rows, w);
-    factor_all<0, true>(x, tid, rows, w, sh, Z, tid, lane, wave);
+    factor_all<0, true, NT>(x, tid, rows, w, sh, Z, tid, lane, wave);
     __syncthreads();
     if (tid < rows) {
 #pragma unroll
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(PT) void tsqr_factor_kernel(const double* __restric
         for (int c = 0; c < PW; ++c)
             if (c < w) Rstack[(size_t) c * ldr + b * w + tid] = (c >= tid && tid < rows) ? x[c] : 0.0;
     }
-    for (int e = tid; e < PW * PW; e += PT) {           // Zloc[b][k][i] = Z(i, k) = v_i^T v_k (i < k < w), else 0
+    for (int e = tid; e < PW * PW; e += NT) {           // Zloc[b][k][i] = Z(i, k) = v_i^T v_k (i < k < w), else 0
         const int i = e % PW, k = e / PW;
         Tloc[(size_t) b * PW * PW + e] = (i < k && k < w) ? Z[k][i] : 0.0;
     }
@@ -227,17 +232,18 @@ __global__ __launch_bounds__(PT) void tsqr_factor_kernel(const double* __restric
 
 // T: the last stack (rows <= 512): R~ -> Rt (ld PW), explicit Q_top [I;0] -> Cout (rows x w) in compact-WY form:
 // Q_top [I;0] = [I;0] - V (T V1^T)
-__global__ __launch_bounds__(PT) void tsqr_top_kernel(const double* __restrict__ stack, int lds, int rows, int w,
+template <int NT>
+__global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__ stack, int lds, int rows, int w,
                                                       double* __restrict__ Rt, double* __restrict__ Cout, int ldc)
 {
-    __shared__ PanelShared sh;
+    __shared__ PanelSharedT<NT / 64> sh;
     __shared__ double Z[PW][PW + 1];
     __shared__ double V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
     __shared__ double tl[PW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double x[PW];
     load_block(x, stack, lds, 0, tid, rows, w);
-    factor_all<0, true>(x, tid, rows, w, sh, Z, tid, lane, wave);
+    factor_all<0, true, NT>(x, tid, rows, w, sh, Z, tid, lane, wave);
     __syncthreads();
     if (tid < PW) {
         tl[tid] = (tid < w) ? sh.tau[tid] : 0.0;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(PT) void tsqr_top_kernel(const double* __restrict__
         }
     }
     __syncthreads();
-    small_m(V1, Cl, Z, tl, Wl, Ml, w, tid);
+    small_m<NT>(V1, Cl, Z, tl, Wl, Ml, w, tid);
     double out[PW];
 #pragma unroll
     for (int q = 0; q < PW; ++q) out[q] = (tid == q && tid < w) ? 1.0 : 0.0;
@@ -264,7 +270,8 @@ __global__ __launch_bounds__(PT) void tsqr_top_kernel(const double* __restrict__
 
 // A: Cout(block rows, :) = Q_local_b [Cin_b ; 0] = [Cin_b; 0] - V_b (T_b V_b1^T Cin_b),
 // Cin_b = rows [b*w, b*w+w) of the parent's output
-__global__ __launch_bounds__(PT) void tsqr_apply_kernel(const double* __restrict__ Vloc, int ldv,
+template <int NT>
+__global__ __launch_bounds__(NT) void tsqr_apply_kernel(const double* __restrict__ Vloc, int ldv,
                                                         const double* __restrict__ tauloc,
                                                         const double* __restrict__ Tloc, int rows_total, int chunk, int w,
                                                         const double* __restrict__ Cin, int ldci,
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(PT) void tsqr_apply_kernel(const double* __restrict
     block_range(rows_total, chunk, b, gridDim.x, start, rows);
     double x[PW];
     load_block(x, Vloc, ldv, start, tid, rows, w);
-    for (int e = tid; e < PW * PW; e += PT) {
+    for (int e = tid; e < PW * PW; e += NT) {
         const int i = e % PW, c = e / PW;
         Zl[c][i] = Tloc[(size_t) b * PW * PW + e];                           // Zl[k][i] = Z(i, k)
         Cl[i][c] = (i < w && c < w) ? Cin[(size_t) c * ldci + b * w + i] : 0.0;
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(PT) void tsqr_apply_kernel(const double* __restrict
             V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[c] : (c == tid ? 1.0 : 0.0)) : 0.0;
     }
     __syncthreads();
-    small_m(V1, Cl, Zl, tl, Wl, Ml, w, tid);
+    small_m<NT>(V1, Cl, Zl, tl, Wl, Ml, w, tid);
     double out[PW];
 #pragma unroll
     for (int q = 0; q < PW; ++q) out[q] = (tid < w) ? Cl[min(tid, PW - 1)][q] : 0.0;
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict
             V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[c] : (c == tid ? 1.0 : 0.0)) : 0.0;
     }
     __syncthreads();
-    small_m(V1, Cl, Zl, tl, Wl, Ml, w, tid);
+    small_m<PT>(V1, Cl, Zl, tl, Wl, Ml, w, tid);
     for (int e = tid; e < PW * PW; e += PT) {           // Wl = Ml Ui ;  Zl (reused) = Cl Ui     (Ui upper triangular)
         const int i = e / PW, q = e % PW;
         double a1 = 0.0, a2 = 0.0;
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double x[PW];
     load_block(x, P, ld, 0, tid, mk, w);
-    factor_all<0, true>(x, tid, mk, w, sh, Z, tid, lane, wave);
+    factor_all<0, true, PT>(x, tid, mk, w, sh, Z, tid, lane, wave);
     __syncthreads();
     if (tid < mk) {
 #pragma unroll
@@ -537,6 +544,42 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// launchers: the workgroup is sized to the tallest block of the launch (64..512 threads) -- a 64-row top stack
+// runs on one wave with no cross-wave reduction instead of eight mostly-idle ones
+static int nt_for(int rows) { return rows <= 64 ? 64 : (rows <= 128 ? 128 : (rows <= 256 ? 256 : 512)); }
+
+static void launch_factor(hipStream_t s, int nblk, int maxrows, const double* src, int lds, int rows_total, int chunk, int w,
+                          double* Vloc, int ldv, double* tauloc, double* Tloc, double* Rstack, int ldr)
+{
+    switch (nt_for(maxrows)) {
+    case 64: hipLaunchKernelGGL(tsqr_factor_kernel<64>, dim3(nblk), dim3(64), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    case 128: hipLaunchKernelGGL(tsqr_factor_kernel<128>, dim3(nblk), dim3(128), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    case 256: hipLaunchKernelGGL(tsqr_factor_kernel<256>, dim3(nblk), dim3(256), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    default: hipLaunchKernelGGL(tsqr_factor_kernel<512>, dim3(nblk), dim3(512), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    }
+}
+
+static void launch_top(hipStream_t s, const double* stack, int lds, int rows, int w, double* Rt, double* Cout, int ldc)
+{
+    switch (nt_for(rows)) {
+    case 64: hipLaunchKernelGGL(tsqr_top_kernel<64>, dim3(1), dim3(64), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
+    case 128: hipLaunchKernelGGL(tsqr_top_kernel<128>, dim3(1), dim3(128), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
+    case 256: hipLaunchKernelGGL(tsqr_top_kernel<256>, dim3(1), dim3(256), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
+    default: hipLaunchKernelGGL(tsqr_top_kernel<512>, dim3(1), dim3(512), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
+    }
+}
+
+static void launch_apply(hipStream_t s, int nblk, int maxrows, const double* Vloc, int ldv, const double* tauloc, const double* Tloc,
+                         int rows_total, int chunk, int w, const double* Cin, int ldci, double* Cout, int ldco)
+{
+    switch (nt_for(maxrows)) {
+    case 64: hipLaunchKernelGGL(tsqr_apply_kernel<64>, dim3(nblk), dim3(64), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
+    case 128: hipLaunchKernelGGL(tsqr_apply_kernel<128>, dim3(nblk), dim3(128), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
+    case 256: hipLaunchKernelGGL(tsqr_apply_kernel<256>, dim3(nblk), dim3(256), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
+    default: hipLaunchKernelGGL(tsqr_apply_kernel<512>, dim3(nblk), dim3(512), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
+    }
+}
+
 extern "C" {
 
 // workspace (doubles) for leaves of up to m rows
@@ -579,8 +622,7 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
     int L = 0;
     lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + PT - 1) / PT; lv_off[0] = 0; lv_tau[0] = 0;
     size_t off = 0, toff = (size_t) lv_nblk[0] * PW;
-    hipLaunchKernelGGL(tsqr_factor_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, P, ld, mk, 0, w, Vloc1, mk, taus, Ts,
-                       stacks, lv_nblk[0] * w);
+    launch_factor(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, lv_nblk[0] * w);
     int cur_rows = lv_nblk[0] * w;
     const int gchunk = (PT / w) * w;
     while (cur_rows > PT) {
@@ -589,19 +631,19 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
         lv_rows[L] = cur_rows; lv_chunk[L] = gchunk; lv_nblk[L] = (cur_rows + gchunk - 1) / gchunk;
         lv_off[L] = off; lv_tau[L] = toff;
         const size_t next_off = off + (size_t) cur_rows * PW;
-        hipLaunchKernelGGL(tsqr_factor_kernel, dim3(lv_nblk[L]), dim3(PT), 0, s, stacks + off, cur_rows, cur_rows, gchunk, w,
-                           Vup + off, cur_rows, taus + toff, Ts + toff * PW, stacks + next_off, lv_nblk[L] * w);
+        launch_factor(s, lv_nblk[L], cur_rows < gchunk ? cur_rows : gchunk, stacks + off, cur_rows, cur_rows, gchunk, w,
+                      Vup + off, cur_rows, taus + toff, Ts + toff * PW, stacks + next_off, lv_nblk[L] * w);
         off = next_off; toff += (size_t) lv_nblk[L] * PW;
         cur_rows = lv_nblk[L] * w;
     }
     // ---- top: factor + explicit Q of the last stack; its output is the coefficient input of the level below
-    hipLaunchKernelGGL(tsqr_top_kernel, dim3(1), dim3(PT), 0, s, stacks + off, cur_rows, cur_rows, w, Rt, Cup + off, cur_rows);
+    launch_top(s, stacks + off, cur_rows, cur_rows, w, Rt, Cup + off, cur_rows);
     // ---- down the tree
     const double* Cin = Cup + off;
     int ldci = cur_rows;
     for (int l = L; l >= 1; --l) {
-        hipLaunchKernelGGL(tsqr_apply_kernel, dim3(lv_nblk[l]), dim3(PT), 0, s, Vup + lv_off[l], lv_rows[l], taus + lv_tau[l], Ts + lv_tau[l] * PW,
-                           lv_rows[l], lv_chunk[l], w, Cin, ldci, Cup + lv_off[l], lv_rows[l]);
+        launch_apply(s, lv_nblk[l], lv_rows[l] < lv_chunk[l] ? lv_rows[l] : lv_chunk[l], Vup + lv_off[l], lv_rows[l], taus + lv_tau[l],
+                     Ts + lv_tau[l] * PW, lv_rows[l], lv_chunk[l], w, Cin, ldci, Cup + lv_off[l], lv_rows[l]);
         Cin = Cup + lv_off[l];
         ldci = lv_rows[l];
     }

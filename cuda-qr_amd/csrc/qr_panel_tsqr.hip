@@ -230,185 +230,6 @@ __global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restric
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Column-split factor kernel.  Same local Householder QR as tsqr_factor_kernel, but a row's 32 columns are split
-// over CG = 4 threads (8 columns each, CG*RT threads per workgroup, RPT rows per thread): the per-column
-// dependent instruction chain of a wave shrinks ~4x (8 products, an 8-value butterfly, 8 updates), which is what
-// bounds the in-workgroup Householder step.  The pivot column each step needs is kept by EVERY thread of the row
-// ("pv"): the owner group publishes the raw next pivot column before the step's first barrier and every thread
-// applies the current reflector to its copy itself, so a step still has exactly two barriers.
-// ---------------------------------------------------------------------------------------------------------
-#define CG 4
-#define CW (PW / CG)
-
-// in: a[k], k < 8, per lane.  out (every lane): sum over the 64 lanes of a[lane >> 3]
-__device__ __forceinline__ double wave_reduce8(const double (&a)[CW], int lane)
-{
-    double b4[4], b2[2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b4[q] = swap_add<true>(a[q], a[q + 4]);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) b2[q] = swap_add<false>(b4[q], b4[q + 2]);
-    const bool up = (lane & 8) != 0;
-    double v = (up ? b2[1] : b2[0]) + dpp_f64(up ? b2[0] : b2[1], 0);     // lane ^ 15
-    v += dpp_f64(v, 1);                                                   // lane ^ 7
-    v += dpp_f64(v, 2);                                                   // lane ^ 2
-    v += dpp_f64(v, 3);                                                   // lane ^ 1
-    return v;
-}
-
-template <int RT, int RPT>
-struct CsShared {
-    double part[CG * RT / 64][CW];
-    double colraw[2][RT * RPT];
-    double rowv[2][PW];
-    double s[PW];
-    double tau[PW];
-    double scal[4];
-    double Z[PW][PW + 1];
-};
-
-template <int J, int RT, int RPT>
-__device__ __forceinline__ void cs_step(double (&x)[RPT][CW], double (&pv)[RPT], int rt, int g, int rows, int w,
-                                        CsShared<RT, RPT>& sh, int tid, int lane, int wave)
-{
-    if (J >= w) return;                                  // uniform
-    constexpr int gJ = J / CW, jl = J % CW, JN = J + 1, gN = (JN < PW ? JN : 0) / CW, jn = (JN < PW ? JN : 0) % CW;
-    constexpr int pp = J & 1, pn = JN & 1;
-    // phase 1: publish the raw next pivot column and the diagonal row
-    if (JN < PW && JN < w && g == gN) {
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) sh.colraw[pn][rt + RT * q] = x[q][jn];
-    }
-    if (rt == J) {
-#pragma unroll
-        for (int k = 0; k < CW; ++k) sh.rowv[pp][g * CW + k] = x[0][k];
-    }
-    // phase 2: partial dot products of the pivot column with this thread's 8 columns
-    {
-        double prod[CW];
-#pragma unroll
-        for (int k = 0; k < CW; ++k) prod[k] = 0.0;
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = rt + RT * q;
-            const double xj = (r > J && r < rows) ? pv[q] : 0.0;
-#pragma unroll
-            for (int k = 0; k < CW; ++k) prod[k] += xj * x[q][k];
-        }
-        const double v = wave_reduce8(prod, lane);
-        if ((lane & 7) == 0) sh.part[wave][lane >> 3] = v;
-    }
-    __syncthreads();
-    // phase 3: 32 lanes finish the sums and form the reflector scalars
-    if (tid < PW) {
-        constexpr int WPG = RT / 64;                     // waves per column group
-        const int gc = tid / CW, kc = tid % CW;
-        double d = 0.0;
-#pragma unroll
-        for (int p = 0; p < WPG; ++p) d += sh.part[gc * WPG + p][kc];
-        const double alpha = sh.rowv[pp][J];
-        const double sigma = __shfl(d, J);
-        double t, b, iu;
-        if (sigma == 0.0) { t = 0.0; b = alpha; iu = 0.0; }
-        else {
-            const double nrm = sqrt(alpha * alpha + sigma);
-            b = -copysign(nrm, alpha);
-            t = (b - alpha) / b;
-            iu = 1.0 / (alpha - b);
-        }
-        const double sc = sh.rowv[pp][tid] + d * iu;
-        sh.s[tid] = sc;
-        if (tid < J) sh.Z[J][tid] = sc;
-        if (tid == 0) { sh.scal[0] = t; sh.scal[1] = b; sh.scal[2] = iu; sh.tau[J] = t; }
-    }
-    __syncthreads();
-    // phase 4: scale the reflector, update this thread's columns and its copy of the next pivot column
-    const double tj = sh.scal[0], beta = sh.scal[1], iu = sh.scal[2];
-    const double sn = (JN < PW) ? sh.s[JN < PW ? JN : 0] : 0.0;
-    double sg[CW];
-#pragma unroll
-    for (int k = 0; k < CW; ++k) sg[k] = sh.s[g * CW + k];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int r = rt + RT * q;
-        const bool below = (r > J) && (r < rows), diag = (r == J);
-        const double vi = below ? pv[q] * iu : (diag ? 1.0 : 0.0);
-        const double coef = tj * vi;
-#pragma unroll
-        for (int k = 0; k < CW; ++k) {
-            const int c = g * CW + k;
-            x[q][k] = (c > J) ? x[q][k] - coef * sg[k] : x[q][k];
-        }
-        if (g == gJ) x[q][jl] = below ? vi : (diag ? beta : x[q][jl]);
-        if (JN < PW && JN < w) pv[q] = sh.colraw[pn][r] - coef * sn;
-    }
-}
-
-template <int J, int RT, int RPT>
-__device__ __forceinline__ void cs_all(double (&x)[RPT][CW], double (&pv)[RPT], int rt, int g, int rows, int w,
-                                       CsShared<RT, RPT>& sh, int tid, int lane, int wave)
-{
-    cs_step<J, RT, RPT>(x, pv, rt, g, rows, w, sh, tid, lane, wave);
-    if constexpr (J + 1 < PW) cs_all<J + 1, RT, RPT>(x, pv, rt, g, rows, w, sh, tid, lane, wave);
-}
-
-// outputs as tsqr_factor_kernel: Vloc (factored block), tauloc, Tloc (= Z, strict upper of T^-1), Rstack
-template <int RT, int RPT>
-__global__ __launch_bounds__(CG * RT) void tsqr_factor_cs_kernel(const double* __restrict__ src, int lds, int rows_total,
-                                                                 int chunk, int w, double* __restrict__ Vloc, int ldv,
-                                                                 double* __restrict__ tauloc, double* __restrict__ Tloc,
-                                                                 double* __restrict__ Rstack, int ldr)
-{
-    __shared__ CsShared<RT, RPT> sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-    const int rt = tid % RT, g = tid / RT;
-    int start, rows;
-    block_range(rows_total, chunk, b, gridDim.x, start, rows);
-    double x[RPT][CW], pv[RPT];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int r = rt + RT * q;
-        const double* p = src + start + min(r, rows - 1);
-#pragma unroll
-        for (int k = 0; k < CW; ++k) {
-            const int c = g * CW + k;
-            const double v = p[(size_t) min(c, w - 1) * lds];
-            x[q][k] = (r < rows && c < w) ? v : 0.0;
-        }
-        if (g == 0) sh.colraw[0][r] = x[q][0];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) pv[q] = sh.colraw[0][rt + RT * q];
-    __syncthreads();
-    cs_all<0, RT, RPT>(x, pv, rt, g, rows, w, sh, tid, lane, wave);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int r = rt + RT * q;
-        if (r < rows) {
-#pragma unroll
-            for (int k = 0; k < CW; ++k) {
-                const int c = g * CW + k;
-                if (c < w) Vloc[(size_t) c * ldv + start + r] = x[q][k];
-            }
-        }
-    }
-    if (rt < w) {
-#pragma unroll
-        for (int k = 0; k < CW; ++k) {
-            const int c = g * CW + k;
-            if (c < w) Rstack[(size_t) c * ldr + b * w + rt] = (c >= rt && rt < rows) ? x[0][k] : 0.0;
-        }
-    }
-    if (tid < w) tauloc[b * PW + tid] = sh.tau[tid];
-    for (int e = tid; e < PW * PW; e += CG * RT) {      // Zloc[b][k][i] = Z(i, k), i < k < w
-        const int i = e % PW, k = e / PW;
-        Tloc[(size_t) b * PW * PW + e] = (i < k && k < w) ? sh.Z[k][i] : 0.0;
-    }
-}
-
 // T: the last stack (rows <= 512): R~ -> Rt (ld PW), explicit Q_top [I;0] -> Cout (rows x w) in compact-WY form:
 // Q_top [I;0] = [I;0] - V (T V1^T)
 template <int NT>
@@ -466,7 +287,7 @@ __global__ __launch_bounds__(NT) void tsqr_apply_kernel(const double* __restrict
     for (int e = tid; e < PW * PW; e += NT) {
         const int i = e % PW, c = e / PW;
         Zl[c][i] = Tloc[(size_t) b * PW * PW + e];                           // Zl[k][i] = Z(i, k)
-        Cl[i][c] = (i < w && c < w) ? (Cin ? Cin[(size_t) c * ldci + b * w + i] : (i == c ? 1.0 : 0.0)) : 0.0;   // nullptr: C = I (tree top)
+        Cl[i][c] = (i < w && c < w) ? Cin[(size_t) c * ldci + b * w + i] : 0.0;
     }
     if (tid < PW) {
         tl[tid] = (tid < w) ? tauloc[b * PW + tid] : 0.0;
@@ -579,7 +400,7 @@ template <int I> struct HrStep {
 
 __global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restrict__ Vloc, int ldvl, const double* __restrict__ tau0,
                                                      const double* __restrict__ Z0, const double* __restrict__ C0, int ldc0,
-                                                     const double* __restrict__ Rt, int ldrt, int w, double* __restrict__ A, int lda,
+                                                     const double* __restrict__ Rt, int w, double* __restrict__ A, int lda,
                                                      double* __restrict__ tau, double* __restrict__ T, int ldt,
                                                      double* __restrict__ Vw, int ldv, double* __restrict__ Umat)
 {
@@ -634,7 +455,7 @@ __global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restric
         const int c = g + HG * q;
         if (c < w) {
             T[(size_t) r * ldt + c] = x[q];                                        // T(c, r) = X(r, c)
-            A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * Rt[(size_t) c * ldrt + r] : b[q];
+            A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * Rt[c * PW + r] : b[q];
             Vw[(size_t) c * ldv + r] = (c < r) ? b[q] : (c == r ? 1.0 : 0.0);
             Umat[c * PW + r] = (c >= r) ? ui[q] : 0.0;                             // Umat := U^-1 (ld PW)
             if (c == r) tau[r] = x[q];
@@ -738,19 +559,6 @@ static void launch_factor(hipStream_t s, int nblk, int maxrows, const double* sr
     }
 }
 
-static void launch_factor_cs(hipStream_t s, int nblk, int maxrows, const double* src, int lds, int rows_total, int chunk, int w,
-                             double* Vloc, int ldv, double* tauloc, double* Tloc, double* Rstack, int ldr)
-{
-    if (maxrows <= 64)
-        hipLaunchKernelGGL((tsqr_factor_cs_kernel<64, 1>), dim3(nblk), dim3(256), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr);
-    else if (maxrows <= 128)
-        hipLaunchKernelGGL((tsqr_factor_cs_kernel<128, 1>), dim3(nblk), dim3(512), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr);
-    else if (maxrows <= 256)
-        hipLaunchKernelGGL((tsqr_factor_cs_kernel<256, 1>), dim3(nblk), dim3(1024), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr);
-    else
-        hipLaunchKernelGGL((tsqr_factor_cs_kernel<256, 2>), dim3(nblk), dim3(1024), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr);
-}
-
 static void launch_top(hipStream_t s, const double* stack, int lds, int rows, int w, double* Rt, double* Cout, int ldc)
 {
     switch (nt_for(rows)) {
@@ -798,7 +606,7 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
     const size_t nblk1cap = (size_t) (m_cap + PT - 1) / PT;
     const size_t up = 2 * nblk1cap * PW + 4 * PT;
     double* Vloc1 = ws;                        // ld = mk
-    double* Q1 = Vloc1 + (size_t) m_cap * PW;  // (unused since the final apply is fused with the reconstruction)
+    double* Q1 = Vloc1 + (size_t) m_cap * PW;  // ld = mk
     double* stacks = Q1 + (size_t) m_cap * PW;
     double* Vup = stacks + up * PW;
     double* Cup = Vup + up * PW;
@@ -806,46 +614,45 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
     double* Ts = taus + (nblk1cap + up / PW + 64) * PW;
     double* Rt = Ts + (nblk1cap + up / PW + 64) * PW * PW;
     double* Umat = Rt + PW * PW;
-    (void) Rt;
 
-    // ---- up the tree: level 0 = the panel rows, level l >= 1 = the stack of level l-1's R factors; stop at 1 block
+    // ---- up the tree
     const int MAXL = 8;
     int lv_rows[MAXL], lv_nblk[MAXL], lv_chunk[MAXL];
-    size_t lv_off[MAXL], lv_tau[MAXL];
-    const int gchunk = (PT / w) * w;
+    size_t lv_off[MAXL], lv_tau[MAXL];        // offsets of level l's input stack / Vloc / C (l >= 1) and tau
+    int L = 0;
     lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + PT - 1) / PT; lv_off[0] = 0; lv_tau[0] = 0;
-    launch_factor_cs(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks,
-                     lv_nblk[0] * w);
     size_t off = 0, toff = (size_t) lv_nblk[0] * PW;
-    int cur_rows = lv_nblk[0] * w, L = 0;
-    const double* Rtop = nullptr;
-    int ldrtop = 0;
-    for (;;) {
+    launch_factor(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, lv_nblk[0] * w);
+    int cur_rows = lv_nblk[0] * w;
+    const int gchunk = (PT / w) * w;
+    while (cur_rows > PT) {
         if (L + 2 >= MAXL) return -6;
         ++L;
         lv_rows[L] = cur_rows; lv_chunk[L] = gchunk; lv_nblk[L] = (cur_rows + gchunk - 1) / gchunk;
         lv_off[L] = off; lv_tau[L] = toff;
         const size_t next_off = off + (size_t) cur_rows * PW;
-        launch_factor_cs(s, lv_nblk[L], cur_rows < gchunk ? cur_rows : gchunk, stacks + off, cur_rows, cur_rows, gchunk, w,
-                         Vup + off, cur_rows, taus + toff, Ts + toff * PW, stacks + next_off, lv_nblk[L] * w);
+        launch_factor(s, lv_nblk[L], cur_rows < gchunk ? cur_rows : gchunk, stacks + off, cur_rows, cur_rows, gchunk, w,
+                      Vup + off, cur_rows, taus + toff, Ts + toff * PW, stacks + next_off, lv_nblk[L] * w);
         off = next_off; toff += (size_t) lv_nblk[L] * PW;
         cur_rows = lv_nblk[L] * w;
-        if (lv_nblk[L] == 1) { Rtop = stacks + off; ldrtop = w; break; }      // R~ of the whole leaf
     }
-    // ---- down the tree (compact-WY): level L starts from the identity
-    const double* Cin = nullptr;
-    int ldci = 0;
+    // ---- top: factor + explicit Q of the last stack; its output is the coefficient input of the level below
+    launch_top(s, stacks + off, cur_rows, cur_rows, w, Rt, Cup + off, cur_rows);
+    // ---- down the tree
+    const double* Cin = Cup + off;
+    int ldci = cur_rows;
     for (int l = L; l >= 1; --l) {
         launch_apply(s, lv_nblk[l], lv_rows[l] < lv_chunk[l] ? lv_rows[l] : lv_chunk[l], Vup + lv_off[l], lv_rows[l], taus + lv_tau[l],
                      Ts + lv_tau[l] * PW, lv_rows[l], lv_chunk[l], w, Cin, ldci, Cup + lv_off[l], lv_rows[l]);
         Cin = Cup + lv_off[l];
         ldci = lv_rows[l];
     }
-    // ---- Householder reconstruction on the top block, then every level-0 block writes its rows of V directly
-    hipLaunchKernelGGL(hr_top_kernel, dim3(1), dim3(64 * HG), 0, s, Vloc1, mk, taus, Ts, Cin, ldci, Rtop, ldrtop, w, P, ld, tau, T,
-                       ldt, Vw, ldv, Umat);
+    // ---- Householder reconstruction on the top block, then every level-1 block writes its rows of V directly
+    hipLaunchKernelGGL(hr_top_kernel, dim3(1), dim3(1024), 0, s, Vloc1, mk, taus, Ts, Cin, ldci, Rt, w, P, ld, tau, T, ldt, Vw,
+                       ldv, Umat);
     hipLaunchKernelGGL(tsqr_final_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, w, Cin, ldci, Umat, P, ld,
                        Vw, ldv);
+    (void) Q1;
     return (int) hipGetLastError();
 }
 

@@ -128,6 +128,27 @@ def test_rank_deficient_and_zero_columns(qr):
     assert np.linalg.norm(Q.T @ Q - np.eye(200)) < 1e-12
 
 
+@pytest.mark.parametrize("m,n,cond", [(3000, 200, 1e8), (3000, 200, 1e14), (700, 130, 1e12), (20000, 64, 1e13)])
+def test_ill_conditioned_matrices_stay_backward_stable(qr, m, n, cond):
+    """Householder QR is backward stable whatever the conditioning: ||A - QR||/||A|| and ||Q^T Q - I|| stay at
+    round-off for graded singular values up to 1e14 (this is what rules out Gram/Cholesky-type shortcuts in the
+    panel and what the TSQR + Householder-reconstruction leaf has to preserve)."""
+    rng = np.random.default_rng(int(np.log10(cond)) + m)
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    sv = np.logspace(0, -np.log10(cond), n)
+    A = (U * sv) @ V.T
+    A[:, n // 2] = A[:, 3] * (1 + 1e-13) + 1e-15 * rng.standard_normal(m)       # an almost exactly repeated column
+    Q, R = qr.qr_thin(A, nb=128, nshards=1)
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 5e-15 * np.sqrt(n)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-13 * n
+    # column scaling by 1e+-150 must not overflow/underflow into garbage (no dlarfg rescaling needed at these scales)
+    D = np.logspace(-100, 100, n)
+    Q2, R2 = qr.qr_thin(A * D, nb=128, nshards=1)
+    assert np.isfinite(R2).all()
+    assert np.linalg.norm(Q2.T @ Q2 - np.eye(n)) < 1e-13 * n
+
+
 @pytest.mark.parametrize("m,n,P", [(1024, 64, 1), (1024, 64, 2), (1024, 64, 4), (4096, 256, 8), (999, 40, 3)])
 def test_qr_thin_tsqr_shard_invariance(qr, oracle, m, n, P):
     """TSQR over P row shards on one device (SURVEY 8e 'test without 8 GPUs'): R is shard-count

@@ -87,11 +87,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    # BENCH_BACKEND=gloo: bring-up only -- lets N ranks share fewer GPUs (RCCL refuses duplicate devices); the R
+    # factors are then all-gathered through host memory.  The default and every reported number use RCCL.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import cuda_qr_amd as qr
     from cuda_qr_amd import tsqr as T
 
@@ -115,7 +121,7 @@ def main():
         raise SystemExit("square configs do not shard (replicas only, DESIGN.md); use --workload tsqr")
 
     be = T.HipBackend(qr, m_local, n, world, nb, args.ib)
-    ts = T.TSQR(be, n, world, rank)
+    ts = T.TSQR(be, n, world, rank, stage_through_host=(world > 1 and backend != "nccl"))
     K, W = args.steps, args.warmup
     bytes_per = 8 * m_local * n
     nbuf = min(K + W, max(1, int(160e9 // bytes_per)))
@@ -147,8 +153,9 @@ def main():
     dt = time.perf_counter() - t0
     prof = be.plan.get_profile()
     be.plan.set_profile(False)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -169,10 +176,15 @@ def main():
         be.plan.sync()
         d, a = be.plan.diffnorm(QR, m_local, m_local, n, row_off=rank * m_local, total_rows=m_total,
                                 seed=seeds[last])
-        sums = torch.tensor([d, a], dtype=torch.float64, device="cuda")
+        sums = torch.tensor([d, a], dtype=torch.float64, device=coll_dev)
         if world > 1:
             dist.all_reduce(sums)
-            dist.all_reduce(G)                                  # Q^T Q = sum over shards
+            if coll_dev == "cpu":
+                Gh = G.cpu()
+                dist.all_reduce(Gh)
+                G.copy_(Gh)
+            else:
+                dist.all_reduce(G)                              # Q^T Q = sum over shards
         o, _ = be.plan.diffnorm(G, n, n, n, mode=1)
         acc = {"resid": float((sums[0] / sums[1]).sqrt().item()), "orth": float(o ** 0.5)}
         del Q, QR, G
@@ -239,7 +251,7 @@ def main():
                        "ib": args.ib or qr.get_block_size()[1],
                        "flops_per_step": flops(m_total, n), "input_buffers": nbuf,
                        "input": "uniform[0,1) counter-hash generator, seed 12+i, resident in HBM",
-                       "collective": "none" if world == 1 else "1 all_gather of n*n doubles per rank (RCCL)"},
+                       "collective": "none" if world == 1 else f"1 all_gather of n*n doubles per rank ({'RCCL' if backend == 'nccl' else backend + ' via host, bring-up only'})"},
             "frac_of_fp64_matrix_peak": value / 1e3 / (FP64_MATRIX_PEAK_TFLOPS * world),
             "accuracy": acc,
             "roofline": roof,

@@ -72,6 +72,10 @@ _sig("qr_fill_uniform_dev", C.c_int, _vp, _vp, C.c_int, C.c_longlong, C.c_int, C
 _sig("qr_uniform_at", C.c_double, C.c_ulonglong, C.c_ulonglong)
 _sig("qr_diffnorm_dev", C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, C.c_longlong,
      C.c_longlong, C.c_ulonglong, C.c_int, _dp)
+_sig("qr_device_malloc", C.c_int, C.POINTER(_vp), C.c_size_t)
+_sig("qr_device_free", C.c_int, _vp)
+_sig("qr_copy_to_device", C.c_int, _vp, _vp, C.c_size_t)
+_sig("qr_copy_to_host", C.c_int, _vp, _vp, C.c_size_t)
 _sig("qr_plan_sync", C.c_int, _vp)
 _sig("qr_plan_stream", _vp, _vp)
 _sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)

@@ -485,6 +485,21 @@ int qr_diffnorm_dev(qr_plan* p, const double* dX, int ldx, const double* dY, int
     return qrd_diff_norm(p->stream, dX, ldx, dY, ldy, rows, cols, row_off, total_rows, seed, mode == 1, sums);
 }
 
+int qr_device_malloc(void** dptr, size_t bytes) { CHECK(ensure_device()); return dptr ? qrd_malloc(dptr, bytes) : QR_E_ARG; }
+int qr_device_free(void* dptr) { return qrd_free(dptr); }
+int qr_copy_to_device(void* dst, const void* src, size_t bytes)
+{
+    CHECK(ensure_device());
+    CHECK(qrd_h2d(NULL, dst, src, bytes));
+    return qrd_stream_sync(NULL);
+}
+int qr_copy_to_host(void* dst, const void* src, size_t bytes)
+{
+    CHECK(ensure_device());
+    CHECK(qrd_d2h(NULL, dst, src, bytes));
+    return qrd_stream_sync(NULL);
+}
+
 int qr_device_info(char* arch, int arch_len, int* cus, int* clock_khz, size_t* hbm)
 {
     CHECK(ensure_device());

@@ -79,8 +79,11 @@ class TSQR:
     """Reusable buffers + the 3(4)-step schedule.  `group` is a torch.distributed process group or
     None for a single process."""
 
-    def __init__(self, backend, n, world, rank, group=None):
+    def __init__(self, backend, n, world, rank, group=None, stage_through_host=False):
+        # stage_through_host: the R factors go through pinned host memory and a CPU collective (gloo).  Only for
+        # bring-up of the multi-rank path on a box with fewer GPUs than ranks; RCCL (backend "nccl") is the product path.
         self.b, self.n, self.world, self.rank, self.group = backend, n, world, rank, group
+        self.stage_through_host = stage_through_host
         self.R_local = backend.new_matrix(n, n)
         self.R = backend.new_matrix(n, n)
         # all ranks' R factors, rank-major: gathered[p] is rank p's n x n (column-major) block
@@ -95,7 +98,13 @@ class TSQR:
             b.local_factor(A, self.R)
             return self.R
         b.local_factor(A, self.R_local)
-        dist.all_gather_into_tensor(self.gathered.view(P * n, n), self.R_local, group=self.group)
+        if self.stage_through_host and self.R_local.is_cuda:
+            loc = self.R_local.cpu()
+            got = torch.empty((P * n, n), dtype=loc.dtype)
+            dist.all_gather_into_tensor(got, loc, group=self.group)
+            self.gathered.view(P * n, n).copy_(got)
+        else:
+            dist.all_gather_into_tensor(self.gathered.view(P * n, n), self.R_local, group=self.group)
         # gathered[p][c][r] = R_p(r, c); the stacked matrix is column-major (P*n) x n with R_p in rows
         # [p*n, (p+1)*n): stack[c][p*n + r] = gathered[p][c][r]
         self.stack.view(n, P, n).copy_(self.gathered.permute(1, 0, 2))

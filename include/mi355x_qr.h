@@ -117,6 +117,13 @@ int qr_diffnorm_dev(qr_plan* plan, const double* dX, int ldx, const double* dY, 
                     int cols, long long row_off, long long total_rows, unsigned long long seed, int mode,
                     double* sums);
 
+/* Device memory helpers so that a caller in any host language can use the device API without binding HIP itself
+ * (the buffers are ordinary hipMalloc memory of the current device; copies are synchronous). */
+int qr_device_malloc(void** dptr, size_t bytes);
+int qr_device_free(void* dptr);
+int qr_copy_to_device(void* dst, const void* src, size_t bytes);
+int qr_copy_to_host(void* dst, const void* src, size_t bytes);
+
 int qr_plan_sync(qr_plan* plan);
 void* qr_plan_stream(qr_plan* plan);          /* the hipStream_t work is queued on */
 

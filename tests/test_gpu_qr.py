@@ -281,3 +281,18 @@ def test_c_caller_links_the_drop_in_symbols(qr, tmp_path, m, n):
     assert rel_resid < 1e-12 and resid < 1e-12 * (m * n) ** 0.5 * 4
     if (m, n) == (6, 4):
         assert "Matrix 6 x 4, row by row:" in out          # printMat, qr.c:21-33
+
+
+def test_qr_device_cli_like_reference_harness(qr):
+    """`qr_device m n` (reference qr.cu:709-806): 3 timed host-pointer mmqr calls, average printed."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cuda-qr_amd", "build", "qr_device")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "cuda-qr_amd"), "build/qr_device"], check=True)
+    out = subprocess.run([exe, "1024", "64"], check=True, capture_output=True, text=True).stdout
+    assert "Exact problem size: 1024x64" in out
+    m = re.search(r"MMQR ran QR on 1024x64 matrix in (\S+) s \(avg over 3\)", out)
+    assert m and 0.0 < float(m.group(1)) < 5.0
+    usage = subprocess.run([exe], capture_output=True, text=True)
+    assert usage.returncode == 1 and "Usage: ./qr_device m n" in usage.stdout

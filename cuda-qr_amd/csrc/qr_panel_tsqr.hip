@@ -51,20 +51,25 @@ __device__ __forceinline__ void block_range(int rows_total, int chunk, int b, in
 // One Householder column on a workgroup-resident block (row r of the block in x[], one row per thread).
 // Same arithmetic as leaf_step_kernel (dlarfg convention; tau = 0 for an exactly-zero tail; qr.c:144-167 for the
 // reference's form).  ZCAP: also record Z(c, J) = v_c^T v_J for c < J (needed only when T is built from Z).
-template <int J, bool ZCAP, int NT>
-__device__ __forceinline__ void house_step(double (&x)[PW], int r, int rows, int w, PanelSharedT<NT / 64>& sh, double (*Z)[PW + 1],
-                                           int tid, int lane, int wave)
+template <int J, bool ZCAP, int NT, int RPT>
+__device__ __forceinline__ void house_step(double (&x)[RPT][PW], int r0, int rows, int w, PanelSharedT<NT / 64>& sh,
+                                           double (*Z)[PW + 1], int tid, int lane, int wave)
 {
     if (J >= w) return;                              // wave-uniform
-    const bool below = (r > J) && (r < rows);
     {
-        const double xj = below ? x[J] : 0.0;
         double prod[PW];
 #pragma unroll
-        for (int c = 0; c < PW; ++c) prod[c] = xj * x[c];
-        if (tid == J) {
+        for (int c = 0; c < PW; ++c) prod[c] = 0.0;
 #pragma unroll
-            for (int c = 0; c < PW; ++c) sh.row[c] = x[c];
+        for (int q = 0; q < RPT; ++q) {
+            const int r = r0 + NT * q;
+            const double xj = ((r > J) && (r < rows)) ? x[q][J] : 0.0;
+#pragma unroll
+            for (int c = 0; c < PW; ++c) prod[c] += xj * x[q][c];
+        }
+        if (tid == J) {                              // local row J is row 0 of thread J
+#pragma unroll
+            for (int c = 0; c < PW; ++c) sh.row[c] = x[0][c];
         }
         const double v = wave_reduce32(prod, lane);
         if ((lane & 1) == 0) sh.part[wave][lane >> 1] = v;
@@ -91,20 +96,24 @@ __device__ __forceinline__ void house_step(double (&x)[PW], int r, int rows, int
     }
     __syncthreads();
     const double tj = sh.scal[0], beta = sh.scal[1], iu = sh.scal[2];
-    const bool diag = (r == J);
-    const double vi = below ? x[J] * iu : (diag ? 1.0 : 0.0);
-    const double coef = tj * vi;
-    x[J] = below ? vi : (diag ? beta : x[J]);
 #pragma unroll
-    for (int c = J + 1; c < PW; ++c) x[c] -= coef * sh.s[c];
+    for (int q = 0; q < RPT; ++q) {
+        const int r = r0 + NT * q;
+        const bool below = (r > J) && (r < rows), diag = (r == J);
+        const double vi = below ? x[q][J] * iu : (diag ? 1.0 : 0.0);
+        const double coef = tj * vi;
+        x[q][J] = below ? vi : (diag ? beta : x[q][J]);
+#pragma unroll
+        for (int c = J + 1; c < PW; ++c) x[q][c] -= coef * sh.s[c];
+    }
 }
 
-template <int J, bool ZCAP, int NT>
-__device__ __forceinline__ void factor_all(double (&x)[PW], int r, int rows, int w, PanelSharedT<NT / 64>& sh, double (*Z)[PW + 1],
-                                           int tid, int lane, int wave)
+template <int J, bool ZCAP, int NT, int RPT>
+__device__ __forceinline__ void factor_all(double (&x)[RPT][PW], int r0, int rows, int w, PanelSharedT<NT / 64>& sh,
+                                           double (*Z)[PW + 1], int tid, int lane, int wave)
 {
-    house_step<J, ZCAP, NT>(x, r, rows, w, sh, Z, tid, lane, wave);
-    if constexpr (J + 1 < PW) factor_all<J + 1, ZCAP, NT>(x, r, rows, w, sh, Z, tid, lane, wave);
+    house_step<J, ZCAP, NT, RPT>(x, r0, rows, w, sh, Z, tid, lane, wave);
+    if constexpr (J + 1 < PW) factor_all<J + 1, ZCAP, NT, RPT>(x, r0, rows, w, sh, Z, tid, lane, wave);
 }
 
 // T (w x w upper triangular, into Tl[PW][PW+1] in LDS) of the block's reflectors from the captured Gram
@@ -198,7 +207,7 @@ __device__ __forceinline__ void load_block(double (&x)[PW], const double* __rest
 // F: local QR of every block of `src` (rows_total x w).  Leaves the factored block (R on top, reflector tails
 // below) in Vloc, its tau in tauloc[b*PW..], the Gram entries Z(i,k) = v_i^T v_k (the strict upper triangle of T^-1)
 // in Tloc[b*PW*PW + k*PW + i], and its R (w x w, zeros below the diagonal) in rows [b*w, b*w+w) of Rstack.
-template <int NT>
+template <int NT, int RPT>
 __global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restrict__ src, int lds, int rows_total, int chunk,
                                                          int w, double* __restrict__ Vloc, int ldv,
                                                          double* __restrict__ tauloc, double* __restrict__ Tloc,
@@ -209,20 +218,25 @@ __global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     int start, rows;
     block_range(rows_total, chunk, b, gridDim.x, start, rows);
-    double x[PW];
-    load_block(x, src, lds, start, tid, rows, w);
-    factor_all<0, true, NT>(x, tid, rows, w, sh, Z, tid, lane, wave);
-    __syncthreads();
-    if (tid < rows) {
+    double x[RPT][PW];
 #pragma unroll
-        for (int c = 0; c < PW; ++c)
-            if (c < w) Vloc[(size_t) c * ldv + start + tid] = x[c];
+    for (int q = 0; q < RPT; ++q) load_block(x[q], src, lds, start, tid + NT * q, rows, w);
+    factor_all<0, true, NT, RPT>(x, tid, rows, w, sh, Z, tid, lane, wave);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + NT * q;
+        if (r < rows) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c)
+                if (c < w) Vloc[(size_t) c * ldv + start + r] = x[q][c];
+        }
     }
     if (tid < w) {
         tauloc[b * PW + tid] = sh.tau[tid];
 #pragma unroll
         for (int c = 0; c < PW; ++c)
-            if (c < w) Rstack[(size_t) c * ldr + b * w + tid] = (c >= tid && tid < rows) ? x[c] : 0.0;
+            if (c < w) Rstack[(size_t) c * ldr + b * w + tid] = (c >= tid && tid < rows) ? x[0][c] : 0.0;
     }
     for (int e = tid; e < PW * PW; e += NT) {           // Zloc[b][k][i] = Z(i, k) = v_i^T v_k (i < k < w), else 0
         const int i = e % PW, k = e / PW;
@@ -241,9 +255,10 @@ __global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__
     __shared__ double V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
     __shared__ double tl[PW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double x[PW];
-    load_block(x, stack, lds, 0, tid, rows, w);
-    factor_all<0, true, NT>(x, tid, rows, w, sh, Z, tid, lane, wave);
+    double x1[1][PW];
+    load_block(x1[0], stack, lds, 0, tid, rows, w);
+    factor_all<0, true, NT, 1>(x1, tid, rows, w, sh, Z, tid, lane, wave);
+    double (&x)[PW] = x1[0];
     __syncthreads();
     if (tid < PW) {
         tl[tid] = (tid < w) ? sh.tau[tid] : 0.0;
@@ -468,29 +483,29 @@ __global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restric
 // (the top w rows were written by hr_top_kernel).  No explicit Q1 round trip through memory.
 __global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict__ Vloc, int ldvl,
                                                         const double* __restrict__ tauloc, const double* __restrict__ Tloc,
-                                                        int rows_total, int w, const double* __restrict__ Cin, int ldci,
+                                                        int rows_total, int nblk, int halves, int w,
+                                                        const double* __restrict__ Cin, int ldci,
                                                         const double* __restrict__ Umat, double* __restrict__ A, int lda,
                                                         double* __restrict__ Vw, int ldv)
 {
     __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1], Ui[PW][PW + 1];
     __shared__ double tl[PW];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    int start, rows;
-    block_range(rows_total, 0, b, gridDim.x, start, rows);
+    const int tid = threadIdx.x, b = blockIdx.x / halves, h = blockIdx.x % halves;
+    int bstart, brows;
+    block_range(rows_total, 0, b, nblk, bstart, brows);             // the level-0 block
+    const int start = bstart + h * PT, rows = min(PT, brows - h * PT);   // this workgroup's rows of it
     double x[PW];
-    load_block(x, Vloc, ldvl, start, tid, rows, w);
+    load_block(x, Vloc, ldvl, start, tid, max(rows, 1), w);
     for (int e = tid; e < PW * PW; e += PT) {
         const int i = e % PW, c = e / PW;
+        const bool in = (i < w && c < w);
         Zl[c][i] = Tloc[(size_t) b * PW * PW + e];                           // Zl[k][i] = Z(i, k)
-        Cl[i][c] = (i < w && c < w) ? Cin[(size_t) c * ldci + b * w + i] : 0.0;
+        Cl[i][c] = in ? Cin[(size_t) c * ldci + b * w + i] : 0.0;
         Ui[i][c] = (i <= c && c < w) ? Umat[c * PW + i] : 0.0;
+        const double v = in ? Vloc[(size_t) c * ldvl + bstart + i] : 0.0;    // unit-lower top of the block
+        V1[i][c] = in ? ((c < i) ? v : (c == i ? 1.0 : 0.0)) : 0.0;
     }
-    if (tid < PW) {
-        tl[tid] = (tid < w) ? tauloc[b * PW + tid] : 0.0;
-#pragma unroll
-        for (int c = 0; c < PW; ++c)
-            V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[c] : (c == tid ? 1.0 : 0.0)) : 0.0;
-    }
+    if (tid < PW) tl[tid] = (tid < w) ? tauloc[b * PW + tid] : 0.0;
     __syncthreads();
     small_m<PT>(V1, Cl, Zl, tl, Wl, Ml, w, tid);
     for (int e = tid; e < PW * PW; e += PT) {           // Wl = Ml Ui ;  Zl (reused) = Cl Ui     (Ui upper triangular)
@@ -501,10 +516,11 @@ __global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict
         Zl[i][q] = a2;
     }
     __syncthreads();
+    const int rb = h * PT + tid;                        // row index inside the level-0 block
     double out[PW];
 #pragma unroll
-    for (int q = 0; q < PW; ++q) out[q] = (tid < w) ? Zl[min(tid, PW - 1)][q] : 0.0;
-    wy_row(x, out, tid, w, Wl);
+    for (int q = 0; q < PW; ++q) out[q] = (rb < w) ? Zl[min(rb, PW - 1)][q] : 0.0;
+    wy_row(x, out, rb, w, Wl);
     if (tid < rows && start + tid >= w) {
         const size_t rg = (size_t) start + tid;
 #pragma unroll
@@ -521,9 +537,10 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
     __shared__ PanelShared sh;
     __shared__ double Z[PW][PW + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double x[PW];
-    load_block(x, P, ld, 0, tid, mk, w);
-    factor_all<0, true, PT>(x, tid, mk, w, sh, Z, tid, lane, wave);
+    double x1[1][PW];
+    load_block(x1[0], P, ld, 0, tid, mk, w);
+    factor_all<0, true, PT, 1>(x1, tid, mk, w, sh, Z, tid, lane, wave);
+    double (&x)[PW] = x1[0];
     __syncthreads();
     if (tid < mk) {
 #pragma unroll
@@ -551,11 +568,15 @@ static int nt_for(int rows) { return rows <= 64 ? 64 : (rows <= 128 ? 128 : (row
 static void launch_factor(hipStream_t s, int nblk, int maxrows, const double* src, int lds, int rows_total, int chunk, int w,
                           double* Vloc, int ldv, double* tauloc, double* Tloc, double* Rstack, int ldr)
 {
+    if (maxrows > PT) {      // two rows per thread: 1024-row blocks, one tree level less for tall leaves
+        hipLaunchKernelGGL((tsqr_factor_kernel<512, 2>), dim3(nblk), dim3(512), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr);
+        return;
+    }
     switch (nt_for(maxrows)) {
-    case 64: hipLaunchKernelGGL(tsqr_factor_kernel<64>, dim3(nblk), dim3(64), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
-    case 128: hipLaunchKernelGGL(tsqr_factor_kernel<128>, dim3(nblk), dim3(128), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
-    case 256: hipLaunchKernelGGL(tsqr_factor_kernel<256>, dim3(nblk), dim3(256), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
-    default: hipLaunchKernelGGL(tsqr_factor_kernel<512>, dim3(nblk), dim3(512), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    case 64: hipLaunchKernelGGL((tsqr_factor_kernel<64, 1>), dim3(nblk), dim3(64), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    case 128: hipLaunchKernelGGL((tsqr_factor_kernel<128, 1>), dim3(nblk), dim3(128), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    case 256: hipLaunchKernelGGL((tsqr_factor_kernel<256, 1>), dim3(nblk), dim3(256), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    default: hipLaunchKernelGGL((tsqr_factor_kernel<512, 1>), dim3(nblk), dim3(512), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
     }
 }
 
@@ -620,7 +641,10 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
     int lv_rows[MAXL], lv_nblk[MAXL], lv_chunk[MAXL];
     size_t lv_off[MAXL], lv_tau[MAXL];        // offsets of level l's input stack / Vloc / C (l >= 1) and tau
     int L = 0;
-    lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + PT - 1) / PT; lv_off[0] = 0; lv_tau[0] = 0;
+    // level-0 blocks: 512 rows (one row per thread) up to 8192 rows -- 16 blocks, a two-level tree --, 1024 rows (two rows
+    // per thread) above, which keeps the tree at two levels up to 16384 rows and three up to 262144
+    const int brows0 = (mk <= 16 * PT) ? PT : 2 * PT;
+    lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + brows0 - 1) / brows0; lv_off[0] = 0; lv_tau[0] = 0;
     size_t off = 0, toff = (size_t) lv_nblk[0] * PW;
     launch_factor(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, lv_nblk[0] * w);
     int cur_rows = lv_nblk[0] * w;
@@ -650,8 +674,9 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
     // ---- Householder reconstruction on the top block, then every level-1 block writes its rows of V directly
     hipLaunchKernelGGL(hr_top_kernel, dim3(1), dim3(1024), 0, s, Vloc1, mk, taus, Ts, Cin, ldci, Rt, w, P, ld, tau, T, ldt, Vw,
                        ldv, Umat);
-    hipLaunchKernelGGL(tsqr_final_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, w, Cin, ldci, Umat, P, ld,
-                       Vw, ldv);
+    const int halves = brows0 / PT;
+    hipLaunchKernelGGL(tsqr_final_kernel, dim3(lv_nblk[0] * halves), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, lv_nblk[0], halves, w,
+                       Cin, ldci, Umat, P, ld, Vw, ldv);
     (void) Q1;
     return (int) hipGetLastError();
 }

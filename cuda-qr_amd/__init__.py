@@ -237,7 +237,9 @@ def colmajor(m, n, device="cuda"):
 def to_device_colmajor(A, device="cuda"):
     """numpy (m x n) -> torch (n, m) buffer holding A column-major."""
     import torch
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(A, dtype=np.float64).T)).to(device)
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(A, dtype=np.float64).T)).to(device)
+    torch.cuda.synchronize()      # the copy ran on torch's stream; the plan's streams are not ordered with it
+    return t
 
 
 def from_device_colmajor(t):

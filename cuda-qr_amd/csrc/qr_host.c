@@ -22,14 +22,24 @@
 
 #define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+#define QR_MAX_PAIRS 4
+#define QR_DEFAULT_SPLIT "64"
 struct qr_plan {
     int m, n, nb, ib, ldv, ldt;
     int use_graph;              /* 1: qr_geqrf_dev is captured into a hipGraph once per argument set and replayed */
     void* graph_exec;
     double *g_dA, *g_dtau; int g_m, g_n, g_lda;
     int lookahead;              /* 1: panel k+1 is factored on `stream` while `stream_u` updates the rest */
-    void* stream;               /* panel / critical-path stream (high priority); the plan's public stream */
-    void* stream_u;             /* wide trailing-update stream */
+    void* stream;               /* stream the next launch of the critical path goes to: s_main outside qr_geqrf_dev,
+                                 * the current phase's panel stream inside it */
+    void* stream_u;             /* wide trailing-update stream of the current phase */
+    void* s_main;               /* the plan's public stream: all compute units */
+    /* CU partition phases: while more than until[i] of the columns remain, the panel chain owns cus[i] compute
+     * units (s_pair[i][0]) and the wide update the rest (s_pair[i][1]).  npairs = 0: no partition. */
+    int npairs, pair_cur;
+    void* s_pair[QR_MAX_PAIRS][2];
+    double pair_until[QR_MAX_PAIRS];
+    void* ev_hop[2];
     void* ev_panel[2];          /* panel set s ready (V, T, VT) */
     void* ev_wide[2];           /* wide update that read panel set s finished */
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
@@ -117,22 +127,37 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     p->lookahead = la ? atoi(la) != 0 : 1;
     const char* gr = getenv("MI355XQR_GRAPH");
     p->use_graph = gr ? atoi(gr) != 0 : 0;
-    /* MI355XQR_PANEL_CUS = c > 0: the panel chain runs on its own c compute units and the wide update on the
-     * other 256-c, so a leaf kernel never queues behind resident GEMM workgroups (0: shared, priority only). */
-    const char* pc = getenv("MI355XQR_PANEL_CUS");
-    /* default: 64 CUs for the panel chain when there is a wide update worth overlapping with (n >= 2048);
-     * tall-skinny problems are all panel, so they keep the whole chip on one stream set */
-    const int panel_cus = pc ? atoi(pc) : (n >= 2048 ? 64 : 0);
-    int rc;
-    if (p->lookahead && panel_cus > 0 && panel_cus < 224) {
+    /* MI355XQR_SPLIT = "c0:f0,c1:f1,...,ck": the panel chain runs on its own c_i compute units and the wide update
+     * on the other 256-c_i while more than the fraction f_i of the columns is still to be factored (last entry: to
+     * the end), so a leaf kernel never queues behind resident GEMM workgroups and the split follows the shrinking
+     * trailing matrix.  "0" = no partition (shared CUs, stream priority only).  MI355XQR_PANEL_CUS=c is the
+     * one-phase form.  Default: partition when there is a wide update worth overlapping with (n >= 2048);
+     * tall-skinny problems are all panel, so they keep the whole chip on one stream set. */
+    int rc = qrd_stream_create(&p->s_main, 1);
+    p->stream = p->s_main;
+    p->pair_cur = -1;
+    if (!rc && p->lookahead) {
+        const char* sp = getenv("MI355XQR_SPLIT");
+        const char* pc = getenv("MI355XQR_PANEL_CUS");
+        char spec[128];
+        if (sp) snprintf(spec, sizeof spec, "%s", sp);
+        else if (pc) snprintf(spec, sizeof spec, "%s", pc);
+        else snprintf(spec, sizeof spec, "%s", n >= 2048 ? QR_DEFAULT_SPLIT : "0");
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
-        rc = qrd_stream_create_cumask(&p->stream, 0, panel_cus);
-        if (!rc) rc = qrd_stream_create_cumask(&p->stream_u, panel_cus, cus - panel_cus);
-    } else {
-        rc = qrd_stream_create(&p->stream, 1);
-        if (!rc) rc = qrd_stream_create(&p->stream_u, 0);
+        for (char* tok = strtok(spec, ","); tok && !rc && p->npairs < QR_MAX_PAIRS; tok = strtok(NULL, ",")) {
+            const int c = atoi(tok);
+            const char* colon = strchr(tok, ':');
+            if (c <= 0 || c >= cus) { p->npairs = 0; break; }
+            const int i = p->npairs++;
+            p->pair_until[i] = colon ? atof(colon + 1) : 0.0;
+            rc = qrd_stream_create_cumask(&p->s_pair[i][0], 0, c);
+            if (!rc) rc = qrd_stream_create_cumask(&p->s_pair[i][1], c, cus - c);
+        }
+        if (p->npairs) p->pair_until[p->npairs - 1] = 0.0;
     }
+    if (!rc && p->npairs == 0) rc = qrd_stream_create(&p->stream_u, 0);
+    for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_hop[e]);
     for (int e = 0; e < 2 && !rc; ++e) {
         rc = qrd_event_create_notiming(&p->ev_panel[e]);
         if (!rc) rc = qrd_event_create_notiming(&p->ev_wide[e]);
@@ -173,8 +198,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
 int qr_plan_destroy(qr_plan* p)
 {
     if (!p) return 0;
-    if (p->stream) qrd_stream_sync(p->stream);
-    if (p->stream_u) qrd_stream_sync(p->stream_u);
+    qr_plan_sync(p);
     qrd_graph_destroy(p->graph_exec);
     for (int e = 0; e < 2; ++e) {
         if (p->ev_panel[e]) qrd_event_destroy(p->ev_panel[e]);
@@ -182,13 +206,18 @@ int qr_plan_destroy(qr_plan* p)
         qrd_free(p->Vw2[e]); qrd_free(p->VT2[e]); qrd_free(p->T2[e]);
     }
     qrd_free(p->Wn); qrd_free(p->slabs_u);
-    if (p->stream_u) qrd_stream_destroy(p->stream_u);
+    for (int i = 0; i < p->npairs; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (p->s_pair[i][j]) qrd_stream_destroy(p->s_pair[i][j]);
+    if (p->npairs == 0 && p->stream_u) qrd_stream_destroy(p->stream_u);
+    for (int e = 0; e < 2; ++e)
+        if (p->ev_hop[e]) qrd_event_destroy(p->ev_hop[e]);
     for (int i = 0; i < 2 * p->prof_cap; ++i)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
     qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws);
-    if (p->stream) qrd_stream_destroy(p->stream);
+    if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
     return 0;
 }
@@ -196,10 +225,13 @@ int qr_plan_destroy(qr_plan* p)
 int qr_plan_sync(qr_plan* p)
 {
     if (!p) return QR_E_ARG;
-    CHECK(qrd_stream_sync(p->stream_u));
-    return qrd_stream_sync(p->stream);
+    for (int i = 0; i < p->npairs; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (p->s_pair[i][j]) CHECK(qrd_stream_sync(p->s_pair[i][j]));
+    if (p->npairs == 0 && p->stream_u) CHECK(qrd_stream_sync(p->stream_u));
+    return p->s_main ? qrd_stream_sync(p->s_main) : 0;
 }
-void* qr_plan_stream(qr_plan* p) { return p ? p->stream : NULL; }
+void* qr_plan_stream(qr_plan* p) { return p ? p->s_main : NULL; }
 
 static int ensure_w(qr_plan* p, size_t elems)
 {
@@ -380,6 +412,31 @@ int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
     return qrd_graph_launch(p->graph_exec, p->stream);
 }
 
+/* CU-partition phase for a step with `remaining` of n columns still to factor */
+static int phase_of(const qr_plan* p, int remaining, int n)
+{
+    int i = 0;
+    while (i + 1 < p->npairs && (double) remaining <= p->pair_until[i] * n) ++i;
+    return p->npairs ? i : -1;
+}
+
+/* Move the critical path (and the wide-update stream) to phase i's streams; -1 = back to the public stream.
+ * Everything queued so far on the old streams is ordered before anything queued later on the new ones. */
+static int enter_phase(qr_plan* p, int i)
+{
+    if (p->npairs == 0 || i == p->pair_cur) return 0;
+    void* ns = i < 0 ? p->s_main : p->s_pair[i][0];
+    void* nu = i < 0 ? NULL : p->s_pair[i][1];
+    CHECK(qrd_event_record(p->ev_hop[0], p->stream));
+    CHECK(qrd_stream_wait_event(ns, p->ev_hop[0]));
+    if (p->stream_u) {
+        CHECK(qrd_event_record(p->ev_hop[1], p->stream_u));
+        CHECK(qrd_stream_wait_event(nu ? nu : ns, p->ev_hop[1]));
+    }
+    p->stream = ns; p->stream_u = nu; p->pair_cur = i;
+    return 0;
+}
+
 static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     const int nb = p->nb;
@@ -401,6 +458,7 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
      *   W(s)  needs P(s) (ev_panel[s&1]) and W(s-1) (stream order);
      *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
     int wide_pending[2] = {0, 0};
+    CHECK(enter_phase(p, phase_of(p, n, n)));
     {
         const int w0 = imin(nb, n);
         use_set(p, 0);
@@ -414,6 +472,7 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
         const int e = s & 1, wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
         if (nt <= 0) break;
         const int wnext = imin(nb, nt), nwide = nt - wnext;
+        CHECK(enter_phase(p, phase_of(p, nt, n)));
         if (s > 0 && wide_pending[e ^ 1]) {
             CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e ^ 1]));
             wide_pending[e ^ 1] = 0;
@@ -435,7 +494,7 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
     for (int e = 0; e < 2; ++e)
         if (wide_pending[e]) CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e]));
     use_set(p, 0);
-    return 0;
+    return enter_phase(p, -1);
 }
 
 int qr_applyq_dev(qr_plan* p, const double* dA, int m, int n, int lda, const double* dtau, double* dC, int ccols,

@@ -5,7 +5,9 @@ import torch
 
 def dev(A):
     """numpy (m x n) -> torch cuda tensor of shape (n, m): the column-major image of A."""
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(A, dtype=np.float64).T)).cuda()
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(A, dtype=np.float64).T)).cuda()
+    torch.cuda.synchronize()      # torch's stream and the plan's (non-blocking) streams are not ordered
+    return t
 
 
 def host(t):
@@ -15,7 +17,9 @@ def host(t):
 
 
 def zeros(m, n):
-    return torch.zeros((n, m), dtype=torch.float64, device="cuda")
+    t = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()      # the fill runs on torch's stream: finish it before a plan stream writes t
+    return t
 
 
 def rel(a, b):

@@ -1,5 +1,5 @@
 """ad-hoc perf exploration (not the bench contract): time geqrf with per-class event profile."""
-import sys, time, json
+import sys, time, json, os
 import torch
 import cuda_qr_amd as q
 
@@ -24,6 +24,19 @@ def run(m, n, nb, ib=32, reps=2):
     for k, v in prof.items():
         if v["launches"]:
             line[k] = {"ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "n": v["launches"]}
+    if os.environ.get("CHECK"):
+        z = lambda r, c: torch.zeros((c, r), dtype=torch.float64, device="cuda")
+        for rep in range(int(os.environ["CHECK"])):
+            p.fill_uniform(dA, m, m, n, seed=12)
+            dQ, dR, dQR = z(m, n), z(n, n), z(m, n)
+            torch.cuda.synchronize()
+            p.geqrf(dA, m, n, m, dtau)
+            p.extract_r(dA, m, n, m, dR, n, n)
+            p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+            p.gemm("N", m, n, n, 1.0, dQ, m, dR, n, 0.0, dQR, m)
+            p.sync()
+            d, a = p.diffnorm(dQR, m, m, n, seed=12)
+            line.setdefault("resid", []).append(float((d / a) ** 0.5))
     print(json.dumps(line), flush=True)
     p.close()
 

@@ -40,6 +40,10 @@ struct qr_plan {
     void* s_pair[QR_MAX_PAIRS][2];
     double pair_until[QR_MAX_PAIRS];
     void* ev_hop[2];
+    void* ev_extra[2];          /* panel-stream share of wide update s finished */
+    double *We, *Ye;            /* its W buffer and raw V^T A2 */
+    double *Yn;                 /* raw V^T A_next of the look-ahead update */
+    double bal_rp, bal_ru, bal_tc0, bal_tc1;   /* load-balance model (TFLOP/s, ms); bal_rp = 0: off */
     void* ev_panel[2];          /* panel set s ready (V, T, VT) */
     void* ev_wide[2];           /* wide update that read panel set s finished */
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
@@ -158,6 +162,17 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     }
     if (!rc && p->npairs == 0) rc = qrd_stream_create(&p->stream_u, 0);
     for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_hop[e]);
+    for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_extra[e]);
+    {
+        /* MI355XQR_BALANCE = "Rp,Ru,tc0,tc1" (TFLOP/s on the panel CUs, on the update CUs; next-panel chain time
+         * tc0 + tc1*mk/16384 ms at nb = 256); "0" = the panel stream takes no share of the wide update */
+        const char* b = getenv("MI355XQR_BALANCE");
+        p->bal_rp = 13.0; p->bal_ru = 43.0; p->bal_tc0 = 1.5; p->bal_tc1 = 1.2;
+        if (b) {
+            p->bal_rp = 0.0;
+            sscanf(b, "%lf,%lf,%lf,%lf", &p->bal_rp, &p->bal_ru, &p->bal_tc0, &p->bal_tc1);
+        }
+    }
     for (int e = 0; e < 2 && !rc; ++e) {
         rc = qrd_event_create_notiming(&p->ev_panel[e]);
         if (!rc) rc = qrd_event_create_notiming(&p->ev_wide[e]);
@@ -177,10 +192,13 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     p->Vw = p->Vw2[0]; p->VT = p->VT2[0]; p->T = p->T2[0];
     if (!rc) rc = qrd_malloc((void**) &p->W, sizeof(double) * p->w_cap);
     if (!rc) rc = qrd_malloc((void**) &p->Wn, sizeof(double) * (size_t) nb * nb);
+    if (!rc && p->npairs && p->bal_rp > 0.0) rc = qrd_malloc((void**) &p->We, sizeof(double) * p->w_cap);
+    if (!rc && p->We) rc = qrd_malloc((void**) &p->Ye, sizeof(double) * p->w_cap);
+    if (!rc) rc = qrd_malloc((void**) &p->Yn, sizeof(double) * (size_t) nb * nb);
     if (!rc) rc = qrd_malloc((void**) &p->slabs_u, sizeof(double) * p->slab_cap);
     if (!rc) rc = qrd_malloc((void**) &p->Tt, sizeof(double) * (size_t) nb * nb);
     if (!rc) rc = qrd_malloc((void**) &p->G, sizeof(double) * (size_t) nb * nb);
-    if (!rc) rc = qrd_malloc((void**) &p->X, sizeof(double) * (size_t) nb * QRD_LEAFW);
+    if (!rc) rc = qrd_malloc((void**) &p->X, sizeof(double) * (size_t) nb * nb);
     if (!rc) rc = qrd_malloc((void**) &p->slabs, sizeof(double) * p->slab_cap);
     if (!rc) rc = qrd_malloc((void**) &p->leaf_scratch, sizeof(double) * QRD_LEAF_SCRATCH);
     {
@@ -205,13 +223,15 @@ int qr_plan_destroy(qr_plan* p)
         if (p->ev_wide[e]) qrd_event_destroy(p->ev_wide[e]);
         qrd_free(p->Vw2[e]); qrd_free(p->VT2[e]); qrd_free(p->T2[e]);
     }
-    qrd_free(p->Wn); qrd_free(p->slabs_u);
+    qrd_free(p->Wn); qrd_free(p->slabs_u); qrd_free(p->We); qrd_free(p->Ye); qrd_free(p->Yn);
     for (int i = 0; i < p->npairs; ++i)
         for (int j = 0; j < 2; ++j)
             if (p->s_pair[i][j]) qrd_stream_destroy(p->s_pair[i][j]);
     if (p->npairs == 0 && p->stream_u) qrd_stream_destroy(p->stream_u);
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e) {
         if (p->ev_hop[e]) qrd_event_destroy(p->ev_hop[e]);
+        if (p->ev_extra[e]) qrd_event_destroy(p->ev_extra[e]);
+    }
     for (int i = 0; i < 2 * p->prof_cap; ++i)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
@@ -332,7 +352,7 @@ int qr_gemm_dev(qr_plan* p, char transa, int M, int N, int K, double alpha, cons
 
 /* ---- factorisation --------------------------------------------------------------------------- */
 /* One outer panel: columns [k, k+wout) over rows [k, m).  Leaves V (explicit, unit lower trapezoid)
- * in p->Vw, the panel's compact-WY T in p->T and V*T in p->VT (the last two only if want_t). */
+ * in p->Vw and the panel's compact-WY T in p->T (only if want_t). */
 static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t)
 {
     const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt;
@@ -363,7 +383,8 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
             CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, p->nb, NULL));          /* Gram */
             CHECK(qrd_larft(p->stream, wout, ib, p->G, p->nb, dtau + k, p->T, ldt, NULL, 0, p->X, p->nb));
         }
-        CHECK(qrd_gemm_nn(p->stream, mk, wout, wout, 1.0, p->Vw, ldv, p->T, ldt, 0.0, p->VT, ldv));
+        /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the
+         * wide update builds V*T itself on its own stream (update_cols), off the critical path */
     }
     return 0;
 }
@@ -371,24 +392,57 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
 static void use_set(qr_plan* p, int e) { p->Vw = p->Vw2[e]; p->VT = p->VT2[e]; p->T = p->T2[e]; }
 
 /* trailing update of columns [c0, c0+nc) with the reflectors of panel set e: W = (V T)^T A ; A -= V W */
+/* Apply panel set e's block reflector to columns [c0, c0+nc):  A2 -= V (T^T (V^T A2)).
+ * profile 1 = the wide update on the update stream: V*T is formed first (class 3) and W = (V T)^T A2 is one long-K
+ *             product (class 1), then A2 -= V W (class 0); kernels under their own profiler names;
+ * profile 0 = look-ahead update of the next panel (inside the panel chain's record), 2 = the share of the wide update
+ *             done on the panel CUs (class 3): Y = V^T A2, W = T^T Y (a small product), A2 -= V W -- no V*T needed.
+ * Ybuf: nc*wout doubles of scratch for profile 0 / 2. */
 static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int k, int mk, int wout, int c0, int nc,
-                       double* Wbuf, double* slabs, int profile)
+                       double* Wbuf, double* Ybuf, double* slabs, int profile)
 {
     double* A2 = dA + (size_t) c0 * lda + k;
     const int ldv = p->ldv;
-    if (profile) CHECK(prof_begin_on(p, 1, stream));
-    if (profile && wout >= 128 && nc >= 128)   /* the wide update: same kernels under their own profiler names */
-        CHECK(qrd_gemm_tn_update(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap));
-    else
-        CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap, NULL, 0));
-    if (profile) CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 8.0 * mk * ((double) nc + wout)));
-    if (profile) CHECK(prof_begin_on(p, 0, stream));
-    if (profile && wout >= 128 && nc >= 128)
-        CHECK(qrd_gemm_nn_update(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
-    else
-        CHECK(qrd_gemm_nn(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
-    if (profile) CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 16.0 * mk * (double) nc + 8.0 * mk * wout));
+    if (profile == 1) {
+        const int tagged = wout >= 128 && nc >= 128;
+        CHECK(prof_begin_on(p, 3, stream));
+        CHECK(qrd_gemm_nn(stream, mk, wout, wout, 1.0, p->Vw2[e], ldv, p->T2[e], p->ldt, 0.0, p->VT2[e], ldv));
+        CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+        CHECK(prof_begin_on(p, 1, stream));
+        if (tagged)
+            CHECK(qrd_gemm_tn_update(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap));
+        else
+            CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap, NULL, 0));
+        CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 8.0 * mk * ((double) nc + wout)));
+        CHECK(prof_begin_on(p, 0, stream));
+        if (tagged)
+            CHECK(qrd_gemm_nn_update(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
+        else
+            CHECK(qrd_gemm_nn(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
+        CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 16.0 * mk * (double) nc + 8.0 * mk * wout));
+        return 0;
+    }
+    if (profile) CHECK(prof_begin_on(p, 3, stream));
+    CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->Vw2[e], ldv, A2, lda, 0.0, Ybuf, wout, slabs, p->slab_cap, NULL, 0));
+    CHECK(qrd_gemm_tn(stream, wout, nc, wout, 1.0, p->T2[e], p->ldt, Ybuf, wout, 0.0, Wbuf, wout, NULL, 0, NULL, 0));
+    CHECK(qrd_gemm_nn(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
+    if (profile) CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
     return 0;
+}
+
+/* Columns of the wide update that the panel stream takes over after it has factored the next panel, so that both
+ * streams finish step s together:  tc + F x / Rp = F (nwide - x) / Ru  with F = 4 mk nb flops per column, tc the
+ * modelled time of the next panel chain, Rp / Ru the GEMM rates of the panel CUs / the update CUs. */
+static int balance_cols(const qr_plan* p, int mk, int wout, int nwide)
+{
+    if (!p->npairs || p->bal_rp <= 0.0 || nwide <= 0) return 0;
+    const double F = 4.0 * mk * (double) wout * 1e-9;                  /* GFLOP per column */
+    const double tc = (p->bal_tc0 + p->bal_tc1 * (double) mk / 16384.0) * (double) wout / 256.0;   /* ms */
+    const double x = (F * nwide / p->bal_ru - tc) / (F * (1.0 / p->bal_rp + 1.0 / p->bal_ru));   /* rates in GFLOP/ms = TFLOP/s */
+    int xi = (int) x;
+    xi -= xi % 128;
+    if (xi < 128) return 0;
+    return xi > nwide ? nwide : xi;
 }
 
 static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau);
@@ -447,7 +501,7 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
             CHECK(prof_begin(p, 2));
             CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
-            if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, p->slabs, 1));
+            if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, NULL, p->slabs, 1));
         }
         return 0;
     }
@@ -457,7 +511,7 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
      *   N(s)  needs P(s) (stream order) and W(s-1) (ev_wide[(s-1)&1]);
      *   W(s)  needs P(s) (ev_panel[s&1]) and W(s-1) (stream order);
      *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
-    int wide_pending[2] = {0, 0};
+    int wide_pending[2] = {0, 0}, extra_pending = 0;
     CHECK(enter_phase(p, phase_of(p, n, n)));
     {
         const int w0 = imin(nb, n);
@@ -477,19 +531,28 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
             CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e ^ 1]));
             wide_pending[e ^ 1] = 0;
         }
-        CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout, wnext, p->Wn, p->slabs, 0));   /* N(s) */
-        if (nwide > 0) {                                                                                      /* W(s) */
+        CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout, wnext, p->Wn, p->Yn, p->slabs, 0));   /* N(s) */
+        const int extra = p->We ? balance_cols(p, mk, wout, nwide) : 0;
+        if (nwide - extra > 0) {                                                                              /* W(s) */
             CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
-            CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout + wnext, nwide, p->W, p->slabs_u, 1));
+            if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));   /* E(s-1) wrote columns W(s) reads */
+            CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout + wnext + extra, nwide - extra, p->W,
+                              NULL, p->slabs_u, 1));
             CHECK(qrd_event_record(p->ev_wide[e], p->stream_u));
             wide_pending[e] = 1;
         }
+        extra_pending = 0;
         const int k1 = k + wout, mk1 = m - k1, nt1 = n - (k1 + wnext);                                        /* P(s+1) */
         use_set(p, e ^ 1);
         CHECK(prof_begin(p, 2));
         CHECK(factor_panel(p, dA, m, lda, k1, wnext, dtau, nt1 > 0));
         CHECK(prof_end(p, 2.0 * mk1 * (double) wnext * wnext, 16.0 * mk1 * wnext));
         CHECK(qrd_event_record(p->ev_panel[e ^ 1], p->stream));
+        if (extra > 0) {                                                                                      /* E(s) */
+            CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout + wnext, extra, p->We, p->Ye, p->slabs, 2));
+            CHECK(qrd_event_record(p->ev_extra[e], p->stream));
+            extra_pending = 1;
+        }
     }
     for (int e = 0; e < 2; ++e)
         if (wide_pending[e]) CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e]));

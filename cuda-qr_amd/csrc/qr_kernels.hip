@@ -201,11 +201,10 @@ __device__ __forceinline__ void gemm_epilogue(const v4d (&acc)[TJ][TI], double* 
 // C = beta*C + alpha*A*B     A: M x K (lda), B: K x N (ldb), C: M x N (ldc), all column-major.
 // Used for: trailing update A2 -= V*W (K = nb), VT = V*T, T merges, Q*R products, Q_local*Q_tree.
 // TAG only gives the wide trailing-update launches their own kernel name in profiler output (TAG = 1).
-template <int TI, int TJ, bool FAST, int TAG = 0>
-__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, double alpha,
-                                                         const double* __restrict__ A, int lda,
-                                                         const double* __restrict__ B, int ldb,
-                                                         double beta, double* __restrict__ C, int ldc)
+template <int TI, int TJ, bool FAST>
+__device__ __forceinline__ void gemm_nn_body(int M, int N, int K, double alpha, const double* __restrict__ A, int lda,
+                                             const double* __restrict__ B, int ldb, double beta,
+                                             double* __restrict__ C, int ldc)
 {
     constexpr int BM = 32 * TI, BN = 32 * TJ, LA = BM + 16;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -246,6 +245,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, do
 
     if (cinit || beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
     else gemm_epilogue<TI, TJ, false>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
+}
+
+template <int TI, int TJ, bool FAST, int TAG = 0>
+__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, double alpha,
+                                                         const double* __restrict__ A, int lda,
+                                                         const double* __restrict__ B, int ldb,
+                                                         double beta, double* __restrict__ C, int ldc)
+{
+    gemm_nn_body<TI, TJ, FAST>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+// blockIdx.z = batch index: the same small product on operands a fixed stride apart (the T-merge tree)
+template <int TI, int TJ, bool FAST>
+__global__ __launch_bounds__(256, 2) void gemm_nn_batch_kernel(int M, int N, int K, double alpha,
+                                                               const double* __restrict__ A, int lda, size_t sA,
+                                                               const double* __restrict__ B, int ldb, size_t sB,
+                                                               double beta, double* __restrict__ C, int ldc, size_t sC)
+{
+    const size_t z = blockIdx.z;
+    gemm_nn_body<TI, TJ, FAST>(M, N, K, alpha, A + z * sA, lda, B + z * sB, ldb, beta, C + z * sC, ldc);
 }
 
 // C = alpha * A^T * B (+ beta*C when not split)   A: K x M (lda), B: K x N (ldb), C: M x N (ldc).
@@ -643,6 +662,32 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, unsigned lo
     if (threadIdx.x == 0 && stamps) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// GEMM-shaped variant: a 4 x 4 grid of accumulators fed by 4 A and 4 B fragments (the register pattern of mma_tile)
+__global__ __launch_bounds__(256) void mfma_grid_kernel(double* out, int iters, double seed)
+{
+    v4d acc[4][4];
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = seed + threadIdx.x * 1e-3 + i; b[i] = 1.0 - threadIdx.x * 1e-4 - i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)       // inline asm: the builtin makes hipcc shuttle the accumulators VGPR<->AGPR every trip
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t) blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // f64 VALU FMA probe (the vector pipe has the same datasheet rate as the matrix pipe on CDNA4)
 __global__ __launch_bounds__(256) void valu_peak_kernel(double* out, int iters, double seed)
 {
@@ -814,8 +859,10 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     if (M <= 0 || N <= 0) return 0;
     if (Tm && M > 256) return -2;
     int ti, tj;
+    const bool shortk = (K <= 512 && Tm == nullptr);     // e.g. W = T^T Y: one K slice, small tiles for parallelism
     if (M <= 32) { ti = 1; tj = (N >= 128 && N % 128 == 0) ? 4 : 1; }   // keep the FAST (unguarded) instantiation
-    else if (M <= 64 || N <= 64) { ti = 2; tj = 2; }
+    else if (shortk && (long long) ((M + 31) / 32) * ((N + 31) / 32) <= 1024) { ti = 1; tj = 1; }
+    else if (M <= 64 || N <= 64 || (shortk && (long long) ((M + 63) / 64) * ((N + 63) / 64) <= 2048)) { ti = 2; tj = 2; }
     else { ti = 4; tj = 4; }
     const int BM = 32 * ti, BN = 32 * tj;
     const long long tiles = (long long) ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -828,6 +875,7 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     if (slabs == nullptr || slab_cap < per) want = 1;
     else if ((size_t) want * per > slab_cap) want = (long long) (slab_cap / per);
     if (want > 256) want = 256;
+    if (shortk) want = 1;
     int ksplit = (int) want;
     int kchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (K + kchunk - 1) / kchunk;
@@ -875,11 +923,31 @@ int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, 
     return (int) hipGetLastError();
 }
 
+int qrd_gemm_nn_batch(void* stream, int M, int N, int K, double alpha, const double* A, int lda, size_t sA,
+                      const double* B, int ldb, size_t sB, double beta, double* C, int ldc, size_t sC, int batch)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+    const size_t shm = sizeof(double) * (2 * BK * (32 + 16) + 2 * 32 * LDKF);
+    dim3 grid((M + 31) / 32, (N + 31) / 32, batch);
+    const bool fast = vec_ok(A, lda) && vec_ok(B, ldb) && (sA % 2) == 0 && (sB % 2) == 0 && (K % BK) == 0 && (M % 32) == 0 &&
+                      (N % 32) == 0;
+    if (fast)
+        hipLaunchKernelGGL((gemm_nn_batch_kernel<1, 1, true>), grid, dim3(256), shm, (hipStream_t) stream, M, N, K, alpha, A,
+                           lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    else
+        hipLaunchKernelGGL((gemm_nn_batch_kernel<1, 1, false>), grid, dim3(256), shm, (hipStream_t) stream, M, N, K, alpha, A,
+                           lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    return (int) hipGetLastError();
+}
+
 // Outer-panel T (nbp x nbp, leaves of width ib) from G = V^T V.  build_diag: diagonal blocks are rebuilt
-// from G and tau (otherwise the leaf kernels already left them in T).  X: nbp x ib scratch (ldx >= nbp).
+// from G and tau (otherwise the leaf kernels already left them in T).  X: scratch of nbp*nbp/2 doubles.
+// Blocks are merged pairwise up a binary tree,  T = [T1, -T1 (V1^T V2) T2; 0, T2],  all pairs of a level in
+// two batched launches: 2*log2(nbp/ib) dependent launches instead of 2*(nbp/ib - 1).
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,
               double* Tt, int build_diag, double* X, int ldx)
 {
+    (void) ldx;
     hipStream_t s = (hipStream_t) stream;
     if (ib > LEAFW || nbp < 1) return -5;
     if (build_diag) {
@@ -887,12 +955,27 @@ int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const dou
         int rc = (int) hipGetLastError();
         if (rc) return rc;
     }
-    for (int cb = ib; cb < nbp; cb += ib) {
-        const int wb = (ib < nbp - cb) ? ib : nbp - cb;
-        int rc = qrd_gemm_nn(stream, cb, wb, wb, 1.0, G + (size_t) cb * ldg, ldg, T + (size_t) cb * ldt + cb, ldt, 0.0, X, ldx);
-        if (rc) return rc;
-        rc = qrd_gemm_nn(stream, cb, wb, cb, -1.0, T, ldt, X, ldx, 0.0, T + (size_t) cb * ldt, ldt);
-        if (rc) return rc;
+    for (int sz = ib; sz < nbp; sz *= 2) {
+        const int nf = nbp / (2 * sz), rem = nbp - 2 * sz * nf;
+        if (nf > 0) {        // full pairs: left [o, o+sz), right [o+sz, o+2sz), o = 2*sz*p
+            int rc = qrd_gemm_nn_batch(stream, sz, sz, sz, 1.0, G + (size_t) sz * ldg, ldg, (size_t) 2 * sz * (ldg + 1),
+                                       T + (size_t) sz * ldt + sz, ldt, (size_t) 2 * sz * (ldt + 1), 0.0, X, sz,
+                                       (size_t) sz * sz, nf);
+            if (rc) return rc;
+            rc = qrd_gemm_nn_batch(stream, sz, sz, sz, -1.0, T, ldt, (size_t) 2 * sz * (ldt + 1), X, sz, (size_t) sz * sz, 0.0,
+                                   T + (size_t) sz * ldt, ldt, (size_t) 2 * sz * (ldt + 1), nf);
+            if (rc) return rc;
+        }
+        if (rem > sz) {      // ragged last pair: left sz, right rem - sz
+            const int o = 2 * sz * nf, w2 = rem - sz;
+            double* Xr = X + (size_t) nf * sz * sz;
+            int rc = qrd_gemm_nn_batch(stream, sz, w2, w2, 1.0, G + (size_t) (o + sz) * ldg + o, ldg, 0,
+                                       T + (size_t) (o + sz) * ldt + o + sz, ldt, 0, 0.0, Xr, sz, 0, 1);
+            if (rc) return rc;
+            rc = qrd_gemm_nn_batch(stream, sz, w2, sz, -1.0, T + (size_t) o * ldt + o, ldt, 0, Xr, sz, 0, 0.0,
+                                   T + (size_t) (o + sz) * ldt + o, ldt, 0, 1);
+            if (rc) return rc;
+        }
     }
     if (Tt) {
         hipLaunchKernelGGL(transpose_kernel, dim3((nbp * nbp + 255) / 256), dim3(256), 0, s, nbp, T, ldt, Tt, ldt);
@@ -1108,6 +1191,28 @@ int qrd_probe_mfma_f64(double* out3)
         out3[2] = (double) blocks * 256 * iters * 16 * 2.0 / (ms * 1e-3) / 1e12;
         hipEventDestroy(a); hipEventDestroy(b); hipFree(o);
     }
+    return 0;
+}
+
+// one probe point: `blocks` workgroups of 4 waves, 4 independent accumulators per wave; out2 = {TFLOP/s, GHz}.
+// With fewer workgroups than CUs this shows the per-CU rate when most of the chip is idle (DVFS head-room).
+int qrd_probe_mfma_f64_point(int blocks, int iters, double* out2)
+{
+    return probe_one<4>(blocks, iters, &out2[0], &out2[1]);
+}
+
+int qrd_probe_mfma_f64_grid(int blocks, int iters, double* tflops)
+{
+    double* out;
+    HIPCHK(hipMalloc(&out, sizeof(double) * blocks * 256));
+    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    hipLaunchKernelGGL(mfma_grid_kernel, dim3(blocks), dim3(256), 0, 0, out, iters / 8, 0.5);
+    HIPCHK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(mfma_grid_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0.5);
+    HIPCHK(hipEventRecord(b, 0)); HIPCHK(hipEventSynchronize(b));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *tflops = (double) blocks * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
+    HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b)); HIPCHK(hipFree(out));
     return 0;
 }
 

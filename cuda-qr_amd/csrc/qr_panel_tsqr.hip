@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restric
 
 // T: the last stack (rows <= 512): R~ -> Rt (ld PW), explicit Q_top [I;0] -> Cout (rows x w) in compact-WY form:
 // Q_top [I;0] = [I;0] - V (T V1^T)
-template <int NT>
+template <int NT, int RPT>
 __global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__ stack, int lds, int rows, int w,
                                                       double* __restrict__ Rt, double* __restrict__ Cout, int ldc)
 {
@@ -255,31 +255,35 @@ __global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__
     __shared__ double V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
     __shared__ double tl[PW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double x1[1][PW];
-    load_block(x1[0], stack, lds, 0, tid, rows, w);
-    factor_all<0, true, NT, 1>(x1, tid, rows, w, sh, Z, tid, lane, wave);
-    double (&x)[PW] = x1[0];
+    double x[RPT][PW];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) load_block(x[q], stack, lds, 0, tid + NT * q, rows, w);
+    factor_all<0, true, NT, RPT>(x, tid, rows, w, sh, Z, tid, lane, wave);
     __syncthreads();
     if (tid < PW) {
         tl[tid] = (tid < w) ? sh.tau[tid] : 0.0;
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
-            if (tid < w && c < w) Rt[c * PW + tid] = (c >= tid) ? x[c] : 0.0;
-            V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[c] : (c == tid ? 1.0 : 0.0)) : 0.0;
+            if (tid < w && c < w) Rt[c * PW + tid] = (c >= tid) ? x[0][c] : 0.0;
+            V1[tid][c] = (tid < w && c < w) ? ((c < tid) ? x[0][c] : (c == tid ? 1.0 : 0.0)) : 0.0;
             Cl[tid][c] = (tid == c && tid < w) ? 1.0 : 0.0;
             if (!(c < tid && tid < w)) Z[tid][c] = 0.0;          // keep only Z(k = tid, i = c < k)
         }
     }
     __syncthreads();
     small_m<NT>(V1, Cl, Z, tl, Wl, Ml, w, tid);
-    double out[PW];
 #pragma unroll
-    for (int q = 0; q < PW; ++q) out[q] = (tid == q && tid < w) ? 1.0 : 0.0;
-    wy_row(x, out, tid, w, Ml);
-    if (tid < rows) {
+    for (int q = 0; q < RPT; ++q) {
+        const int r = tid + NT * q;
+        double out[PW];
 #pragma unroll
-        for (int q = 0; q < PW; ++q)
-            if (q < w) Cout[(size_t) q * ldc + tid] = out[q];
+        for (int c = 0; c < PW; ++c) out[c] = (r == c && r < w) ? 1.0 : 0.0;
+        wy_row(x[q], out, r, w, Ml);
+        if (r < rows) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c)
+                if (c < w) Cout[(size_t) c * ldc + r] = out[c];
+        }
     }
 }
 
@@ -565,30 +569,46 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
 // runs on one wave with no cross-wave reduction instead of eight mostly-idle ones
 static int nt_for(int rows) { return rows <= 64 ? 64 : (rows <= 128 ? 128 : (rows <= 256 ? 256 : 512)); }
 
+// MI355XQR_LEAF_WAVES=8: 512-thread workgroups (two waves per SIMD) for the 512- and 1024-row blocks; default 4: the same
+// rows on 256 threads, one wave per SIMD -- per Householder step a SIMD then runs ONE transposing wave reduction instead
+// of two and the cross-wave sum has 4 partials instead of 8
+static int leaf_waves(void)
+{
+    static int v = 0;
+    if (!v) { const char* e = getenv("MI355XQR_LEAF_WAVES"); v = (e && atoi(e) == 8) ? 8 : 4; }
+    return v;
+}
+
+#define LAUNCH_F(NT, RPT) hipLaunchKernelGGL((tsqr_factor_kernel<NT, RPT>), dim3(nblk), dim3(NT), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr)
 static void launch_factor(hipStream_t s, int nblk, int maxrows, const double* src, int lds, int rows_total, int chunk, int w,
                           double* Vloc, int ldv, double* tauloc, double* Tloc, double* Rstack, int ldr)
 {
-    if (maxrows > PT) {      // two rows per thread: 1024-row blocks, one tree level less for tall leaves
-        hipLaunchKernelGGL((tsqr_factor_kernel<512, 2>), dim3(nblk), dim3(512), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr);
+    const bool w4 = leaf_waves() == 4;
+    if (maxrows > PT) {      // 1024-row blocks, one tree level less for tall leaves
+        LAUNCH_F(512, 2);        // (256 threads x 4 rows needs 360 VGPRs and measured slower)
         return;
     }
     switch (nt_for(maxrows)) {
-    case 64: hipLaunchKernelGGL((tsqr_factor_kernel<64, 1>), dim3(nblk), dim3(64), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
-    case 128: hipLaunchKernelGGL((tsqr_factor_kernel<128, 1>), dim3(nblk), dim3(128), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
-    case 256: hipLaunchKernelGGL((tsqr_factor_kernel<256, 1>), dim3(nblk), dim3(256), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
-    default: hipLaunchKernelGGL((tsqr_factor_kernel<512, 1>), dim3(nblk), dim3(512), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr); break;
+    case 64: LAUNCH_F(64, 1); break;
+    case 128: LAUNCH_F(128, 1); break;
+    case 256: LAUNCH_F(256, 1); break;
+    default: if (w4) LAUNCH_F(256, 2); else LAUNCH_F(512, 1); break;
     }
 }
+#undef LAUNCH_F
 
+#define LAUNCH_T(NT, RPT) hipLaunchKernelGGL((tsqr_top_kernel<NT, RPT>), dim3(1), dim3(NT), 0, s, stack, lds, rows, w, Rt, Cout, ldc)
 static void launch_top(hipStream_t s, const double* stack, int lds, int rows, int w, double* Rt, double* Cout, int ldc)
 {
     switch (nt_for(rows)) {
-    case 64: hipLaunchKernelGGL(tsqr_top_kernel<64>, dim3(1), dim3(64), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
-    case 128: hipLaunchKernelGGL(tsqr_top_kernel<128>, dim3(1), dim3(128), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
-    case 256: hipLaunchKernelGGL(tsqr_top_kernel<256>, dim3(1), dim3(256), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
-    default: hipLaunchKernelGGL(tsqr_top_kernel<512>, dim3(1), dim3(512), 0, s, stack, lds, rows, w, Rt, Cout, ldc); break;
+    case 64: LAUNCH_T(64, 1); break;
+    case 128: LAUNCH_T(128, 1); break;
+    case 256: LAUNCH_T(256, 1); break;
+    default: if (leaf_waves() == 4) LAUNCH_T(256, 2); else LAUNCH_T(512, 1); break;
     }
 }
+#undef LAUNCH_T
+
 
 static void launch_apply(hipStream_t s, int nblk, int maxrows, const double* Vloc, int ldv, const double* tauloc, const double* Tloc,
                          int rows_total, int chunk, int w, const double* Cin, int ldci, double* Cout, int ldco)

@@ -238,7 +238,7 @@ def test_larft(q, oracle, nbp, ib, build_diag):
     T0[np.tril_indices(nbp, -1)] = np.where(np.isnan(T0[np.tril_indices(nbp, -1)]), 0.0, T0[np.tril_indices(nbp, -1)])
     for cb in range(0, nbp, ib):                       # sub-diagonal blocks are zero in the plan's T buffer
         T0[cb + ib:, cb:cb + ib] = 0.0
-    dG, dtau, dT, dTt, dX = dev(G), dev(tau[:, None]), dev(T0), zeros(nbp, nbp), zeros(nbp, 32)
+    dG, dtau, dT, dTt, dX = dev(G), dev(tau[:, None]), dev(T0), zeros(nbp, nbp), zeros(nbp, nbp)
     torch.cuda.synchronize()
     q.check(q.lib.qrd_larft(None, nbp, ib, dG.data_ptr(), nbp, dtau.data_ptr(), dT.data_ptr(), nbp, dTt.data_ptr(),
                             build_diag, dX.data_ptr(), nbp))

@@ -1,0 +1,9 @@
+import sys, torch
+import cuda_qr_amd as q
+m, n, nb = (int(x) for x in sys.argv[1].split("x"))
+p = q.Plan(m, n, nb, 32)
+dA = torch.empty((n, m), dtype=torch.float64, device="cuda"); dtau = torch.empty(n, dtype=torch.float64, device="cuda")
+for r in range(2):
+    p.fill_uniform(dA, m, m, n, seed=12); p.sync()
+    p.geqrf(dA, m, n, m, dtau); p.sync()
+p.close()

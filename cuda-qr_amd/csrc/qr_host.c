@@ -355,7 +355,7 @@ int qr_gemm_dev(qr_plan* p, char transa, int M, int N, int K, double alpha, cons
  * in p->Vw and the panel's compact-WY T in p->T (only if want_t). */
 static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t)
 {
-    const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt;
+    const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt, nb = p->nb;
     double* Ak = dA + (size_t) k * lda + k;
     CHECK(qrd_zero_block(p->stream, p->Vw, ldv, wout, wout));
     for (int c = 0; c < wout; c += ib) {
@@ -378,15 +378,11 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
             CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
         }
     }
-    if (want_t) {
-        if (wout > ib) {
-            CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, p->nb, NULL));          /* Gram */
-            CHECK(qrd_larft(p->stream, wout, ib, p->G, p->nb, dtau + k, p->T, ldt, NULL, 0, p->X, p->nb));
-        }
-        /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the
-         * wide update builds V*T itself on its own stream (update_cols), off the critical path */
-    }
-    return 0;
+    if (!want_t || wout <= ib) return 0;
+    CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, nb, NULL));                  /* Gram */
+    /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the
+     * wide update builds V*T itself on its own stream (update_cols), off the critical path */
+    return qrd_larft(p->stream, wout, ib, p->G, nb, dtau + k, p->T, ldt, NULL, 0, p->X, nb);
 }
 
 static void use_set(qr_plan* p, int e) { p->Vw = p->Vw2[e]; p->VT = p->VT2[e]; p->T = p->T2[e]; }

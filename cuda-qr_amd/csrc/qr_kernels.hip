@@ -740,6 +740,9 @@ static int launch_nn(hipStream_t s, int M, int N, int K, double alpha, const dou
     const bool al = vec_ok(A, lda) && vec_ok(B, ldb) && (K % BK) == 0;
     const int Mi = al ? (M / BM) * BM : 0, Ni = al ? (N / BN) * BN : 0;
     if (!(Mi > 0 && Ni > 0)) return launch_nn1<TI, TJ, false>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    // small ragged products sit on the panel's critical path, where a second (edge) launch costs more than guarded loads
+    if ((Mi < M || Ni < N) && (double) M * N * K < 4e8)
+        return launch_nn1<TI, TJ, false>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
     int rc = launch_nn1<TI, TJ, true, TAG>(s, Mi, Ni, K, alpha, A, lda, B, ldb, beta, C, ldc);
     if (!rc && Ni < N)      /* right strip: all rows, columns [Ni, N) */
         rc = launch_nn1<TI, TJ, false>(s, M, N - Ni, K, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta,

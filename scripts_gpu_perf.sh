@@ -8,7 +8,7 @@ for l in sys.stdin:
     except: print(l.strip()[:300]); continue
     print(d['m'],d['n'],d['nb'],'ms %.1f'%d['ms'],'TF %.2f'%d['tflops'], d.get('resid'), {k:(round(v['ms'],1),v['tflops']) for k,v in d.items() if isinstance(v,dict)})
 "; }
-export CHECK=1
-run MI355XQR_LEAF_WAVES=4
-run MI355XQR_LEAF_WAVES=8
-run MI355XQR_LEAF_WAVES=4 MI355XQR_LOOKAHEAD=0
+export CHECK=2
+run MI355XQR_X=1
+
+run MI355XQR_LOOKAHEAD=0

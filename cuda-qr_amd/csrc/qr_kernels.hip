@@ -642,28 +642,9 @@ __global__ __launch_bounds__(256) void diff_norm_kernel(const double* __restrict
 // MFMA fp64 issue-rate probe: each wave runs `iters` x NACC independent accumulators back to back and
 // stamps shader clock (s_memtime) and the 100 MHz wall counter (s_memrealtime) around the loop, so the
 // sustained in-kernel clock is known next to the rate (DVFS: MI355X_MICROARCH.md 'DVFS give-back').
-template <int NACC>
-__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, unsigned long long* stamps, int iters, double seed)
-{
-    v4d acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = (v4d){0.0, 0.0, 0.0, 0.0};
-    double x = seed + threadIdx.x * 1e-3, y = 1.0 - threadIdx.x * 1e-4;
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[a], 0, 0, 0);
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) s += acc[a][0] + acc[a][1] + acc[a][2] + acc[a][3];
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    out[(size_t) blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0 && stamps) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
-}
-
-// GEMM-shaped variant: a 4 x 4 grid of accumulators fed by 4 A and 4 B fragments (the register pattern of mma_tile)
-__global__ __launch_bounds__(256) void mfma_grid_kernel(double* out, int iters, double seed)
+// a 4 x 4 grid of accumulators fed by 4 A and 4 B fragments (the register pattern of mma_tile), 16 independent
+// v_mfma_f64_16x16x4_f64 per trip
+__global__ __launch_bounds__(256) void mfma_grid_kernel(double* out, unsigned long long* stamps, int iters, double seed)
 {
     v4d acc[4][4];
     double a[4], b[4];
@@ -673,6 +654,7 @@ __global__ __launch_bounds__(256) void mfma_grid_kernel(double* out, int iters, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -685,7 +667,9 @@ __global__ __launch_bounds__(256) void mfma_grid_kernel(double* out, int iters, 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[(size_t) blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && stamps) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
 // f64 VALU FMA probe (the vector pipe has the same datasheet rate as the matrix pipe on CDNA4)
@@ -1145,23 +1129,22 @@ int qrd_device_info(char* name, int name_len, int* cus, int* clock_khz, size_t* 
 // {1,2,4 workgroups per CU} x {4,8 accumulators}; out[1] = in-kernel shader clock (GHz) of that best run;
 // out[2] = f64 VALU FMA TFLOP/s.
 }   // extern "C" (templates need C++ linkage)
-template <int NACC>
 static int probe_one(int blocks, int iters, double* tflops, double* ghz)
 {
     double* out; unsigned long long* st;
     HIPCHK(hipMalloc(&out, sizeof(double) * blocks * 256));
     HIPCHK(hipMalloc(&st, sizeof(unsigned long long) * 2 * blocks));
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    hipLaunchKernelGGL(mfma_peak_kernel<NACC>, dim3(blocks), dim3(256), 0, 0, out, st, iters / 8, 0.5);   // warm
+    hipLaunchKernelGGL(mfma_grid_kernel, dim3(blocks), dim3(256), 0, 0, out, st, iters / 8, 0.5);   // warm
     HIPCHK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(mfma_peak_kernel<NACC>, dim3(blocks), dim3(256), 0, 0, out, st, iters, 0.5);
+    hipLaunchKernelGGL(mfma_grid_kernel, dim3(blocks), dim3(256), 0, 0, out, st, iters, 0.5);
     HIPCHK(hipEventRecord(b, 0)); HIPCHK(hipEventSynchronize(b));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
-    *tflops = (double) blocks * 4 * iters * NACC * 2048.0 / (ms * 1e-3) / 1e12;
+    *tflops = (double) blocks * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
     unsigned long long h[2];
     HIPCHK(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
-    *ghz = h[1] ? (double) h[0] / (double) h[1] * 0.1 : 0.0;      // shader cycles per 10 ns tick
-    hipEventDestroy(a); hipEventDestroy(b); hipFree(out); hipFree(st);
+    *ghz = h[1] ? (double) h[0] / (double) h[1] * 0.1 : 0.0;      // s_memtime ticks per 10 ns of s_memrealtime
+    HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b)); HIPCHK(hipFree(out)); HIPCHK(hipFree(st));
     return 0;
 }
 extern "C" {
@@ -1174,10 +1157,7 @@ int qrd_probe_mfma_f64(double* out3)
     double best = 0.0, best_ghz = 0.0;
     for (int bpc = 1; bpc <= 4; bpc *= 2) {
         double t, g;
-        int rc = probe_one<4>(cus * bpc, 16000 / bpc, &t, &g);
-        if (rc) return rc;
-        if (t > best) { best = t; best_ghz = g; }
-        rc = probe_one<8>(cus * bpc, 8000 / bpc, &t, &g);
+        int rc = probe_one(cus * bpc, 4000 / bpc, &t, &g);
         if (rc) return rc;
         if (t > best) { best = t; best_ghz = g; }
     }
@@ -1197,26 +1177,10 @@ int qrd_probe_mfma_f64(double* out3)
     return 0;
 }
 
-// one probe point: `blocks` workgroups of 4 waves, 4 independent accumulators per wave; out2 = {TFLOP/s, GHz}.
-// With fewer workgroups than CUs this shows the per-CU rate when most of the chip is idle (DVFS head-room).
+// one probe point: `blocks` workgroups of 4 waves; out2 = {TFLOP/s, s_memtime GHz}
 int qrd_probe_mfma_f64_point(int blocks, int iters, double* out2)
 {
-    return probe_one<4>(blocks, iters, &out2[0], &out2[1]);
-}
-
-int qrd_probe_mfma_f64_grid(int blocks, int iters, double* tflops)
-{
-    double* out;
-    HIPCHK(hipMalloc(&out, sizeof(double) * blocks * 256));
-    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    hipLaunchKernelGGL(mfma_grid_kernel, dim3(blocks), dim3(256), 0, 0, out, iters / 8, 0.5);
-    HIPCHK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(mfma_grid_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, 0.5);
-    HIPCHK(hipEventRecord(b, 0)); HIPCHK(hipEventSynchronize(b));
-    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
-    *tflops = (double) blocks * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
-    HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b)); HIPCHK(hipFree(out));
-    return 0;
+    return probe_one(blocks, iters, &out2[0], &out2[1]);
 }
 
 int qrd_probe_copy(double* gbps)

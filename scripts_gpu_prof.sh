@@ -17,3 +17,14 @@ python -c "
 import json; d=json.load(open('$R/bench_c3.json')); print('C3', d['value'], d['ms_per_step'], d['accuracy'], d['roofline']['achieved'], d['roofline']['companion_tn']['achieved'])
 d=json.load(open('$R/bench_tsqr.json')); print('TSQR', d['value'], d['ms_per_step'], d['accuracy'])"
 head -12 $R/bench_c3/bench_kernel_stats.csv | cut -c1-150
+python3 tools_probe_mfma.py 2>&1 | grep -v amdgpu.ids > $R/probe_mfma_vs_cus.txt
+python3 tools_probe_gemmk.py 2>&1 | grep -v amdgpu.ids | grep gemm_nn > $R/probe_gemm_vs_k.txt
+python3 tools_clock_probe.py 2>&1 | grep -v amdgpu.ids | grep -v "Exception\|Traceback\|File\|Attribute" > $R/probe_clock_power.txt
+python3 - <<'PY' 2>&1 | grep -v amdgpu.ids > $R/device_probes.txt
+import cuda_qr_amd as q, json
+print(json.dumps(q.device_info()))
+for i in range(2):
+    print(json.dumps(q.probe_mfma_f64_tflops()))
+print("copy_gbps", q.probe_copy_gbps())
+PY
+cat $R/device_probes.txt

@@ -28,7 +28,7 @@ def load(kind, secs):
             p.sync(); n += 50
         else:
             out = (C.c_double * 2)()
-            lib.qrd_probe_mfma_f64_point(1024, 64000, out); n += 1
+            lib.qrd_probe_mfma_f64_point(1024, 16000, out); n += 1
     print(kind, "launches", n, flush=True)
 lib.qrd_probe_mfma_f64_point.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
 for kind in ("gemm", "mfma"):

@@ -6,7 +6,7 @@ lib = q.lib
 lib.qrd_probe_mfma_f64_point.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
 out = (C.c_double * 2)()
 for blocks in (8, 32, 64, 128, 192, 256, 512, 1024):
-    lib.qrd_probe_mfma_f64_point(blocks, 16000, out)
+    lib.qrd_probe_mfma_f64_point(blocks, 4000, out)
     busy = min(blocks, 256)
     print(json.dumps({"probe": "mfma_f64", "blocks": blocks, "tflops": round(out[0], 2), "per_cu_gflops": round(out[0] * 1e3 / busy, 1),
                       "memtime_ghz": round(out[1], 3), "implied_clock_ghz_at_64cyc": round(out[0] * 1e12 / busy / 4 / 2048 * 64 / 1e9, 3)}), flush=True)

@@ -185,6 +185,7 @@ def main():
                 G.copy_(Gh)
             else:
                 dist.all_reduce(G)                              # Q^T Q = sum over shards
+            torch.cuda.synchronize()                            # the plan's streams are not ordered with torch's
         o, _ = be.plan.diffnorm(G, n, n, n, mode=1)
         acc = {"resid": float((sums[0] / sums[1]).sqrt().item()), "orth": float(o ** 0.5)}
         del Q, QR, G
@@ -238,6 +239,28 @@ def main():
                 "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None,
                 "measured_probe": measured}
 
+    # ---- N = 1 only: the one-GPU leg of the multi-GPU (TSQR, weak scaling) series, so that the N > 1 lines of this
+    # bench (262144 x 512 per GPU) have their own denominator next to the C3 headline
+    weak_base = None
+    if world == 1 and wl == "c3":
+        bufs.clear()
+        be.close()
+        be = T.HipBackend(qr, 262144, 512, 1, 128, args.ib)
+        ts1 = T.TSQR(be, 512, 1, 0)
+        reps = max(2, min(K, 5))
+        tb = [be.new_matrix(262144, 512) for _ in range(reps)]
+        for i, A in enumerate(tb):
+            be.fill(A, 262144, 512, 0, 262144, 12 + i)
+        ts1.factor(tb[0]); be.fill(tb[0], 262144, 512, 0, 262144, 12)      # warm-up, then restore the input
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            ts1.factor(tb[i])
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t0) / reps
+        weak_base = {"workload": "one 262144x512 TSQR shard on 1 GPU (the per-GPU work of the N>1 lines of this bench)",
+                     "value": flops(262144, 512) / dtb / 1e9, "unit": "GFLOP/s", "ms_per_step": dtb * 1e3, "steps": reps}
+
     line = None
     if rank == 0:
         cpu = None
@@ -257,6 +280,7 @@ def main():
             "frac_of_fp64_matrix_peak": value / 1e3 / (FP64_MATRIX_PEAK_TFLOPS * world),
             "accuracy": acc,
             "roofline": roof,
+            "weak_scaling_base_1gpu": weak_base,
             "cpu_baseline": cpu,
             "device": info,
         }

@@ -23,6 +23,9 @@ int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, 
 size_t qrd_panel_ws_size(int m);
 int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                    double* ws, int m_cap);
+#define QRD_CHOLQR_WS (4 * 32 * 32 + 16)
+int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap);
 int qrd_gemm_nn_batch(void* stream, int M, int N, int K, double alpha, const double* A, int lda, size_t sA,
                       const double* B, int ldb, size_t sB, double beta, double* C, int ldc, size_t sC, int batch);
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,

@@ -24,6 +24,7 @@
 
 #define QR_MAX_PAIRS 4
 #define QR_DEFAULT_SPLIT "64"
+#define QR_DEFAULT_PANEL 1
 struct qr_plan {
     int m, n, nb, ib, ldv, ldt;
     int use_graph;              /* 1: qr_geqrf_dev is captured into a hipGraph once per argument set and replayed */
@@ -49,7 +50,9 @@ struct qr_plan {
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
     double *Vw2[2], *VT2[2], *T2[2];
     double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *leaf_scratch, *panel_ws;
-    int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height */
+    int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height;
+                                 * 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
+    double* chol_ws;
     int tsqr_min_rows;
     size_t slab_cap, w_cap;
     /* profiling */
@@ -203,11 +206,12 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     if (!rc) rc = qrd_malloc((void**) &p->leaf_scratch, sizeof(double) * QRD_LEAF_SCRATCH);
     {
         const char* pa = getenv("MI355XQR_PANEL");
-        p->panel_tsqr = !pa ? 1 : (strcmp(pa, "col") == 0 ? 0 : (strcmp(pa, "tsqr") == 0 ? 1 : 2));
+        p->panel_tsqr = !pa ? QR_DEFAULT_PANEL : (strcmp(pa, "col") == 0 ? 0 : (strcmp(pa, "tsqr") == 0 ? 1 : (strcmp(pa, "cholqr") == 0 ? 3 : 2)));
         const char* tm = getenv("MI355XQR_TSQR_MIN_ROWS");
         p->tsqr_min_rows = tm ? atoi(tm) : 100000;
     }
     if (!rc && p->panel_tsqr) rc = qrd_malloc((void**) &p->panel_ws, sizeof(double) * qrd_panel_ws_size(m));
+    if (!rc && p->panel_tsqr == 3) rc = qrd_malloc((void**) &p->chol_ws, sizeof(double) * QRD_CHOLQR_WS);
     if (rc) { qr_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -236,7 +240,7 @@ int qr_plan_destroy(qr_plan* p)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
-    qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws);
+    qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws); qrd_free(p->chol_ws);
     if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
     return 0;
@@ -366,7 +370,10 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
         /* leaf algorithm (MI355XQR_PANEL = tsqr [default] | col | auto): the TSQR + Householder-reconstruction leaf
          * reads the leaf twice whatever its height and needs 4-6 launches; the one-launch-per-column leaf needs 34
          * launches and ~25 passes */
-        if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
+        if (p->panel_tsqr == 3)
+            CHECK(qrd_panel_cholqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
+                                   p->slabs, p->slab_cap));
+        else if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
             CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
         else
             CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));

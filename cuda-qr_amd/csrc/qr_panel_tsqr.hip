@@ -211,8 +211,9 @@ template <int NT, int RPT>
 __global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restrict__ src, int lds, int rows_total, int chunk,
                                                          int w, double* __restrict__ Vloc, int ldv,
                                                          double* __restrict__ tauloc, double* __restrict__ Tloc,
-                                                         double* __restrict__ Rstack, int ldr)
+                                                         double* __restrict__ Rstack, int ldr, const int* __restrict__ guard)
 {
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ PanelSharedT<NT / 64> sh;
     __shared__ double Z[PW][PW + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -248,8 +249,9 @@ __global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restric
 // Q_top [I;0] = [I;0] - V (T V1^T)
 template <int NT, int RPT>
 __global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__ stack, int lds, int rows, int w,
-                                                      double* __restrict__ Rt, double* __restrict__ Cout, int ldc)
+                                                      double* __restrict__ Rt, double* __restrict__ Cout, int ldc, const int* __restrict__ guard)
 {
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ PanelSharedT<NT / 64> sh;
     __shared__ double Z[PW][PW + 1];
     __shared__ double V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
@@ -294,8 +296,9 @@ __global__ __launch_bounds__(NT) void tsqr_apply_kernel(const double* __restrict
                                                         const double* __restrict__ tauloc,
                                                         const double* __restrict__ Tloc, int rows_total, int chunk, int w,
                                                         const double* __restrict__ Cin, int ldci,
-                                                        double* __restrict__ Cout, int ldco)
+                                                        double* __restrict__ Cout, int ldco, const int* __restrict__ guard)
 {
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
     __shared__ double tl[PW];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -421,8 +424,9 @@ __global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restric
                                                      const double* __restrict__ Z0, const double* __restrict__ C0, int ldc0,
                                                      const double* __restrict__ Rt, int w, double* __restrict__ A, int lda,
                                                      double* __restrict__ tau, double* __restrict__ T, int ldt,
-                                                     double* __restrict__ Vw, int ldv, double* __restrict__ Umat)
+                                                     double* __restrict__ Vw, int ldv, double* __restrict__ Umat, const int* __restrict__ guard)
 {
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ double Bs[PW][PW + 1], V1[PW][PW + 1], Cs[PW][PW + 1];
     __shared__ double colb[2][PW];
     __shared__ double Ss[PW], t0[PW];
@@ -490,8 +494,9 @@ __global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict
                                                         int rows_total, int nblk, int halves, int w,
                                                         const double* __restrict__ Cin, int ldci,
                                                         const double* __restrict__ Umat, double* __restrict__ A, int lda,
-                                                        double* __restrict__ Vw, int ldv)
+                                                        double* __restrict__ Vw, int ldv, const int* __restrict__ guard)
 {
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1], Ui[PW][PW + 1];
     __shared__ double tl[PW];
     const int tid = threadIdx.x, b = blockIdx.x / halves, h = blockIdx.x % halves;
@@ -564,6 +569,235 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
     }
 }
 
+
+// =========================================================================================================
+// CholeskyQR2 + Householder reconstruction leaf (fast path; the Householder TSQR kernels above are its guard):
+//   G1 = A^T A (split-K MFMA product)            R1 = chol(G1),  Q = A R1^-1  -> Vw          cholq_kernel
+//   G2 = Q^T Q                                   refuse unless max|G2 - I| <= 1/64 (then a second pass brings Q to
+//   R2 = chol(G2), Q1 = Q R2^-1, R~ = R2 R1      working-precision orthogonality: Yamamoto et al., CholeskyQR2)
+//   Householder reconstruction of Q1 exactly as in hr_top_kernel: LU(Q1_top - S) = L1 U, T = -U S L1^-T,
+//   R = S R~, V = Q1 U^-1 = Q (R2^-1 U^-1)                                                   hr2_kernel, final2_kernel
+// A zero, dependent or badly conditioned leaf (cond above ~1e4..1e7) makes a pivot non-positive or G2 far from I; the
+// guard word then stays 1, nothing of the leaf has been overwritten, and the Householder TSQR launches that follow do
+// the work.  The result has the same form either way: unit-lower V below R, tau, T.
+// =========================================================================================================
+#define QRD_GUARD_THR (1.0 / 64.0)
+
+// right-looking Cholesky G = R^T R on one wave: lane j (< 32) holds column j in g[]; on exit g[k] = R(k, j), k <= j
+template <int K> struct CholStep {
+    static __device__ __forceinline__ void run(double (&g)[PW], int lane, bool& ok)
+    {
+        const double p = readlane_f64(g[K], K);
+        ok = ok && (p > 0.0);                       // false for NaN as well
+        const double inv = 1.0 / sqrt(p);
+        const double rk = (lane >= K) ? g[K] * inv : 0.0;
+        g[K] = rk;
+#pragma unroll
+        for (int i = K + 1; i < PW; ++i) g[i] -= readlane_f64(rk, i) * rk;
+        if constexpr (K + 1 < PW) CholStep<K + 1>::run(g, lane, ok);
+    }
+};
+
+// wave 0: Gs (symmetric, identity outside w x w) -> Rs (upper, zero below), returns ok (wave-uniform)
+__device__ __forceinline__ bool chol_wave(const double* __restrict__ G, int w, int lane, double (*Rs)[PW + 1])
+{
+    double g[PW];
+    const int j = lane & (PW - 1);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) g[i] = (i < w && j < w) ? G[(size_t) j * PW + i] : (i == j ? 1.0 : 0.0);
+    bool ok = true;
+    CholStep<0>::run(g, j, ok);
+    if (lane < PW) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) Rs[k][lane] = (k <= lane) ? g[k] : 0.0;
+    }
+    return ok;
+}
+
+// wave 0: X = R^-1 (upper) by back substitution, lane j computes column j; Rs in LDS
+__device__ __forceinline__ void triu_inv_wave(double (*Rs)[PW + 1], int lane, double (*Xs)[PW + 1])
+{
+    double x[PW];
+#pragma unroll
+    for (int i = PW - 1; i >= 0; --i) {
+        double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = i + 1; k < PW; ++k) acc -= Rs[i][k] * x[k];
+        x[i] = (i <= lane) ? acc / Rs[i][i] : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane < PW) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) Xs[i][lane] = x[i];
+    }
+}
+
+// K2: every workgroup factors G1 itself (one wave, ~2 us) and turns its 512 rows of A into rows of Q = A R1^-1 (-> Vw)
+// FULL = (w == 32): no per-column predicates.  (With `if (c < w)` around each store LLVM sinks the arithmetic of column c
+// into that column's block, i.e. reorders the solve column-major, keeping all 270 LDS loads live: 3.5 KB of scratch.)
+template <bool FULL>
+__global__ __launch_bounds__(PT) void cholq_kernel(const double* __restrict__ P, int ld, int mk, int w,
+                                                   const double* __restrict__ G1, double* __restrict__ R1,
+                                                   double* __restrict__ Vw, int ldv, int* __restrict__ guard)
+{
+    __shared__ double Rs[PW][PW + 1];
+    __shared__ double rinv[PW];
+    __shared__ int okf;
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int r = b * PT + tid;
+    double a[PW];
+    {
+        const double* p = P + min(r, mk - 1);
+#pragma unroll
+        for (int c = 0; c < PW; ++c) a[c] = (FULL || c < w) ? p[(size_t) c * ld] : 0.0;      // issued before the factorisation
+    }
+    if (tid < 64) {
+        const bool ok = chol_wave(G1, w, lane, Rs);
+        if (lane == 0) okf = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < PW) rinv[tid] = 1.0 / Rs[tid][tid];
+    const bool ok = okf != 0;
+    if (b == 0) {
+        if (tid == 0) *guard = ok ? 0 : 1;
+        if (ok && tid < PW) {
+#pragma unroll
+            for (int k = 0; k < PW; ++k) R1[tid * PW + k] = Rs[k][tid];          // column tid
+        }
+    }
+    if (!ok) return;
+    __syncthreads();
+    if (r >= mk) return;
+    double q[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {                                              // q R1 = a, column by column
+        q[k] = a[k] * rinv[k];
+#pragma unroll
+        for (int c = k + 1; c < PW; ++c) a[c] -= q[k] * Rs[k][c];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < PW; ++c)
+        if (FULL || c < w) Vw[(size_t) c * ldv + r] = q[c];
+}
+
+// K4: second Cholesky pass + Householder reconstruction of the top block, one 16-wave workgroup (layout of hr_top_kernel:
+// lane r < 32 of wave g owns row r of the columns c = g + 16 q)
+__global__ __launch_bounds__(64 * HG) void hr2_kernel(const double* __restrict__ G2, const double* __restrict__ R1,
+                                                  double* __restrict__ Vw, int ldv, int w, double* __restrict__ A, int lda,
+                                                  double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                  double* __restrict__ Mout, int* __restrict__ guard)
+{
+    __shared__ double Bs[PW][PW + 1], R1s[PW][PW + 1], R2s[PW][PW + 1], R2i[PW][PW + 1], Qs[PW][PW + 1];
+    __shared__ double colb[2][PW];
+    __shared__ double Ss[PW];
+    __shared__ int flags[2];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r = lane;
+    const bool ra = r < w;
+    if (*guard != 0) return;                               // pass 1 already refused
+    if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+    __syncthreads();
+    for (int el = threadIdx.x; el < PW * PW; el += 64 * HG) {
+        const int i = el % PW, c = el / PW;
+        const bool in = (i < w && c < w);
+        R1s[i][c] = (in && i <= c) ? R1[c * PW + i] : 0.0;
+        Qs[i][c] = in ? Vw[(size_t) c * ldv + i] : 0.0;
+        if (in) {
+            const double d = G2[(size_t) c * PW + i] - (i == c ? 1.0 : 0.0);
+            if (!(fabs(d) <= QRD_GUARD_THR)) flags[0] = 1;  // also catches NaN
+        }
+    }
+    __syncthreads();
+    if (flags[0]) { if (threadIdx.x == 0) *guard = 1; return; }
+    if (g == 0) {
+        const bool ok = chol_wave(G2, w, lane, R2s);
+        if (!ok && lane == 0) flags[1] = 1;
+    }
+    __syncthreads();
+    if (flags[1]) { if (threadIdx.x == 0) *guard = 1; return; }
+    if (g == 0) triu_inv_wave(R2s, lane, R2i);
+    __syncthreads();
+    double b[HQ], rt[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const int c = g + HG * q;
+        double acc = 0.0, acr = 0.0;
+        if (ra && c < w) {
+            for (int k = 0; k <= c; ++k) acc += Qs[r][k] * R2i[k][c];             // Q1_top = Q_top R2^-1
+            for (int k = r; k <= c; ++k) acr += R2s[r][k] * R1s[k][c];            // R~ = R2 R1
+        }
+        b[q] = acc; rt[q] = acr;
+    }
+    HrStep<0>::lu(b, r, g, w, colb, Ss);
+    __syncthreads();
+    if (r < PW) {
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) Bs[r][g + HG * q] = b[q];
+    }
+    __syncthreads();
+    double x[HQ], ui[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const int c = g + HG * q;
+        x[q] = (ra && c <= r) ? -Ss[r] * Bs[c][r] : 0.0;          // -S U^T
+        ui[q] = (ra && r == c) ? 1.0 : 0.0;
+    }
+    HrStep<0>::xsolve(x, r, w, Bs);
+    HrStep<PW - 1>::uinv(ui, r, w, Bs);
+    __syncthreads();                                              // everyone is done with Qs
+    if (r < PW) {
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) Qs[r][g + HG * q] = (ra && g + HG * q >= r) ? ui[q] : 0.0;     // Qs := U^-1
+    }
+    __syncthreads();
+    if (!ra) return;
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const int c = g + HG * q;
+        if (c < w) {
+            double m = 0.0;
+            for (int k = r; k <= c; ++k) m += R2i[r][k] * Qs[k][c];            // M = R2^-1 U^-1 (upper)
+            Mout[c * PW + r] = (c >= r) ? m : 0.0;
+            T[(size_t) r * ldt + c] = x[q];                                        // T(c, r) = X(r, c)
+            A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * rt[q] : b[q];
+            Vw[(size_t) c * ldv + r] = (c < r) ? b[q] : (c == r ? 1.0 : 0.0);
+            if (c == r) tau[r] = x[q];
+        }
+    }
+}
+
+// K5: rows >= w of V = Q M, written into Vw and below the diagonal block of the panel
+template <bool FULL>
+__global__ __launch_bounds__(PT) void final2_kernel(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Mm,
+                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
+{
+    __shared__ double Ms[PW][PW + 1];
+    if (*guard != 0) return;
+    const int tid = threadIdx.x, r = blockIdx.x * PT + tid;
+    for (int el = tid; el < PW * PW; el += PT) {
+        const int i = el % PW, c = el / PW;
+        Ms[i][c] = (i < w && c < w && i <= c) ? Mm[c * PW + i] : 0.0;
+    }
+    double q[PW], v[PW];
+    {
+        const double* p = Vw + min(r, mk - 1);
+#pragma unroll
+        for (int c = 0; c < PW; ++c) { q[c] = (FULL || c < w) ? p[(size_t) c * ldv] : 0.0; v[c] = 0.0; }
+    }
+    __syncthreads();
+    if (r < w || r >= mk) return;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+#pragma unroll
+        for (int c = k; c < PW; ++c) v[c] += q[k] * Ms[k][c];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < PW; ++c)
+        if (FULL || c < w) { Vw[(size_t) c * ldv + r] = v[c]; A[(size_t) c * lda + r] = v[c]; }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers: the workgroup is sized to the tallest block of the launch (64..512 threads) -- a 64-row top stack
 // runs on one wave with no cross-wave reduction instead of eight mostly-idle ones
@@ -579,9 +813,9 @@ static int leaf_waves(void)
     return v;
 }
 
-#define LAUNCH_F(NT, RPT) hipLaunchKernelGGL((tsqr_factor_kernel<NT, RPT>), dim3(nblk), dim3(NT), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr)
+#define LAUNCH_F(NT, RPT) hipLaunchKernelGGL((tsqr_factor_kernel<NT, RPT>), dim3(nblk), dim3(NT), 0, s, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr, guard)
 static void launch_factor(hipStream_t s, int nblk, int maxrows, const double* src, int lds, int rows_total, int chunk, int w,
-                          double* Vloc, int ldv, double* tauloc, double* Tloc, double* Rstack, int ldr)
+                          double* Vloc, int ldv, double* tauloc, double* Tloc, double* Rstack, int ldr, const int* guard)
 {
     const bool w4 = leaf_waves() == 4;
     if (maxrows > PT) {      // 1024-row blocks, one tree level less for tall leaves
@@ -597,8 +831,8 @@ static void launch_factor(hipStream_t s, int nblk, int maxrows, const double* sr
 }
 #undef LAUNCH_F
 
-#define LAUNCH_T(NT, RPT) hipLaunchKernelGGL((tsqr_top_kernel<NT, RPT>), dim3(1), dim3(NT), 0, s, stack, lds, rows, w, Rt, Cout, ldc)
-static void launch_top(hipStream_t s, const double* stack, int lds, int rows, int w, double* Rt, double* Cout, int ldc)
+#define LAUNCH_T(NT, RPT) hipLaunchKernelGGL((tsqr_top_kernel<NT, RPT>), dim3(1), dim3(NT), 0, s, stack, lds, rows, w, Rt, Cout, ldc, guard)
+static void launch_top(hipStream_t s, const double* stack, int lds, int rows, int w, double* Rt, double* Cout, int ldc, const int* guard)
 {
     switch (nt_for(rows)) {
     case 64: LAUNCH_T(64, 1); break;
@@ -611,13 +845,13 @@ static void launch_top(hipStream_t s, const double* stack, int lds, int rows, in
 
 
 static void launch_apply(hipStream_t s, int nblk, int maxrows, const double* Vloc, int ldv, const double* tauloc, const double* Tloc,
-                         int rows_total, int chunk, int w, const double* Cin, int ldci, double* Cout, int ldco)
+                         int rows_total, int chunk, int w, const double* Cin, int ldci, double* Cout, int ldco, const int* guard)
 {
     switch (nt_for(maxrows)) {
-    case 64: hipLaunchKernelGGL(tsqr_apply_kernel<64>, dim3(nblk), dim3(64), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
-    case 128: hipLaunchKernelGGL(tsqr_apply_kernel<128>, dim3(nblk), dim3(128), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
-    case 256: hipLaunchKernelGGL(tsqr_apply_kernel<256>, dim3(nblk), dim3(256), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
-    default: hipLaunchKernelGGL(tsqr_apply_kernel<512>, dim3(nblk), dim3(512), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco); break;
+    case 64: hipLaunchKernelGGL(tsqr_apply_kernel<64>, dim3(nblk), dim3(64), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco, guard); break;
+    case 128: hipLaunchKernelGGL(tsqr_apply_kernel<128>, dim3(nblk), dim3(128), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco, guard); break;
+    case 256: hipLaunchKernelGGL(tsqr_apply_kernel<256>, dim3(nblk), dim3(256), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco, guard); break;
+    default: hipLaunchKernelGGL(tsqr_apply_kernel<512>, dim3(nblk), dim3(512), 0, s, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco, guard); break;
     }
 }
 
@@ -634,8 +868,8 @@ size_t qrd_panel_ws_size(int m)
          + 2 * PW * PW + PW + 64;   /* Rt, Umat + reciprocal diagonal */
 }
 
-int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
-                   double* ws, int m_cap)
+static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                           double* ws, int m_cap, const int* guard)
 {
     hipStream_t s = (hipStream_t) stream;
     if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
@@ -666,7 +900,7 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
     const int brows0 = (mk <= 16 * PT) ? PT : 2 * PT;
     lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + brows0 - 1) / brows0; lv_off[0] = 0; lv_tau[0] = 0;
     size_t off = 0, toff = (size_t) lv_nblk[0] * PW;
-    launch_factor(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, lv_nblk[0] * w);
+    launch_factor(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, lv_nblk[0] * w, guard);
     int cur_rows = lv_nblk[0] * w;
     const int gchunk = (PT / w) * w;
     while (cur_rows > PT) {
@@ -676,29 +910,61 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
         lv_off[L] = off; lv_tau[L] = toff;
         const size_t next_off = off + (size_t) cur_rows * PW;
         launch_factor(s, lv_nblk[L], cur_rows < gchunk ? cur_rows : gchunk, stacks + off, cur_rows, cur_rows, gchunk, w,
-                      Vup + off, cur_rows, taus + toff, Ts + toff * PW, stacks + next_off, lv_nblk[L] * w);
+                      Vup + off, cur_rows, taus + toff, Ts + toff * PW, stacks + next_off, lv_nblk[L] * w, guard);
         off = next_off; toff += (size_t) lv_nblk[L] * PW;
         cur_rows = lv_nblk[L] * w;
     }
     // ---- top: factor + explicit Q of the last stack; its output is the coefficient input of the level below
-    launch_top(s, stacks + off, cur_rows, cur_rows, w, Rt, Cup + off, cur_rows);
+    launch_top(s, stacks + off, cur_rows, cur_rows, w, Rt, Cup + off, cur_rows, guard);
     // ---- down the tree
     const double* Cin = Cup + off;
     int ldci = cur_rows;
     for (int l = L; l >= 1; --l) {
         launch_apply(s, lv_nblk[l], lv_rows[l] < lv_chunk[l] ? lv_rows[l] : lv_chunk[l], Vup + lv_off[l], lv_rows[l], taus + lv_tau[l],
-                     Ts + lv_tau[l] * PW, lv_rows[l], lv_chunk[l], w, Cin, ldci, Cup + lv_off[l], lv_rows[l]);
+                     Ts + lv_tau[l] * PW, lv_rows[l], lv_chunk[l], w, Cin, ldci, Cup + lv_off[l], lv_rows[l], guard);
         Cin = Cup + lv_off[l];
         ldci = lv_rows[l];
     }
     // ---- Householder reconstruction on the top block, then every level-1 block writes its rows of V directly
     hipLaunchKernelGGL(hr_top_kernel, dim3(1), dim3(1024), 0, s, Vloc1, mk, taus, Ts, Cin, ldci, Rt, w, P, ld, tau, T, ldt, Vw,
-                       ldv, Umat);
+                       ldv, Umat, guard);
     const int halves = brows0 / PT;
     hipLaunchKernelGGL(tsqr_final_kernel, dim3(lv_nblk[0] * halves), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, lv_nblk[0], halves, w,
-                       Cin, ldci, Umat, P, ld, Vw, ldv);
+                       Cin, ldci, Umat, P, ld, Vw, ldv, guard);
     (void) Q1;
     return (int) hipGetLastError();
+}
+
+int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                   double* ws, int m_cap)
+{
+    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, nullptr);
+}
+
+// Leaf = CholeskyQR2 + Householder reconstruction, guarded: 7 short launches, then the Householder-TSQR leaf above as
+// launches that return at once unless the guard word says the Cholesky route was refused for this leaf.
+// cws: QRD_CHOLQR_WS doubles (G1, G2, R1, M, guard word).
+int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap)
+{
+    hipStream_t s = (hipStream_t) stream;
+    if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
+    // one workgroup covers the leaf / ragged last leaf (the per-column predicates a narrow leaf needs cost the
+    // Cholesky kernels 3.5 KB of scratch per thread): Householder path directly
+    if (mk <= PT || w < PW) return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, nullptr);
+    double *G1 = cws, *G2 = cws + PW * PW, *R1 = cws + 2 * PW * PW, *Mm = cws + 3 * PW * PW;
+    int* guard = (int*) (cws + 4 * PW * PW);
+    const int nblk = (mk + PT - 1) / PT;
+    int rc = qrd_gemm_tn(stream, w, w, mk, 1.0, P, ld, P, ld, 0.0, G1, PW, slabs, slab_cap, nullptr, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cholq_kernel<true>, dim3(nblk), dim3(PT), 0, s, P, ld, mk, w, G1, R1, Vw, ldv, guard);
+    rc = qrd_gemm_tn(stream, w, w, mk, 1.0, Vw, ldv, Vw, ldv, 0.0, G2, PW, slabs, slab_cap, nullptr, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(hr2_kernel, dim3(1), dim3(64 * HG), 0, s, G2, R1, Vw, ldv, w, P, ld, tau, T, ldt, Mm, guard);
+    hipLaunchKernelGGL(final2_kernel<true>, dim3(nblk), dim3(PT), 0, s, Vw, ldv, mk, w, Mm, P, ld, guard);
+    rc = (int) hipGetLastError();
+    if (rc) return rc;
+    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard);
 }
 
 }   // extern "C"

@@ -202,6 +202,105 @@ def test_panel_tsqr_zero_and_dependent_columns(q):
     assert np.abs(np.tril(QtP, -1)).max() < 1e-11 and np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-11
 
 
+def _cholqr_leaf(q, P, ld=None, ldv=None, ldt=None):
+    mk, w = P.shape
+    ld, ldv, ldt = ld or mk, ldv or mk, ldt or w
+    buf = np.full((ld, w), 7.0); buf[:mk] = P
+    dP = dev(buf)
+    dtau, dT, dV = zeros(w, 1), dev(np.full((ldt, w), np.nan)), dev(np.full((ldv, w), np.nan))
+    ws = torch.zeros(int(q.lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
+    cws = torch.zeros(4 * 32 * 32 + 16, dtype=torch.float64, device="cuda")
+    slabs = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_panel_cholqr(None, dP.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), ldt, dV.data_ptr(), ldv,
+                                   ws.data_ptr(), mk, cws.data_ptr(), slabs.data_ptr(), 1 << 20))
+    _sync(q)
+    guard = int(cws[4 * 32 * 32:].view(torch.int32)[0].item())
+    return host(dP), host(dtau)[:, 0], host(dT)[:w], host(dV)[:mk], guard, buf
+
+
+def _check_compact_wy(oracle, P, out, tau, T, V, rtol=1e-13):
+    mk, w = P.shape
+    assert np.isfinite(out).all() and np.isfinite(T).all() and np.isfinite(V).all()
+    R = np.triu(out[:w])
+    assert np.array_equal(np.triu(V[:w], 1), np.zeros((w, w))) and np.array_equal(np.diag(V[:w]), np.ones(w))
+    assert np.array_equal(np.tril(V, -1), np.tril(out[:mk], -1)), "explicit V and in-place tails must agree"
+    assert np.abs(np.tril(T, -1)).max(initial=0.0) == 0.0 and np.abs(np.diag(T) - tau).max() == 0.0
+    QtP = P - V @ (T.T @ (V.T @ P))
+    tol = 2e-13 * np.sqrt(mk) * max(1.0, np.abs(R).max())
+    assert np.abs(QtP[:w] - R).max() < tol and np.abs(QtP[w:]).max(initial=0.0) < tol
+    ref = oracle.sign_normalise(np.linalg.qr(P, mode="r"))
+    assert np.linalg.norm(oracle.sign_normalise(R) - ref) / np.linalg.norm(ref) < rtol * max(1.0, np.sqrt(mk) / 30)
+    if mk <= 4096:
+        H = np.eye(mk) - V @ T @ V.T
+        assert np.abs(H.T @ H - np.eye(mk)).max() < 1e-12
+
+
+@pytest.mark.parametrize("mk", [513, 1000, 4096, 8192, 16384, 70000, 262144])
+def test_panel_cholqr2_fast_path(q, oracle, mk):
+    """CholeskyQR2 + Householder reconstruction leaf on a well-conditioned panel: the guard word must read 0 (the
+    Householder-TSQR launches behind it were no-ops) and the output must be the same kind of compact-WY panel."""
+    w = 32
+    P = np.random.default_rng(mk).random((mk, w))
+    out, tau, T, V, guard, buf = _cholqr_leaf(q, P, ld=mk + 6, ldv=mk + 2, ldt=w + 3)
+    assert guard == 0
+    assert np.array_equal(out[mk:], buf[mk:])
+    _check_compact_wy(oracle, P, out, tau, T, V)
+    vv = (V * V).sum(axis=0)
+    assert np.abs(tau - 2.0 / vv).max() < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["zero_column", "dependent", "cond1e10", "graded", "nan_free_tiny"])
+def test_panel_cholqr2_guard_falls_back_to_householder(q, oracle, kind):
+    """Panels CholeskyQR2 must refuse (zero / dependent columns, cond 1e10): the guard word stays 1 and the Householder
+    TSQR launches do the work.  Column grading and a tiny overall scale do not hurt CholeskyQR (it is invariant to column
+    scaling); whichever route is taken there, the accuracy must be that of the Householder path."""
+    mk, w = 6000, 32
+    rng = np.random.default_rng(7)
+    P = rng.random((mk, w))
+    rtol = 1e-13
+    if kind == "zero_column":
+        P[:, 5] = 0.0
+    elif kind == "dependent":
+        P[:, 9] = P[:, 2]
+    elif kind == "cond1e10":
+        U, _ = np.linalg.qr(rng.standard_normal((mk, w))); Vr, _ = np.linalg.qr(rng.standard_normal((w, w)))
+        P = (U * np.logspace(0, -10, w)) @ Vr.T
+        rtol = 1e-5                                    # forward error of R ~ cond * eps
+    elif kind == "graded":
+        P = P * np.logspace(0, -12, w)                 # column scaling: badly conditioned Gram matrix
+        rtol = 1e-12
+    else:
+        P = P * 1e-160                                 # Gram matrix underflows to zero
+        rtol = 1e-12
+    out, tau, T, V, guard, _ = _cholqr_leaf(q, P)
+    if kind in ("zero_column", "dependent", "cond1e10"):
+        assert guard == 1
+    assert np.isfinite(out).all() and np.isfinite(T).all() and np.isfinite(V).all()
+    QtP = P - V @ (T.T @ (V.T @ P))
+    cs = np.maximum(np.abs(P).max(axis=0), 1e-300)          # column-wise scale (graded columns)
+    assert (np.abs(np.tril(QtP, -1)) / cs).max() < 1e-11 * np.sqrt(mk)
+    assert (np.abs(np.triu(QtP[:w]) - np.triu(out[:w])) / cs).max() < 1e-11 * np.sqrt(mk)
+    if kind in ("cond1e10", "graded", "nan_free_tiny"):
+        ref = oracle.sign_normalise(np.linalg.qr(P, mode="r"))
+        R = np.triu(out[:w])
+        assert np.linalg.norm(oracle.sign_normalise(R) - ref) / np.linalg.norm(ref) < rtol
+
+
+def test_panel_cholqr2_moderate_condition_stays_accurate(q, oracle):
+    """cond ~ 1e3: inside the range where the fast path is taken; orthogonality and residual must be at Householder level."""
+    mk, w = 20000, 32
+    rng = np.random.default_rng(11)
+    U, _ = np.linalg.qr(rng.standard_normal((mk, w))); Vr, _ = np.linalg.qr(rng.standard_normal((w, w)))
+    P = (U * np.logspace(0, -3, w)) @ Vr.T
+    out, tau, T, V, guard, _ = _cholqr_leaf(q, P)
+    R = np.triu(out[:w])
+    QtP = P - V @ (T.T @ (V.T @ P))
+    assert np.abs(QtP[:w] - R).max() < 1e-13 * np.sqrt(mk) and np.abs(QtP[w:]).max() < 1e-13 * np.sqrt(mk)
+    ref = oracle.sign_normalise(np.linalg.qr(P, mode="r"))
+    assert np.linalg.norm(oracle.sign_normalise(R) - ref) / np.linalg.norm(ref) < 1e-11
+
+
 def test_leaf_panel_zero_column_gives_tau_zero(q):
     """Deviation from the reference stated in include/mi355x_qr.h: zero tail -> tau = 0 (reference: NaN)."""
     mk, w = 300, 8

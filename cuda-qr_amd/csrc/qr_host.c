@@ -24,7 +24,7 @@
 
 #define QR_MAX_PAIRS 4
 #define QR_DEFAULT_SPLIT "64"
-#define QR_DEFAULT_PANEL 1
+#define QR_DEFAULT_PANEL 3
 struct qr_plan {
     int m, n, nb, ib, ldv, ldt;
     int use_graph;              /* 1: qr_geqrf_dev is captured into a hipGraph once per argument set and replayed */

@@ -824,6 +824,21 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
                         int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
                         int ldt, int tag);
 
+// compute units behind a stream (CU-masked streams register themselves; anything else: the whole device)
+static struct { hipStream_t s; int cus; } g_stream_cus[32];
+static int g_nstream_cus = 0, g_device_cus = 0;
+static int stream_cus(hipStream_t s)
+{
+    for (int i = 0; i < g_nstream_cus; ++i)
+        if (g_stream_cus[i].s == s) return g_stream_cus[i].cus;
+    if (!g_device_cus) {
+        hipDeviceProp_t p; int dev = 0;
+        g_device_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    return g_device_cus;
+}
+
+
 int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                 int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
                 int ldt)
@@ -853,17 +868,26 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     else { ti = 4; tj = 4; }
     const int BM = 32 * ti, BN = 32 * tj;
     const long long tiles = (long long) ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    // aim at ~2 blocks per CU; each K slice at least 8 k-tiles long
-    long long want = (512 + tiles - 1) / tiles;
-    long long maxk = (K + 8 * BK - 1) / (8 * BK);
-    if (want > maxk) want = maxk;
-    if (want < 1) want = 1;
     const size_t per = (size_t) M * N;
-    if (slabs == nullptr || slab_cap < per) want = 1;
-    else if ((size_t) want * per > slab_cap) want = (long long) (slab_cap / per);
-    if (want > 256) want = 256;
-    if (shortk) want = 1;
-    int ksplit = (int) want;
+    // K split: minimise  rounds(k) * (K/k + fixed) + reduce(k)  over k, where rounds = ceil(tiles*k / slots), slots =
+    // 2 workgroups per compute unit OF THE STREAM (a CU-masked stream has fewer than the device), `fixed` the per-workgroup
+    // overhead in K rows and reduce(k) the slab traffic of slab_reduce_kernel.  (The old rule aimed at 512 workgroups
+    // whatever the stream: 624 workgroups on the 192-CU update stream = 1.6 rounds.)
+    long long kmax = (K + 8 * BK - 1) / (8 * BK);             // each K slice at least 8 k-tiles long
+    if (kmax > 256) kmax = 256;
+    if (slabs == nullptr || slab_cap < per) kmax = 1;
+    else if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
+    if (kmax < 1 || shortk) kmax = 1;
+    const int slots = 2 * stream_cus(s);
+    const double row_us = 2.0 * BM * BN / 0.113e6;            // one K row of one tile on one workgroup slot
+    const double red_rows = (double) per * 8.0 / 2.0e6 / row_us;   // reading one slab of the output at ~2 TB/s, in K rows
+    int ksplit = 1;
+    double best = 1e300;
+    for (long long k = 1; k <= kmax; ++k) {
+        const long long wgs = tiles * k, rounds = (wgs + slots - 1) / slots;
+        const double cost = (double) rounds * ((double) K / (double) k + 96.0) + (k > 1 ? (double) k * red_rows + 30.0 : 0.0);
+        if (cost < best) { best = cost; ksplit = (int) k; }
+    }
     int kchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (K + kchunk - 1) / kchunk;
     if (ksplit < 1) ksplit = 1;
@@ -1082,9 +1106,15 @@ int qrd_stream_create_cumask(void** s, int first, int count)
     const uint32_t words = (uint32_t) ((p.multiProcessorCount + 31) / 32);
     hipError_t e = hipExtStreamCreateWithCUMask(&st, words, mask);
     *s = (void*) st;
+    if (e == hipSuccess && g_nstream_cus < 32) { g_stream_cus[g_nstream_cus].s = st; g_stream_cus[g_nstream_cus].cus = count; ++g_nstream_cus; }
     return (int) e;
 }
-int qrd_stream_destroy(void* s) { return (int) hipStreamDestroy((hipStream_t) s); }
+int qrd_stream_destroy(void* s)
+{
+    for (int i = 0; i < g_nstream_cus; ++i)
+        if (g_stream_cus[i].s == (hipStream_t) s) { g_stream_cus[i] = g_stream_cus[--g_nstream_cus]; break; }
+    return (int) hipStreamDestroy((hipStream_t) s);
+}
 // hipGraph capture of a whole factorisation (thousands of dependent launches replayed by one call)
 int qrd_capture_begin(void* s) { return (int) hipStreamBeginCapture((hipStream_t) s, hipStreamCaptureModeRelaxed); }
 int qrd_capture_end(void* s, void** exec)

@@ -5,14 +5,14 @@ import sys, json
 for l in sys.stdin:
     try: d=json.loads(l)
     except: print(l.strip()[:300]); continue
-    print(d['m'],d['n'],d['nb'],'ms %.1f'%d['ms'],'TF %.2f'%d['tflops'], d.get('resid'), {k:(round(v['ms'],1),v['tflops']) for k,v in d.items() if isinstance(v,dict)})
+    print(d['m'],d['n'],d['nb'],'ms %.1f'%d['ms'],'TF %.2f'%d['tflops'], {k:(round(v['ms'],1),v['tflops']) for k,v in d.items() if isinstance(v,dict)})
 "; }
-SHAPES="16384x16384x256 16384x16384x128 8192x8192x256 4096x4096x128"
-export CHECK=1
-run MI355XQR_BALANCE=0
-run MI355XQR_BALANCE=13,43,1.5,1.2
-run MI355XQR_BALANCE=13,43,1.0,1.0
-run MI355XQR_BALANCE=13,43,2.0,1.5
-run MI355XQR_BALANCE=10,43,1.5,1.2
-run MI355XQR_BALANCE=16,43,1.5,1.2
-run MI355XQR_BALANCE=20,40,1.5,1.2 MI355XQR_SPLIT=96
+SHAPES="16384x16384x256 16384x16384x128 8192x8192x256"
+run MI355XQR_SPLIT=64
+run MI355XQR_SPLIT=64 MI355XQR_BALANCE=13,43,0.9,0.5
+run MI355XQR_SPLIT=64 MI355XQR_BALANCE=13,43,0.6,0.4
+run MI355XQR_SPLIT=32 MI355XQR_BALANCE=6,50,1.0,0.6
+run MI355XQR_SPLIT=32 MI355XQR_BALANCE=0
+run MI355XQR_SPLIT=32 MI355XQR_BALANCE=6,50,1.5,1.0
+run MI355XQR_SPLIT=96 MI355XQR_BALANCE=20,36,0.8,0.5
+run MI355XQR_SPLIT=32:0.5,64 MI355XQR_BALANCE=10,45,0.9,0.5

@@ -112,7 +112,9 @@ __device__ __forceinline__ void store_kfast(const v2d (&reg)[TC], double* __rest
 // ---- shared GEMM pieces -----------------------------------------------------------------------
 // One BK-deep step of the wave tile from LDS.  AROW: the row operand comes from a row-fast image
 // (NN kernel), else from a k-fast image (TN kernel).  The column operand image is always k-fast.
-template <int TI, int TJ, bool AROW>
+// PRIO: s_setprio around the MFMA burst.  Measured on the C3 update shapes: +3 % for the TN kernel, -2 % for the NN kernel,
+// so only the k-fast (TN) instantiation raises its priority.
+template <int TI, int TJ, bool AROW, bool PRIO = !AROW>
 __device__ __forceinline__ void mma_tile(v4d (&acc)[TJ][TI], const double* __restrict__ as,
                                          const double* __restrict__ bs, int wi, int wj, int l15, int l4)
 {
@@ -126,11 +128,13 @@ __device__ __forceinline__ void mma_tile(v4d (&acc)[TJ][TI], const double* __res
             rowv[b] = AROW ? as[kk * LA + wi * 16 * TI + 16 * b + l15] : as[(wi * 16 * TI + 16 * b + l15) * LDKF + kk];
 #pragma unroll
         for (int a = 0; a < TJ; ++a) colv[a] = bs[(wj * 16 * TJ + 16 * a + l15) * LDKF + kk];
+        if (PRIO) __builtin_amdgcn_s_setprio(1);      // keep the MFMA pipe for the wave that has its fragments
 #pragma unroll
         for (int a = 0; a < TJ; ++a)
 #pragma unroll
             for (int b = 0; b < TI; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[a], rowv[b], acc[a][b], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 }
 

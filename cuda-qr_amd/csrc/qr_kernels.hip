@@ -271,6 +271,71 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_batch_kernel(int M, int N, int
     gemm_nn_body<TI, TJ, FAST>(M, N, K, alpha, A + z * sA, lda, B + z * sB, ldb, beta, C + z * sC, ldc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide trailing update, 8-wave form: the same 128 x 128 block tile and LDS images as gemm_nn_kernel<4,4>, but 512 threads
+// = 8 waves arranged 2 (rows) x 4 (cols), each wave a 64 x 32 tile (8 accumulators, 64 VGPRs).  Two workgroups per CU
+// then put 4 waves on every SIMD instead of 2: with K = nb = 256 a tile is only 16 K-steps between a 128 KiB read and a
+// 128 KiB write of C, and two waves per SIMD left the MFMA pipe idle 35 % of the time (rocprofv3 MfmaUtil 65 %).
+// Tile-aligned interior only (M % 128 == N % 128 == K % 16 == 0 parts, 16-byte aligned operands), C += alpha*A*B.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void gemm_nn_w8_kernel(int M, int N, int K, double alpha,
+                                                            const double* __restrict__ A, int lda,
+                                                            const double* __restrict__ B, int ldb,
+                                                            double* __restrict__ C, int ldc)
+{
+    constexpr int TI = 4, TJ = 2, BM = 128, BN = 128, LA = BM + 16, ASZ = BK * LA, BSZ = BN * LDKF;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                      // [2][BK][LA]
+    double* Bs = smem + 2 * ASZ;            // [2][BN][LDKF]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const double inv_alpha = 1.0 / alpha;
+    v4d acc[TJ][TI];
+#pragma unroll
+    for (int a = 0; a < TJ; ++a)
+#pragma unroll
+        for (int b = 0; b < TI; ++b) {
+            const int i = i0 + wi * 16 * TI + 16 * b + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + wj * 16 * TJ + 16 * a + l4 + 4 * r;
+                acc[a][b][r] = C[(size_t) j * ldc + i] * inv_alpha;
+            }
+        }
+    // tile loaders: A tile BK x BM row-fast (64 double2 per column), B tile BN x BK k-fast (8 double2 per column); 2 each
+    v2d ra[2], rb[2];
+    const int nk = K / BK;
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 512 * q;
+            ra[q] = *reinterpret_cast<const v2d*>(A + (size_t) (k0 + idx / 64) * lda + i0 + 2 * (idx % 64));
+            rb[q] = *reinterpret_cast<const v2d*>(B + (size_t) (j0 + idx / 8) * ldb + k0 + 2 * (idx % 8));
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + 512 * q;
+            *reinterpret_cast<v2d*>(As + buf * ASZ + (idx / 64) * LA + 2 * (idx % 64)) = ra[q];
+            *reinterpret_cast<v2d*>(Bs + buf * BSZ + (idx / 8) * LDKF + 2 * (idx % 8)) = rb[q];
+        }
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        mma_tile<TI, TJ, true, false>(acc, As + buf * ASZ, Bs + buf * BSZ, wi, wj, l15, l4);
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, 1.0, wi, wj, l15, l4);
+}
+
 // C = alpha * A^T * B (+ beta*C when not split)   A: K x M (lda), B: K x N (ldb), C: M x N (ldc).
 // K is the long dimension (panel height): gridDim.z K-slices each write their own slab
 // (slab z at C + z*slab_stride, ld = ldc) and slab_reduce_kernel sums them in a fixed order
@@ -786,6 +851,7 @@ int qrd_init(void)
     int rc = 0;
     rc |= allow_lds(gemm_nn_kernel<4, 4, true>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, true, 1>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
+    rc |= allow_lds(gemm_nn_w8_kernel, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
@@ -794,11 +860,31 @@ int qrd_init(void)
 }
 
 // the wide trailing update A2 -= V*W: always the 128x128 tile, its own kernel name (TAG = 1) for the profiler
+// MI355XQR_NN_WAVES=4 selects the 4-wave kernel for the wide update (default 8, see gemm_nn_w8_kernel)
+static int nn_waves(void)
+{
+    static int v = 0;
+    if (!v) { const char* e = getenv("MI355XQR_NN_WAVES"); v = (e && atoi(e) == 4) ? 4 : 8; }
+    return v;
+}
+
 int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return launch_nn<4, 4, 1>((hipStream_t) stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    hipStream_t s = (hipStream_t) stream;
+    const bool al = vec_ok(A, lda) && vec_ok(B, ldb) && (K % BK) == 0;
+    const int Mi = (M / 128) * 128, Ni = (N / 128) * 128;
+    if (nn_waves() != 8 || beta != 1.0 || !al || Mi == 0 || Ni == 0)
+        return launch_nn<4, 4, 1>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    const size_t shm = sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF);
+    hipLaunchKernelGGL(gemm_nn_w8_kernel, dim3(Mi / 128, Ni / 128), dim3(512), shm, s, Mi, Ni, K, alpha, A, lda, B, ldb, C, ldc);
+    int rc = (int) hipGetLastError();
+    if (!rc && Ni < N)      /* right strip: all rows, columns [Ni, N) */
+        rc = launch_nn1<4, 4, false>(s, M, N - Ni, K, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta, C + (size_t) Ni * ldc, ldc);
+    if (!rc && Mi < M)      /* bottom strip: rows [Mi, M), columns [0, Ni) */
+        rc = launch_nn1<4, 4, false>(s, M - Mi, Ni, K, alpha, A + Mi, lda, B, ldb, beta, C + Mi, ldc);
+    return rc;
 }
 
 int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,

@@ -206,9 +206,9 @@ def main():
     if wl in ("c2", "c3") and upd["launches"]:
         ach = upd["flops"] / (upd["ms"] * 1e-3) / 1e12
         if tj and wl == "c3" and nb == 256:
-            traffic = tj["gemm_nn_kernel<4,4,true>"]["hbm_bytes_per_launch"]
+            traffic = (tj.get("gemm_nn_w8_kernel") or {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma",
-                "kernel": "gemm_nn_kernel<4, 4, true, 1> (trailing update A2 -= V*W, v_mfma_f64_16x16x4_f64)",
+                "kernel": "gemm_nn_w8_kernel (trailing update A2 -= V*W, v_mfma_f64_16x16x4_f64)",
                 "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_note": ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction) from a separate "
@@ -219,6 +219,7 @@ def main():
                 "measured_mfma_f64_sustained_tflops": measured["mfma_f64_tflops"] if measured else None,
                 "frac_of_measured_sustained": ach / measured["mfma_f64_tflops"] if measured else None,
                 "cu_partition_note": "with look-ahead the update runs on 192 of 256 CUs (the panel chain owns 64)",
+                "rocprof_pmc": "profiles/r01_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
                 "measured_probe": measured,
                 "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],
                 "algorithmic_flops_per_launch": upd["flops"] / upd["launches"],

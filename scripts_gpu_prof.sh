@@ -7,7 +7,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_c3 -o bench -- 
 python3 tools_trace_summary.py $R/bench_c3/bench_kernel_trace.csv > $R/bench_c3_trace_summary.txt; rm -f $R/bench_c3/bench_kernel_trace.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_tsqr -o bench -- python3 bench.py --workload tsqr --steps 3 --warmup 1 --no-cpu-baseline > $R/bench_tsqr.json 2> $R/bench_tsqr.err
 rm -f $R/bench_tsqr/bench_kernel_trace.csv
-for ctr in FETCH_SIZE WRITE_SIZE; do
+for ctr in FETCH_SIZE WRITE_SIZE MfmaUtil LdsUtil LdsBankConflict; do
   MI355XQR_PANEL_CUS=0 rocprofv3 --pmc $ctr --output-format csv -d $R/pmc_$ctr -o pmc -- python3 tools_pmc_driver.py 256 > $R/pmc_${ctr}_driver.json 2> $R/pmc_$ctr.err
   f=$(find $R/pmc_$ctr -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 tools_pmc_summary.py $f $ctr > $R/pmc_${ctr}_summary.txt && rm -f $f

@@ -3,8 +3,8 @@
 rocprofv3 counter collection crashes on this pool beyond ~16k dispatches per process and on CU-masked
 streams, so the counters are taken on (a) calibration kernels with known byte counts in the access widths
 the GEMMs use and (b) the trailing-update GEMM pair at the exact C3 shapes of every 8th outer step
-(mk = nt + nb = 16384 - k, K = nb), launched through qr_gemm_dev -- the same kernels, tiles and split-K
-the factorisation uses -- instead of all ~17k dispatches of a full factorisation."""
+(mk = nt + nb = 16384 - k, K = nb), launched through the wide update's own launch helpers (qrd_gemm_tn_update / qrd_gemm_nn_update) -- the same
+kernels, tiles and split-K the factorisation uses -- instead of all ~17k dispatches of a full factorisation."""
 import json
 import sys
 
@@ -23,12 +23,22 @@ p.fill_uniform(A, m, m, n, seed=12)                   # fill_uniform_kernel: m*n
 p.fill_uniform(V, m, m, nb, seed=13)
 p.sync()
 p.diffnorm(A, m, m, n, seed=12)                       # diff_norm_kernel: m*n*8 B read, 8 B/lane
+import ctypes as C
+lib = q.lib
+lib.qrd_gemm_tn_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+lib.qrd_gemm_nn_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double,
+                                   C.c_void_p, C.c_int]
+st = p.stream
+slabs = torch.empty(16 << 20, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
 shapes = []
 for k in range(0, n - nb, 8 * nb):
     mk, nt = m - k, n - k - nb
     a2 = A.data_ptr() + 8 * ((k + nb) * m + k)
-    p.gemm("T", nb, nt, mk, 1.0, V.data_ptr() + 8 * k, m, a2, m, 0.0, W, nb)          # W = (V T)^T A2
-    p.gemm("N", mk, nt, nb, -1.0, V.data_ptr() + 8 * k, m, W, nb, 1.0, a2, m)          # A2 -= V W
+    # the launch helpers of the wide update themselves (qr_device.h), i.e. gemm_tn_kernel<4,4,true,1> and gemm_nn_w8_kernel
+    q.check(lib.qrd_gemm_tn_update(st, nb, nt, mk, 1.0, V.data_ptr() + 8 * k, m, a2, m, 0.0, W.data_ptr(), nb, slabs.data_ptr(), slabs.numel()))   # W = (V T)^T A2
+    q.check(lib.qrd_gemm_nn_update(st, mk, nt, nb, -1.0, V.data_ptr() + 8 * k, m, W.data_ptr(), nb, 1.0, a2, m))                                # A2 -= V W
     shapes.append({"k": k, "mk": mk, "nt": nt, "nb": nb, "nn_alg_bytes": 16 * mk * nt + 8 * mk * nb + 8 * nb * nt,
                    "tn_alg_bytes": 8 * mk * (nt + nb), "flops_each": 2 * mk * nt * nb})
 p.sync()

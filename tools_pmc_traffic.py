@@ -26,7 +26,7 @@ out = {
    "FETCH_SIZE_KiB": F["stream_copy_kernel"][1], "true_read_KiB": 1048576, "WRITE_SIZE_KiB": Wr["stream_copy_kernel"][1], "true_write_KiB": 1048576},
   "diff_norm_kernel (8 B/lane, 2 GiB read)": {"FETCH_SIZE_KiB": F["diff_norm_kernel"][1], "true_read_KiB": 2097152},
   "conclusion": "FETCH_SIZE reports exactly 1/2 of coalesced reads at both widths on gfx950 (x2 correction, as MI355X_MICROARCH.md says); WRITE_SIZE is exact"},
- "gemm_nn_kernel<4,4,true>": entry("gemm_nn_kernel<4, 4, true, 0>", nn_alg),
- "gemm_tn_kernel<4,4,true>": entry("gemm_tn_kernel<4, 4, true, 0>", tn_alg),
+ "gemm_nn_w8_kernel": entry("gemm_nn_w8_kernel", nn_alg),
+ "gemm_tn_kernel<4,4,true,1>": entry("gemm_tn_kernel<4, 4, true, 1>", tn_alg),
 }
 json.dump(out, sys.stdout, indent=1)

@@ -367,9 +367,9 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
         double* P = Ak + (size_t) c * lda + c;
         double* Vl = p->Vw + (size_t) c * ldv + c;
         double* Tl = p->T + (size_t) c * ldt + c;
-        /* leaf algorithm (MI355XQR_PANEL = tsqr [default] | col | auto): the TSQR + Householder-reconstruction leaf
-         * reads the leaf twice whatever its height and needs 4-6 launches; the one-launch-per-column leaf needs 34
-         * launches and ~25 passes */
+        /* leaf algorithm (MI355XQR_PANEL = cholqr [default] | tsqr | col | auto): CholeskyQR2 + Householder reconstruction
+         * (7 short launches) guarded by the Householder TSQR leaf (4-6 launches, no-ops unless the guard trips); tsqr = the
+         * Householder TSQR leaf alone; col = one launch per column (34 launches, ~25 passes over the leaf) */
         if (p->panel_tsqr == 3)
             CHECK(qrd_panel_cholqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
                                    p->slabs, p->slab_cap));

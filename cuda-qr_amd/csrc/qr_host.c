@@ -170,7 +170,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         /* MI355XQR_BALANCE = "Rp,Ru,tc0,tc1" (TFLOP/s on the panel CUs, on the update CUs; next-panel chain time
          * tc0 + tc1*mk/16384 ms at nb = 256); "0" = the panel stream takes no share of the wide update */
         const char* b = getenv("MI355XQR_BALANCE");
-        p->bal_rp = 13.0; p->bal_ru = 43.0; p->bal_tc0 = 1.5; p->bal_tc1 = 1.2;
+        p->bal_rp = 14.0; p->bal_ru = 44.0; p->bal_tc0 = 1.1; p->bal_tc1 = 0.6;
         if (b) {
             p->bal_rp = 0.0;
             sscanf(b, "%lf,%lf,%lf,%lf", &p->bal_rp, &p->bal_ru, &p->bal_tc0, &p->bal_tc1);

@@ -9,6 +9,5 @@ for l in sys.stdin:
     print(d['m'],d['n'],d['nb'],'ms %.1f'%d['ms'],'TF %.2f'%d['tflops'], d.get('resid'), {k:(round(v['ms'],1),v['tflops']) for k,v in d.items() if isinstance(v,dict)})
 "; }
 export CHECK=1
-run MI355XQR_NN_WAVES=8
-run MI355XQR_NN_WAVES=4
+run MI355XQR_X=1
 run MI355XQR_LOOKAHEAD=0

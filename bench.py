@@ -190,6 +190,21 @@ def main():
         acc = {"resid": float((sums[0] / sums[1]).sqrt().item()), "orth": float(o ** 0.5)}
         del Q, QR, G
 
+    # ---- N > 1 only, outside the timed region: where a TSQR step goes (local shard QR vs exchange + stacked QR)
+    tsqr_split = None
+    if world > 1:
+        reps = max(1, min(K, 3))
+        for i in range(reps):
+            be.fill(bufs[i % nbuf], m_local, n, rank * m_local, m_total, seeds[i % nbuf])
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(reps):
+            be.local_factor(bufs[i % nbuf], ts.R_local)
+        torch.cuda.synchronize()
+        loc_ms = (time.perf_counter() - t1) / reps * 1e3
+        tsqr_split = {"local_qr_ms": loc_ms, "exchange_and_stacked_qr_ms": dt / K * 1e3 - loc_ms,
+                      "note": "this rank; the stacked (world*n) x n factorisation is redundant on every rank and latency-bound"}
+
     # ---- roofline of the dominant kernel
     upd, tn, pan = prof["update_nn"], prof["vta_tn"], prof["panel"]
     measured = None
@@ -282,6 +297,10 @@ def main():
             "accuracy": acc,
             "roofline": roof,
             "weak_scaling_base_1gpu": weak_base,
+            "tsqr_step_split": tsqr_split,
+            "scaling_note": ("the N = 1 line of this bench is the square C3 headline, a different workload: the weak-scaling "
+                             "denominator of this line is weak_scaling_base_1gpu of the N = 1 line (one 262144x512 shard on "
+                             "one GPU)") if world > 1 else None,
             "cpu_baseline": cpu,
             "device": info,
         }

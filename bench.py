@@ -132,6 +132,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
+        ts.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -140,7 +141,8 @@ def main():
         A = bufs[i % nbuf]
         if i >= nbuf:                       # only when K+W exceeds the buffer pool: regenerate (stated in config)
             be.fill(A, m_local, n, rank * m_local, m_total, seeds[i % nbuf])
-        return ts.factor(A)
+        return ts.factor(A, pipelined=True)      # independent factorisations: the small stacked QR of step i runs under
+                                                  # the local QR of step i+1 (everything is finished inside the timed bracket)
 
     for i in range(W):
         step(i)

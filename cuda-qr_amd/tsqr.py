@@ -45,12 +45,18 @@ class HipBackend:
         self.plan.extract_r(A, self.m, self.n, self.m, R_out, self.n, self.n)
         self.plan.sync()            # hand R_out to the collective's stream
 
-    def stack_factor(self, S, R_out):
-        """in-place QR of the stacked (P*n) x n matrix; R_out = final R."""
+    def stack_factor(self, S, R_out, wait=True):
+        """in-place QR of the stacked (P*n) x n matrix; R_out = final R.  wait=False leaves it queued on the stack
+        plan's streams (stack_sync() before S, R_out or the factors are touched again)."""
         sm = self.world * self.n
         self.plan_stack.geqrf(S, sm, self.n, sm, self.tau_stack)
         self.plan_stack.extract_r(S, sm, self.n, sm, R_out, self.n, self.n)
-        self.plan_stack.sync()
+        if wait:
+            self.plan_stack.sync()
+
+    def stack_sync(self):
+        if self.plan_stack:
+            self.plan_stack.sync()
 
     def tree_q(self, S, Qt):
         sm = self.world * self.n
@@ -90,9 +96,12 @@ class TSQR:
         self.gathered = backend.new_matrix(n, n * world).view(world, n, n) if world > 1 else None
         self.stack = backend.new_matrix(world * n, n) if world > 1 else None
 
-    def factor(self, A):
+    def factor(self, A, pipelined=False):
         """Steps 1-3.  A (this rank's shard, column-major buffer) is overwritten with its local factors.
-        Returns the buffer holding the final R (n x n, column-major, identical on every rank)."""
+        Returns the buffer holding the final R (n x n, column-major, identical on every rank).
+        pipelined=True: the stacked factorisation (small, latency-bound, redundant on every rank) is left queued on its
+        own plan's streams, so that in a sequence of independent factorisations it runs under the next shard's local QR;
+        call sync() before reading R or calling form_q()."""
         b, n, P = self.b, self.n, self.world
         if P == 1:
             b.local_factor(A, self.R)
@@ -107,17 +116,27 @@ class TSQR:
             dist.all_gather_into_tensor(self.gathered.view(P * n, n), self.R_local, group=self.group)
         # gathered[p][c][r] = R_p(r, c); the stacked matrix is column-major (P*n) x n with R_p in rows
         # [p*n, (p+1)*n): stack[c][p*n + r] = gathered[p][c][r]
+        if pipelined and hasattr(b, "stack_sync"):
+            b.stack_sync()                      # the previous stacked factorisation still owns self.stack / self.R
         self.stack.view(n, P, n).copy_(self.gathered.permute(1, 0, 2))
         if self.stack.is_cuda:
             torch.cuda.current_stream().synchronize()
-        b.stack_factor(self.stack, self.R)
+        if pipelined and hasattr(b, "stack_sync"):
+            b.stack_factor(self.stack, self.R, wait=False)
+        else:
+            b.stack_factor(self.stack, self.R)
         return self.R
+
+    def sync(self):
+        if hasattr(self.b, "stack_sync"):
+            self.b.stack_sync()
 
     def form_q(self, A):
         """Step 4 after factor(A): returns this rank's m_local x n block of the thin Q (new buffer)."""
         b, n, P = self.b, self.n, self.world
         if P == 1:
             return b.thin_q(A)
+        self.sync()
         Qt = b.new_matrix(P * n, n)
         b.tree_q(self.stack, Qt)
         C = b.new_matrix(b.m, n)

@@ -224,6 +224,27 @@ def test_lookahead_matches_sequential_schedule(qr, oracle):
     assert rel(oracle.sign_normalise(outs[0]), oracle.sign_normalise(outs[1])) < 1e-13
 
 
+def test_tsqr_backend_pipelined_stack_factor(qr, oracle):
+    """HipBackend.stack_factor(wait=False) leaves the stacked QR queued on its own plan while the next local QR runs
+    (bench.py's pipelined TSQR steps): same R as the synchronous call."""
+    from cuda_qr_amd import tsqr as T
+    m, n, P = 8192, 256, 4
+    be = T.HipBackend(qr, m, n, P, 128, 32)
+    A = be.new_matrix(m, n); be.fill(A, m, n, 0, m, 3)
+    S1 = be.new_matrix(P * n, n); S2 = be.new_matrix(P * n, n)
+    be.plan.fill_uniform(S1, P * n, P * n, n, seed=9); be.plan.fill_uniform(S2, P * n, P * n, n, seed=9); be.plan.sync()
+    Ra, Rb, Rl = be.new_matrix(n, n), be.new_matrix(n, n), be.new_matrix(n, n)
+    be.stack_factor(S1, Ra)                                   # synchronous
+    be.stack_factor(S2, Rb, wait=False)                       # queued ...
+    be.local_factor(A, Rl)                                    # ... under a local factorisation on the other plan
+    be.stack_sync()
+    assert np.array_equal(host(Ra), host(Rb))
+    Ah = qr.uniform_matrix_host(P * n, n, seed=9)
+    ref = oracle.sign_normalise(np.linalg.qr(Ah, mode="r"))
+    assert rel(oracle.sign_normalise(np.triu(host(Ra))), ref) < 1e-13
+    be.close()
+
+
 def test_tall_skinny_65536x256_properties(qr):
     """One C4 shard (262144 x 256 over 4 GPUs -> 65536 x 256 per GPU)."""
     m, n = 65536, 256

@@ -23,6 +23,7 @@ int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, 
 size_t qrd_panel_ws_size(int m);
 int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                    double* ws, int m_cap);
+int qrd_slab_reduce(void* stream, int M, int N, int nslab, const double* slabs, int lds, size_t stride, double* out, int ldo);
 #define QRD_CHOLQR_WS (4 * 32 * 32 + 16)
 int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                      double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap);

@@ -937,6 +937,14 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
 }
 
 // the wide W = (V T)^T A2 of the trailing update: same kernel under its own profiler name (TAG = 1)
+// out (M x N, ldo) = sum of nslab slabs (slab z at slabs + z*stride, ld lds), fixed order
+int qrd_slab_reduce(void* stream, int M, int N, int nslab, const double* slabs, int lds, size_t stride, double* out, int ldo)
+{
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, (M + 255) / 256), dim3(256), 0, (hipStream_t) stream, M, N, nslab, slabs, lds, stride,
+                       (const double*) nullptr, 0, 0.0, out, ldo);
+    return (int) hipGetLastError();
+}
+
 int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap)
 {

@@ -632,6 +632,74 @@ __device__ __forceinline__ void triu_inv_wave(double (*Rs)[PW + 1], int lane, do
     }
 }
 
+// G_z = A_z^T A_z for the K slice z of a tall mk x 32 leaf (A = the leaf itself or its Q): a streaming kernel instead of the
+// general split-K TN product with A = B -- the slice is loaded ONCE (the TN kernel fetches it as both operands), 512
+// contiguous bytes per column per step (128 there), and 16 MFMAs per wave between two barriers (4 there).  Slab z (32 x 32,
+// ld 32) goes to slabs + z*1024 for slab_reduce_kernel.  Rows past mk read as zero.  16-byte aligned A, even ld and mk (else the general TN product).
+#define GKB 64
+#define GLD (GKB + 2)
+__global__ __launch_bounds__(256) void gram32_kernel(const double* __restrict__ A, int ld, int mk, int rows_per,
+                                                     double* __restrict__ slabs)
+{
+    __shared__ __attribute__((aligned(16))) double img[2][PW * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1, l15 = lane & 15, l4 = lane >> 4;
+    const int kbeg = blockIdx.x * rows_per, kend = min(mk, kbeg + rows_per);
+    const int nk = (kend - kbeg + GKB - 1) / GKB;
+    v2d reg[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, col = idx >> 5, k = k0 + 2 * (idx & 31);
+            const v2d v = *reinterpret_cast<const v2d*>(A + (size_t) col * ld + min(k, mk - 2));
+            reg[q] = (v2d){(k < kend) ? v[0] : 0.0, (k + 1 < kend) ? v[1] : 0.0};
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            *reinterpret_cast<v2d*>(&img[buf][(idx >> 5) * GLD + 2 * (idx & 31)]) = reg[q];
+        }
+    };
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (nk > 0) { gload(kbeg); sstore(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kbeg + (kt + 1) * GKB);
+        const double* ia = &img[buf][(16 * wi + l15) * GLD];
+        const double* ib = &img[buf][(16 * wj + l15) * GLD];
+#pragma unroll
+        for (int ks = 0; ks < GKB / 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ib[4 * ks + l4], ia[4 * ks + l4], acc, 0, 0, 0);
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    // D reg r of lane l holds [p = l4 + 4r][q = l15] with p indexing the first operand (ib: column 16wj + p of G) and q the
+    // second (ia: row 16wi + q): G(16wi + l15, 16wj + l4 + 4r)
+    double* out = slabs + (size_t) blockIdx.x * PW * PW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(16 * wj + l4 + 4 * r) * PW + 16 * wi + l15] = acc[r];
+}
+
+// G (32 x 32, ld 32) = A^T A for a tall mk x 32 block: gram32_kernel slabs + slab_reduce (through qrd_slab_reduce32)
+static int gram32(hipStream_t s, const double* A, int ld, int mk, double* G, double* slabs, size_t slab_cap)
+{
+    const bool ok = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (ld % 2 == 0) && (mk % 2 == 0) && mk >= 2;
+    if (!ok) return qrd_gemm_tn((void*) s, PW, PW, mk, 1.0, A, ld, A, ld, 0.0, G, PW, slabs, slab_cap, nullptr, 0);
+    int nslab = (mk + 127) / 128;                      // 128 rows (2 steps) per workgroup, at most 512 workgroups: the short
+                                                       // leaves of square problems are latency-bound, the tall ones bandwidth-bound
+    if (nslab > 512) nslab = 512;
+    if ((size_t) nslab * PW * PW > slab_cap) nslab = (int) (slab_cap / (PW * PW));
+    if (nslab < 1) return -3;
+    int rows_per = (mk + nslab - 1) / nslab;
+    rows_per = (rows_per + GKB - 1) / GKB * GKB;
+    nslab = (mk + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(gram32_kernel, dim3(nslab), dim3(256), 0, s, A, ld, mk, rows_per, slabs);
+    return qrd_slab_reduce(s, PW, PW, nslab, slabs, PW, (size_t) PW * PW, G, PW);
+}
+
 // K2: every workgroup factors G1 itself (one wave, ~2 us) and turns its 512 rows of A into rows of Q = A R1^-1 (-> Vw)
 // FULL = (w == 32): no per-column predicates.  (With `if (c < w)` around each store LLVM sinks the arithmetic of column c
 // into that column's block, i.e. reorders the solve column-major, keeping all 270 LDS loads live: 3.5 KB of scratch.)
@@ -955,10 +1023,10 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
     double *G1 = cws, *G2 = cws + PW * PW, *R1 = cws + 2 * PW * PW, *Mm = cws + 3 * PW * PW;
     int* guard = (int*) (cws + 4 * PW * PW);
     const int nblk = (mk + PT - 1) / PT;
-    int rc = qrd_gemm_tn(stream, w, w, mk, 1.0, P, ld, P, ld, 0.0, G1, PW, slabs, slab_cap, nullptr, 0);
+    int rc = gram32(s, P, ld, mk, G1, slabs, slab_cap);
     if (rc) return rc;
     hipLaunchKernelGGL(cholq_kernel<true>, dim3(nblk), dim3(PT), 0, s, P, ld, mk, w, G1, R1, Vw, ldv, guard);
-    rc = qrd_gemm_tn(stream, w, w, mk, 1.0, Vw, ldv, Vw, ldv, 0.0, G2, PW, slabs, slab_cap, nullptr, 0);
+    rc = gram32(s, Vw, ldv, mk, G2, slabs, slab_cap);
     if (rc) return rc;
     hipLaunchKernelGGL(hr2_kernel, dim3(1), dim3(64 * HG), 0, s, G2, R1, Vw, ldv, w, P, ld, tau, T, ldt, Mm, guard);
     hipLaunchKernelGGL(final2_kernel<true>, dim3(nblk), dim3(PT), 0, s, Vw, ldv, mk, w, Mm, P, ld, guard);

@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_qr.py -q -m gpu --timeout=600 -x > gpurun_out/tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/tests.log
-run() { echo "== $*"; env "$@" timeout 600 python tools_perf.py 16384x16384x256 16384x16384x128 8192x8192x256 4096x4096x128 262144x512x128 65536x256x128 2>&1 | grep -v amdgpu.ids | python -c "
+run() { echo "== $*"; env "$@" timeout 600 python devtools/tools_perf.py 16384x16384x256 16384x16384x128 8192x8192x256 4096x4096x128 262144x512x128 65536x256x128 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     try: d=json.loads(l)

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-run() { echo "== $*"; env "$@" timeout 600 python tools_perf.py $SHAPES 2>&1 | grep -v amdgpu.ids | python -c "
+run() { echo "== $*"; env "$@" timeout 600 python devtools/tools_perf.py $SHAPES 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     try: d=json.loads(l)

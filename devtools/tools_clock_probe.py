@@ -1,4 +1,6 @@
 """sample the SMI clocks while a long GEMM / MFMA loop is running (is fp64 MFMA clock-throttled?)."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import subprocess, threading, time, json, ctypes as C
 import torch
 import cuda_qr_amd as q

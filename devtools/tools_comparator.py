@@ -1,5 +1,7 @@
 """Comparator only (the role MAGMA plays in the reference, qr.cu:555-565): rocSOLVER dgeqrf through torch.geqrf next to
 this library on the same shapes, matrix resident in HBM.  Not part of the product path or of bench.py."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import json, time, sys
 import torch
 import cuda_qr_amd as q

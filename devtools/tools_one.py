@@ -1,3 +1,5 @@
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import sys, torch
 import cuda_qr_amd as q
 m, n, nb = (int(x) for x in sys.argv[1].split("x"))

@@ -1,4 +1,6 @@
 """ad-hoc perf exploration (not the bench contract): time geqrf with per-class event profile."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import sys, time, json, os
 import torch
 import cuda_qr_amd as q

@@ -5,6 +5,8 @@ streams, so the counters are taken on (a) calibration kernels with known byte co
 the GEMMs use and (b) the trailing-update GEMM pair at the exact C3 shapes of every 8th outer step
 (mk = nt + nb = 16384 - k, K = nb), launched through the wide update's own launch helpers (qrd_gemm_tn_update / qrd_gemm_nn_update) -- the same
 kernels, tiles and split-K the factorisation uses -- instead of all ~17k dispatches of a full factorisation."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import json
 import sys
 

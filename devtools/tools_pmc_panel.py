@@ -1,5 +1,7 @@
 """Leaf-panel workload for the PMC / kernel-trace passes: the CholeskyQR2 + Householder-reconstruction leaf (and, with
 argv[1] = tsqr, the Householder TSQR leaf) on tall mk x 32 panels, launched through the library's own leaf entry points."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import sys, json, ctypes as C
 import torch
 import cuda_qr_amd as q

@@ -1,5 +1,7 @@
 """HBM GB/s of the leaf-panel kernels: FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch from two --pmc passes, duration per
 dispatch from a --kernel-trace pass of the same driver; dispatches are matched by order within each kernel name."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import csv, sys, collections, json
 fetch_csv, write_csv, trace_csv = sys.argv[1:4]
 def per_dispatch(path, counter):

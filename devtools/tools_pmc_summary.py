@@ -1,4 +1,6 @@
 """Sum a rocprofv3 --pmc counter per kernel name from the counter_collection CSV."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import csv, sys, collections
 path, counter = sys.argv[1], sys.argv[2]
 tot = collections.defaultdict(lambda: [0.0, 0])

@@ -1,5 +1,7 @@
 """profiles/r01_pmc_traffic.json from the two PMC summaries + the driver's shape list:
 python tools_pmc_traffic.py profiles/r01_pmc_FETCH_SIZE_summary.txt profiles/r01_pmc_WRITE_SIZE_summary.txt profiles/r01_pmc_driver_shapes.json"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import json, sys, re
 
 def avg(path):

@@ -1,4 +1,6 @@
 """NN and TN wide-update GEMMs at C3 step shapes on the whole chip (A/B experiments on the kernels)"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import ctypes as C, time, json
 import torch
 import cuda_qr_amd as q

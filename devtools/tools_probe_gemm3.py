@@ -1,4 +1,6 @@
 """wide-update NN kernel: 4-wave vs 8-wave form (MI355XQR_NN_WAVES) on C3 step shapes, whole chip and 192 CUs, with a check"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import ctypes as C, time, json, os
 import torch
 import cuda_qr_amd as q

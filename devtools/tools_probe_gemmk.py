@@ -1,4 +1,6 @@
 """GEMM NN rate against K (is the 26% gap to the MFMA peak in the main loop or in the per-tile prologue/epilogue?)"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import ctypes as C, time, json
 import torch
 import cuda_qr_amd as q

@@ -1,4 +1,6 @@
 """MFMA f64 rate against the number of busy CUs (power/DVFS head-room) and GEMM rate against CU-mask width."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import ctypes as C, time, json, sys
 import torch
 import cuda_qr_amd as q

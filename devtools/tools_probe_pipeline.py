@@ -1,4 +1,6 @@
 """single process, one GPU: does the stacked QR of step i really run under the local QR of step i+1?"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import time, json, torch
 import cuda_qr_amd as q
 from cuda_qr_amd import tsqr as T

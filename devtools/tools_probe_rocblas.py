@@ -1,4 +1,6 @@
 """Reference point only: what does the vendor DGEMM (rocBLAS/hipBLASLt through torch) reach on the update's shapes?"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import time, json, torch
 for (M, N, K) in ((16128, 15872, 256), (8192, 7936, 256), (16128, 15872, 4096), (256, 15872, 16128)):
     A = torch.rand((M, K), dtype=torch.float64, device="cuda"); B = torch.rand((K, N), dtype=torch.float64, device="cuda")

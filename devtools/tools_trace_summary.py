@@ -1,4 +1,6 @@
 """summarise a rocprofv3 kernel-trace CSV: per-kernel busy time and the idle gaps between consecutive kernels."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

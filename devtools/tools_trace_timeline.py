@@ -1,4 +1,6 @@
 """per-queue timeline of one window of a rocprofv3 kernel trace: python tools_trace_timeline.py trace.csv frac window_ms"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))   # repo root: cuda_qr_amd, oracle
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 frac = float(sys.argv[2]); win = float(sys.argv[3]) * 1e6

@@ -193,9 +193,10 @@ def test_c2_4096_square_nb64_properties(qr):
     p.close()
 
 
-@pytest.mark.parametrize("nb", [128, 256])
+@pytest.mark.parametrize("nb", [32, 64, 128, 256])
 def test_c3_16384_square_properties(qr, nb):
-    """BASELINE config C3 at full size (16384 x 16384): residual < 1e-12 (north-star), orthogonality.
+    """BASELINE config C3 at full size (16384 x 16384) over its block-size sweep 32/64/128/256: residual < 1e-12
+    (north-star), orthogonality.
     Also the regression test for the look-ahead race fixed in round 1 (panel and wide update sharing
     one W buffer only went wrong once the wide GEMM outlasted the next panel, i.e. at this size)."""
     m = n = 16384
@@ -243,6 +244,34 @@ def test_tsqr_backend_pipelined_stack_factor(qr, oracle):
     ref = oracle.sign_normalise(np.linalg.qr(Ah, mode="r"))
     assert rel(oracle.sign_normalise(np.triu(host(Ra))), ref) < 1e-13
     be.close()
+
+
+@pytest.mark.parametrize("m,n", [(262144, 256), (262144, 512)])
+def test_c4_c5_full_height_properties(qr, m, n):
+    """C4 at its full size on one GPU (262144 x 256) and one C5 shard (262144 x 512): residual, orthogonality of the thin
+    Q, upper-triangular R with the column norms of A on... (||R||_F = ||A||_F)."""
+    p = qr.Plan(m, n, 128, 32)
+    dA = zeros(m, n)
+    p.fill_uniform(dA, m, m, n, seed=12)
+    p.sync()
+    resid, orth, dR = _device_metrics(qr, p, dA, m, n, 12)
+    assert resid < 1e-12 and orth < 1e-11
+    R = host(dR)
+    assert np.array_equal(np.tril(R, -1), np.zeros_like(R))
+    # ||R||_F^2 = ||A||_F^2 = sum of squares of uniform[0,1) entries ~ m*n/3
+    assert abs(np.linalg.norm(R) ** 2 / (m * n / 3.0) - 1.0) < 1e-2
+    p.close()
+
+
+def test_c4_virtual_shards_match_single_factorisation(qr, oracle):
+    """C4-shaped TSQR on one device: 4 virtual row shards (the steps of the 4-GPU run with a memcpy in place of the
+    all-gather) give the same sign-normalised R as the unsharded factorisation."""
+    m, n = 65536, 256                         # C4 / 4: the per-GPU shard height of the 4-GPU run, 4 virtual shards of it
+    A = qr.uniform_matrix_host(m, n, seed=12)
+    Q1, R1 = qr.qr_thin(A, nb=128, nshards=1)
+    Q4, R4 = qr.qr_thin(A, nb=128, nshards=4)
+    assert rel(oracle.sign_normalise(R4), oracle.sign_normalise(R1)) < 1e-13
+    assert rel(Q4 @ R4, A) < 1e-13 and np.abs(Q4.T @ Q4 - np.eye(n)).max() < 1e-12
 
 
 def test_tall_skinny_65536x256_properties(qr):

@@ -65,12 +65,14 @@ struct qr_plan {
 
 /* ---------------------------------------------------------------------------------------------- */
 static int g_nb = 0, g_ib = 0, g_inited = 0;
+static int g_nb_explicit = 0;      /* MI355XQR_NB or qr_set_block_size chose nb: no automatic 256 for large square problems */
 
 static void defaults_from_env(void)
 {
     if (g_nb == 0) {
         const char* e = getenv("MI355XQR_NB");
         g_nb = e ? atoi(e) : 128;
+        g_nb_explicit = e != NULL;
         e = getenv("MI355XQR_IB");
         g_ib = e ? atoi(e) : 32;
         if (g_ib < 1 || g_ib > QRD_LEAFW) g_ib = 32;
@@ -81,7 +83,7 @@ static void defaults_from_env(void)
 int qr_set_block_size(int nb, int ib)
 {
     if (ib < 1 || ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
-    g_nb = nb; g_ib = ib;
+    g_nb = nb; g_ib = ib; g_nb_explicit = 1;
     return 0;
 }
 
@@ -122,7 +124,12 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     if (!out || m < 1 || n < 1 || m < n) return QR_E_ARG;
     CHECK(ensure_device());
     defaults_from_env();
-    if (nb <= 0) nb = g_nb;
+    if (nb <= 0) {
+        nb = g_nb;
+        /* large square problems are update-bound: K = 256 lifts the update GEMMs (C3: 155 -> 151 ms); everything smaller or
+         * tall-skinny is panel-bound and better off with 128 */
+        if (!g_nb_explicit && m >= 8192 && n >= 8192 && 256 % (ib > 0 ? ib : g_ib) == 0) nb = 256;
+    }
     if (ib <= 0) ib = g_ib;
     if (ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
     qr_plan* p = (qr_plan*) calloc(1, sizeof(qr_plan));

@@ -64,7 +64,8 @@ int dgemm_status(double* A, double* B, double* C, int k, int m, int n);
 const char* qr_strerror(int status);
 
 /* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 256;
- * leaf width ib <= 32).  Defaults 128 / 32; env MI355XQR_NB / MI355XQR_IB override the defaults. */
+ * leaf width ib <= 32).  Defaults 128 / 32 (256 / 32 when both m and n are >= 8192 and nothing was set explicitly);
+ * env MI355XQR_NB / MI355XQR_IB override the defaults. */
 int qr_set_block_size(int nb, int ib);
 void qr_get_block_size(int* nb, int* ib);
 

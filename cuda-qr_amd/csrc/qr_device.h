@@ -18,6 +18,13 @@ int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const do
                        int ldb, double beta, double* C, int ldc);
 int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap);
+/* second-generation wide update (qr_gemm_nt.hip): W kept transposed, direct-to-LDS tile loads */
+int qrd_gemm2_init(void);
+int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc);
+int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt,
+                double* C, int ldc, int gm, unsigned long long* stamps);
+int qrd_gemm_tnt(void* stream, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* Ct, int ldct,
+                 double* slabs, size_t slab_cap, int ksplit, int cus, int gm);
 int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
                    int ldv, double* scratch);
 size_t qrd_panel_ws_size(int m);
@@ -68,6 +75,10 @@ int qrd_stream_wait_event(void* s, void* e);
 int qrd_event_elapsed_ms(void* a, void* b, float* ms);
 int qrd_device_count(int* n);
 int qrd_set_device(int d);
+int qrd_get_device(int* d);
+int qrd_stream_cus(void* s);
+int qrd_host_register(void* p, size_t bytes);
+int qrd_host_unregister(void* p);
 const char* qrd_error_string(int e);
 int qrd_device_info(char* name, int name_len, int* cus, int* clock_khz, size_t* mem_bytes);
 int qrd_probe_mfma_f64(double* out3);

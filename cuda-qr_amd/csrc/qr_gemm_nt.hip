@@ -1,0 +1,381 @@
+// qr_gemm_nt.hip -- the wide trailing update of the blocked Householder QR on gfx950 (MI355X), second generation.
+//
+// Replaces, for the tile-aligned interior of the wide update, the pair gemm_tn_kernel<4,4> / gemm_nn_w8_kernel of
+// qr_kernels.hip (reference: trailingUpdateKernel qr.cu:335-465, host loop qr.c:255-293):
+//
+//     Wt = A2^T (V T)          (nt x nbp, "W transposed": the long dimension nt is the contiguous one)    gemm_tnt_kernel
+//     A2 -= V Wt^T             (mk x nt)                                                                  gemm_nt_kernel
+//
+// Storing W transposed makes BOTH operands of the update "row-fast": for a fixed k the 128 rows of a V tile and
+// the 128 columns of a Wt tile are each 1 KiB of contiguous memory, i.e. exactly one global_load_lds_dwordx4 wave
+// instruction (64 lanes x 16 B, LDS destination = wave-uniform base + lane*16).  So the tiles go HBM/L2 -> LDS
+// directly: no staging VGPRs, no ds_write pass, no wait between a load and its LDS store.
+//
+// Fragment maps (v_mfma_f64_16x16x4_f64: A-operand lane l = Aop[p = l&15][k = l>>4], B-operand lane l =
+// Bop[k = l>>4][q = l&15], D lane l reg r = D[p = (l>>4) + 4r][q = l&15]):
+//   * rows go on p, columns on q, and the 16 rows of MFMA tile b of a wave are NOT consecutive: tile pair (2c, 2c+1)
+//     covers wave rows 32c .. 32c+31 with   row(b, p) = 32c + 2p + (b & 1).
+//     - a lane's A fragments for tiles 2c and 2c+1 are two adjacent doubles of the LDS row -> ONE ds_read_b128, and
+//       the 16 lanes of a bank group read 256 contiguous bytes: conflict-free on the unpadded [k][128] image
+//       (row stride 1024 B = 0 mod 256 B, which is what the b128 lane groups need);
+//     - the D registers r of tiles 2c, 2c+1 in one lane are rows 32c + 2(l4 + 4r) + {0, 1} of one column: 16
+//       contiguous bytes, so C moves with global_load/store_dwordx4 and the 4 lanes l4 of a column cover 64
+//       contiguous bytes per instruction.
+//   * columns: tile a of a wave holds columns 2q + a, so both B fragments of a lane are one ds_read_b128.
+// Per 4-deep MFMA step a wave issues 3 ds_read_b128 for 8 MFMAs (the first generation: 6 ds_read_b64, plus 4
+// ds_write_b128 and 4 global_load_dwordx4 per 16-deep tile).
+// C enters through the accumulators and the product is subtracted by the MFMA's own negate-A modifier
+// (blgp = 1 -> "neg:[1,0,0]"), so prologue and epilogue are 16 loads and 16 stores per lane, nothing else.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "qr_device.h"
+#include "qr_common.h"
+
+#define NT_BM 128
+#define NT_BN 128
+#define NT_BK 16
+#define NT_STAGE (2 * NT_BK * 128)          /* doubles per pipeline stage: A image [16][128] + B image [16][128] */
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*) (p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*) (p))
+
+// Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2), so the
+// linear id is first turned into "XCD-major" order (each XCD gets a contiguous range of tile indices), and tile
+// indices walk the grid in groups of GM row tiles x all column tiles: the ~64 workgroups an XCD runs at a time then
+// form a compact GM x (64/GM) block of the tile grid that shares GM V tiles and 64/GM Wt tiles in that XCD's L2.
+// Speed only: any bijection is correct.
+__device__ __forceinline__ void tile_of_block(int bid, int gx, int gy, int gm, int& tx, int& ty)
+{
+    const int nwg = gx * gy;
+    int id = bid;
+    if (gm > 0) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int per = gm * gy, g = id / per, in = id - g * per;
+        const int rows = min(gm, gx - g * gm);            // the last group may be shorter
+        tx = g * gm + in % rows;
+        ty = in / rows;
+    } else {
+        tx = id % gx;
+        ty = id / gx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C (M x N, ldc) -= A (M x K, lda) * Bt (N x K, ldbt)^T      (NEG; else +=)
+// M % 128 == N % 128 == K % 16 == 0, K >= 16, operands 16-byte aligned with even leading dimensions (host-checked).
+// 512 threads = 8 waves as 2 (rows) x 4 (cols), wave tile 64 x 32 = 4 x 2 MFMA tiles, two LDS stages of 32 KiB.
+// ------------------------------------------------------------------------------------------------
+template <bool NEG, int STAMP>
+__global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, const double* __restrict__ A, int lda,
+                                                         const double* __restrict__ Bt, int ldbt,
+                                                         double* __restrict__ C, int ldc, int gx, int gy, int gm,
+                                                         unsigned long long* __restrict__ stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int tx, ty;
+    tile_of_block(blockIdx.x, gx, gy, gm, tx, ty);
+    const int i0 = tx * NT_BM, j0 = ty * NT_BN;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (STAMP) t0 = __builtin_amdgcn_s_memtime();
+
+    // --- tile loader: wave w brings k-rows w and w + 8 of both images; every instruction is 1 KiB contiguous
+    const double* ga = A + (size_t) wave * lda + i0 + 2 * lane;
+    const double* gb = Bt + (size_t) wave * ldbt + j0 + 2 * lane;
+    const size_t a8 = (size_t) 8 * lda, b8 = (size_t) 8 * ldbt;
+    auto issue = [&](int kt, int stage) {
+        const double* pa = ga + (size_t) kt * NT_BK * lda;
+        const double* pb = gb + (size_t) kt * NT_BK * ldbt;
+        double* sa = smem + stage * NT_STAGE + wave * 128;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa), LDS_PTR(sa), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + a8), LDS_PTR(sa + 8 * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb), LDS_PTR(sa + NT_BK * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + b8), LDS_PTR(sa + NT_BK * 128 + 8 * 128), 16, 0, 0);
+    };
+    issue(0, 0);
+    __builtin_amdgcn_sched_barrier(0);      // the tile loads go out before the C loads (whose consumers wait vmcnt(0))
+
+    // --- C tile -> accumulators: acc[a][b][r] = C(i0 + 64 wi + 32 (b>>1) + 2 (l4 + 4r) + (b&1), j0 + 32 wj + 2 l15 + a)
+    v4d acc[2][4];
+    double* cp[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        cp[a] = C + (size_t) (j0 + 32 * wj + 2 * l15 + a) * ldc + i0 + 64 * wi + 2 * l4;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const v2d v = *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
+                acc[a][2 * c][r] = v[0];
+                acc[a][2 * c + 1][r] = v[1];
+            }
+    }
+    __syncthreads();                                   // vmcnt(0): stage 0 and the C tile have landed
+    if (STAMP) t1 = __builtin_amdgcn_s_memtime();
+
+    const int nk = K / NT_BK;
+    const int aoff = 64 * wi + 2 * l15, boff = NT_BK * 128 + 32 * wj + 2 * l15;
+    // LDS reads run one 4-deep step ahead of the MFMAs that consume them (two fragment sets, order pinned with
+    // sched_barrier: left alone, hipcc sinks every read to its first use and waits lgkmcnt(0) in front of each MFMA group)
+    v2d fa[2][2], fb[2];
+#define NT_READ(set, ks)                                                                   \
+    do {                                                                                   \
+        const double* row_ = st + (ks) * 4 * 128;                                          \
+        fa[set][0] = *reinterpret_cast<const v2d*>(row_ + aoff);                           \
+        fa[set][1] = *reinterpret_cast<const v2d*>(row_ + aoff + 32);                      \
+        fb[set] = *reinterpret_cast<const v2d*>(row_ + boff);                              \
+    } while (0)
+#define NT_MMA(set)                                                                                                   \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                               \
+            acc[a][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][0][0], fb[set][a], acc[a][0], 0, 0, NEG ? 1 : 0); \
+            acc[a][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][0][1], fb[set][a], acc[a][1], 0, 0, NEG ? 1 : 0); \
+            acc[a][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][1][0], fb[set][a], acc[a][2], 0, 0, NEG ? 1 : 0); \
+            acc[a][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][1][1], fb[set][a], acc[a][3], 0, 0, NEG ? 1 : 0); \
+        }                                                                                                             \
+    } while (0)
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const double* st = smem + (kt & 1) * NT_STAGE + l4 * 128;
+        NT_READ(0, 0);
+        NT_READ(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        NT_MMA(0);
+        __builtin_amdgcn_sched_barrier(0);
+        NT_READ(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        NT_MMA(1);
+        __builtin_amdgcn_sched_barrier(0);
+        NT_READ(1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        NT_MMA(0);
+        NT_MMA(1);
+        __syncthreads();     // every wave is done with this stage; the next stage's loads (vmcnt(0)) have landed
+    }
+#undef NT_READ
+#undef NT_MMA
+    if (STAMP) t2 = __builtin_amdgcn_s_memtime();
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]};
+    if (STAMP && tid == 0) {
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* s = stamps + 4 * (size_t) blockIdx.x;
+        s[0] = t0; s[1] = t1; s[2] = t2; s[3] = t3;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Slab z of  Ct (M x N) = A^T B   over rows [z*kchunk, min(K, (z+1)*kchunk))    A: K x M (lda), B: K x N (ldb)
+// (in the update: A = A2, M = nt; B = V T, N = nbp; Ct = Wt).  Both operands are k-contiguous in memory: a tile is
+// 128 columns x 16 k = 128 B per column.  One global_load_lds instruction brings 8 columns x 128 B; the LDS image is
+// [column][8 slots of 16 B] with the slot index XOR-ed with (column >> 1) & 7 -- applied on the SOURCE address (the
+// LDS destination of a global_load_lds is linear) and again on the read.  MFMA k-rows are assigned so that a lane
+// needs k and k + 1 in consecutive steps: kappa(step s, l4) = 2 l4 + (s & 1) + 8 (s >> 1), so one ds_read_b128
+// feeds two steps; with the swizzle the 16 lanes of every b128 bank group hit 16 distinct slots.
+// D: columns of Ct on p (registers), rows of Ct on q (lanes): 16 lanes store 128 contiguous bytes.
+// M % 128 == N % 128 == 0, kchunk % 16 == 0, K % 16 == 0, 16-byte aligned operands, even lda / ldb.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void gemm_tnt_kernel(int M, int N, int K, int kchunk, const double* __restrict__ A, int lda,
+                                                          const double* __restrict__ B, int ldb,
+                                                          double* __restrict__ Ct, int ldct, size_t slab_stride,
+                                                          int gx, int gy, int gm)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int per_z = gx * gy;
+    const int z = blockIdx.x / per_z;
+    int tx, ty;
+    tile_of_block(blockIdx.x - z * per_z, gx, gy, gm, tx, ty);
+    const int i0 = tx * 128, j0 = ty * 128;             // rows (A columns) / columns (B columns) of the Ct tile
+    const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg) / NT_BK;
+
+    // loader: instruction n (= wave, wave + 8) covers image columns 8n .. 8n+7; lane L -> column 8n + (L >> 3),
+    // destination slot L & 7, source k-pair (L & 7) ^ ((column >> 1) & 7)
+    const int lc = lane >> 3, ls = lane & 7;
+    const int c0 = 8 * wave + lc, c1 = c0 + 64;
+    const double* ga0 = A + (size_t) (i0 + c0) * lda + kbeg + 2 * (ls ^ ((c0 >> 1) & 7));
+    const double* ga1 = A + (size_t) (i0 + c1) * lda + kbeg + 2 * (ls ^ ((c1 >> 1) & 7));
+    const double* gb0 = B + (size_t) (j0 + c0) * ldb + kbeg + 2 * (ls ^ ((c0 >> 1) & 7));
+    const double* gb1 = B + (size_t) (j0 + c1) * ldb + kbeg + 2 * (ls ^ ((c1 >> 1) & 7));
+    auto issue = [&](int kt, int stage) {
+        double* sa = smem + stage * NT_STAGE + wave * 128;
+        const int ko = kt * NT_BK;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga0 + ko), LDS_PTR(sa), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga1 + ko), LDS_PTR(sa + 8 * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb0 + ko), LDS_PTR(sa + NT_BK * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb1 + ko), LDS_PTR(sa + NT_BK * 128 + 8 * 128), 16, 0, 0);
+    };
+    v4d acc[2][4];                                      // [a: Ct column tile][b: Ct row tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (nk > 0) issue(0, 0);
+    __syncthreads();
+    // fragment addresses: image column c of the A image (rows of Ct) = 64 wi + 16 b + l15, of the B image = 32 wj + 16 a + l15
+    int arow[4], brow[2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) arow[b] = 64 * wi + 16 * b + l15;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) brow[a] = 32 * wj + 16 * a + l15;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const double* st = smem + (kt & 1) * NT_STAGE;
+        v2d fa[2][4], fb[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                   // k-pair l4 + 4u: MFMA steps 2u and 2u + 1
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                fa[u][b] = *reinterpret_cast<const v2d*>(st + arow[b] * 16 + 2 * ((l4 + 4 * u) ^ ((arow[b] >> 1) & 7)));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                fb[u][a] = *reinterpret_cast<const v2d*>(st + NT_BK * 128 + brow[a] * 16 + 2 * ((l4 + 4 * u) ^ ((brow[a] >> 1) & 7)));
+        }
+        __builtin_amdgcn_sched_barrier(0);              // all 12 reads are in flight before the first MFMA
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[u][a][e], fa[u][b][e], acc[a][b], 0, 0, 0);
+        __syncthreads();
+    }
+    // D reg r of lane (l4, l15) of tile (a, b): Ct(row i0 + 64 wi + 16 b + l15, column j0 + 32 wj + 16 a + l4 + 4 r)
+    double* out = Ct + (size_t) z * slab_stride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* col = out + (size_t) (j0 + 32 * wj + 16 * a + l4 + 4 * r) * ldct + i0 + 64 * wi + l15;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) col[16 * b] = acc[a][b][r];
+        }
+}
+
+// out[e] = sum_z slabs[z][e]  for a dense n-element array (n % 2 == 0), fixed summation order
+__global__ __launch_bounds__(256) void slab_sum_kernel(size_t n2, int nslab, const v2d* __restrict__ slabs, size_t stride2,
+                                                       v2d* __restrict__ out)
+{
+    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t) gridDim.x * blockDim.x) {
+        v2d s0 = slabs[e], s1 = (v2d){0.0, 0.0};
+        int z = 1;
+        for (; z + 1 < nslab; z += 2) { s1 += slabs[(size_t) z * stride2 + e]; s0 += slabs[(size_t) (z + 1) * stride2 + e]; }
+        if (z < nslab) s1 += slabs[(size_t) z * stride2 + e];
+        out[e] = s0 + s1;
+    }
+}
+
+// ================================================================================================
+static int g_nt_gm = -1;
+static int nt_gm(void)
+{
+    if (g_nt_gm < 0) { const char* e = getenv("MI355XQR_NT_GM"); g_nt_gm = e ? atoi(e) : 8; }
+    return g_nt_gm;
+}
+
+static inline bool al16(const void* p, int ld) { return (((uintptr_t) p) & 15) == 0 && (ld & 1) == 0; }
+
+extern "C" {
+
+int qrd_gemm2_init(void)
+{
+    int rc = 0;
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tnt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
+    return rc;
+}
+
+// 1 if (M, N, K, operands) can go to gemm_nt_kernel as they are
+int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc)
+{
+    return M >= 128 && N >= 128 && M % 128 == 0 && N % 128 == 0 && K >= 16 && K % 16 == 0 && al16(A, lda) && al16(Bt, ldbt) && al16(C, ldc);
+}
+
+// C -= A Bt^T (sign < 0) or C += A Bt^T (sign > 0) on the tile-aligned problem; gm < 0: library default
+int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt,
+                double* C, int ldc, int gm, unsigned long long* stamps)
+{
+    if (!qrd_gemm_nt_ok(M, N, K, A, lda, Bt, ldbt, C, ldc)) return -7;
+    const int gx = M / 128, gy = N / 128;
+    if (gm < 0) gm = nt_gm();
+    const size_t shm = 2 * NT_STAGE * sizeof(double);
+    hipStream_t s = (hipStream_t) stream;
+    if (stamps)
+        hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
+    else if (sign < 0)
+        hipLaunchKernelGGL((gemm_nt_kernel<true, 0>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<false, 0>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
+    return (int) hipGetLastError();
+}
+
+// Ct (M x N, ldct) = A^T B with split-K over `ksplit` slabs (ksplit <= 0: chosen here from the CU count `cus` of the
+// stream); M % 128 == N % 128 == K % 16 == 0.  slabs: >= ksplit * M * N doubles when ksplit > 1.
+int qrd_gemm_tnt(void* stream, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* Ct, int ldct,
+                 double* slabs, size_t slab_cap, int ksplit, int cus, int gm)
+{
+    if (!(M >= 128 && N >= 128 && M % 128 == 0 && N % 128 == 0 && K >= 16 && K % 16 == 0 && al16(A, lda) && al16(B, ldb) && (ldct & 1) == 0 &&
+          (((uintptr_t) Ct) & 15) == 0))
+        return -7;
+    hipStream_t s = (hipStream_t) stream;
+    const int gx = M / 128, gy = N / 128;
+    const size_t per = (size_t) M * N;
+    if (gm < 0) gm = nt_gm();
+    if (ksplit <= 0) {
+        // same cost model as gemm_tn_impl: rounds(k) * (K/k + fixed) + reduce(k)
+        long long kmax = K / (8 * NT_BK);
+        if (kmax > 64) kmax = 64;
+        if (slabs == nullptr || slab_cap < per) kmax = 1;
+        else if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
+        if (kmax < 1) kmax = 1;
+        const int slots = 2 * (cus > 0 ? cus : 256);
+        const double row_us = 2.0 * 128 * 128 / 0.113e6;
+        const double red_rows = (double) per * 8.0 / 2.0e6 / row_us;
+        double best = 1e300;
+        ksplit = 1;
+        for (long long k = 1; k <= kmax; ++k) {
+            const long long wgs = (long long) gx * gy * k, rounds = (wgs + slots - 1) / slots;
+            const double cost = (double) rounds * ((double) K / (double) k + 96.0) + (k > 1 ? (double) k * red_rows + 30.0 : 0.0);
+            if (cost < best) { best = cost; ksplit = (int) k; }
+        }
+    }
+    int kchunk = ((K + ksplit - 1) / ksplit + NT_BK - 1) / NT_BK * NT_BK;
+    ksplit = (K + kchunk - 1) / kchunk;
+    if (ksplit > 1 && (slabs == nullptr || (size_t) ksplit * per > slab_cap)) return -3;
+    const size_t shm = 2 * NT_STAGE * sizeof(double);
+    if (ksplit == 1) {
+        hipLaunchKernelGGL(gemm_tnt_kernel, dim3(gx * gy), dim3(512), shm, s, M, N, K, kchunk, A, lda, B, ldb, Ct, ldct, (size_t) 0, gx, gy, gm);
+        return (int) hipGetLastError();
+    }
+    hipLaunchKernelGGL(gemm_tnt_kernel, dim3(gx * gy * ksplit), dim3(512), shm, s, M, N, K, kchunk, A, lda, B, ldb, slabs, M, per, gx, gy, gm);
+    int rc = (int) hipGetLastError();
+    if (rc) return rc;
+    if (ldct == M) {
+        const size_t n2 = per / 2;
+        int blocks = (int) ((n2 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, s, n2, ksplit, (const v2d*) slabs, per / 2, (v2d*) Ct);
+        return (int) hipGetLastError();
+    }
+    return qrd_slab_reduce(stream, M, N, ksplit, slabs, M, per, Ct, ldct);
+}
+
+}   // extern "C"

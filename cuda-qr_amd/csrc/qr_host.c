@@ -13,6 +13,8 @@
  *     G = V^T V ; T = larft(G, leaf T's) ; VT = V T                             [qr.c:170-213]
  *     W = VT^T A2 ; A2 -= V W                                                   [qr.c:255-293]
  */
+#define _POSIX_C_SOURCE 200809L      /* strtok_r, pthread under -std=c99 */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -64,10 +66,16 @@ struct qr_plan {
 };
 
 /* ---------------------------------------------------------------------------------------------- */
-static int g_nb = 0, g_ib = 0, g_inited = 0;
+/* Process-wide state, all of it behind g_lock: the default block sizes and which devices have had their kernel
+ * attributes set.  Everything else lives in a qr_plan, which belongs to one host thread at a time ("callable
+ * from one host thread per GPU"). */
+#define QR_MAX_DEVICES 64
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static int g_nb = 0, g_ib = 0;
 static int g_nb_explicit = 0;      /* MI355XQR_NB or qr_set_block_size chose nb: no automatic 256 for large square problems */
+static unsigned char g_dev_inited[QR_MAX_DEVICES];
 
-static void defaults_from_env(void)
+static void defaults_from_env_locked(void)
 {
     if (g_nb == 0) {
         const char* e = getenv("MI355XQR_NB");
@@ -80,28 +88,53 @@ static void defaults_from_env(void)
     }
 }
 
+/* the block sizes a plan for an m x n problem gets when the caller passes nb = 0 / ib = 0 */
+static void default_blocks(int m, int n, int* nb, int* ib)
+{
+    pthread_mutex_lock(&g_lock);
+    defaults_from_env_locked();
+    int b = g_nb;
+    /* large square problems are update-bound: K = 256 lifts the update GEMMs (C3: 155 -> 151 ms); everything smaller or
+     * tall-skinny is panel-bound and better off with 128 */
+    if (!g_nb_explicit && m >= 8192 && n >= 8192 && 256 % g_ib == 0) b = 256;
+    if (nb) *nb = b;
+    if (ib) *ib = g_ib;
+    pthread_mutex_unlock(&g_lock);
+}
+
 int qr_set_block_size(int nb, int ib)
 {
     if (ib < 1 || ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
+    pthread_mutex_lock(&g_lock);
     g_nb = nb; g_ib = ib; g_nb_explicit = 1;
+    pthread_mutex_unlock(&g_lock);
     return 0;
 }
 
 void qr_get_block_size(int* nb, int* ib)
 {
-    defaults_from_env();
+    pthread_mutex_lock(&g_lock);
+    defaults_from_env_locked();
     if (nb) *nb = g_nb;
     if (ib) *ib = g_ib;
+    pthread_mutex_unlock(&g_lock);
 }
 
+/* kernel attributes (dynamic-LDS caps) are per device: initialise the CURRENT device of the calling thread once */
 static int ensure_device(void)
 {
-    if (g_inited) return 0;
-    int n = 0;
+    int n = 0, dev = 0;
     if (qrd_device_count(&n) != 0 || n < 1) return QR_E_NODEVICE;
-    CHECK(qrd_init());
-    g_inited = 1;
-    return 0;
+    CHECK(qrd_get_device(&dev));
+    if (dev < 0 || dev >= QR_MAX_DEVICES) return QR_E_INTERNAL;
+    pthread_mutex_lock(&g_lock);
+    int rc = 0;
+    if (!g_dev_inited[dev]) {
+        rc = qrd_init();
+        if (!rc) g_dev_inited[dev] = 1;
+    }
+    pthread_mutex_unlock(&g_lock);
+    return rc;
 }
 
 const char* qr_strerror(int status)
@@ -123,14 +156,12 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
 {
     if (!out || m < 1 || n < 1 || m < n) return QR_E_ARG;
     CHECK(ensure_device());
-    defaults_from_env();
-    if (nb <= 0) {
-        nb = g_nb;
-        /* large square problems are update-bound: K = 256 lifts the update GEMMs (C3: 155 -> 151 ms); everything smaller or
-         * tall-skinny is panel-bound and better off with 128 */
-        if (!g_nb_explicit && m >= 8192 && n >= 8192 && 256 % (ib > 0 ? ib : g_ib) == 0) nb = 256;
+    {
+        int dnb, dib;
+        default_blocks(m, n, &dnb, &dib);
+        if (ib <= 0) ib = dib;
+        if (nb <= 0) nb = (dnb % ib == 0) ? dnb : 128;
     }
-    if (ib <= 0) ib = g_ib;
     if (ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
     qr_plan* p = (qr_plan*) calloc(1, sizeof(qr_plan));
     if (!p) return QR_E_ALLOC;
@@ -159,10 +190,16 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         else snprintf(spec, sizeof spec, "%s", n >= 2048 ? QR_DEFAULT_SPLIT : "0");
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
-        for (char* tok = strtok(spec, ","); tok && !rc && p->npairs < QR_MAX_PAIRS; tok = strtok(NULL, ",")) {
+        char* save = NULL;
+        for (char* tok = strtok_r(spec, ",", &save); tok && !rc && p->npairs < QR_MAX_PAIRS; tok = strtok_r(NULL, ",", &save)) {
             const int c = atoi(tok);
             const char* colon = strchr(tok, ':');
-            if (c <= 0 || c >= cus) { p->npairs = 0; break; }
+            if (c <= 0 || c >= cus) {           /* "0" or a bad entry: no partition; drop what was already created */
+                for (int i = 0; i < p->npairs; ++i)
+                    for (int j = 0; j < 2; ++j) { qrd_stream_destroy(p->s_pair[i][j]); p->s_pair[i][j] = NULL; }
+                p->npairs = 0;
+                break;
+            }
             const int i = p->npairs++;
             p->pair_until[i] = colon ? atof(colon + 1) : 0.0;
             rc = qrd_stream_create_cumask(&p->s_pair[i][0], 0, c);
@@ -268,6 +305,8 @@ static int ensure_w(qr_plan* p, size_t elems)
 {
     if (elems <= p->w_cap) return 0;
     CHECK(qr_plan_sync(p));
+    qrd_graph_destroy(p->graph_exec);       /* a captured factorisation holds the old W pointer */
+    p->graph_exec = NULL; p->g_dA = NULL;
     qrd_free(p->W);
     p->W = NULL; p->w_cap = 0;
     CHECK(qrd_malloc((void**) &p->W, sizeof(double) * elems));
@@ -501,7 +540,22 @@ static int enter_phase(qr_plan* p, int i)
     return 0;
 }
 
+static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, double* dtau);
+
+/* a failure in the middle of the schedule must not leave the plan pointing at a phase's masked streams */
 static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
+{
+    const int rc = geqrf_issue_inner(p, dA, m, n, lda, dtau);
+    if (rc) {
+        p->stream = p->s_main;
+        p->stream_u = p->npairs ? NULL : p->stream_u;
+        p->pair_cur = -1;
+        use_set(p, 0);
+    }
+    return rc;
+}
+
+static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     const int nb = p->nb;
     if (!p->lookahead) {
@@ -645,33 +699,153 @@ int qr_probe_copy_gbps(double* g) { CHECK(ensure_device()); return qrd_probe_cop
  * ---------------------------------------------------------------------------------------------- */
 void getPanelDims(int m, int n, int* rowPanels, int* colPanels)
 {
-    (void) m;
-    defaults_from_env();
-    if (colPanels) *colPanels = n / g_nb + (n % g_nb != 0);
+    int nb = 128;
+    default_blocks(m, n, &nb, NULL);          /* the block size mmqr will really use for this shape */
+    if (colPanels) *colPanels = n / nb + (n % nb != 0);
     if (rowPanels) *rowPanels = 1;
+}
+
+/* ---- cached plans for the host-pointer entry points -------------------------------------------------------------
+ * The reference's callers invoke mmqr / explicitQR back to back on same-sized matrices (qr.cu:776-789 times three calls in
+ * a row).  Creating a plan is ~25 hipMallocs, 2-6 streams and a dozen events -- about 10 ms, i.e. 60x the factorisation of
+ * a 256 x 64 matrix -- so the drop-in entry points keep their last few plans (and the device copies of A / tau / Q / R)
+ * keyed by (device, m, n, nb).  A slot is used by one call at a time; a concurrent call of the same shape from another
+ * thread simply builds a private plan.  Shapes above QR_CACHE_MAX_ELEMS are never cached (their set-up cost is noise next
+ * to the work, and the cache would pin gigabytes).  MI355XQR_PLAN_CACHE=0 turns it off; qr_release_cached_plans() empties it. */
+#define QR_CACHE_SLOTS 4
+#define QR_CACHE_MAX_ELEMS ((size_t) 1 << 26)
+typedef struct host_slot {
+    int used, busy, cached, dev, m, n, nb;
+    unsigned long long stamp;
+    qr_plan* p;
+    double *dA, *dtau, *dQ, *dR;
+    size_t q_cap, r_cap;            /* doubles */
+} host_slot;
+static host_slot g_slots[QR_CACHE_SLOTS];
+static unsigned long long g_stamp = 0;
+
+/* frees what the slot holds; a reserved cache slot keeps its busy flag (it is handed back through g_lock only) */
+static void slot_free_contents(host_slot* sl, int keep_reserved)
+{
+    qrd_free(sl->dA); qrd_free(sl->dtau); qrd_free(sl->dQ); qrd_free(sl->dR);
+    qr_plan_destroy(sl->p);
+    sl->p = NULL; sl->dA = sl->dtau = sl->dQ = sl->dR = NULL;
+    sl->q_cap = sl->r_cap = 0;
+    sl->m = sl->n = sl->nb = 0;
+    if (keep_reserved) return;
+    pthread_mutex_lock(&g_lock);
+    sl->used = 0; sl->cached = 0; sl->busy = 0;
+    pthread_mutex_unlock(&g_lock);
+}
+
+static int slot_fill(host_slot* sl, int dev, int m, int n, int nb)
+{
+    int rc = qr_plan_create(&sl->p, m, n, nb, 0);
+    if (!rc) rc = qrd_malloc((void**) &sl->dA, sizeof(double) * (size_t) m * n);
+    if (!rc) rc = qrd_malloc((void**) &sl->dtau, sizeof(double) * (size_t) n);
+    sl->dev = dev; sl->m = m; sl->n = n; sl->nb = nb;
+    return rc;
+}
+
+/* returns a slot whose plan fits (m, n) exactly: a cached one, or `priv` filled as a private one-shot slot */
+static int slot_acquire(int m, int n, host_slot* priv, host_slot** out)
+{
+    CHECK(ensure_device());
+    int dev = 0, nb = 128;
+    CHECK(qrd_get_device(&dev));
+    default_blocks(m, n, &nb, NULL);
+    const char* e = getenv("MI355XQR_PLAN_CACHE");
+    const int cacheable = (!e || atoi(e) != 0) && (size_t) m * n <= QR_CACHE_MAX_ELEMS;
+    host_slot* sl = NULL;
+    int reuse = 0;
+    if (cacheable) {
+        pthread_mutex_lock(&g_lock);
+        for (int i = 0; i < QR_CACHE_SLOTS && !sl; ++i)
+            if (g_slots[i].used && !g_slots[i].busy && g_slots[i].dev == dev && g_slots[i].m == m && g_slots[i].n == n && g_slots[i].nb == nb) {
+                sl = &g_slots[i];
+                reuse = 1;
+            }
+        if (!sl) {                       /* a free slot, else the least recently used idle one */
+            for (int i = 0; i < QR_CACHE_SLOTS; ++i) {
+                if (g_slots[i].busy) continue;
+                if (!g_slots[i].used) { sl = &g_slots[i]; break; }
+                if (!sl || g_slots[i].stamp < sl->stamp) sl = &g_slots[i];
+            }
+        }
+        if (sl) sl->busy = 1;            /* reserved: nobody else touches it until slot_release */
+        pthread_mutex_unlock(&g_lock);
+    }
+    if (sl && reuse) { *out = sl; return 0; }
+    if (sl) {                            /* rebuild the reserved slot outside the lock (busy stays 1 throughout) */
+        if (sl->used) slot_free_contents(sl, 1);
+        sl->cached = 1;
+        const int rc = slot_fill(sl, dev, m, n, nb);
+        if (rc) {
+            slot_free_contents(sl, 0);   /* the slot is free again */
+            return rc;
+        }
+        pthread_mutex_lock(&g_lock);
+        sl->used = 1;
+        pthread_mutex_unlock(&g_lock);
+        *out = sl;
+        return 0;
+    }
+    memset(priv, 0, sizeof(*priv));
+    const int rc = slot_fill(priv, dev, m, n, nb);
+    if (rc) { slot_free_contents(priv, 1); return rc; }
+    *out = priv;
+    return 0;
+}
+
+static void slot_release(host_slot* sl)
+{
+    if (!sl) return;
+    if (!sl->cached) { slot_free_contents(sl, 1); return; }
+    pthread_mutex_lock(&g_lock);
+    sl->stamp = ++g_stamp;
+    sl->busy = 0;
+    pthread_mutex_unlock(&g_lock);
+}
+
+static int slot_need(double** buf, size_t* cap, size_t elems)
+{
+    if (*cap >= elems) return 0;
+    qrd_free(*buf);
+    *buf = NULL; *cap = 0;
+    CHECK(qrd_malloc((void**) buf, sizeof(double) * elems));
+    *cap = elems;
+    return 0;
+}
+
+int qr_release_cached_plans(void)
+{
+    for (int i = 0; i < QR_CACHE_SLOTS; ++i) {
+        pthread_mutex_lock(&g_lock);
+        const int take = g_slots[i].used && !g_slots[i].busy;
+        if (take) g_slots[i].busy = 1;
+        pthread_mutex_unlock(&g_lock);
+        if (take) slot_free_contents(&g_slots[i], 0);
+    }
+    return 0;
 }
 
 int mmqr_status(double* mat, double** tau, int m, int n)
 {
     if (!mat || !tau || n < 1 || m < n) return QR_E_ARG;
-    int rp, cp;
-    getPanelDims(m, n, &rp, &cp);
-    const size_t ntau = (size_t) rp * cp * g_nb;
-    double* htau = (double*) calloc(ntau, sizeof(double));          /* zero-filled like qr.c:61-62 */
-    if (!htau) return QR_E_ALLOC;
-    qr_plan* p = NULL;
-    double *dA = NULL, *dtau = NULL;
-    int rc = qr_plan_create(&p, m, n, 0, 0);
+    host_slot priv, *sl = NULL;
+    CHECK(slot_acquire(m, n, &priv, &sl));
+    qr_plan* p = sl->p;
+    const size_t ntau = (size_t) ((n + p->nb - 1) / p->nb) * p->nb;           /* rowPanels * colPanels * nb, qr.c:61 sizing rule */
+    double* htau = (double*) calloc(ntau, sizeof(double));                    /* zero-filled like qr.c:61-62 */
+    if (!htau) { slot_release(sl); return QR_E_ALLOC; }
     const size_t bytes = sizeof(double) * (size_t) m * n;
-    if (!rc) rc = qrd_malloc((void**) &dA, bytes);
-    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * n);
-    if (!rc) rc = qrd_h2d(p->stream, dA, mat, bytes);
-    if (!rc) rc = qr_geqrf_dev(p, dA, m, n, m, dtau);
-    if (!rc) rc = qrd_d2h(p->stream, mat, dA, bytes);
-    if (!rc) rc = qrd_d2h(p->stream, htau, dtau, sizeof(double) * n);
+    int rc = qrd_h2d(p->stream, sl->dA, mat, bytes);
+    if (!rc) rc = qr_geqrf_dev(p, sl->dA, m, n, m, sl->dtau);
+    if (!rc) rc = qrd_d2h(p->stream, mat, sl->dA, bytes);
+    if (!rc) rc = qrd_d2h(p->stream, htau, sl->dtau, sizeof(double) * n);
     if (!rc) rc = qrd_stream_sync(p->stream);
-    qrd_free(dA); qrd_free(dtau);
-    qr_plan_destroy(p);
+    else qr_plan_sync(p);
+    slot_release(sl);
     if (rc) { free(htau); return rc; }
     *tau = htau;
     return 0;
@@ -680,23 +854,21 @@ int mmqr_status(double* mat, double** tau, int m, int n)
 int explicitQR_status(double* A, double* tau, double* Q, double* R, int m, int n)
 {
     if (!A || !tau || !Q || !R || n < 1 || m < n) return QR_E_ARG;
-    qr_plan* p = NULL;
-    double *dA = NULL, *dtau = NULL, *dQ = NULL, *dR = NULL;
+    host_slot priv, *sl = NULL;
+    CHECK(slot_acquire(m, n, &priv, &sl));
+    qr_plan* p = sl->p;
     const size_t abytes = sizeof(double) * (size_t) m * n, qbytes = sizeof(double) * (size_t) m * m;
-    int rc = qr_plan_create(&p, m, n, 0, 0);
-    if (!rc) rc = qrd_malloc((void**) &dA, abytes);
-    if (!rc) rc = qrd_malloc((void**) &dR, abytes);
-    if (!rc) rc = qrd_malloc((void**) &dQ, qbytes);
-    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * n);
-    if (!rc) rc = qrd_h2d(p->stream, dA, A, abytes);
-    if (!rc) rc = qrd_h2d(p->stream, dtau, tau, sizeof(double) * n);
-    if (!rc) rc = qr_extract_r_dev(p, dA, m, n, m, dR, m, m);
-    if (!rc) rc = qr_applyq_dev(p, dA, m, n, m, dtau, dQ, m, m, 1);
-    if (!rc) rc = qrd_d2h(p->stream, R, dR, abytes);
-    if (!rc) rc = qrd_d2h(p->stream, Q, dQ, qbytes);
+    int rc = slot_need(&sl->dQ, &sl->q_cap, (size_t) m * m);
+    if (!rc) rc = slot_need(&sl->dR, &sl->r_cap, (size_t) m * n);
+    if (!rc) rc = qrd_h2d(p->stream, sl->dA, A, abytes);
+    if (!rc) rc = qrd_h2d(p->stream, sl->dtau, tau, sizeof(double) * n);
+    if (!rc) rc = qr_extract_r_dev(p, sl->dA, m, n, m, sl->dR, m, m);
+    if (!rc) rc = qr_applyq_dev(p, sl->dA, m, n, m, sl->dtau, sl->dQ, m, m, 1);
+    if (!rc) rc = qrd_d2h(p->stream, R, sl->dR, abytes);
+    if (!rc) rc = qrd_d2h(p->stream, Q, sl->dQ, qbytes);
     if (!rc) rc = qrd_stream_sync(p->stream);
-    qrd_free(dA); qrd_free(dR); qrd_free(dQ); qrd_free(dtau);
-    qr_plan_destroy(p);
+    else qr_plan_sync(p);
+    slot_release(sl);
     return rc;
 }
 

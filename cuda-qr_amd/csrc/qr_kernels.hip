@@ -21,6 +21,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <utility>
+#include <mutex>
 #include "qr_device.h"
 #include "qr_common.h"
 
@@ -219,9 +220,10 @@ __device__ __forceinline__ void gemm_nn_body(int M, int N, int K, double alpha, 
     const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // beta == 1 (the trailing update C -= V*W): C enters through the accumulators, acc = C/alpha, so the
-    // epilogue is stores only.  alpha = +-1 there, so the scaling is exact.
-    const bool cinit = (beta == 1.0);
+    // beta == 1 with alpha = +-1 (the trailing update C -= V*W): C enters through the accumulators, acc = C/alpha
+    // (exact), so the epilogue is stores only.  Any other alpha takes the generic beta epilogue: C/alpha would round C
+    // twice, overflow for tiny |alpha| and produce 0 * inf for alpha = 0.
+    const bool cinit = (beta == 1.0) && (alpha == 1.0 || alpha == -1.0);
     const double inv_alpha = 1.0 / alpha;
     v4d acc[TJ][TI];
     if (cinit) {          // one uniform branch, straight-line body: all TI*TJ*4 loads in flight together
@@ -856,6 +858,7 @@ int qrd_init(void)
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, false>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= qrd_gemm2_init();
     return rc;
 }
 
@@ -875,7 +878,7 @@ int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const do
     hipStream_t s = (hipStream_t) stream;
     const bool al = vec_ok(A, lda) && vec_ok(B, ldb) && (K % BK) == 0;
     const int Mi = (M / 128) * 128, Ni = (N / 128) * 128;
-    if (nn_waves() != 8 || beta != 1.0 || !al || Mi == 0 || Ni == 0)
+    if (nn_waves() != 8 || beta != 1.0 || (alpha != 1.0 && alpha != -1.0) || !al || Mi == 0 || Ni == 0)
         return launch_nn<4, 4, 1>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
     const size_t shm = sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF);
     hipLaunchKernelGGL(gemm_nn_w8_kernel, dim3(Mi / 128, Ni / 128), dim3(512), shm, s, Mi, Ni, K, alpha, A, lda, B, ldb, C, ldc);
@@ -896,6 +899,7 @@ int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A
         if (beta == 1.0) return 0;
         return -1;
     }
+    if (alpha == 0.0 && beta == 1.0) return 0;      // C unchanged (and no 0 * inf from the C/alpha shortcut)
     // tile choice: big square tiles when the grid still fills the chip, smaller otherwise
     const long long t44 = (long long) ((M + 127) / 128) * ((N + 127) / 128);
     if (N > 64 && M > 64 && t44 >= 192) return launch_nn<4, 4>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
@@ -915,17 +919,22 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
                         int ldt, int tag);
 
 // compute units behind a stream (CU-masked streams register themselves; anything else: the whole device)
-static struct { hipStream_t s; int cus; } g_stream_cus[32];
-static int g_nstream_cus = 0, g_device_cus = 0;
+// (one table for the process, any device, any host thread: guarded by g_stream_mutex)
+#define QRD_MAX_MASKED_STREAMS 256
+static struct { hipStream_t s; int cus; } g_stream_cus[QRD_MAX_MASKED_STREAMS];
+static int g_nstream_cus = 0;
+static std::mutex g_stream_mutex;
 static int stream_cus(hipStream_t s)
 {
-    for (int i = 0; i < g_nstream_cus; ++i)
-        if (g_stream_cus[i].s == s) return g_stream_cus[i].cus;
-    if (!g_device_cus) {
-        hipDeviceProp_t p; int dev = 0;
-        g_device_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        for (int i = 0; i < g_nstream_cus; ++i)
+            if (g_stream_cus[i].s == s) return g_stream_cus[i].cus;
     }
-    return g_device_cus;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        return cus;
+    return 256;
 }
 
 
@@ -1181,38 +1190,48 @@ int qrd_d2h_2d(void* stream, void* h, size_t hpitch, const void* d, size_t dpitc
 { return (int) hipMemcpy2DAsync(h, hpitch, d, dpitch, width, height, hipMemcpyDeviceToHost, (hipStream_t) stream); }
 int qrd_stream_create(void** s, int high_priority)
 {
-    hipStream_t st;
+    hipStream_t st = nullptr;
     int lo = 0, hi = 0;
     hipError_t e;
+    *s = nullptr;
     if (high_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
         e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
     else
         e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    *s = (void*) st;
+    if (e == hipSuccess) *s = (void*) st;       // the output stays NULL on failure: nothing to destroy
     return (int) e;
 }
 // Stream restricted to CUs [first, first+count) of the device (count = 0: no restriction).  Used to give
 // the latency-critical panel chain its own compute units while the wide update saturates the rest.
 int qrd_stream_create_cumask(void** s, int first, int count)
 {
-    hipStream_t st;
-    if (count <= 0) { hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); *s = (void*) st; return (int) e; }
+    hipStream_t st = nullptr;
+    *s = nullptr;
+    if (count <= 0) { hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); if (e == hipSuccess) *s = (void*) st; return (int) e; }
     uint32_t mask[16] = {0};
     for (int c = first; c < first + count && c < 512; ++c) mask[c >> 5] |= 1u << (c & 31);
-    hipDeviceProp_t p; int dev = 0;
-    HIPCHK(hipGetDevice(&dev)); HIPCHK(hipGetDeviceProperties(&p, dev));
-    const uint32_t words = (uint32_t) ((p.multiProcessorCount + 31) / 32);
+    int dev = 0, cus = 0;
+    HIPCHK(hipGetDevice(&dev)); HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint32_t words = (uint32_t) ((cus + 31) / 32);
     hipError_t e = hipExtStreamCreateWithCUMask(&st, words, mask);
+    if (e != hipSuccess) return (int) e;
     *s = (void*) st;
-    if (e == hipSuccess && g_nstream_cus < 32) { g_stream_cus[g_nstream_cus].s = st; g_stream_cus[g_nstream_cus].cus = count; ++g_nstream_cus; }
-    return (int) e;
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    if (g_nstream_cus < QRD_MAX_MASKED_STREAMS) { g_stream_cus[g_nstream_cus].s = st; g_stream_cus[g_nstream_cus].cus = count; ++g_nstream_cus; }
+    return 0;
 }
 int qrd_stream_destroy(void* s)
 {
-    for (int i = 0; i < g_nstream_cus; ++i)
-        if (g_stream_cus[i].s == (hipStream_t) s) { g_stream_cus[i] = g_stream_cus[--g_nstream_cus]; break; }
+    if (!s) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        for (int i = 0; i < g_nstream_cus; ++i)
+            if (g_stream_cus[i].s == (hipStream_t) s) { g_stream_cus[i] = g_stream_cus[--g_nstream_cus]; break; }
+    }
     return (int) hipStreamDestroy((hipStream_t) s);
 }
+// compute units behind a stream created here (CU-masked: its mask; else the device)
+int qrd_stream_cus(void* s) { return stream_cus((hipStream_t) s); }
 // hipGraph capture of a whole factorisation (thousands of dependent launches replayed by one call)
 int qrd_capture_begin(void* s) { return (int) hipStreamBeginCapture((hipStream_t) s, hipStreamCaptureModeRelaxed); }
 int qrd_capture_end(void* s, void** exec)
@@ -1230,8 +1249,14 @@ int qrd_graph_launch(void* exec, void* s) { return (int) hipGraphLaunch((hipGrap
 int qrd_graph_destroy(void* exec) { return exec ? (int) hipGraphExecDestroy((hipGraphExec_t) exec) : 0; }
 int qrd_stream_sync(void* s) { return (int) hipStreamSynchronize((hipStream_t) s); }
 int qrd_device_sync(void) { return (int) hipDeviceSynchronize(); }
-int qrd_event_create(void** e) { hipEvent_t ev; hipError_t r = hipEventCreate(&ev); *e = (void*) ev; return (int) r; }
-int qrd_event_create_notiming(void** e) { hipEvent_t ev; hipError_t r = hipEventCreateWithFlags(&ev, hipEventDisableTiming); *e = (void*) ev; return (int) r; }
+int qrd_event_create(void** e) { hipEvent_t ev = nullptr; hipError_t r = hipEventCreate(&ev); *e = (r == hipSuccess) ? (void*) ev : nullptr; return (int) r; }
+int qrd_event_create_notiming(void** e)
+{
+    hipEvent_t ev = nullptr;
+    hipError_t r = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    *e = (r == hipSuccess) ? (void*) ev : nullptr;
+    return (int) r;
+}
 int qrd_event_destroy(void* e) { return (int) hipEventDestroy((hipEvent_t) e); }
 int qrd_event_record(void* e, void* s) { return (int) hipEventRecord((hipEvent_t) e, (hipStream_t) s); }
 int qrd_event_sync(void* e) { return (int) hipEventSynchronize((hipEvent_t) e); }
@@ -1239,12 +1264,19 @@ int qrd_stream_wait_event(void* s, void* e) { return (int) hipStreamWaitEvent((h
 int qrd_event_elapsed_ms(void* a, void* b, float* ms) { return (int) hipEventElapsedTime(ms, (hipEvent_t) a, (hipEvent_t) b); }
 int qrd_device_count(int* n) { return (int) hipGetDeviceCount(n); }
 int qrd_set_device(int d) { return (int) hipSetDevice(d); }
+int qrd_get_device(int* d) { return (int) hipGetDevice(d); }
+int qrd_host_register(void* p, size_t bytes) { return (int) hipHostRegister(p, bytes, hipHostRegisterDefault); }
+int qrd_host_unregister(void* p) { return (int) hipHostUnregister(p); }
 const char* qrd_error_string(int e) { return hipGetErrorString((hipError_t) e); }
 int qrd_device_info(char* name, int name_len, int* cus, int* clock_khz, size_t* mem_bytes)
 {
-    hipDeviceProp_t p;
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
+    if (!name && !clock_khz && !mem_bytes) {        // cheap path (plan creation only wants the CU count)
+        if (cus) HIPCHK(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+        return 0;
+    }
+    hipDeviceProp_t p;
     HIPCHK(hipGetDeviceProperties(&p, dev));
     if (name && name_len > 0) { strncpy(name, p.gcnArchName, (size_t) name_len - 1); name[name_len - 1] = 0; }
     if (cus) *cus = p.multiProcessorCount;

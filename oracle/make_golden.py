@@ -19,6 +19,7 @@ sys.path[0] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import oracle as O  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(O.HERE), "tests", "golden")
+ONLY_MISSING = "--only-missing" in sys.argv      # keep existing fixtures, generate the new ones (the 2024^2 case takes ~3 min)
 
 
 def sha(a):
@@ -31,11 +32,14 @@ def metrics(A, Q, R):
             np.linalg.norm(Q64.T @ Q64 - np.eye(Q64.shape[0])))
 
 
-def case(m, n, PR, PC, dtype, store_full, with_q):
-    A = O.fill_rand(m, n, 12, dtype)
-    F, tau = O.ref_mmqr(A, PR, PC)
+def case(m, n, PR, PC, dtype, store_full, with_q, partial=False):
     tag = "f64" if dtype == np.float64 else "f32"
     name = f"ref_{m}x{n}_{tag}_{PR}x{PC}"
+    if ONLY_MISSING and os.path.exists(os.path.join(OUT, name + ".npz")):
+        print(name, "kept")
+        return name
+    A = O.fill_rand(m, n, 12, dtype)
+    F, tau = O.ref_mmqr(A, PR, PC)
     d = dict(m=m, n=n, PR=PR, PC=PC, seed=12,
              A00=A[0, 0], A10=A[1, 0], normA=np.linalg.norm(A.astype(np.float64)),
              sha_A=sha(A), sha_F=sha(F), sha_tau=sha(tau),
@@ -54,8 +58,13 @@ def case(m, n, PR, PC, dtype, store_full, with_q):
         d.update(resid=resid, orth=orth)
         if store_full:
             d.update(Q=Q, R=R)
-    # store only the upper triangle for the big one
-    if not store_full:
+    # store only the upper triangle for the big ones; `partial`: only slices of it (leading rows, trailing
+    # columns, the diagonal and the row norms) plus a digest of the whole triangle, to keep the fixture small
+    if partial:
+        Rn = d.pop("Rn")
+        d.update(Rn_rows_head=Rn[:32, :].copy(), Rn_cols_tail=Rn[:, -64:].copy(), Rn_diag=np.diag(Rn).copy(),
+                 Rn_rownorm=np.linalg.norm(Rn, axis=1), Rn_fro=np.linalg.norm(Rn), sha_Rn=sha(Rn))
+    elif not store_full:
         iu = np.triu_indices(n)
         d["Rn_triu"] = d.pop("Rn")[iu]
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
@@ -75,6 +84,11 @@ def main():
         case(64, 20, 16, 4, np.float64, True, True),
         case(512, 128, 64, 8, np.float64, False, True),  # C1 (BASELINE.json configs[0])
         case(512, 128, 4, 2, np.float64, False, False),  # C1 with the window as committed
+        # multi-panel cases for the blocked GPU path (5 / 10 outer panels at nb = 128 / 64; the sample bench.py times
+        # as cpu_baseline) and a square one (16 outer panels at nb = 128): these reach the trailing update, the
+        # look-ahead schedule and the CholeskyQR2 leaf, which the single-panel cases above cannot
+        case(1184, 640, 64, 8, np.float64, False, False),
+        case(2024, 2024, 64, 8, np.float64, False, False, partial=True),
     ]
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump({"generated_by": "oracle/make_golden.py", "source": "reference qr.c via oracle/_ref",

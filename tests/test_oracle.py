@@ -20,6 +20,7 @@ CASES = [  # m, n, PR, PC, dtype
     (64, 20, 16, 4, np.float64),
     (512, 128, 64, 8, np.float64),
     (512, 128, 4, 2, np.float64),
+    (1184, 640, 64, 8, np.float64),      # multi-panel fixture for the blocked GPU path (the restatement takes ~5 s on it)
 ]
 
 
@@ -101,7 +102,7 @@ def test_panel_dims(oracle):
     assert oracle.panel_dims(4, 4, 4, 2) == (1, 2)
 
 
-@pytest.mark.parametrize("m,n,PR,PC", [(128, 32, 4, 2), (120, 32, 64, 8), (512, 128, 64, 8), (512, 128, 4, 2)])
+@pytest.mark.parametrize("m,n,PR,PC", [(128, 32, 4, 2), (120, 32, 64, 8), (512, 128, 64, 8), (512, 128, 4, 2), (1184, 640, 64, 8)])
 @pytest.mark.parametrize("nb", [8, 32])
 def test_blocked_mirror_matches_reference_R(oracle, m, n, PR, PC, nb):
     """The blocked compact-WY algorithm (numpy mirror of the HIP path) gives the reference's R
@@ -118,6 +119,20 @@ def test_blocked_mirror_matches_reference_R(oracle, m, n, PR, PC, nb):
     Q = oracle.np_orgqr(F, tau, n, nb)
     assert np.linalg.norm(A - Q @ np.triu(F[:n])) / np.linalg.norm(A) < 1e-14
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-13
+
+
+def test_big_square_fixture_is_self_consistent(oracle):
+    """ref_2024x2024 (161 s of the real reference, made once by oracle/make_golden.py) holds slices of the sign-normalised
+    R plus digests; here: the generator digest, and the slices against LAPACK on the same input (the restatement itself is
+    not re-run on it: 160 s)."""
+    g = load_golden("ref_2024x2024_f64_64x8")
+    A = oracle.fill_rand(2024, 2024)
+    assert _sha(A) == str(g["sha_A"])
+    Rl = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert np.linalg.norm(Rl[:32] - g["Rn_rows_head"]) / np.linalg.norm(g["Rn_rows_head"]) < 1e-12
+    assert np.linalg.norm(Rl[:, -64:] - g["Rn_cols_tail"]) / np.linalg.norm(g["Rn_cols_tail"]) < 1e-12
+    assert np.abs(np.diag(Rl) - g["Rn_diag"]).max() < 1e-11 * g["Rn_diag"].max()
+    assert abs(np.linalg.norm(Rl) - float(g["Rn_fro"])) < 1e-9
 
 
 def test_blocked_mirror_tsqr_shard_invariance(oracle):

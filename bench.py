@@ -8,11 +8,12 @@ A "step" is one full fp64 Householder QR factorisation of a synthetic dense matr
 resident in HBM when the timed region starts (uniform[0,1) from the library's counter-based
 generator, seed-indexed per step; no regeneration, copy or PCIe traffic inside the timed region).
 
-  N = 1   BASELINE config C3: 16384 x 16384 on one MI355X (--workload c2 for 4096 x 4096, nb 64;
-          --workload tsqr for one 262144 x 512 shard)
-  N > 1   TSQR, weak scaling: every rank owns a 262144 x 512 row shard of a (N*262144) x 512 matrix
-          (N = 8 is exactly BASELINE config C5, 2097152 x 512); local QR + ONE RCCL all-gather of the
-          R factors + redundant stacked QR.  --workload c4 runs 262144 x 256 split over the ranks instead.
+  N = 1      BASELINE config C3: 16384 x 16384 on one MI355X (--workload c2 for 4096 x 4096, nb 64;
+             --workload tsqr for one 262144 x 512 shard)
+  N = 2, 4   BASELINE config C4: tall-skinny 262144 x 256, row blocks of 262144/N rows per GPU (strong scaling)
+  N = 8      BASELINE config C5: 2097152 x 512, one 262144 x 512 row block per GPU
+  (other N, or --workload tsqr: the weak series, 262144 x 512 per GPU)
+             TSQR = local QR + ONE RCCL all-gather of the R factors + redundant stacked QR.
 
 Prints ONE JSON line on rank 0: metric fp64 GFLOP/s (F = 2mn^2 - 2n^3/3 per factorisation, whole job),
 plus `roofline` for the dominant kernel (the trailing-update MFMA GEMM; for TSQR the panel kernels),
@@ -39,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tsqr", "c4"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tsqr", "c4", "c5"])
     ap.add_argument("--nb", type=int, default=0)
     ap.add_argument("--ib", type=int, default=0)
     ap.add_argument("--no-check", action="store_true", help="skip the post-run residual/orthogonality check")
@@ -102,8 +103,8 @@ def main():
     from cuda_qr_amd import tsqr as T
 
     wl = args.workload
-    if wl == "auto":
-        wl = "c3" if world == 1 else "tsqr"
+    if wl == "auto":        # the driver's --gpus N lands on BASELINE's configs: C3 / C4 / C4 / C5
+        wl = {1: "c3", 2: "c4", 4: "c4", 8: "c5"}.get(world, "tsqr")
     if wl == "c2":
         m_local, n, nb, desc = 4096, 4096, args.nb or 64, "C2: 4096x4096 square fp64 QR, block size 64"
     elif wl == "c3":
@@ -112,13 +113,17 @@ def main():
     elif wl == "c4":
         m_local, n, nb = 262144 // world, 256, args.nb or 128
         desc = f"C4: tall-skinny 262144x256 fp64 TSQR, row-block sharded over {world} GPU(s)"
+    elif wl == "c5":
+        m_local, n, nb = 2097152 // world, 512, args.nb or 128
+        desc = f"C5: tall-skinny 2097152x512 fp64 TSQR, row-block sharded over {world} GPU(s)"
     else:
         m_local, n, nb = 262144, 512, args.nb or 128
         desc = (f"TSQR weak scaling: {world} x (262144x512) row shards = {262144 * world}x512 fp64"
                 + (" (= C5)" if world == 8 else ""))
     m_total = m_local * world
     if wl in ("c2", "c3") and world > 1:
-        raise SystemExit("square configs do not shard (replicas only, DESIGN.md); use --workload tsqr")
+        raise SystemExit("square configs do not shard (replicas only, DESIGN.md); use --workload c4 | c5 | tsqr")
+    scaling = "strong" if wl in ("c4", "c5") else "weak"      # c4 / c5: the total matrix is fixed, shards shrink with N
 
     be = T.HipBackend(qr, m_local, n, world, nb, args.ib)
     ts = T.TSQR(be, n, world, rank, stage_through_host=(world > 1 and backend != "nccl"))
@@ -288,7 +293,7 @@ def main():
         line = {
             "metric": "fp64 GFLOP/s (% of roofline) + ||A-QR||_F/||A||_F, m x n QR at 1/2/4/8 GPUs",
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "m": m_total, "n": n, "m_per_gpu": m_local, "nb": nb,
                        "ib": args.ib or qr.get_block_size()[1],

@@ -60,6 +60,8 @@ _sig("qr_strerror", C.c_char_p, C.c_int)
 _sig("qr_set_block_size", C.c_int, C.c_int, C.c_int)
 _sig("qr_get_block_size", None, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("qr_thin", C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int)
+_sig("qr_thin_mgpu", C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int)
+_sig("qr_release_cached_plans", C.c_int)
 _sig("qr_plan_create", C.c_int, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("qr_plan_destroy", C.c_int, _vp)
 _sig("qr_geqrf_dev", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp)
@@ -80,6 +82,7 @@ _sig("qr_plan_sync", C.c_int, _vp)
 _sig("qr_plan_stream", _vp, _vp)
 _sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)
 _sig("qr_plan_get_profile", C.c_int, _vp, C.POINTER(Profile))
+_sig("qr_plan_get_profile_records", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), _dp, _dp)
 _sig("qr_device_info", C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t))
 _sig("qr_probe_mfma_f64_tflops", C.c_int, _dp)
 _sig("qr_probe_copy_gbps", C.c_int, _dp)
@@ -94,6 +97,9 @@ LEAF_SCRATCH = 2 * (256 * 32 + 32) + 32 * 32
 _sig("qrd_panel_ws_size", C.c_size_t, C.c_int)
 _sig("qrd_panel_tsqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
 _sig("qrd_panel_cholqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t)
+_sig("qrd_gemm_nt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp)
+_sig("qrd_gemm_tnt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_size_t,
+     C.c_int, C.c_int, C.c_int)
 _sig("qrd_init", C.c_int)
 _sig("qrd_device_sync", C.c_int)
 
@@ -197,6 +203,20 @@ def qr_thin(A, nb=0, nshards=1):
     return Q, R
 
 
+def qr_thin_mgpu(A, nb=0, ngpu=1):
+    """Thin QR over `ngpu` devices of this node through the C-level TSQR entry (one host thread per GPU, one RCCL all-gather)."""
+    A = _f(A)
+    m, n = A.shape
+    Q = np.empty((m, n), order="F")
+    R = np.empty((n, n), order="F")
+    check(lib.qr_thin_mgpu(_p(A), m, n, _p(Q), _p(R), nb, ngpu), "qr_thin_mgpu")
+    return Q, R
+
+
+def release_cached_plans():
+    check(lib.qr_release_cached_plans(), "qr_release_cached_plans")
+
+
 def device_info():
     name = C.create_string_buffer(64)
     cus, clk, mem = C.c_int(), C.c_int(), C.c_size_t()
@@ -297,6 +317,16 @@ class Plan:
 
     def set_profile(self, on):
         check(lib.qr_plan_set_profile(self.h, int(on)), "qr_plan_set_profile")
+
+    def get_profile_records(self, max_records=65536):
+        """[(class, start_ms, end_ms)] of the last profiled run, in issue order (call before get_profile)."""
+        cls = (C.c_int * max_records)()
+        t0 = (C.c_double * max_records)()
+        t1 = (C.c_double * max_records)()
+        n = lib.qr_plan_get_profile_records(self.h, max_records, cls, t0, t1)
+        if n < 0:
+            check(n, "qr_plan_get_profile_records")
+        return [(cls[i], t0[i], t1[i]) for i in range(n)]
 
     def get_profile(self):
         pr = Profile()

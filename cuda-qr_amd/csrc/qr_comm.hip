@@ -1,0 +1,72 @@
+// qr_comm.hip -- RCCL glue for the C-level multi-GPU TSQR entry point (qr_thin_mgpu in qr_host.c).
+//
+// The library does not link librccl: the single-GPU drop-in path must not pay for loading a collective library it never
+// uses.  The first multi-GPU call dlopen()s librccl.so and resolves the four entry points it needs.  One communicator per
+// device, created together by ncclCommInitAll from the calling thread; afterwards every device is driven by its own host
+// thread (one thread per GPU) and the only collective of the algorithm is ONE ncclAllGather of the n x n R
+// factors (RCCL has no user-defined reduction, so the "all-reduce of R" is all-gather + redundant stacked QR).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <mutex>
+#include "qr_device.h"
+
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    int state = 0;      // 0 = not tried, 1 = loaded, -1 = unavailable
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+int load_rccl()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.state) return g_rccl.state > 0 ? 0 : QRD_E_NORCCL;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.handle) break;
+    }
+    if (!g_rccl.handle) { g_rccl.state = -1; return QRD_E_NORCCL; }
+    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(dlsym(g_rccl.handle, "ncclCommInitAll"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.state = -1; return QRD_E_NORCCL; }
+    g_rccl.state = 1;
+    return 0;
+}
+}   // namespace
+
+extern "C" {
+
+// comms: array of n opaque communicator handles, one per entry of devs (all on this node)
+int qrd_comm_init_all(void** comms, int n, const int* devs)
+{
+    int rc = load_rccl();
+    if (rc) return rc;
+    static_assert(sizeof(ncclComm_t) == sizeof(void*), "communicator handles travel as void*");
+    const ncclResult_t r = g_rccl.CommInitAll(reinterpret_cast<ncclComm_t*>(comms), n, devs);
+    return r == ncclSuccess ? 0 : QRD_E_RCCL - (int) r;
+}
+
+int qrd_comm_destroy(void* comm)
+{
+    if (!comm || g_rccl.state <= 0) return 0;
+    return g_rccl.CommDestroy((ncclComm_t) comm) == ncclSuccess ? 0 : QRD_E_RCCL;
+}
+
+// every rank contributes `count` doubles at `send`; `recv` receives world * count doubles in rank order.  Stream-ordered.
+int qrd_allgather_f64(void* comm, void* stream, const double* send, double* recv, size_t count)
+{
+    if (g_rccl.state <= 0) return QRD_E_NORCCL;
+    const ncclResult_t r = g_rccl.AllGather(send, recv, count, ncclDouble, (ncclComm_t) comm, (hipStream_t) stream);
+    return r == ncclSuccess ? 0 : QRD_E_RCCL - (int) r;
+}
+
+}   // extern "C"

@@ -28,6 +28,7 @@ int qrd_gemm_tnt(void* stream, int M, int N, int K, const double* A, int lda, co
 int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
                    int ldv, double* scratch);
 size_t qrd_panel_ws_size(int m);
+int qrd_panel_tsqr_init(void);
 int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                    double* ws, int m_cap);
 int qrd_slab_reduce(void* stream, int M, int N, int nslab, const double* slabs, int lds, size_t stride, double* out, int ldo);
@@ -48,6 +49,13 @@ int qrd_fill_uniform(void* stream, double* A, int ld, long long rows, int cols, 
 double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx);
 int qrd_diff_norm(void* stream, const double* X, int ldx, const double* Y, int ldy, long long rows, int cols,
                   long long row_off, long long total_rows, unsigned long long seed, int sub_identity, double* out);
+
+/* RCCL glue (qr_comm.hip): librccl is dlopen()ed on first use, never linked */
+#define QRD_E_NORCCL (-120)   /* librccl.so could not be loaded */
+#define QRD_E_RCCL   (-130)   /* an RCCL call failed: -130 - ncclResult_t */
+int qrd_comm_init_all(void** comms, int n, const int* devs);
+int qrd_comm_destroy(void* comm);
+int qrd_allgather_f64(void* comm, void* stream, const double* send, double* recv, size_t count);
 
 int qrd_malloc(void** p, size_t bytes);
 int qrd_free(void* p);

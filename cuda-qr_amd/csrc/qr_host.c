@@ -25,6 +25,8 @@
 #define CHECK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 #define QR_MAX_PAIRS 4
+#define QR_MAX_NB 512           /* outer block (the K of the wide update) */
+#define QR_HALF 256             /* outer blocks wider than this are factored half by half (two-level panel, factor_panel) */
 #define QR_DEFAULT_SPLIT "64"
 #define QR_DEFAULT_PANEL 3
 struct qr_plan {
@@ -47,6 +49,10 @@ struct qr_plan {
     double *We, *Ye;            /* its W buffer and raw V^T A2 */
     double *Yn;                 /* raw V^T A_next of the look-ahead update */
     double bal_rp, bal_ru, bal_tc0, bal_tc1;   /* load-balance model (TFLOP/s, ms); bal_rp = 0: off */
+    void* ev_half[2];           /* W_a(s): the wide update has finished the columns of panel s+1 that N(s) left out (its second half) */
+    void* ev_next[2];           /* look-ahead update N(s) of the next panel's columns finished (when it runs on the update stream) */
+    int next_on_update;         /* 1: N(s) runs on the update stream's CUs, ahead of W(s); 0: on the panel stream; 2: on the panel
+                                 * stream while the factorisation is update-bound, on the update stream once it is chain-bound */
     void* ev_panel[2];          /* panel set s ready (V, T, VT) */
     void* ev_wide[2];           /* wide update that read panel set s finished */
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
@@ -84,7 +90,7 @@ static void defaults_from_env_locked(void)
         e = getenv("MI355XQR_IB");
         g_ib = e ? atoi(e) : 32;
         if (g_ib < 1 || g_ib > QRD_LEAFW) g_ib = 32;
-        if (g_nb < g_ib || g_nb > 256 || g_nb % g_ib) g_nb = 128;
+        if (g_nb < g_ib || g_nb > QR_MAX_NB || g_nb % g_ib || (g_nb > QR_HALF && g_nb % QR_HALF)) g_nb = 128;
     }
 }
 
@@ -104,7 +110,7 @@ static void default_blocks(int m, int n, int* nb, int* ib)
 
 int qr_set_block_size(int nb, int ib)
 {
-    if (ib < 1 || ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
+    if (ib < 1 || ib > QRD_LEAFW || nb < ib || nb > QR_MAX_NB || nb % ib || (nb > QR_HALF && nb % QR_HALF)) return QR_E_ARG;
     pthread_mutex_lock(&g_lock);
     g_nb = nb; g_ib = ib; g_nb_explicit = 1;
     pthread_mutex_unlock(&g_lock);
@@ -162,7 +168,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         if (ib <= 0) ib = dib;
         if (nb <= 0) nb = (dnb % ib == 0) ? dnb : 128;
     }
-    if (ib > QRD_LEAFW || nb < ib || nb > 256 || nb % ib) return QR_E_ARG;
+    if (ib > QRD_LEAFW || nb < ib || nb > QR_MAX_NB || nb % ib || (nb > QR_HALF && nb % QR_HALF)) return QR_E_ARG;
     qr_plan* p = (qr_plan*) calloc(1, sizeof(qr_plan));
     if (!p) return QR_E_ALLOC;
     p->m = m; p->n = n; p->nb = nb; p->ib = ib;
@@ -210,11 +216,26 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     if (!rc && p->npairs == 0) rc = qrd_stream_create(&p->stream_u, 0);
     for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_hop[e]);
     for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_extra[e]);
+    for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_next[e]);
+    for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_half[e]);
+    {
+        /* MI355XQR_NEXT=panel|update|auto: which stream applies panel s to the columns of panel s+1 (the look-ahead update
+         * N(s)).  On the update stream it is a 60 us job for 190+ CUs instead of a 180 us one for the panel stream's few --
+         * but while the update stream is busy back to back it would only delay W(s); auto (default) switches with the phase. */
+        const char* nx = getenv("MI355XQR_NEXT");
+        p->next_on_update = !nx ? 2 : (strcmp(nx, "update") == 0 ? 1 : (strcmp(nx, "panel") == 0 ? 0 : 2));   /* 2 = by phase */
+    }
     {
         /* MI355XQR_BALANCE = "Rp,Ru,tc0,tc1" (TFLOP/s on the panel CUs, on the update CUs; next-panel chain time
          * tc0 + tc1*mk/16384 ms at nb = 256); "0" = the panel stream takes no share of the wide update */
         const char* b = getenv("MI355XQR_BALANCE");
         p->bal_rp = 14.0; p->bal_ru = 44.0; p->bal_tc0 = 1.1; p->bal_tc1 = 0.6;
+        if (p->npairs) {            /* measured ~0.22 TFLOP/s per CU for the K = 256 update GEMMs on either side of the partition */
+            int cus = 256;
+            qrd_device_info(NULL, 0, &cus, NULL, NULL);
+            const int pc = qrd_stream_cus(p->s_pair[0][0]);
+            p->bal_rp = 0.22 * pc; p->bal_ru = 0.23 * (cus - pc);
+        }
         if (b) {
             p->bal_rp = 0.0;
             sscanf(b, "%lf,%lf,%lf,%lf", &p->bal_rp, &p->bal_ru, &p->bal_tc0, &p->bal_tc1);
@@ -279,6 +300,8 @@ int qr_plan_destroy(qr_plan* p)
     for (int e = 0; e < 2; ++e) {
         if (p->ev_hop[e]) qrd_event_destroy(p->ev_hop[e]);
         if (p->ev_extra[e]) qrd_event_destroy(p->ev_extra[e]);
+        if (p->ev_next[e]) qrd_event_destroy(p->ev_next[e]);
+        if (p->ev_half[e]) qrd_event_destroy(p->ev_half[e]);
     }
     for (int i = 0; i < 2 * p->prof_cap; ++i)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
@@ -373,7 +396,7 @@ int qr_plan_get_profile(qr_plan* p, qr_profile* out)
     for (int r = 0; r < p->prof_count; ++r) {
         float ms = 0.f;
         CHECK(qrd_event_elapsed_ms(p->prof_ev[2 * r], p->prof_ev[2 * r + 1], &ms));
-        const int c = p->prof_cls[r];
+        const int c = p->prof_cls[r] < QR_PROF_CLASSES ? p->prof_cls[r] : 3;     /* look-ahead / balance updates count as misc */
         out->ms[c] += ms;
         out->flops[c] += p->prof_flops[r];
         out->bytes[c] += p->prof_bytes[r];
@@ -381,6 +404,22 @@ int qr_plan_get_profile(qr_plan* p, qr_profile* out)
     }
     p->prof_count = 0;
     return 0;
+}
+
+/* raw records of the last profiled run, in issue order: internal class (0..3 as in the header; 4 = look-ahead update N(s),
+ * 5 = the panel stream's share E(s) of a wide update), start and end in ms since the first record's start.  Does not reset. */
+int qr_plan_get_profile_records(qr_plan* p, int max, int* cls, double* t0_ms, double* t1_ms)
+{
+    if (!p || max < 0) return QR_E_ARG;
+    if (qr_plan_sync(p)) return QR_E_INTERNAL;
+    int n = p->prof_count < max ? p->prof_count : max;
+    for (int r = 0; r < n; ++r) {
+        float a = 0.f, b = 0.f;
+        if (qrd_event_elapsed_ms(p->prof_ev[0], p->prof_ev[2 * r], &a) || qrd_event_elapsed_ms(p->prof_ev[0], p->prof_ev[2 * r + 1], &b))
+            return QR_E_INTERNAL;
+        cls[r] = p->prof_cls[r]; t0_ms[r] = a; t1_ms[r] = b;
+    }
+    return n;
 }
 
 /* ---- thin wrappers --------------------------------------------------------------------------- */
@@ -403,60 +442,107 @@ int qr_gemm_dev(qr_plan* p, char transa, int M, int N, int K, double alpha, cons
 /* ---- factorisation --------------------------------------------------------------------------- */
 /* One outer panel: columns [k, k+wout) over rows [k, m).  Leaves V (explicit, unit lower trapezoid)
  * in p->Vw and the panel's compact-WY T in p->T (only if want_t). */
-static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t)
+static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, const double* T, int ldt, int mk, int kw, double* A2,
+                         int lda, int nc, double* Wbuf, double* Ybuf, double* slabs);
+
+/* One outer panel: columns [k, k+wout) over rows [k, m).  Leaves V (explicit, unit lower trapezoid) in p->Vw and the panel's
+ * compact-WY T in p->T (only if want_t).
+ * Two-level panel: an outer block wider than QR_HALF is factored half by half -- the leaves of a half update only the rest of
+ * THAT half (K = 32), and the next half receives the whole previous part in one block update with K = 256 ... (the in-panel
+ * traffic of a 512-wide block would otherwise be 4x that of a 256-wide one).  The wide trailing update then runs with
+ * K = wout = 512: half the C traffic per flop of K = 256, which is what bounds it.
+ * half_ready: event the second half's columns must wait for (the wide update of the previous panel reaches them on the
+ * update stream while the first half is being factored), or NULL. */
+static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t, void* half_ready)
 {
     const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt, nb = p->nb;
     double* Ak = dA + (size_t) k * lda + k;
     CHECK(qrd_zero_block(p->stream, p->Vw, ldv, wout, wout));
-    for (int c = 0; c < wout; c += ib) {
-        const int w = imin(ib, wout - c), mkl = mk - c;
-        double* P = Ak + (size_t) c * lda + c;
-        double* Vl = p->Vw + (size_t) c * ldv + c;
-        double* Tl = p->T + (size_t) c * ldt + c;
-        /* leaf algorithm (MI355XQR_PANEL = cholqr [default] | tsqr | col | auto): CholeskyQR2 + Householder reconstruction
-         * (7 short launches) guarded by the Householder TSQR leaf (4-6 launches, no-ops unless the guard trips); tsqr = the
-         * Householder TSQR leaf alone; col = one launch per column (34 launches, ~25 passes over the leaf) */
-        if (p->panel_tsqr == 3)
-            CHECK(qrd_panel_cholqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
-                                   p->slabs, p->slab_cap));
-        else if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
-            CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
-        else
-            CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
-        const int nrest = wout - (c + w);
-        if (nrest > 0) {
-            double* Arest = P + (size_t) w * lda;
-            /* Wn, not W: with look-ahead the wide update on stream_u owns p->W while this panel runs */
-            CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->Wn, w, Tl));                  /* T_l^T V_l^T A_rest */
-            CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
+    const int nhalf = (wout + QR_HALF - 1) / QR_HALF;
+    for (int h = 0; h < nhalf; ++h) {
+        const int c0 = h * QR_HALF, wh = imin(QR_HALF, wout - c0), cend = c0 + wh;
+        if (h > 0) {
+            /* A(:, c0:cend) <- (I - V T V^T)^T A(:, c0:cend) with the c0 reflectors factored so far */
+            if (half_ready) CHECK(qrd_stream_wait_event(p->stream, half_ready));
+            CHECK(apply_small_t(p, p->stream, p->Vw, ldv, p->T, ldt, mk, c0, Ak + (size_t) c0 * lda, lda, wh, p->Wn, p->Yn, p->slabs));
+        }
+        for (int c = c0; c < cend; c += ib) {
+            const int w = imin(ib, cend - c), mkl = mk - c;
+            double* P = Ak + (size_t) c * lda + c;
+            double* Vl = p->Vw + (size_t) c * ldv + c;
+            double* Tl = p->T + (size_t) c * ldt + c;
+            /* leaf algorithm (MI355XQR_PANEL = cholqr [default] | tsqr | col | auto): CholeskyQR2 + Householder reconstruction
+             * (4 short launches) guarded by the Householder TSQR leaf (4-6 launches, no-ops unless the guard trips); tsqr = the
+             * Householder TSQR leaf alone; col = one launch per column (34 launches, ~25 passes over the leaf) */
+            if (p->panel_tsqr == 3)
+                CHECK(qrd_panel_cholqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
+                                       p->slabs, p->slab_cap));
+            else if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
+                CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
+            else
+                CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
+            const int nrest = cend - (c + w);
+            if (nrest > 0) {
+                double* Arest = P + (size_t) w * lda;
+                /* Wn, not W: with look-ahead the wide update on stream_u owns p->W while this panel runs */
+                CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->Wn, w, Tl));                  /* T_l^T V_l^T A_rest */
+                CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
+            }
+        }
+        const int need_t = want_t || h + 1 < nhalf;          /* the next half's block update needs T of everything before it */
+        if (!need_t) continue;
+        double* Vh = p->Vw + (size_t) c0 * ldv + c0;          /* this half's V: rows from c0 (zero above) */
+        double* Thh = p->T + (size_t) c0 * ldt + c0;
+        if (wh > ib) {
+            double* Ghh = p->G + (size_t) c0 * nb + c0;
+            CHECK(tn(p, wh, wh, mk - c0, Vh, ldv, Vh, ldv, Ghh, nb, NULL));                        /* Gram of the half */
+            /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the
+             * wide update builds V*T itself on its own stream (update_cols), off the critical path */
+            CHECK(qrd_larft(p->stream, wh, ib, Ghh, nb, dtau + k + c0, Thh, ldt, NULL, 0, p->X, nb));
+        }
+        if (h > 0) {
+            /* T(0:c0, c0:cend) = -T(0:c0, 0:c0) (V(:, 0:c0)^T V(:, c0:cend)) T(c0:cend, c0:cend) */
+            double* G12 = p->G + (size_t) c0 * nb;
+            CHECK(tn(p, c0, wh, mk - c0, p->Vw + c0, ldv, Vh, ldv, G12, nb, NULL));
+            CHECK(qrd_gemm_nn(p->stream, c0, wh, wh, 1.0, G12, nb, Thh, ldt, 0.0, p->X, c0));
+            CHECK(qrd_gemm_nn(p->stream, c0, wh, c0, -1.0, p->T, ldt, p->X, c0, 0.0, p->T + (size_t) c0 * ldt, ldt));
         }
     }
-    if (!want_t || wout <= ib) return 0;
-    CHECK(tn(p, wout, wout, mk, p->Vw, ldv, p->Vw, ldv, p->G, nb, NULL));                  /* Gram */
-    /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the
-     * wide update builds V*T itself on its own stream (update_cols), off the critical path */
-    return qrd_larft(p->stream, wout, ib, p->G, nb, dtau + k, p->T, ldt, NULL, 0, p->X, nb);
+    return 0;
 }
 
 static void use_set(qr_plan* p, int e) { p->Vw = p->Vw2[e]; p->VT = p->VT2[e]; p->T = p->T2[e]; }
 
-/* trailing update of columns [c0, c0+nc) with the reflectors of panel set e: W = (V T)^T A ; A -= V W */
+/* A2 (mk x nc) <- (I - V T V^T)^T A2 for V: mk x kw, T: kw x kw upper, WITHOUT forming V T:  Y = V^T A2 (long-K product),
+ * W = T^T Y (small), A2 -= V W.  Used where V*T does not exist yet: look-ahead update, mid-panel update, the panel stream's
+ * share of a wide update.  Ybuf, Wbuf: kw * nc doubles each. */
+static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, const double* T, int ldt, int mk, int kw, double* A2,
+                         int lda, int nc, double* Wbuf, double* Ybuf, double* slabs)
+{
+    CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Ybuf, kw, slabs, p->slab_cap, NULL, 0));
+    CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
+    return qrd_gemm_nn(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
+}
+
 /* Apply panel set e's block reflector to columns [c0, c0+nc):  A2 -= V (T^T (V^T A2)).
- * profile 1 = the wide update on the update stream: V*T is formed first (class 3) and W = (V T)^T A2 is one long-K
- *             product (class 1), then A2 -= V W (class 0); kernels under their own profiler names;
- * profile 0 = look-ahead update of the next panel (inside the panel chain's record), 2 = the share of the wide update
- *             done on the panel CUs (class 3): Y = V^T A2, W = T^T Y (a small product), A2 -= V W -- no V*T needed.
+ * profile 1 = the wide update on the update stream: V*T is formed first when form_vt is set (class 3) and W = (V T)^T A2 is
+ *             one long-K product (class 1), then A2 -= V W (class 0); kernels under their own profiler names;
+ * profile 0 = look-ahead update of the next panel (class 4), 2 = the share of the wide update done on the panel CUs
+ *             (class 5): Y = V^T A2, W = T^T Y (a small product), A2 -= V W -- no V*T needed.
  * Ybuf: nc*wout doubles of scratch for profile 0 / 2. */
 static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int k, int mk, int wout, int c0, int nc,
-                       double* Wbuf, double* Ybuf, double* slabs, int profile)
+                       double* Wbuf, double* Ybuf, double* slabs, int profile, int form_vt)
 {
     double* A2 = dA + (size_t) c0 * lda + k;
     const int ldv = p->ldv;
+    if (nc <= 0) return 0;
     if (profile == 1) {
         const int tagged = wout >= 128 && nc >= 128;
-        CHECK(prof_begin_on(p, 3, stream));
-        CHECK(qrd_gemm_nn(stream, mk, wout, wout, 1.0, p->Vw2[e], ldv, p->T2[e], p->ldt, 0.0, p->VT2[e], ldv));
-        CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+        if (form_vt) {
+            CHECK(prof_begin_on(p, 3, stream));
+            CHECK(qrd_gemm_nn(stream, mk, wout, wout, 1.0, p->Vw2[e], ldv, p->T2[e], p->ldt, 0.0, p->VT2[e], ldv));
+            CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+        }
         CHECK(prof_begin_on(p, 1, stream));
         if (tagged)
             CHECK(qrd_gemm_tn_update(stream, wout, nc, mk, 1.0, p->VT2[e], ldv, A2, lda, 0.0, Wbuf, wout, slabs, p->slab_cap));
@@ -471,11 +557,9 @@ static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int
         CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 16.0 * mk * (double) nc + 8.0 * mk * wout));
         return 0;
     }
-    if (profile) CHECK(prof_begin_on(p, 3, stream));
-    CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->Vw2[e], ldv, A2, lda, 0.0, Ybuf, wout, slabs, p->slab_cap, NULL, 0));
-    CHECK(qrd_gemm_tn(stream, wout, nc, wout, 1.0, p->T2[e], p->ldt, Ybuf, wout, 0.0, Wbuf, wout, NULL, 0, NULL, 0));
-    CHECK(qrd_gemm_nn(stream, mk, nc, wout, -1.0, p->Vw2[e], ldv, Wbuf, wout, 1.0, A2, lda));
-    if (profile) CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
+    CHECK(prof_begin_on(p, profile ? 5 : 4, stream));
+    CHECK(apply_small_t(p, stream, p->Vw2[e], ldv, p->T2[e], p->ldt, mk, wout, A2, lda, nc, Wbuf, Ybuf, slabs));
+    CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
     return 0;
 }
 
@@ -492,6 +576,18 @@ static int balance_cols(const qr_plan* p, int mk, int wout, int nwide)
     xi -= xi % 128;
     if (xi < 128) return 0;
     return xi > nwide ? nwide : xi;
+}
+
+/* 1 when the wide update W(s) is predicted to outlast the next panel's chain (same model as balance_cols): the update
+ * stream is then busy back to back and the look-ahead update N(s) is better off on the panel stream, concurrent with the
+ * start of W(s); in the chain-bound phase the update stream has nothing else to do and runs N(s) 3x faster than the panel
+ * stream's few CUs would. */
+static int update_bound(const qr_plan* p, int mk, int wout, int nwide)
+{
+    if (!p->npairs || p->bal_ru <= 0.0 || nwide <= 0) return 0;
+    const double F = 4.0 * mk * (double) wout * 1e-9;
+    const double tc = (p->bal_tc0 + p->bal_tc1 * (double) mk / 16384.0) * (double) wout / 256.0;
+    return F * nwide / p->bal_ru > tc;
 }
 
 static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau);
@@ -563,17 +659,19 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         for (int k = 0; k < n; k += nb) {
             const int wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
             CHECK(prof_begin(p, 2));
-            CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0));
+            CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0, NULL));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
-            if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, NULL, p->slabs, 1));
+            if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, NULL, p->slabs, 1, 1));
         }
         return 0;
     }
-    /* Look-ahead (depth 1).  Step s: P(s) factor panel s, N(s) update only the next panel's columns,
-     * W(s) update everything to the right of that.  Critical chain P(s) -> N(s) -> P(s+1) runs on
-     * p->stream (high priority); W(s) runs on p->stream_u concurrently with P(s+1).
-     *   N(s)  needs P(s) (stream order) and W(s-1) (ev_wide[(s-1)&1]);
+    /* Look-ahead (depth 1).  Step s: P(s) factor panel s, N(s) update the FIRST HALF (<= 256 columns) of the next panel,
+     * W(s) update everything to the right of that, in two pieces: W_a(s) the second half of the next panel (two-level
+     * panels only; ev_half when done), then W_b(s) the rest.  Critical chain P(s) -> N(s) -> P(s+1) runs on p->stream
+     * (or, for N(s) in the chain-bound phase, on the update stream); W(s) runs on p->stream_u concurrently with P(s+1).
+     *   N(s)  needs P(s) (stream order / ev_panel) and W(s-1) (ev_wide[(s-1)&1] / stream order);
      *   W(s)  needs P(s) (ev_panel[s&1]) and W(s-1) (stream order);
+     *   P(s+1)'s second half needs W_a(s) (ev_half[s&1]);
      *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
     int wide_pending[2] = {0, 0}, extra_pending = 0;
     CHECK(enter_phase(p, phase_of(p, n, n)));
@@ -581,7 +679,7 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         const int w0 = imin(nb, n);
         use_set(p, 0);
         CHECK(prof_begin(p, 2));
-        CHECK(factor_panel(p, dA, m, lda, 0, w0, dtau, n > w0));
+        CHECK(factor_panel(p, dA, m, lda, 0, w0, dtau, n > w0, NULL));
         CHECK(prof_end(p, 2.0 * m * (double) w0 * w0, 16.0 * m * w0));
         CHECK(qrd_event_record(p->ev_panel[0], p->stream));
     }
@@ -590,18 +688,41 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         const int e = s & 1, wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
         if (nt <= 0) break;
         const int wnext = imin(nb, nt), nwide = nt - wnext;
+        const int nfirst = imin(QR_HALF, wnext), nhalf2 = wnext - nfirst;    /* N(s) covers nfirst columns, W_a(s) the other nhalf2 */
         CHECK(enter_phase(p, phase_of(p, nt, n)));
-        if (s > 0 && wide_pending[e ^ 1]) {
-            CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e ^ 1]));
-            wide_pending[e ^ 1] = 0;
-        }
-        CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout, wnext, p->Wn, p->Yn, p->slabs, 0));   /* N(s) */
         const int extra = p->We ? balance_cols(p, mk, wout, nwide) : 0;
-        if (nwide - extra > 0) {                                                                              /* W(s) */
+        const int n_on_u = p->stream_u != NULL && p->npairs > 0 &&
+                           (p->next_on_update == 1 || (p->next_on_update == 2 && !update_bound(p, mk, wout, nwide)));
+        if (n_on_u) {
+            /* N(s) on the update stream: behind W(s-1) by stream order, after P(s) (ev_panel) and E(s-1) (ev_extra) */
             CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
-            if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));   /* E(s-1) wrote columns W(s) reads */
-            CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout + wnext + extra, nwide - extra, p->W,
-                              NULL, p->slabs_u, 1));
+            if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));
+            CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout, nfirst, p->Wn, p->Yn, p->slabs_u, 0, 0));
+            CHECK(qrd_event_record(p->ev_next[e], p->stream_u));
+            CHECK(qrd_stream_wait_event(p->stream, p->ev_next[e]));
+            wide_pending[e ^ 1] = 0;                 /* W(s-1) is ordered before N(s), hence before everything the panel stream does next */
+        } else {
+            if (s > 0 && wide_pending[e ^ 1]) {
+                CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e ^ 1]));
+                wide_pending[e ^ 1] = 0;
+            }
+            CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout, nfirst, p->Wn, p->Yn, p->slabs, 0, 0));   /* N(s) */
+        }
+        const int wide_cols = nhalf2 + nwide - extra;
+        if (wide_cols > 0) {                                                                                  /* W(s) */
+            if (!n_on_u) {
+                CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
+                if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));   /* E(s-1) wrote columns W(s) reads */
+            }
+            int formed = 0;
+            if (nhalf2 > 0) {                                                                                 /* W_a(s) */
+                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout + nfirst, nhalf2, p->W, NULL, p->slabs_u, 1, 1));
+                CHECK(qrd_event_record(p->ev_half[e], p->stream_u));
+                formed = 1;
+            }
+            if (nwide - extra > 0)                                                                            /* W_b(s) */
+                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout + wnext + extra, nwide - extra, p->W,
+                                  NULL, p->slabs_u, 1, !formed));
             CHECK(qrd_event_record(p->ev_wide[e], p->stream_u));
             wide_pending[e] = 1;
         }
@@ -609,11 +730,11 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         const int k1 = k + wout, mk1 = m - k1, nt1 = n - (k1 + wnext);                                        /* P(s+1) */
         use_set(p, e ^ 1);
         CHECK(prof_begin(p, 2));
-        CHECK(factor_panel(p, dA, m, lda, k1, wnext, dtau, nt1 > 0));
+        CHECK(factor_panel(p, dA, m, lda, k1, wnext, dtau, nt1 > 0, nhalf2 > 0 ? p->ev_half[e] : NULL));
         CHECK(prof_end(p, 2.0 * mk1 * (double) wnext * wnext, 16.0 * mk1 * wnext));
         CHECK(qrd_event_record(p->ev_panel[e ^ 1], p->stream));
         if (extra > 0) {                                                                                      /* E(s) */
-            CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout + wnext, extra, p->We, p->Ye, p->slabs, 2));
+            CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout + wnext, extra, p->We, p->Ye, p->slabs, 2, 0));
             CHECK(qrd_event_record(p->ev_extra[e], p->stream));
             extra_pending = 1;
         }
@@ -969,5 +1090,131 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
     if (!rc) rc = qrd_stream_sync(p->stream);
     qrd_free(dA); qrd_free(dQ); qrd_free(dtau); qrd_free(dR); qrd_free(dS); qrd_free(dQt); qrd_free(dtau2);
     qr_plan_destroy(p); qr_plan_destroy(p2);
+    return rc;
+}
+
+/* ---- thin QR over the GPUs of one node: TSQR with one RCCL all-gather ---------------------------------
+ * One host thread per device (created here); device d owns the contiguous row block d of A.  Steps, per device:
+ *   1. H2D of its rows, local qr_geqrf_dev -> R_d
+ *   2. ONE all-gather of the n x n R factors (RCCL over xGMI; latency-bound: n = 512 is 2 MiB per rank)
+ *   3. redundant QR of the stacked (P n) x n matrix on every device -> final R (identical bits everywhere) and the device's
+ *      n x n block of the tree's Q
+ *   4. Q_d = Q_local_d [Qtree_d; 0], D2H of its rows of Q
+ * No reference counterpart: the reference is single-device (qr.cu:711,737). */
+typedef struct mg_ctx {
+    int rank, ngpu, dev, m, n, nb, r0, rows, rc;
+    const double* A;
+    double *Q, *R;
+    void* comm;
+    pthread_barrier_t* bar;
+    int* any_fail;
+} mg_ctx;
+
+static int mg_run(mg_ctx* c)
+{
+    const int n = c->n, rows = c->rows, P = c->ngpu, sm = P * n;
+    const size_t nn = (size_t) n * n;
+    qr_plan *p = NULL, *p2 = NULL;
+    double *dA = NULL, *dQ = NULL, *dtau = NULL, *dRp = NULL, *dRall = NULL, *dS = NULL, *dQt = NULL, *dtau2 = NULL, *dR = NULL;
+    int rc = qrd_set_device(c->dev);
+    if (!rc) rc = qr_plan_create(&p, rows, n, c->nb, 0);
+    if (!rc) rc = qr_plan_create(&p2, sm, n, c->nb, 0);
+    if (!rc) rc = qrd_malloc((void**) &dA, sizeof(double) * (size_t) rows * n);
+    if (!rc) rc = qrd_malloc((void**) &dQ, sizeof(double) * (size_t) rows * n);
+    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * n);
+    if (!rc) rc = qrd_malloc((void**) &dtau2, sizeof(double) * n);
+    if (!rc) rc = qrd_malloc((void**) &dRp, sizeof(double) * nn);
+    if (!rc) rc = qrd_malloc((void**) &dR, sizeof(double) * nn);
+    if (!rc) rc = qrd_malloc((void**) &dRall, sizeof(double) * nn * P);
+    if (!rc) rc = qrd_malloc((void**) &dS, sizeof(double) * (size_t) sm * n);
+    if (!rc) rc = qrd_malloc((void**) &dQt, sizeof(double) * (size_t) sm * n);
+    /* 1. rows [r0, r0 + rows) of the column-major host matrix (ld m) -> its own column-major array (ld rows) */
+    if (!rc) rc = qrd_h2d_2d(p->stream, dA, sizeof(double) * rows, c->A + c->r0, sizeof(double) * c->m, sizeof(double) * rows, n);
+    if (!rc) rc = qr_geqrf_dev(p, dA, rows, n, rows, dtau);
+    if (!rc) rc = qr_extract_r_dev(p, dA, rows, n, rows, dRp, n, n);
+    /* every thread reaches the collective or none does: a rank that failed before it would leave the others hanging */
+    if (rc) __atomic_store_n(c->any_fail, 1, __ATOMIC_SEQ_CST);
+    pthread_barrier_wait(c->bar);
+    if (__atomic_load_n(c->any_fail, __ATOMIC_SEQ_CST)) { if (!rc) rc = QR_E_INTERNAL; goto done; }
+    /* 2. the one collective */
+    if (P > 1) rc = qrd_allgather_f64(c->comm, p->stream, dRp, dRall, nn);
+    else rc = qrd_d2d(p->stream, dRall, dRp, sizeof(double) * nn);
+    for (int q = 0; q < P && !rc; ++q)
+        rc = qrd_copy_block(p->stream, dRall + (size_t) q * nn, n, dS + (size_t) q * n, sm, n, n);
+    if (!rc) rc = qrd_stream_sync(p->stream);
+    /* 3. stacked factorisation, redundantly on every device */
+    if (!rc) rc = qr_geqrf_dev(p2, dS, sm, n, sm, dtau2);
+    if (!rc) rc = qr_extract_r_dev(p2, dS, sm, n, sm, dR, n, n);
+    if (!rc) rc = qr_applyq_dev(p2, dS, sm, n, sm, dtau2, dQt, n, sm, 1);
+    if (!rc) rc = qr_plan_sync(p2);
+    /* 4. Q_d = Q_local_d [Qtree_d ; 0] */
+    if (!rc) rc = qrd_memset(p->stream, dQ, 0, sizeof(double) * (size_t) rows * n);
+    if (!rc) rc = qrd_copy_block(p->stream, dQt + (size_t) c->rank * n, sm, dQ, rows, n, n);
+    if (!rc) rc = qr_applyq_dev(p, dA, rows, n, rows, dtau, dQ, n, rows, 0);
+    if (!rc) rc = qrd_d2h_2d(p->stream, c->Q + c->r0, sizeof(double) * c->m, dQ, sizeof(double) * rows, sizeof(double) * rows, n);
+    if (!rc && c->rank == 0) rc = qrd_d2h(p->stream, c->R, dR, sizeof(double) * nn);
+    if (!rc) rc = qr_plan_sync(p);
+done:
+    qrd_free(dA); qrd_free(dQ); qrd_free(dtau); qrd_free(dtau2); qrd_free(dRp); qrd_free(dR); qrd_free(dRall); qrd_free(dS); qrd_free(dQt);
+    qr_plan_destroy(p); qr_plan_destroy(p2);
+    return rc;
+}
+
+static void* mg_worker(void* arg)
+{
+    mg_ctx* c = (mg_ctx*) arg;
+    c->rc = mg_run(c);
+    return NULL;
+}
+
+int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, int ngpu)
+{
+    if (!A || !Q || !R || n < 1 || m < n || ngpu < 1 || ngpu > QR_MAX_DEVICES) return QR_E_ARG;
+    int ndev = 0;
+    if (qrd_device_count(&ndev) != 0 || ndev < 1) return QR_E_NODEVICE;
+    if (ngpu > ndev) return QR_E_ARG;                       /* more shards than visible devices */
+    const int ms = (m + ngpu - 1) / ngpu;
+    if (m - (ngpu - 1) * ms < n) return QR_E_ARG;           /* every shard needs at least n rows */
+    int prev = 0;
+    qrd_get_device(&prev);
+    void* comms[QR_MAX_DEVICES];
+    int devs[QR_MAX_DEVICES];
+    memset(comms, 0, sizeof comms);
+    for (int d = 0; d < ngpu; ++d) devs[d] = d;
+    if (ngpu > 1) CHECK(qrd_comm_init_all(comms, ngpu, devs));
+    pthread_barrier_t bar;
+    if (pthread_barrier_init(&bar, NULL, (unsigned) ngpu)) return QR_E_INTERNAL;
+    mg_ctx ctx[QR_MAX_DEVICES];
+    pthread_t th[QR_MAX_DEVICES];
+    int started = 0, any_fail = 0, rc = 0;
+    for (int d = 0; d < ngpu; ++d) {
+        mg_ctx* c = &ctx[d];
+        memset(c, 0, sizeof *c);
+        c->rank = d; c->ngpu = ngpu; c->dev = devs[d]; c->m = m; c->n = n; c->nb = nb;
+        c->r0 = d * ms; c->rows = imin(ms, m - d * ms);
+        c->A = A; c->Q = Q; c->R = R; c->comm = comms[d]; c->bar = &bar; c->any_fail = &any_fail;
+    }
+    if (ngpu == 1) {
+        mg_worker(&ctx[0]);                                 /* no thread, no communicator */
+        rc = ctx[0].rc;
+    } else {
+        for (int d = 0; d < ngpu; ++d) {
+            if (pthread_create(&th[d], NULL, mg_worker, &ctx[d])) break;
+            ++started;
+        }
+        if (started < ngpu) {
+            /* the running workers would wait for the missing ones at the barrier: make them bail out, then stand in */
+            __atomic_store_n(&any_fail, 1, __ATOMIC_SEQ_CST);
+            for (int d = started; d < ngpu; ++d) pthread_barrier_wait(&bar);
+            rc = QR_E_INTERNAL;
+        }
+        for (int d = 0; d < started; ++d) {
+            pthread_join(th[d], NULL);
+            if (!rc && ctx[d].rc) rc = ctx[d].rc;
+        }
+    }
+    for (int d = 0; d < ngpu; ++d) qrd_comm_destroy(comms[d]);
+    pthread_barrier_destroy(&bar);
+    qrd_set_device(prev);
     return rc;
 }

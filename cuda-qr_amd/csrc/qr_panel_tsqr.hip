@@ -19,6 +19,7 @@
 // 4 launches (mk <= 8192), 6 (mk <= 131072), 2 passes over the leaf.  mk <= 512: panel_single_kernel, 1 launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "qr_device.h"
 #include "qr_common.h"
 
@@ -208,17 +209,16 @@ __device__ __forceinline__ void load_block(double (&x)[PW], const double* __rest
 // below) in Vloc, its tau in tauloc[b*PW..], the Gram entries Z(i,k) = v_i^T v_k (the strict upper triangle of T^-1)
 // in Tloc[b*PW*PW + k*PW + i], and its R (w x w, zeros below the diagonal) in rows [b*w, b*w+w) of Rstack.
 template <int NT, int RPT>
-__global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restrict__ src, int lds, int rows_total, int chunk,
-                                                         int w, double* __restrict__ Vloc, int ldv,
-                                                         double* __restrict__ tauloc, double* __restrict__ Tloc,
-                                                         double* __restrict__ Rstack, int ldr, const int* __restrict__ guard)
+__device__ __forceinline__ void tsqr_factor_body(int b, int nblk, const double* __restrict__ src, int lds, int rows_total, int chunk,
+                                                 int w, double* __restrict__ Vloc, int ldv,
+                                                 double* __restrict__ tauloc, double* __restrict__ Tloc,
+                                                 double* __restrict__ Rstack, int ldr)
 {
-    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ PanelSharedT<NT / 64> sh;
     __shared__ double Z[PW][PW + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int start, rows;
-    block_range(rows_total, chunk, b, gridDim.x, start, rows);
+    block_range(rows_total, chunk, b, nblk, start, rows);
     double x[RPT][PW];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) load_block(x[q], src, lds, start, tid + NT * q, rows, w);
@@ -245,13 +245,22 @@ __global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restric
     }
 }
 
+template <int NT, int RPT>
+__global__ __launch_bounds__(NT) void tsqr_factor_kernel(const double* __restrict__ src, int lds, int rows_total, int chunk,
+                                                         int w, double* __restrict__ Vloc, int ldv,
+                                                         double* __restrict__ tauloc, double* __restrict__ Tloc,
+                                                         double* __restrict__ Rstack, int ldr, const int* __restrict__ guard)
+{
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
+    tsqr_factor_body<NT, RPT>(blockIdx.x, gridDim.x, src, lds, rows_total, chunk, w, Vloc, ldv, tauloc, Tloc, Rstack, ldr);
+}
+
 // T: the last stack (rows <= 512): R~ -> Rt (ld PW), explicit Q_top [I;0] -> Cout (rows x w) in compact-WY form:
 // Q_top [I;0] = [I;0] - V (T V1^T)
 template <int NT, int RPT>
-__global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__ stack, int lds, int rows, int w,
-                                                      double* __restrict__ Rt, double* __restrict__ Cout, int ldc, const int* __restrict__ guard)
+__device__ __forceinline__ void tsqr_top_body(const double* __restrict__ stack, int lds, int rows, int w,
+                                              double* __restrict__ Rt, double* __restrict__ Cout, int ldc)
 {
-    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ PanelSharedT<NT / 64> sh;
     __shared__ double Z[PW][PW + 1];
     __shared__ double V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
@@ -287,6 +296,14 @@ __global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__
                 if (c < w) Cout[(size_t) c * ldc + r] = out[c];
         }
     }
+}
+
+template <int NT, int RPT>
+__global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__ stack, int lds, int rows, int w,
+                                                      double* __restrict__ Rt, double* __restrict__ Cout, int ldc, const int* __restrict__ guard)
+{
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
+    tsqr_top_body<NT, RPT>(stack, lds, rows, w, Rt, Cout, ldc);
 }
 
 // A: Cout(block rows, :) = Q_local_b [Cin_b ; 0] = [Cin_b; 0] - V_b (T_b V_b1^T Cin_b),
@@ -345,36 +362,36 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-template <int I> struct HrStep {
+template <int I, int HGx = HG> struct HrStep {
     // back substitution step i (descending): row I of M is final; eliminate it from rows < I
-    static __device__ __forceinline__ void msolve(double (&e)[HQ], int r, int w, const double* t0, double (*Zs)[PW + 1])
+    static __device__ __forceinline__ void msolve(double (&e)[PW / HGx], int r, int w, const double* t0, double (*Zs)[PW + 1])
     {
         if (I < w) {
             const double ti = t0[I];
             const double z = (r < I) ? Zs[r][I] : 0.0;
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) {
+            for (int q = 0; q < PW / HGx; ++q) {
                 e[q] = (r == I) ? e[q] * ti : e[q];
                 e[q] -= z * readlane_f64(e[q], I);
             }
         }
-        if constexpr (I > 0) HrStep<I - 1>::msolve(e, r, w, t0, Zs);
+        if constexpr (I > 0) HrStep<I - 1, HGx>::msolve(e, r, w, t0, Zs);
     }
     // Q1_top(r, :) -= V1(r, k) M(k, :), k ascending
-    static __device__ __forceinline__ void q1top(double (&b)[HQ], const double (&e)[HQ], int r, int w, double (*V1)[PW + 1])
+    static __device__ __forceinline__ void q1top(double (&b)[PW / HGx], const double (&e)[PW / HGx], int r, int w, double (*V1)[PW + 1])
     {
         if (I < w) {
             const double v = (I <= r) ? V1[r][I] : 0.0;
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) b[q] -= v * readlane_f64(e[q], I);
+            for (int q = 0; q < PW / HGx; ++q) b[q] -= v * readlane_f64(e[q], I);
         }
-        if constexpr (I + 1 < PW) HrStep<I + 1>::q1top(b, e, r, w, V1);
+        if constexpr (I + 1 < PW) HrStep<I + 1, HGx>::q1top(b, e, r, w, V1);
     }
     // modified LU step j = I (ascending); column j multipliers go through LDS (one barrier per step)
-    static __device__ __forceinline__ void lu(double (&b)[HQ], int r, int g, int w, double (*colb)[PW], double* Ss)
+    static __device__ __forceinline__ void lu(double (&b)[PW / HGx], int r, int g, int w, double (*colb)[PW], double* Ss)
     {
         if (I < w) {
-            constexpr int pp = I & 1, qj = I / HG, gj = I % HG;
+            constexpr int pp = I & 1, qj = I / HGx, gj = I % HGx;
             if (g == gj && r < PW) colb[pp][r] = b[qj];
             __syncthreads();
             const double p = colb[pp][I];
@@ -382,8 +399,8 @@ template <int I> struct HrStep {
             const double piv = p - S;
             const double l = (r > I && r < w) ? colb[pp][r] / piv : 0.0;
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) {
-                const int c = g + HG * q;
+            for (int q = 0; q < PW / HGx; ++q) {
+                const int c = g + HGx * q;
                 const double u = readlane_f64(b[q], I);
                 if (c > I) b[q] -= l * u;
             }
@@ -392,48 +409,48 @@ template <int I> struct HrStep {
                 if (r == I) Ss[I] = S;
             }
         }
-        if constexpr (I + 1 < PW) HrStep<I + 1>::lu(b, r, g, w, colb, Ss);
+        if constexpr (I + 1 < PW) HrStep<I + 1, HGx>::lu(b, r, g, w, colb, Ss);
     }
     // forward substitution L1 X = RHS, step k = I (ascending): row I of X is final
-    static __device__ __forceinline__ void xsolve(double (&x)[HQ], int r, int w, double (*Bs)[PW + 1])
+    static __device__ __forceinline__ void xsolve(double (&x)[PW / HGx], int r, int w, double (*Bs)[PW + 1])
     {
         if (I < w) {
             const double l = (r > I && r < w) ? Bs[r][I] : 0.0;
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) x[q] -= l * readlane_f64(x[q], I);
+            for (int q = 0; q < PW / HGx; ++q) x[q] -= l * readlane_f64(x[q], I);
         }
-        if constexpr (I + 1 < PW) HrStep<I + 1>::xsolve(x, r, w, Bs);
+        if constexpr (I + 1 < PW) HrStep<I + 1, HGx>::xsolve(x, r, w, Bs);
     }
     // back substitution U Uinv = I, step k = I (descending)
-    static __device__ __forceinline__ void uinv(double (&ui)[HQ], int r, int w, double (*Bs)[PW + 1])
+    static __device__ __forceinline__ void uinv(double (&ui)[PW / HGx], int r, int w, double (*Bs)[PW + 1])
     {
         if (I < w) {
             const double d = 1.0 / Bs[I][I];
             const double u = (r < I) ? Bs[r][I] : 0.0;
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) {
+            for (int q = 0; q < PW / HGx; ++q) {
                 ui[q] = (r == I) ? ui[q] * d : ui[q];
                 ui[q] -= u * readlane_f64(ui[q], I);
             }
         }
-        if constexpr (I > 0) HrStep<I - 1>::uinv(ui, r, w, Bs);
+        if constexpr (I > 0) HrStep<I - 1, HGx>::uinv(ui, r, w, Bs);
     }
 };
 
-__global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restrict__ Vloc, int ldvl, const double* __restrict__ tau0,
+template <int HGx>
+__device__ __forceinline__ void hr_top_body(const double* __restrict__ Vloc, int ldvl, const double* __restrict__ tau0,
                                                      const double* __restrict__ Z0, const double* __restrict__ C0, int ldc0,
                                                      const double* __restrict__ Rt, int w, double* __restrict__ A, int lda,
                                                      double* __restrict__ tau, double* __restrict__ T, int ldt,
-                                                     double* __restrict__ Vw, int ldv, double* __restrict__ Umat, const int* __restrict__ guard)
+                                                     double* __restrict__ Vw, int ldv, double* __restrict__ Umat)
 {
-    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ double Bs[PW][PW + 1], V1[PW][PW + 1], Cs[PW][PW + 1];
     __shared__ double colb[2][PW];
     __shared__ double Ss[PW], t0[PW];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r = lane;                          // lanes >= 32 carry zeros and write nothing
     const bool ra = r < w;
-    for (int el = threadIdx.x; el < PW * PW; el += 64 * HG) {
+    for (int el = threadIdx.x; el < PW * PW; el += 64 * HGx) {
         const int i = el % PW, c = el / PW;
         const bool in = (i < w && c < w);
         const double v = in ? Vloc[(size_t) c * ldvl + i] : 0.0;
@@ -443,39 +460,39 @@ __global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restric
     }
     if (threadIdx.x < PW) t0[threadIdx.x] = (threadIdx.x < w) ? tau0[threadIdx.x] : 0.0;
     __syncthreads();
-    double e[HQ], b[HQ];
+    double e[PW / HGx], b[PW / HGx];
 #pragma unroll
-    for (int q = 0; q < HQ; ++q) {               // W = V1^T C0
-        const int c = g + HG * q;
+    for (int q = 0; q < PW / HGx; ++q) {               // W = V1^T C0
+        const int c = g + HGx * q;
         double acc = 0.0;
         if (r < PW)
             for (int k = r; k < w; ++k) acc += V1[k][r] * Cs[k][c];
         e[q] = acc;
         b[q] = (ra && c < w) ? Cs[r][c] : 0.0;
     }
-    HrStep<PW - 1>::msolve(e, r, w, t0, Bs);     // e := M_0 rows
-    HrStep<0>::q1top(b, e, ra ? r : -1, w, V1);  // b := Q1_top rows (inactive lanes: no update)
+    HrStep<PW - 1, HGx>::msolve(e, r, w, t0, Bs);     // e := M_0 rows
+    HrStep<0, HGx>::q1top(b, e, ra ? r : -1, w, V1);  // b := Q1_top rows (inactive lanes: no update)
     __syncthreads();                             // everyone is done with Bs as Z
-    HrStep<0>::lu(b, r, g, w, colb, Ss);
+    HrStep<0, HGx>::lu(b, r, g, w, colb, Ss);
     __syncthreads();
     if (r < PW) {
 #pragma unroll
-        for (int q = 0; q < HQ; ++q) Bs[r][g + HG * q] = b[q];
+        for (int q = 0; q < PW / HGx; ++q) Bs[r][g + HGx * q] = b[q];
     }
     __syncthreads();
-    double x[HQ], ui[HQ];
+    double x[PW / HGx], ui[PW / HGx];
 #pragma unroll
-    for (int q = 0; q < HQ; ++q) {
-        const int c = g + HG * q;
+    for (int q = 0; q < PW / HGx; ++q) {
+        const int c = g + HGx * q;
         x[q] = (ra && c <= r) ? -Ss[r] * Bs[c][r] : 0.0;          // -S U^T
         ui[q] = (ra && r == c) ? 1.0 : 0.0;
     }
-    HrStep<0>::xsolve(x, r, w, Bs);
-    HrStep<PW - 1>::uinv(ui, r, w, Bs);
+    HrStep<0, HGx>::xsolve(x, r, w, Bs);
+    HrStep<PW - 1, HGx>::uinv(ui, r, w, Bs);
     if (!ra) return;
 #pragma unroll
-    for (int q = 0; q < HQ; ++q) {
-        const int c = g + HG * q;
+    for (int q = 0; q < PW / HGx; ++q) {
+        const int c = g + HGx * q;
         if (c < w) {
             T[(size_t) r * ldt + c] = x[q];                                        // T(c, r) = X(r, c)
             A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * Rt[c * PW + r] : b[q];
@@ -486,20 +503,29 @@ __global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restric
     }
 }
 
+__global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restrict__ Vloc, int ldvl, const double* __restrict__ tau0,
+                                                     const double* __restrict__ Z0, const double* __restrict__ C0, int ldc0,
+                                                     const double* __restrict__ Rt, int w, double* __restrict__ A, int lda,
+                                                     double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                     double* __restrict__ Vw, int ldv, double* __restrict__ Umat, const int* __restrict__ guard)
+{
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
+    hr_top_body<HG>(Vloc, ldvl, tau0, Z0, C0, ldc0, Rt, w, A, lda, tau, T, ldt, Vw, ldv, Umat);
+}
+
 // A1 + H2 fused (level 1, last launch of the leaf): V(rows, :) = Q1(rows, :) U^-1 with Q1 = [C_b; 0] - V_b M_b, i.e.
 // V(r, :) = [C_b U^-1; 0](r, :) - V_b(r, :) (M_b U^-1), written straight into the panel and Vw for global rows >= w
 // (the top w rows were written by hr_top_kernel).  No explicit Q1 round trip through memory.
-__global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict__ Vloc, int ldvl,
-                                                        const double* __restrict__ tauloc, const double* __restrict__ Tloc,
-                                                        int rows_total, int nblk, int halves, int w,
-                                                        const double* __restrict__ Cin, int ldci,
-                                                        const double* __restrict__ Umat, double* __restrict__ A, int lda,
-                                                        double* __restrict__ Vw, int ldv, const int* __restrict__ guard)
+__device__ __forceinline__ void tsqr_final_body(int bid, const double* __restrict__ Vloc, int ldvl,
+                                                const double* __restrict__ tauloc, const double* __restrict__ Tloc,
+                                                int rows_total, int nblk, int halves, int w,
+                                                const double* __restrict__ Cin, int ldci,
+                                                const double* __restrict__ Umat, double* __restrict__ A, int lda,
+                                                double* __restrict__ Vw, int ldv)
 {
-    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
     __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1], Ui[PW][PW + 1];
     __shared__ double tl[PW];
-    const int tid = threadIdx.x, b = blockIdx.x / halves, h = blockIdx.x % halves;
+    const int tid = threadIdx.x, b = bid / halves, h = bid % halves;
     int bstart, brows;
     block_range(rows_total, 0, b, nblk, bstart, brows);             // the level-0 block
     const int start = bstart + h * PT, rows = min(PT, brows - h * PT);   // this workgroup's rows of it
@@ -536,6 +562,77 @@ __global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict
         for (int q = 0; q < PW; ++q)
             if (q < w) { A[(size_t) q * lda + rg] = out[q]; Vw[(size_t) q * ldv + rg] = out[q]; }
     }
+}
+
+__global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict__ Vloc, int ldvl,
+                                                        const double* __restrict__ tauloc, const double* __restrict__ Tloc,
+                                                        int rows_total, int nblk, int halves, int w,
+                                                        const double* __restrict__ Cin, int ldci,
+                                                        const double* __restrict__ Umat, double* __restrict__ A, int lda,
+                                                        double* __restrict__ Vw, int ldv, const int* __restrict__ guard)
+{
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
+    tsqr_final_body(blockIdx.x, Vloc, ldvl, tauloc, Tloc, rows_total, nblk, halves, w, Cin, ldci, Umat, A, lda, Vw, ldv);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The whole Householder-TSQR guard route of a SHORT leaf (one tree level: mk <= 16 blocks of 1024 rows) as ONE launch.
+// Behind a CholeskyQR2 leaf the guard route is almost never needed, and as four separate launches it cost four dependent
+// kernel boundaries (~5 us each, 20 us of a ~140 us leaf) just to find the guard word clear.  Here the four phases
+// (factor | top | reconstruction | final) are separated by software grid barriers instead: nblk <= 16 workgroups, one per
+// compute unit at most, all co-resident; a monotone arrival counter with agent-scope release / acquire around it
+// (MI355X_MICROARCH.md, "barrier-counter": ~7 us each, paid only when the guard trips).  The counter is zeroed by the leaf's
+// reconstruction kernel (hr3_kernel, which always runs before this launch), so nothing has to be reset here.  Spins are
+// bounded: a barrier that is not completed after ~1 s poisons tau with NaN and lets the launch end instead of hanging.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool coop_barrier(unsigned* cnt, unsigned target)
+{
+    __shared__ int timed_out;
+    __syncthreads();                                              // every wave has waited for its own stores (vmcnt(0))
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // write back what this workgroup produced
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int to = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1u << 20)) { to = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // drop this CU's stale lines before anyone reads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        timed_out = to;
+    }
+    __syncthreads();
+    return timed_out == 0;
+}
+
+__global__ __launch_bounds__(PT) void tsqr_coop_kernel(const double* P, int ld, int mk, int w, int nblk, int halves,
+                                                       double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
+                                                       double* __restrict__ stack, double* __restrict__ Rt, double* __restrict__ Ctop,
+                                                       double* __restrict__ Umat, double* A /* == P */, int lda,
+                                                       double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                       double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
+                                                       const int* __restrict__ guard)
+{
+    if (*guard == 0) return;                 // the CholeskyQR2 leaf succeeded: nothing to do, one kernel boundary paid
+    const int b = blockIdx.x, G = gridDim.x, rows_stack = nblk * w;
+    bool ok = true;
+    // F: local Householder QR of this workgroup's row block (<= 1024 rows: two rows per thread)
+    tsqr_factor_body<PT, 2>(b, nblk, P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stack, rows_stack);
+    ok = coop_barrier(bar, (unsigned) G) && ok;
+    // T: QR of the stacked R factors and its explicit Q [I; 0]
+    if (b == 0) tsqr_top_body<PT, 1>(stack, rows_stack, rows_stack, w, Rt, Ctop, rows_stack);
+    ok = coop_barrier(bar, 2u * (unsigned) G) && ok;
+    // H: Householder reconstruction of the top block
+    if (b == 0) hr_top_body<PT / 64>(Vloc1, mk, taus, Ts, Ctop, rows_stack, Rt, w, A, lda, tau, T, ldt, Vw, ldv, Umat);
+    ok = coop_barrier(bar, 3u * (unsigned) G) && ok;
+    // Fin: every block writes its rows of V
+    for (int h = 0; h < halves; ++h) {
+        tsqr_final_body(b * halves + h, Vloc1, mk, taus, Ts, mk, nblk, halves, w, Ctop, rows_stack, Umat, A, lda, Vw, ldv);
+        __syncthreads();
+    }
+    if (!ok && b == 0 && threadIdx.x < w) tau[threadIdx.x] = __builtin_nan("");
 }
 
 // mk <= 512: the whole leaf in one workgroup -- V, R, tau and T in a single launch.
@@ -583,13 +680,32 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
 // =========================================================================================================
 #define QRD_GUARD_THR (1.0 / 64.0)
 
+// 1/sqrt(p) from the hardware estimate (v_rsq_f64, ~2^-26 relative) and two Newton steps y <- y (3/2 - p/2 y^2): full double
+// accuracy to an ulp or two in ~10 dependent instructions.  The IEEE sqrt + division this replaces is ~60 instructions
+// deep and sat 32 times on the one-wave critical path of every Cholesky (4 of its 7 us).  p <= 0 / NaN is caught by the caller.
+__device__ __forceinline__ double rsqrt_newton(double p)
+{
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+__device__ __forceinline__ double rcp_newton(double p)
+{
+    double y = __builtin_amdgcn_rcp(p);
+    y = y * (2.0 - p * y);
+    y = y * (2.0 - p * y);
+    return y;
+}
+
 // right-looking Cholesky G = R^T R on one wave: lane j (< 32) holds column j in g[]; on exit g[k] = R(k, j), k <= j
 template <int K> struct CholStep {
     static __device__ __forceinline__ void run(double (&g)[PW], int lane, bool& ok)
     {
         const double p = readlane_f64(g[K], K);
         ok = ok && (p > 0.0);                       // false for NaN as well
-        const double inv = 1.0 / sqrt(p);
+        const double inv = rsqrt_newton(p);
         const double rk = (lane >= K) ? g[K] * inv : 0.0;
         g[K] = rk;
 #pragma unroll
@@ -866,6 +982,355 @@ __global__ __launch_bounds__(PT) void final2_kernel(double* __restrict__ Vw, int
         if (FULL || c < w) { Vw[(size_t) c * ldv + r] = v[c]; A[(size_t) c * lda + r] = v[c]; }
 }
 
+
+// =========================================================================================================
+// Second-generation CholeskyQR2 leaf: the same mathematics in 4 launches instead of 7 (plus the guard launches).
+//   gram32_kernel          G1 slabs (at most CQ2_MAXSLAB of them, so that a consumer can sum them itself)
+//   cholq2_kernel          every workgroup: G1 = sum of slabs, R1 = chol(G1) (one wave), its 512 rows of Q = A R1^-1 -> Vw,
+//                          AND its share of G2 = Q^T Q on the MFMA pipe (rows staged through LDS 256 at a time) -> slab2[b]
+//   hr3_kernel             one workgroup: G2 = sum of slab2 (or a pre-reduced G2), guard, R2 = chol(G2), then the modified LU
+//                          of the reconstruction run directly on Q_top:  with U' = U R2,
+//                              LU(Q_top - S R2) = L1 U'     (same L1, same S as LU(Q_top R2^-1 - S) = L1 U: R2 is upper
+//                          triangular with a positive diagonal, so Schur complements only get multiplied by R2's trailing
+//                          block; row j of S R2 is added when step j fixes S_j = -sign of the current (j, j) entry),
+//                          so neither R2^-1 nor Q1_top = Q_top R2^-1 is ever formed.  Then, concurrently on different
+//                          waves, U = U' R2^-1 (row solves) and L1^-1 (column solves), T = -U S L1^-T as a product,
+//                          R = S R2 R1.
+//   final3_kernel          rows >= w:  V = Q U'^-1 as the row-parallel triangular solve v U' = q  (V = Q1 U^-1 =
+//                          Q R2^-1 U^-1 = Q (U R2)^-1)
+// The old route needed R2^-1, U^-1 and their product M (three more 32-step recurrences) plus two slab_reduce launches and a
+// second gram32 launch with its own pass over Q.
+// =========================================================================================================
+// elements 2t, 2t+1 of the sum of `nslab` dense 32 x 32 slabs (1024 doubles apart), slabs added in index order; 16 loads
+// are issued before the first add (the previous two-at-a-time loop paid one L2 round trip per pair: ~10 us for 14 slabs)
+__device__ __forceinline__ v2d slab_sum2(const double* __restrict__ slabs, int nslab, int t)
+{
+    const v2d* p = reinterpret_cast<const v2d*>(slabs) + t;
+    v2d acc = (v2d){0.0, 0.0};
+    for (int z0 = 0; z0 < nslab; z0 += 16) {
+        v2d v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(size_t) min(z0 + u, nslab - 1) * (PW * PW / 2)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (z0 + u < nslab) acc += v[u];
+    }
+    return acc;
+}
+
+#define CQ2_MAXSLAB 32
+#define CQ2_HALF 256
+#define CQ2_LDQ (CQ2_HALF + 2)
+#define CQ2_LDS_DOUBLES (PW * CQ2_LDQ + 2 * PW * (PW + 1) + PW + 8)
+
+template <bool FULL>
+__global__ __launch_bounds__(PT) void cholq2_kernel(const double* __restrict__ P, int ld, int mk, int w,
+                                                    const double* __restrict__ gslabs, int nslab, double* __restrict__ R1,
+                                                    double* __restrict__ Vw, int ldv, double* __restrict__ slab2,
+                                                    int* __restrict__ guard)
+{
+    extern __shared__ __attribute__((aligned(16))) double cq_smem[];
+    double* Qs = cq_smem;                                                    // [PW][CQ2_LDQ]; later 8 partial Grams [8][PW*PW]
+    double (*Gs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * CQ2_LDQ);
+    double (*Rs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * CQ2_LDQ + PW * (PW + 1));
+    double* rinv = cq_smem + PW * CQ2_LDQ + 2 * PW * (PW + 1);
+    int* okf = reinterpret_cast<int*>(rinv + PW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int r = b * PT + tid;
+    double a[PW];
+    {
+        const double* p = P + min(r, mk - 1);
+#pragma unroll
+        for (int c = 0; c < PW; ++c) a[c] = (FULL || c < w) ? p[(size_t) c * ld] : 0.0;      // in flight under the Gram sum
+    }
+    // G1 = sum of the slabs (fixed order; every workgroup forms the same bits).  Stored column-major, ld PW.
+    {
+        const v2d gsum = slab_sum2(gslabs, nslab, tid);                       // elements 2 tid, 2 tid + 1
+        const int e = 2 * tid;
+        Gs[e / PW][e % PW] = gsum[0];                                         // Gs[j][i] = G(i, j)
+        Gs[e / PW][e % PW + 1] = gsum[1];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // chol_wave reads G(i, j) as G[j * PW + i]: hand it the padded image row by row
+        double g[PW];
+        const int j = lane & (PW - 1);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) g[i] = (i < w && j < w) ? Gs[j][i] : (i == j ? 1.0 : 0.0);
+        bool ok = true;
+        CholStep<0>::run(g, j, ok);
+        if (lane < PW) {
+#pragma unroll
+            for (int k = 0; k < PW; ++k) Rs[k][lane] = (k <= lane) ? g[k] : 0.0;
+        }
+        if (lane == 0) *okf = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < PW) rinv[tid] = 1.0 / Rs[tid][tid];
+    const bool ok = *okf != 0;
+    if (b == 0) {
+        if (tid == 0) *guard = ok ? 0 : 1;
+        if (ok && tid < PW) {
+#pragma unroll
+            for (int k = 0; k < PW; ++k) R1[tid * PW + k] = Rs[k][tid];          // column tid
+        }
+    }
+    if (!ok) return;                                                          // workgroup-uniform
+    __syncthreads();
+    double q[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {                                              // q R1 = a, column by column
+        q[k] = a[k] * rinv[k];
+#pragma unroll
+        for (int c = k + 1; c < PW; ++c) a[c] -= q[k] * Rs[k][c];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool live = r < mk;
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+            if (FULL || c < w) Vw[(size_t) c * ldv + r] = q[c];
+    }
+    // ---- this workgroup's share of G2 = Q^T Q: rows staged 256 at a time as a [column][row] image (ld 258: the 16 columns a
+    // half-wave reads are 16 B apart in the bank row -> conflict-free ds_read_b64), wave v takes rows [32v, 32v+32) of the half
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < PT / CQ2_HALF; ++h) {
+        if ((tid >> 8) == h) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c) Qs[c * CQ2_LDQ + (tid & (CQ2_HALF - 1))] = live ? q[c] : 0.0;
+        }
+        __syncthreads();
+        const double* base = Qs + 32 * wave + l4;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const double f0 = base[l15 * CQ2_LDQ + 4 * ks], f1 = base[(16 + l15) * CQ2_LDQ + 4 * ks];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D reg rr of lane (l4, l15) of tile (ti, tj) = G(16 ti + l4 + 4 rr, 16 tj + l15); partial of this wave -> LDS (over Qs)
+    double* red = Qs + wave * PW * PW;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[(16 * tj + l15) * PW + 16 * ti + l4 + 4 * rr] = acc[ti][tj][rr];
+    __syncthreads();
+    for (int e = tid; e < PW * PW; e += PT) {
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < PT / 64; ++v) s += Qs[v * PW * PW + e];
+        slab2[(size_t) b * PW * PW + e] = s;
+    }
+}
+
+// Cholesky + modified LU of the reconstruction on ONE wave, no LDS and no barrier: lane c (< 32) holds column c of both
+// matrices in registers -- g[k] = R2(k, c) and b[r] = (Q_top - S R2)(r, c) being eliminated -- so a row of the pivot step is one
+// register per lane and only the multiplier column (the registers of lane I) is broadcast, with v_readlane.  The 8-wave
+// version with one workgroup barrier per step took 16 us of the kernel's 41; this is the same arithmetic in ~5 us.
+// (See the header of this section for why the LU runs on Q_top - S R2 instead of Q_top R2^-1 - S.)
+// On exit: b = L1 below the diagonal, U' = U R2 on and above it; sgn = S_c in lane c.
+#define H3G 8
+template <int K> struct Chol3Step {
+    static __device__ __forceinline__ void run(double (&g)[PW], int lane, bool& ok, double& dinv)
+    {
+        const double p = readlane_f64(g[K], K);
+        ok = ok && (p > 0.0);                       // false for NaN as well
+        const double inv = rsqrt_newton(p);
+        if (lane == K) dinv = inv;                  // 1 / R2(K, K)
+        const double rk = (lane >= K) ? g[K] * inv : 0.0;
+        g[K] = rk;
+#pragma unroll
+        for (int i = K + 1; i < PW; ++i) g[i] -= readlane_f64(rk, i) * rk;
+        if constexpr (K + 1 < PW) Chol3Step<K + 1>::run(g, lane, ok, dinv);
+    }
+};
+template <int I> struct Hr3Lu {
+    static __device__ __forceinline__ void run(double (&b)[PW], const double (&g)[PW], int lane, double& sgn)
+    {
+        const double x = readlane_f64(b[I], I);                 // current (I, I) entry, S_I not yet applied
+        const double S = (x >= 0.0) ? -1.0 : 1.0;
+        b[I] -= S * g[I];                                        // row I of S R2 (g[I] = R2(I, lane) is zero left of the diagonal)
+        const double piv = readlane_f64(b[I], I);                // x - S R2(I, I): |piv| >= R2(I, I) > 0
+        const double inv = rcp_newton(piv);
+        if (lane == I) sgn = S;
+        const double scale = (lane == I) ? inv : 1.0;
+        const double u = (lane > I) ? b[I] : 0.0;
+#pragma unroll
+        for (int r = I + 1; r < PW; ++r) {
+            b[r] *= scale;                                       // lane I: multiplier l_r
+            b[r] -= readlane_f64(b[r], I) * u;                   // lanes right of I: a(r, c) -= l_r u_c
+        }
+        if constexpr (I + 1 < PW) Hr3Lu<I + 1>::run(b, g, lane, sgn);
+    }
+};
+
+// upper-triangular row solve  u R = u'  for lane = row (rows beyond 31 compute garbage that is never stored):
+// u(c) = (u'(c) - sum_{k<c} u(k) R(k, c)) / R(c, c)
+template <int C> struct RowSolve {
+    static __device__ __forceinline__ void run(double (&u)[PW], double (*Rm)[PW + 1], const double* rinv)
+    {
+        double acc = u[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc -= u[k] * Rm[k][C];
+        u[C] = acc * rinv[C];
+        if constexpr (C + 1 < PW) RowSolve<C + 1>::run(u, Rm, rinv);
+    }
+};
+// unit-lower column solve  L x = e_lane : x(i) = delta(i, lane) - sum_{k<i} L(i, k) x(k)
+template <int I> struct UnitLowerInv {
+    static __device__ __forceinline__ void run(double (&x)[PW], double (*Lm)[PW + 1], int lane)
+    {
+        double acc = (I == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < I; ++k) acc -= Lm[I][k] * x[k];
+        x[I] = acc;
+        if constexpr (I + 1 < PW) UnitLowerInv<I + 1>::run(x, Lm, lane);
+    }
+};
+
+__global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restrict__ G2s, int nslab, const double* __restrict__ R1,
+                                                      double* __restrict__ Vw, int ldv, double* __restrict__ A, int lda,
+                                                      double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                      double* __restrict__ Uout, int* __restrict__ guard, unsigned* __restrict__ bar)
+{
+    __shared__ double Bs[PW][PW + 1], R1s[PW][PW + 1], R2s[PW][PW + 1], Us[PW][PW + 1], Ls[PW][PW + 1], Gs[PW][PW + 1];
+    __shared__ double Ss[PW], r2inv[PW];
+    __shared__ int flags[2];
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const int rc = lane & (PW - 1);
+    if (tid == 0) *bar = 0u;                               // arrival counter of the one-launch guard route that follows (tsqr_coop_kernel)
+    if (*guard != 0) return;                               // pass 1 already refused
+    if (tid < 2) flags[tid] = 0;
+    double b[PW];
+    if (g == 0) {                                          // column rc of Q_top: 32 consecutive doubles, in flight under the sum
+        const v2d* col = reinterpret_cast<const v2d*>(Vw + (size_t) rc * ldv);
+#pragma unroll
+        for (int r2 = 0; r2 < PW / 2; ++r2) { const v2d v = col[r2]; b[2 * r2] = v[0]; b[2 * r2 + 1] = v[1]; }
+    }
+    __syncthreads();
+    {
+        const v2d gsum = slab_sum2(G2s, nslab, tid);       // elements 2 tid, 2 tid + 1 of G2 (column-major, ld 32)
+        const int e = 2 * tid, i = e % PW, c = e / PW;
+        Gs[c][i] = gsum[0];                                // Gs[j][i] = G2(i, j)
+        Gs[c][i + 1] = gsum[1];
+        const double d0 = gsum[0] - (i == c ? 1.0 : 0.0), d1 = gsum[1] - (i + 1 == c ? 1.0 : 0.0);
+        if (!(fabs(d0) <= QRD_GUARD_THR) || !(fabs(d1) <= QRD_GUARD_THR)) flags[0] = 1;     // also catches NaN
+        R1s[i][c] = (i <= c) ? R1[e] : 0.0;
+        R1s[i + 1][c] = (i + 1 <= c) ? R1[e + 1] : 0.0;
+    }
+    __syncthreads();
+    if (flags[0]) { if (tid == 0) *guard = 1; return; }
+    if (g == 0) {
+        double gg[PW];
+#pragma unroll
+        for (int i = 0; i < PW; ++i) gg[i] = Gs[rc][i];
+        bool ok = true;
+        double dinv = 1.0, sgn = 1.0;
+        Chol3Step<0>::run(gg, rc, ok, dinv);
+        if (ok) {
+            Hr3Lu<0>::run(b, gg, rc, sgn);
+            if (lane < PW) {
+#pragma unroll
+                for (int k = 0; k < PW; ++k) { R2s[k][lane] = gg[k]; Bs[k][lane] = b[k]; }
+                r2inv[lane] = dinv;
+                Ss[lane] = sgn;
+            }
+        } else if (lane == 0) flags[1] = 1;
+    }
+    __syncthreads();
+    if (flags[1]) { if (tid == 0) *guard = 1; return; }
+    // wave 0: U = U' R2^-1 (row i in lane i); wave 1: L1^-1 (column j in lane j); the other six waves: R = S (R2 R1) and L1
+    // -> A, unit-lower L1 -> Vw, U' -> Uout
+    if (g == 0) {
+        double u[PW];
+#pragma unroll
+        for (int c = 0; c < PW; ++c) u[c] = (c >= rc) ? Bs[rc][c] : 0.0;
+        RowSolve<0>::run(u, R2s, r2inv);
+        if (lane < PW) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c) Us[lane][c] = (c >= lane) ? u[c] : 0.0;
+        }
+    } else if (g == 1) {
+        double x[PW];
+        UnitLowerInv<0>::run(x, Bs, rc);
+        if (lane < PW) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) Ls[i][lane] = (i >= lane) ? x[i] : 0.0;       // Ls[i][j] = L1^-1(i, j)
+        }
+    } else {
+        for (int el = tid - 128; el < PW * PW; el += 64 * H3G - 128) {
+            const int i = el % PW, c = el / PW;
+            if (c >= i) {
+                double acc = 0.0;
+                for (int k = i; k <= c; ++k) acc += R2s[i][k] * R1s[k][c];
+                A[(size_t) c * lda + i] = Ss[i] * acc;
+                Uout[el] = Bs[i][c];
+            } else {
+                A[(size_t) c * lda + i] = Bs[i][c];
+                Uout[el] = 0.0;
+            }
+            Vw[(size_t) c * ldv + i] = (c < i) ? Bs[i][c] : (c == i ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    // T = -U S L1^-T:  T(i, c) = -sum_{k = i .. c} U(i, k) S_k L1^-1(c, k)      (upper triangular; T(i, i) = -U(i, i) S_i = tau_i)
+    for (int el = tid; el < PW * PW; el += 64 * H3G) {
+        const int i = el % PW, c = el / PW;
+        double acc = 0.0;
+        if (c >= i)
+            for (int k = i; k <= c; ++k) acc -= Us[i][k] * Ss[k] * Ls[c][k];
+        T[(size_t) c * ldt + i] = acc;
+        if (i == c) tau[i] = acc;
+    }
+}
+
+// rows >= w of V: v U' = q by forward substitution over the columns (U' upper triangular), one row per thread
+template <bool FULL>
+__global__ __launch_bounds__(PT) void final3_kernel(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Um,
+                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
+{
+    __shared__ double Usm[PW][PW + 1];
+    __shared__ double uinv[PW];
+    if (*guard != 0) return;
+    const int tid = threadIdx.x, r = blockIdx.x * PT + tid;
+    double a[PW];
+    {
+        const double* p = Vw + min(r, mk - 1);
+#pragma unroll
+        for (int c = 0; c < PW; ++c) a[c] = (FULL || c < w) ? p[(size_t) c * ldv] : 0.0;
+    }
+    for (int el = tid; el < PW * PW; el += PT) {
+        const int i = el % PW, c = el / PW;
+        const double u = (i < w && c < w && i <= c) ? Um[c * PW + i] : (i == c ? 1.0 : 0.0);
+        Usm[i][c] = u;
+        if (i == c) uinv[i] = 1.0 / u;
+    }
+    __syncthreads();
+    if (r < w || r >= mk) return;
+    double v[PW];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        v[k] = a[k] * uinv[k];
+#pragma unroll
+        for (int c = k + 1; c < PW; ++c) a[c] -= v[k] * Usm[k][c];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < PW; ++c)
+        if (FULL || c < w) { Vw[(size_t) c * ldv + r] = v[c]; A[(size_t) c * lda + r] = v[c]; }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers: the workgroup is sized to the tallest block of the launch (64..512 threads) -- a 64-row top stack
 // runs on one wave with no cross-wave reduction instead of eight mostly-idle ones
@@ -936,8 +1401,16 @@ size_t qrd_panel_ws_size(int m)
          + 2 * PW * PW + PW + 64;   /* Rt, Umat + reciprocal diagonal */
 }
 
+// MI355XQR_COOP=0: the guard route always as separate launches (default 1: one cooperative launch for short leaves)
+static int coop_enabled(void)
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MI355XQR_COOP"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    return v;
+}
+
 static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
-                           double* ws, int m_cap, const int* guard)
+                           double* ws, int m_cap, const int* guard, unsigned* bar = nullptr)
 {
     hipStream_t s = (hipStream_t) stream;
     if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
@@ -967,6 +1440,12 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     // per thread) above, which keeps the tree at two levels up to 16384 rows and three up to 262144
     const int brows0 = (mk <= 16 * PT) ? PT : 2 * PT;
     lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + brows0 - 1) / brows0; lv_off[0] = 0; lv_tau[0] = 0;
+    if (guard && bar && coop_enabled() && lv_nblk[0] * w <= PT) {
+        // short leaf behind a CholeskyQR2 attempt: the whole guard route in one launch (grid barriers inside)
+        hipLaunchKernelGGL(tsqr_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, P, ld, mk, w, lv_nblk[0], brows0 / PT, Vloc1, taus, Ts, stacks,
+                           Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
+        return (int) hipGetLastError();
+    }
     size_t off = 0, toff = (size_t) lv_nblk[0] * PW;
     launch_factor(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, lv_nblk[0] * w, guard);
     int cur_rows = lv_nblk[0] * w;
@@ -1012,6 +1491,21 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
 // Leaf = CholeskyQR2 + Householder reconstruction, guarded: 7 short launches, then the Householder-TSQR leaf above as
 // launches that return at once unless the guard word says the Cholesky route was refused for this leaf.
 // cws: QRD_CHOLQR_WS doubles (G1, G2, R1, M, guard word).
+// MI355XQR_LEAF=1 selects the first-generation launch sequence (7 launches + guards), default 2 (4 launches + guards)
+static int leaf_gen(void)
+{
+    static int v = 0;
+    if (!v) { const char* e = getenv("MI355XQR_LEAF"); v = (e && atoi(e) == 1) ? 1 : 2; }
+    return v;
+}
+
+int qrd_panel_tsqr_init(void)
+{
+    int rc = (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) (CQ2_LDS_DOUBLES * sizeof(double)));
+    return rc;
+}
+
 int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                      double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap)
 {
@@ -1022,17 +1516,51 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
     if (mk <= PT || w < PW) return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, nullptr);
     double *G1 = cws, *G2 = cws + PW * PW, *R1 = cws + 2 * PW * PW, *Mm = cws + 3 * PW * PW;
     int* guard = (int*) (cws + 4 * PW * PW);
+    unsigned* bar = (unsigned*) (guard + 2);             // zeroed by hr3_kernel: second-generation leaf only
+    bool have_bar = false;
     const int nblk = (mk + PT - 1) / PT;
-    int rc = gram32(s, P, ld, mk, G1, slabs, slab_cap);
-    if (rc) return rc;
-    hipLaunchKernelGGL(cholq_kernel<true>, dim3(nblk), dim3(PT), 0, s, P, ld, mk, w, G1, R1, Vw, ldv, guard);
-    rc = gram32(s, Vw, ldv, mk, G2, slabs, slab_cap);
-    if (rc) return rc;
-    hipLaunchKernelGGL(hr2_kernel, dim3(1), dim3(64 * HG), 0, s, G2, R1, Vw, ldv, w, P, ld, tau, T, ldt, Mm, guard);
-    hipLaunchKernelGGL(final2_kernel<true>, dim3(nblk), dim3(PT), 0, s, Vw, ldv, mk, w, Mm, P, ld, guard);
+    const bool al = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && (ld % 2 == 0) && (mk % 2 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(Vw) & 15) == 0) && (ldv % 2 == 0);
+    int rc;
+    if (leaf_gen() == 2 && al && slab_cap >= (size_t) (CQ2_MAXSLAB + nblk) * PW * PW) {
+        double* slab2 = slabs + (size_t) CQ2_MAXSLAB * PW * PW;
+        if (nblk <= CQ2_MAXSLAB) {
+            // short leaf (square problems): at most CQ2_MAXSLAB Gram slabs of >= 128 rows, summed by their consumers
+            int rows_per = ((mk + CQ2_MAXSLAB - 1) / CQ2_MAXSLAB + GKB - 1) / GKB * GKB;
+            if (rows_per < 2 * GKB) rows_per = 2 * GKB;
+            const int nslab = (mk + rows_per - 1) / rows_per;
+            hipLaunchKernelGGL(gram32_kernel, dim3(nslab), dim3(256), 0, s, P, ld, mk, rows_per, slabs);
+            hipLaunchKernelGGL(cholq2_kernel<true>, dim3(nblk), dim3(PT), CQ2_LDS_DOUBLES * sizeof(double), s, P, ld, mk, w, slabs, nslab,
+                               R1, Vw, ldv, slab2, guard);
+        } else {
+            // tall leaf: the Gram pass needs hundreds of workgroups to reach HBM bandwidth, so its slabs go through a reduce launch
+            rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk * PW * PW);      // the tail of the buffer holds slab2
+            if (rc) return rc;
+            slab2 = slabs + (slab_cap - (size_t) nblk * PW * PW);
+            hipLaunchKernelGGL(cholq2_kernel<true>, dim3(nblk), dim3(PT), CQ2_LDS_DOUBLES * sizeof(double), s, P, ld, mk, w, G1, 1,
+                               R1, Vw, ldv, slab2, guard);
+        }
+        if (nblk <= 2 * CQ2_MAXSLAB) {
+            hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+        } else {           // tall leaf: hundreds of partial Grams are summed by a grid, not by the one reconstruction workgroup
+            rc = qrd_slab_reduce(s, PW, PW, nblk, slab2, PW, (size_t) PW * PW, G2, PW);
+            if (rc) return rc;
+            hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+        }
+        hipLaunchKernelGGL(final3_kernel<true>, dim3(nblk), dim3(PT), 0, s, Vw, ldv, mk, w, Mm, P, ld, guard);
+        have_bar = true;
+    } else {
+        rc = gram32(s, P, ld, mk, G1, slabs, slab_cap);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cholq_kernel<true>, dim3(nblk), dim3(PT), 0, s, P, ld, mk, w, G1, R1, Vw, ldv, guard);
+        rc = gram32(s, Vw, ldv, mk, G2, slabs, slab_cap);
+        if (rc) return rc;
+        hipLaunchKernelGGL(hr2_kernel, dim3(1), dim3(64 * HG), 0, s, G2, R1, Vw, ldv, w, P, ld, tau, T, ldt, Mm, guard);
+        hipLaunchKernelGGL(final2_kernel<true>, dim3(nblk), dim3(PT), 0, s, Vw, ldv, mk, w, Mm, P, ld, guard);
+    }
     rc = (int) hipGetLastError();
     if (rc) return rc;
-    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard);
+    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr);
 }
 
 }   // extern "C"

@@ -64,8 +64,12 @@ int dgemm_status(double* A, double* B, double* C, int k, int m, int n);
 const char* qr_strerror(int status);
 
 /* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 256;
- * leaf width ib <= 32).  Defaults 128 / 32 (256 / 32 when both m and n are >= 8192 and nothing was set explicitly);
- * env MI355XQR_NB / MI355XQR_IB override the defaults. */
+ * leaf width ib <= 32).  Defaults 128 / 32 (256 / 32 when both m and n are >= 8192 and nothing was set explicitly --
+ * getPanelDims(m, n, ..) reports the panel grid of the block size that shape will really get);
+ * env MI355XQR_NB / MI355XQR_IB override the defaults.
+ * Threading: the library may be used from one host thread per GPU (each thread with its own current device and its own
+ * plans; a plan belongs to one thread at a time).  Process-wide state (these defaults, per-device kernel attributes, the
+ * plan cache of the host-pointer entry points) is guarded internally. */
 int qr_set_block_size(int nb, int ib);
 void qr_get_block_size(int* nb, int* ib);
 
@@ -75,6 +79,19 @@ void qr_get_block_size(int* nb, int* ib);
  * independently and combines their R factors (TSQR on one device; the multi-GPU form of the same
  * steps is driven through the device API below with an RCCL all-gather between steps 1 and 2). */
 int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nshards);
+
+/* The same over `ngpu` REAL devices of this node ("qr_thin(..., int nb, int ngpu) ... owns its own threads /
+ * RCCL communicator").  Device d (0 <= d < ngpu) factors the contiguous row block d of A on its own host thread; the R factors
+ * travel in ONE ncclAllGather (librccl is dlopen()ed on the first call with ngpu > 1, never linked), every device factors
+ * the stacked (ngpu*n) x n matrix redundantly and forms its rows of Q.  ngpu = 1 needs no communicator and gives exactly
+ * qr_thin(..., nshards = 1).  Returns QR_E_ARG when ngpu exceeds the visible devices or a shard would have fewer than n rows.
+ * Q is m x n, R is n x n (host memory).  No reference counterpart (the reference is single-device, qr.cu:711,737). */
+int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, int ngpu);
+
+/* The host-pointer entry points (mmqr, explicitQR) keep their last few plans and device buffers, keyed by (device, m, n, nb),
+ * so that repeated calls on same-sized matrices -- what the reference's harness does, qr.cu:776-789 -- do not pay ~10 ms of
+ * allocation and stream creation each time.  This frees them (idle ones); MI355XQR_PLAN_CACHE=0 disables the cache. */
+int qr_release_cached_plans(void);
 
 /* ---------------------------------------------------------------------------------------------
  * 2. Device-resident API (all d* pointers are device memory of the current HIP device)
@@ -140,6 +157,10 @@ typedef struct qr_profile {
 } qr_profile;
 int qr_plan_set_profile(qr_plan* plan, int on);
 int qr_plan_get_profile(qr_plan* plan, qr_profile* out);   /* synchronises, sums, resets */
+/* The individual records behind the sums, in issue order (call before qr_plan_get_profile): class as above, plus 4 = the
+ * look-ahead update of the next panel's columns and 5 = the panel stream's share of a wide update (both summed into class 3
+ * by qr_plan_get_profile); start / end in ms since the first record began.  Returns the number of records written (<= max). */
+int qr_plan_get_profile_records(qr_plan* plan, int max, int* cls, double* t0_ms, double* t1_ms);
 
 /* Device facts + micro-probes used by bench.py / DESIGN.md (measured, not datasheet). */
 int qr_device_info(char* arch, int arch_len, int* compute_units, int* clock_khz, size_t* hbm_bytes);

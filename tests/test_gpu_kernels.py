@@ -28,13 +28,61 @@ def test_gemm_nn(q, M, N, K):
     """C = beta*C + alpha*A*B on f64 MFMA tiles; asymmetric random data catches any row/col swap."""
     rng = np.random.default_rng(M * 7 + N * 3 + K)
     A, B, C0 = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((M, N))
-    for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.5, -2.0)):
+    # (0, 1) and (0.5, 1): beta = 1 only takes the "C enters through the accumulators" shortcut for alpha = +-1
+    for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.5, -2.0), (0.0, 1.0), (0.5, 1.0), (1.0, 1.0)):
         dA, dB, dC = dev(A), dev(B), dev(C0)
         torch.cuda.synchronize()
         q.check(q.lib.qrd_gemm_nn(None, M, N, K, alpha, dA.data_ptr(), M, dB.data_ptr(), K, beta, dC.data_ptr(), M))
         _sync(q)
         ref = alpha * (A @ B) + beta * C0
         assert rel(host(dC), ref) < 1e-13, (M, N, K, alpha, beta)
+
+
+@pytest.mark.parametrize("M,N,K,lda,ldbt,ldc", [(128, 128, 16, 128, 128, 128), (384, 256, 64, 384, 256, 384), (1024, 640, 256, 1030, 700, 1100),
+                                               (2048, 1920, 128, 2048, 2048, 2048), (256, 4096, 512, 300, 4096, 258)])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_gemm_nt_update(q, M, N, K, lda, ldbt, ldc, sign):
+    """Second-generation trailing update C -+= A Bt^T (W stored transposed, direct-to-LDS tile loads, permuted MFMA rows):
+    asymmetric random data, every XCD tile-order variant."""
+    rng = np.random.default_rng(M + N + K)
+    A, Bt, C0 = rng.standard_normal((lda, K)), rng.standard_normal((ldbt, K)), rng.standard_normal((ldc, N))
+    ref = C0.copy()
+    ref[:M] += sign * (A[:M] @ Bt[:N].T)
+    for gm in (0, 8, 3):
+        dA, dB, dC = dev(A), dev(Bt), dev(C0)
+        torch.cuda.synchronize()
+        q.check(q.lib.qrd_gemm_nt(None, M, N, K, sign, dA.data_ptr(), lda, dB.data_ptr(), ldbt, dC.data_ptr(), ldc, gm, None))
+        _sync(q)
+        out = host(dC)
+        assert rel(out[:M], ref[:M]) < 1e-13 and np.array_equal(out[M:], C0[M:]), (gm,)
+
+
+def test_gemm_nt_rejects_ragged_shapes(q):
+    d = zeros(256, 256)
+    assert q.lib.qrd_gemm_nt(None, 200, 128, 16, -1, d.data_ptr(), 256, d.data_ptr(), 256, d.data_ptr(), 256, 0, None) != 0
+    assert q.lib.qrd_gemm_nt(None, 128, 128, 8, -1, d.data_ptr(), 256, d.data_ptr(), 256, d.data_ptr(), 256, 0, None) != 0
+    assert q.lib.qrd_gemm_nt(None, 128, 128, 16, -1, d.data_ptr(), 255, d.data_ptr(), 256, d.data_ptr(), 256, 0, None) != 0
+
+
+@pytest.mark.parametrize("M,N,K,ksplit", [(128, 128, 16, 1), (256, 128, 1040, 1), (256, 128, 1040, 3), (1024, 256, 20000, 0), (128, 256, 4096, 7)])
+def test_gemm_tnt_split_k(q, M, N, K, ksplit):
+    """Ct = A^T B with both operands k-contiguous (XOR-swizzled direct-to-LDS images), split-K slabs summed in a fixed order:
+    bitwise reproducible."""
+    rng = np.random.default_rng(M * 3 + N + K)
+    lda, ldb = K + 2, K + 4
+    A, B = rng.standard_normal((lda, M)), rng.standard_normal((ldb, N))
+    ref = A[:K].T @ B[:K]
+    outs = []
+    for rep in range(2):
+        dA, dB, dC = dev(A), dev(B), dev(np.full((M, N), np.nan))
+        slabs = torch.zeros(8 * M * N, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        q.check(q.lib.qrd_gemm_tnt(None, M, N, K, dA.data_ptr(), lda, dB.data_ptr(), ldb, dC.data_ptr(), M, slabs.data_ptr(), 8 * M * N,
+                                   ksplit, 256, 8))
+        _sync(q)
+        outs.append(host(dC))
+    assert rel(outs[0], ref) < 1e-13
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_gemm_nn_with_leading_dimensions(q):

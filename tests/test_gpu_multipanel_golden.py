@@ -29,7 +29,7 @@ def _golden_R(g, n):
     return R
 
 
-@pytest.mark.parametrize("nb", [128, 64, 256, 32])
+@pytest.mark.parametrize("nb", [128, 64, 256, 32, 512])
 def test_1184x640_blocked_path_vs_reference_R(qr, oracle, nb):
     m, n = 1184, 640
     g = load_golden("ref_1184x640_f64_64x8")
@@ -79,6 +79,10 @@ np.save(sys.argv[1], O.sign_normalise(F))
     (256, {"MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0"}),
     (128, {"MI355XQR_PANEL": "tsqr"}),                                                # Householder-TSQR leaf only
     (64, {"MI355XQR_LOOKAHEAD": "0"}),                                                # single-stream schedule
+    (512, {}),                                                                        # two-level panels (K = 512 wide update)
+    (512, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_NEXT": "update"}),
+    (512, {"MI355XQR_LOOKAHEAD": "0"}),
+    (128, {"MI355XQR_LEAF": "1"}),                                                    # first-generation CholeskyQR2 leaf
 ])
 def test_2024_square_vs_reference_R_slices(qr, oracle, tmp_path, nb, env):
     """16 (nb = 128) / 8 / 32 outer panels: wide update, look-ahead, CU partition, balance_cols -- against slices of the

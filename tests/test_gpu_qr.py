@@ -74,7 +74,7 @@ SHAPES = [(1, 1), (2, 2), (7, 3), (33, 33), (100, 64), (129, 128), (257, 130), (
 
 
 @pytest.mark.parametrize("m,n", SHAPES)
-@pytest.mark.parametrize("nb,ib", [(128, 32), (32, 8)])
+@pytest.mark.parametrize("nb,ib", [(128, 32), (32, 8), (512, 32)])
 def test_geqrf_applyq_ragged_shapes(qr, oracle, m, n, nb, ib):
     """Edge cases the reference cannot even run (it needs (m-PR)%(PR-PC)==0, n%PC==0): any m >= n."""
     rng = np.random.default_rng(m * 31 + n)
@@ -161,6 +161,51 @@ def test_qr_thin_tsqr_shard_invariance(qr, oracle, m, n, P):
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-13 * n
 
 
+@pytest.mark.parametrize("m,n", [(4096, 256), (999, 40)])
+def test_qr_thin_mgpu_single_device_matches_qr_thin(qr, oracle, m, n):
+    """C-level TSQR entry with ngpu = 1 (no communicator): same factors as qr_thin; ngpu beyond the visible devices is refused."""
+    A = qr.uniform_matrix_host(m, n, seed=12)
+    Q1, R1 = qr.qr_thin(A, nb=32 if n < 128 else 128, nshards=1)
+    Qg, Rg = qr.qr_thin_mgpu(A, nb=32 if n < 128 else 128, ngpu=1)
+    assert rel(oracle.sign_normalise(Rg), oracle.sign_normalise(R1)) < 1e-13
+    assert rel(Qg @ Rg, A) < 1e-13 and np.abs(Qg.T @ Qg - np.eye(n)).max() < 1e-12
+    with pytest.raises(qr.QRError, match="invalid argument"):
+        qr.qr_thin_mgpu(A, ngpu=torch.cuda.device_count() + 1)
+
+
+def test_qr_thin_mgpu_all_visible_devices(qr, oracle):
+    """One host thread per GPU + one RCCL all-gather, on every device of the node (skipped on a 1-GPU box)."""
+    P = torch.cuda.device_count()
+    if P < 2:
+        pytest.skip("needs at least 2 GPUs")
+    m, n = 65536, 256
+    A = qr.uniform_matrix_host(m, n, seed=12)
+    Q1, R1 = qr.qr_thin(A, nb=128, nshards=1)
+    Qg, Rg = qr.qr_thin_mgpu(A, nb=128, ngpu=P)
+    assert rel(oracle.sign_normalise(Rg), oracle.sign_normalise(R1)) < 1e-13
+    assert rel(Qg @ Rg, A) < 1e-13 and np.abs(Qg.T @ Qg - np.eye(n)).max() < 1e-12
+
+
+def test_dropin_mmqr_reuses_its_plan(qr, oracle):
+    """Repeated host-pointer calls on same-sized matrices (the reference harness: qr.cu:776-789) run on a cached plan: the
+    second and third call must not pay plan creation again, and results stay identical."""
+    import time
+    A = oracle.fill_rand(1024, 64)
+    qr.release_cached_plans()
+    outs, times = [], []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        F, tau = qr.mmqr(A)
+        times.append(time.perf_counter() - t0)
+        outs.append((F, tau))
+    for F, tau in outs[1:]:
+        assert np.array_equal(F, outs[0][0]) and np.array_equal(tau, outs[0][1])
+    assert min(times[1:]) < 2e-3, times                 # < 2 ms per call once the plan exists (was ~10 ms every call)
+    qr.release_cached_plans()
+    F2, _ = qr.mmqr(A)
+    assert np.array_equal(F2, outs[0][0])
+
+
 def _device_metrics(qr, p, dA, m, n, seed):
     """||A - QR||_F/||A||_F and ||Q^T Q - I||_F computed on the device for sizes numpy would crawl on."""
     dtau, dQ, dR = zeros(n, 1), zeros(m, n), zeros(n, n)
@@ -193,7 +238,7 @@ def test_c2_4096_square_nb64_properties(qr):
     p.close()
 
 
-@pytest.mark.parametrize("nb", [32, 64, 128, 256])
+@pytest.mark.parametrize("nb", [32, 64, 128, 256, 512])
 def test_c3_16384_square_properties(qr, nb):
     """BASELINE config C3 at full size (16384 x 16384) over its block-size sweep 32/64/128/256: residual < 1e-12
     (north-star), orthogonality.
@@ -261,6 +306,42 @@ def test_c4_c5_full_height_properties(qr, m, n):
     # ||R||_F^2 = ||A||_F^2 = sum of squares of uniform[0,1) entries ~ m*n/3
     assert abs(np.linalg.norm(R) ** 2 / (m * n / 3.0) - 1.0) < 1e-2
     p.close()
+
+
+def test_c5_full_size_single_gpu_and_8_virtual_shards(qr, oracle):
+    """BASELINE config C5 at its FULL size on one GPU: 2 097 152 x 512 (8 GiB, generated in place by the counter hash -- no
+    host copy), (a) factored whole (the P = 1 denominator of the 8-GPU run) with residual and orthogonality
+    computed on the device, and (b) as 8 row shards of 262144 x 512 through the device API with a copy in place of the
+    all-gather: R must be shard-count invariant after sign normalisation."""
+    m, n, P = 2097152, 512, 8
+    ms = m // P
+    dA = zeros(m, n)
+    p1 = qr.Plan(m, n, 128, 32)
+    p1.fill_uniform(dA, m, m, n, seed=12)
+    p1.sync()
+    resid, orth, dR = _device_metrics(qr, p1, dA, m, n, 12)
+    assert resid < 1e-12 and orth < 1e-11
+    R1 = host(dR)
+    assert np.array_equal(np.tril(R1, -1), np.zeros_like(R1))
+    assert abs(np.linalg.norm(R1) ** 2 / (m * n / 3.0) - 1.0) < 1e-2          # ||R||_F^2 = ||A||_F^2 ~ m n / 3
+    p1.close()
+    # (b) 8 shards: rows [s ms, (s+1) ms) of the SAME matrix (regenerated in place), each factored with lda = m
+    ps, p2 = qr.Plan(ms, n, 128, 32), qr.Plan(P * n, n, 128, 32)
+    ps.fill_uniform(dA, m, m, n, seed=12)
+    ps.sync()
+    dS, dtaus, dtau2, dR8 = zeros(P * n, n), zeros(n, P), zeros(n, 1), zeros(n, n)
+    torch.cuda.synchronize()
+    for sh in range(P):
+        sub = dA.data_ptr() + 8 * sh * ms
+        ps.geqrf(sub, ms, n, m, dtaus.data_ptr() + 8 * n * sh)
+        ps.extract_r(sub, ms, n, m, dS.data_ptr() + 8 * n * sh, n, P * n)       # R_s into rows [s n, (s+1) n) of the stack
+    ps.sync()
+    p2.geqrf(dS, P * n, n, P * n, dtau2)
+    p2.extract_r(dS, P * n, n, P * n, dR8, n, n)
+    p2.sync()
+    R8 = host(dR8)
+    assert rel(oracle.sign_normalise(R8), oracle.sign_normalise(R1)) < 1e-13
+    ps.close(); p2.close()
 
 
 def test_c4_virtual_shards_match_single_factorisation(qr, oracle):

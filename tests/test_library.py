@@ -72,6 +72,24 @@ def test_no_cpu_fallback_without_device(qr):
         qr.Plan(64, 32)
 
 
+def test_qr_thin_mgpu_argument_checks(qr):
+    """The C-level multi-GPU TSQR entry: argument errors come before anything touches a device; asking for more
+    GPUs than are visible is QR_E_ARG on a GPU box and QR_E_NODEVICE where there is none."""
+    import torch
+    A = np.random.rand(64, 8)
+    with pytest.raises(qr.QRError, match="invalid argument"):
+        qr.qr_thin_mgpu(A, ngpu=0)
+    with pytest.raises(qr.QRError, match="invalid argument"):
+        qr.qr_thin_mgpu(np.zeros((4, 6)), ngpu=1)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        with pytest.raises(qr.QRError, match="no HIP device"):
+            qr.qr_thin_mgpu(A, ngpu=1)
+    else:
+        with pytest.raises(qr.QRError, match="invalid argument"):
+            qr.qr_thin_mgpu(A, ngpu=ndev + 1)
+
+
 def test_product_never_touches_the_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for dp, _, files in os.walk(os.path.join(root, "cuda-qr_amd")):

@@ -220,33 +220,51 @@ def main():
             measured = qr.probe_mfma_f64_tflops()       # sustained v_mfma_f64_16x16x4_f64 rate of THIS device
         except Exception:
             measured = None
-    traffic = None
-    try:                                                 # PMC pass of the same kernels/shapes, see profiles/README.md
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 counter passes cannot share a process with the
+    # timed region, and crash on CU-masked streams on this pool).  The committed round-2 PMC pass (profiles/r02_pmc_traffic.json,
+    # devtools/scripts_r2_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
+    # ITS algorithmic bytes, and `traffic` itself only when that file was made for this block size; otherwise null.
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
     except Exception:
         tj = None
+    gen = 1 if os.environ.get("MI355XQR_UPDATE") == "1" else 2
+    kname = ("gemm_nt_kernel<true, 0> (trailing update A2 -= V*Wt^T, W kept transposed, direct-to-LDS tiles, v_mfma_f64_16x16x4_f64)"
+             if gen == 2 else "gemm_nn_w8_kernel<0> (trailing update A2 -= V*W, v_mfma_f64_16x16x4_f64)")
     if wl in ("c2", "c3") and upd["launches"]:
         ach = upd["flops"] / (upd["ms"] * 1e-3) / 1e12
-        if tj and wl == "c3" and nb == 256:
-            traffic = (tj.get("gemm_nn_w8_kernel") or {}).get("hbm_bytes_per_launch")
+        if tj and wl == "c3" and nb == tj.get("nb") and gen == 2 and "gemm_nt_kernel" in tj:
+            e = tj["gemm_nt_kernel"]
+            traffic = e["hbm_bytes_per_launch"]
+            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "git_head_of_pass": tj.get("git_head"),
+                           "launch_mix": tj.get("config"),
+                           "algorithmic_bytes_per_launch_same_mix": e["algorithmic_bytes_per_launch"],
+                           "ratio_traffic_to_algorithmic": e["ratio"],
+                           "method": "2*FETCH_SIZE + WRITE_SIZE per dispatch (gfx950 correction, MI355X_MICROARCH.md HBM section), "
+                                     "separate rocprofv3 --pmc passes; replayed from the committed file, not measured in this run"}
+        cus_u = None
+        try:
+            cus_u = int(be.plan.update_cus())
+        except Exception:
+            pass
         roof = {"bound": "mfma",
-                "kernel": "gemm_nn_w8_kernel (trailing update A2 -= V*W, v_mfma_f64_16x16x4_f64)",
+                "kernel": kname,
                 "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_note": ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction) from a separate "
-                                 "rocprofv3 --pmc pass of the same kernel at every 8th C3 step, profiles/r01_pmc_traffic.json"
-                                 if traffic else None),
+                "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "peak_source": "AMD MI355X datasheet fp64 matrix 78.6 TFLOP/s (MI355X_MICROARCH.md has no fp64 MFMA row)",
                 # back-to-back independent v_mfma_f64_16x16x4_f64 (16 accumulators per wave, inline asm) on all CUs
                 "measured_mfma_f64_sustained_tflops": measured["mfma_f64_tflops"] if measured else None,
                 "frac_of_measured_sustained": ach / measured["mfma_f64_tflops"] if measured else None,
-                "cu_partition_note": "with look-ahead the update runs on 192 of 256 CUs (the panel chain owns 64)",
-                "rocprof_pmc": "profiles/r01_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
+                "cu_partition_note": ("with look-ahead the wide update runs on the update stream's compute units "
+                                      "(16384^2: 224 of 256, the panel chain owns one XCD = 32; smaller problems 192 / 64)"),
+                "update_stream_cus": cus_u,
+                "rocprof_pmc": "profiles/r02_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
                 "measured_probe": measured,
                 "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],
                 "algorithmic_flops_per_launch": upd["flops"] / upd["launches"],
                 "algorithmic_bytes_per_launch": upd["bytes"] / upd["launches"],
-                "companion_tn": {"kernel": "gemm_tn_kernel<4, 4, true, 1> + slab_reduce_kernel (W = (V T)^T A2)",
+                "companion_tn": {"kernel": "gemm_tn_kernel<4, 4, true, 1> + slab_reduce_kernel (Wt = A2^T (V T))",
                                  "achieved": tn["flops"] / (tn["ms"] * 1e-3) / 1e12 if tn["ms"] else None,
                                  "launches": tn["launches"]},
                 "panel_ms_per_step": pan["ms"] / K}

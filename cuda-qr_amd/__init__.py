@@ -80,6 +80,7 @@ _sig("qr_copy_to_device", C.c_int, _vp, _vp, C.c_size_t)
 _sig("qr_copy_to_host", C.c_int, _vp, _vp, C.c_size_t)
 _sig("qr_plan_sync", C.c_int, _vp)
 _sig("qr_plan_stream", _vp, _vp)
+_sig("qr_plan_update_cus", C.c_int, _vp)
 _sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)
 _sig("qr_plan_get_profile", C.c_int, _vp, C.POINTER(Profile))
 _sig("qr_plan_get_profile_records", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), _dp, _dp)
@@ -314,6 +315,9 @@ class Plan:
         check(lib.qr_diffnorm_dev(self.h, _dptr(dX), ldx, _dptr(dY), ldy, rows, cols, row_off,
                                   rows if total_rows is None else total_rows, seed, mode, out), "qr_diffnorm_dev")
         return out[0], out[1]
+
+    def update_cus(self):
+        return lib.qr_plan_update_cus(self.h)
 
     def set_profile(self, on):
         check(lib.qr_plan_set_profile(self.h, int(on)), "qr_plan_set_profile")

@@ -16,6 +16,8 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
                 int ldt);
 int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc);
+int qrd_gemm_nn_update2(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                        int ldb, double beta, double* C, int ldc);
 int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap);
 /* second-generation wide update (qr_gemm_nt.hip): W kept transposed, direct-to-LDS tile loads */

@@ -28,6 +28,12 @@
 #define QR_MAX_NB 512           /* outer block (the K of the wide update) */
 #define QR_HALF 256             /* outer blocks wider than this are factored half by half (two-level panel, factor_panel) */
 #define QR_DEFAULT_SPLIT "64"
+/* large square problems are update-bound for most of their flops: one XCD (32 CUs) for the panel chain, seven for the wide
+ * update, and the look-ahead update N(s) on the update stream (it would crawl on 32 CUs).  Measured at 16384^2: the same
+ * 140 ms as 64 / 192, but the update GEMMs run on 224 CUs instead of 192 (50 instead of 43 TFLOP/s per launch); at 8192^2
+ * and below the chain dominates and 64 CUs (two XCDs) are 6 % faster.  CU masks must follow XCD boundaries (32 CUs each):
+ * 48 / 208 leaves the update stream an XCD with half its CUs and costs 15 %. */
+#define QR_DEFAULT_SPLIT_BIG "32"
 #define QR_DEFAULT_PANEL 3
 struct qr_plan {
     int m, n, nb, ib, ldv, ldt;
@@ -47,10 +53,12 @@ struct qr_plan {
     void* ev_hop[2];
     void* ev_extra[2];          /* panel-stream share of wide update s finished */
     double *We, *Ye;            /* its W buffer and raw V^T A2 */
+    double *Ye2;                /* raw V^T A2 of a wide update that applies T to the small product (tall-skinny plans) */
     double *Yn;                 /* raw V^T A_next of the look-ahead update */
     double bal_rp, bal_ru, bal_tc0, bal_tc1;   /* load-balance model (TFLOP/s, ms); bal_rp = 0: off */
     void* ev_half[2];           /* W_a(s): the wide update has finished the columns of panel s+1 that N(s) left out (its second half) */
     void* ev_next[2];           /* look-ahead update N(s) of the next panel's columns finished (when it runs on the update stream) */
+    int update_gen;             /* wide update kernels: 1 = gemm_tn<4,4> + gemm_nn_w8 (W), 2 = gemm_tn<4,4> + gemm_nt (W transposed, direct-to-LDS) */
     int next_on_update;         /* 1: N(s) runs on the update stream's CUs, ahead of W(s); 0: on the panel stream; 2: on the panel
                                  * stream while the factorisation is update-bound, on the update stream once it is chain-bound */
     void* ev_panel[2];          /* panel set s ready (V, T, VT) */
@@ -193,7 +201,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         char spec[128];
         if (sp) snprintf(spec, sizeof spec, "%s", sp);
         else if (pc) snprintf(spec, sizeof spec, "%s", pc);
-        else snprintf(spec, sizeof spec, "%s", n >= 2048 ? QR_DEFAULT_SPLIT : "0");
+        else snprintf(spec, sizeof spec, "%s", n >= 2048 ? ((m >= 12288 && n >= 12288) ? QR_DEFAULT_SPLIT_BIG : QR_DEFAULT_SPLIT) : "0");
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
         char* save = NULL;
@@ -222,8 +230,11 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         /* MI355XQR_NEXT=panel|update|auto: which stream applies panel s to the columns of panel s+1 (the look-ahead update
          * N(s)).  On the update stream it is a 60 us job for 190+ CUs instead of a 180 us one for the panel stream's few --
          * but while the update stream is busy back to back it would only delay W(s); auto (default) switches with the phase. */
+        const char* ug = getenv("MI355XQR_UPDATE");
+        p->update_gen = (ug && atoi(ug) == 1) ? 1 : 2;
         const char* nx = getenv("MI355XQR_NEXT");
         p->next_on_update = !nx ? 2 : (strcmp(nx, "update") == 0 ? 1 : (strcmp(nx, "panel") == 0 ? 0 : 2));   /* 2 = by phase */
+        if (!nx && p->npairs && qrd_stream_cus(p->s_pair[0][0]) <= 32) p->next_on_update = 1;
     }
     {
         /* MI355XQR_BALANCE = "Rp,Ru,tc0,tc1" (TFLOP/s on the panel CUs, on the update CUs; next-panel chain time
@@ -263,6 +274,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     if (!rc && p->npairs && p->bal_rp > 0.0) rc = qrd_malloc((void**) &p->We, sizeof(double) * p->w_cap);
     if (!rc && p->We) rc = qrd_malloc((void**) &p->Ye, sizeof(double) * p->w_cap);
     if (!rc) rc = qrd_malloc((void**) &p->Yn, sizeof(double) * (size_t) nb * nb);
+    if (!rc && (size_t) n * 8 <= (size_t) m) rc = qrd_malloc((void**) &p->Ye2, sizeof(double) * p->w_cap);
     if (!rc) rc = qrd_malloc((void**) &p->slabs_u, sizeof(double) * p->slab_cap);
     if (!rc) rc = qrd_malloc((void**) &p->Tt, sizeof(double) * (size_t) nb * nb);
     if (!rc) rc = qrd_malloc((void**) &p->G, sizeof(double) * (size_t) nb * nb);
@@ -292,7 +304,7 @@ int qr_plan_destroy(qr_plan* p)
         if (p->ev_wide[e]) qrd_event_destroy(p->ev_wide[e]);
         qrd_free(p->Vw2[e]); qrd_free(p->VT2[e]); qrd_free(p->T2[e]);
     }
-    qrd_free(p->Wn); qrd_free(p->slabs_u); qrd_free(p->We); qrd_free(p->Ye); qrd_free(p->Yn);
+    qrd_free(p->Wn); qrd_free(p->slabs_u); qrd_free(p->We); qrd_free(p->Ye); qrd_free(p->Yn); qrd_free(p->Ye2);
     for (int i = 0; i < p->npairs; ++i)
         for (int j = 0; j < 2; ++j)
             if (p->s_pair[i][j]) qrd_stream_destroy(p->s_pair[i][j]);
@@ -323,6 +335,16 @@ int qr_plan_sync(qr_plan* p)
     return p->s_main ? qrd_stream_sync(p->s_main) : 0;
 }
 void* qr_plan_stream(qr_plan* p) { return p ? p->s_main : NULL; }
+
+/* compute units the wide trailing update runs on (the update stream's share of the CU partition, or the whole device) */
+int qr_plan_update_cus(qr_plan* p)
+{
+    if (!p) return QR_E_ARG;
+    if (p->npairs) return qrd_stream_cus(p->s_pair[0][1]);
+    int cus = 0;
+    if (qrd_device_info(NULL, 0, &cus, NULL, NULL)) return QR_E_INTERNAL;
+    return cus;
+}
 
 static int ensure_w(qr_plan* p, size_t elems)
 {
@@ -521,6 +543,9 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
 {
     CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Ybuf, kw, slabs, p->slab_cap, NULL, 0));
     CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
+    /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
+     * it hands anything it cannot take (ragged, unaligned) to the generic path itself */
+    if (mk >= 2048 && nc >= 128) return qrd_gemm_nn_update2(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
     return qrd_gemm_nn(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
 }
 
@@ -536,6 +561,30 @@ static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int
     double* A2 = dA + (size_t) c0 * lda + k;
     const int ldv = p->ldv;
     if (nc <= 0) return 0;
+    if (profile == 1 && (size_t) nc * 8 <= (size_t) mk && (Ybuf || p->Ye2)) {
+        /* tall-skinny: forming V*T (mk x wout, 16 mk wout bytes, 2 mk wout^2 flops) would cost more than the few columns it is
+         * applied to; apply T to the small product instead (262144 x 512: 1.1 GB less HBM traffic per factorisation) */
+        CHECK(prof_begin_on(p, 3, stream));
+        CHECK(apply_small_t(p, stream, p->Vw2[e], ldv, p->T2[e], p->ldt, mk, wout, A2, lda, nc, Wbuf, Ybuf ? Ybuf : p->Ye2, slabs));
+        CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
+        return 0;
+    }
+    if (profile == 1 && p->update_gen == 2 && qrd_gemm_nt_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda)) {
+        /* second-generation wide update: W kept transposed (Wt = A2^T (V T), nc x wout), so that both operands of
+         * A2 -= V Wt^T are row-fast and go HBM -> LDS directly (qr_gemm_nt.hip) */
+        if (form_vt) {
+            CHECK(prof_begin_on(p, 3, stream));
+            CHECK(qrd_gemm_nn(stream, mk, wout, wout, 1.0, p->Vw2[e], ldv, p->T2[e], p->ldt, 0.0, p->VT2[e], ldv));
+            CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+        }
+        CHECK(prof_begin_on(p, 1, stream));
+        CHECK(qrd_gemm_tn_update(stream, nc, wout, mk, 1.0, A2, lda, p->VT2[e], ldv, 0.0, Wbuf, nc, slabs, p->slab_cap));
+        CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 8.0 * mk * ((double) nc + wout)));
+        CHECK(prof_begin_on(p, 0, stream));
+        CHECK(qrd_gemm_nt(stream, mk, nc, wout, -1, p->Vw2[e], ldv, Wbuf, nc, A2, lda, -1, NULL));
+        CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 16.0 * mk * (double) nc + 8.0 * mk * wout));
+        return 0;
+    }
     if (profile == 1) {
         const int tagged = wout >= 128 && nc >= 128;
         if (form_vt) {

@@ -280,6 +280,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_batch_kernel(int M, int N, int
 // 128 KiB write of C, and two waves per SIMD left the MFMA pipe idle 35 % of the time (rocprofv3 MfmaUtil 65 %).
 // Tile-aligned interior only (M % 128 == N % 128 == K % 16 == 0 parts, 16-byte aligned operands), C += alpha*A*B.
 // ------------------------------------------------------------------------------------------------
+// TAG only names the launch for profilers: 0 = the wide trailing update (the kernel bench.py's roofline is quoted on),
+// 1 = every other use (look-ahead / mid-panel updates), so that rocprofv3's per-kernel average is the wide update's alone.
+template <int TAG>
 __global__ __launch_bounds__(512, 4) void gemm_nn_w8_kernel(int M, int N, int K, double alpha,
                                                             const double* __restrict__ A, int lda,
                                                             const double* __restrict__ B, int ldb,
@@ -379,13 +382,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 // short dependency chains even for hundreds of slabs.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(int M, int N, int nslab, const double* __restrict__ slabs, int lds,
                                                           size_t slab_stride, const double* __restrict__ Tm, int ldt,
-                                                          double beta, double* __restrict__ out, int ldo)
+                                                          double beta, double* __restrict__ out, int ldo, int chunk)
 {
     __shared__ double red[256];
     __shared__ double col[256];
     const int j = blockIdx.x, tid = threadIdx.x;
-    // rows [i0, i0 + Mc) of the column: one 256-row chunk per blockIdx.y when M > 256 (then nz = 1, no Tm)
-    const int i0 = blockIdx.y * 256, Mc = min(256, M - i0);
+    // rows [i0, i0 + Mc) of the column: one `chunk`-row piece per blockIdx.y (chunk = 256, or 32 / 64 for reductions over many
+    // slabs: the 256 threads then split the slab index 8 / 4 ways instead of walking hundreds of slabs one after the other; no Tm then)
+    const int i0 = blockIdx.y * chunk, Mc = min(chunk, M - i0);
     const int Mp = (Mc + 31) & ~31, nz = 256 / Mp;
     const int i = tid % Mp, zp = tid / Mp;
     double s = 0.0;
@@ -853,7 +857,8 @@ int qrd_init(void)
     int rc = 0;
     rc |= allow_lds(gemm_nn_kernel<4, 4, true>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, true, 1>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
-    rc |= allow_lds(gemm_nn_w8_kernel, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
+    rc |= allow_lds(gemm_nn_w8_kernel<0>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
+    rc |= allow_lds(gemm_nn_w8_kernel<1>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
@@ -872,8 +877,24 @@ static int nn_waves(void)
     return v;
 }
 
+static int gemm_nn_update_impl(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                               int ldb, double beta, double* C, int ldc, int tag);
+
 int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc)
+{
+    return gemm_nn_update_impl(stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0);
+}
+
+// the same 8-wave kernel for tall C -= A*B products outside the wide update (look-ahead / mid-panel updates)
+int qrd_gemm_nn_update2(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                        int ldb, double beta, double* C, int ldc)
+{
+    return gemm_nn_update_impl(stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 1);
+}
+
+static int gemm_nn_update_impl(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                               int ldb, double beta, double* C, int ldc, int tag)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t) stream;
@@ -882,7 +903,10 @@ int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const do
     if (nn_waves() != 8 || beta != 1.0 || (alpha != 1.0 && alpha != -1.0) || !al || Mi == 0 || Ni == 0)
         return launch_nn<4, 4, 1>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
     const size_t shm = sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF);
-    hipLaunchKernelGGL(gemm_nn_w8_kernel, dim3(Mi / 128, Ni / 128), dim3(512), shm, s, Mi, Ni, K, alpha, A, lda, B, ldb, C, ldc);
+    if (tag == 0)
+        hipLaunchKernelGGL(gemm_nn_w8_kernel<0>, dim3(Mi / 128, Ni / 128), dim3(512), shm, s, Mi, Ni, K, alpha, A, lda, B, ldb, C, ldc);
+    else
+        hipLaunchKernelGGL(gemm_nn_w8_kernel<1>, dim3(Mi / 128, Ni / 128), dim3(512), shm, s, Mi, Ni, K, alpha, A, lda, B, ldb, C, ldc);
     int rc = (int) hipGetLastError();
     if (!rc && Ni < N)      /* right strip: all rows, columns [Ni, N) */
         rc = launch_nn1<4, 4, false>(s, M, N - Ni, K, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta, C + (size_t) Ni * ldc, ldc);
@@ -951,7 +975,7 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
 int qrd_slab_reduce(void* stream, int M, int N, int nslab, const double* slabs, int lds, size_t stride, double* out, int ldo)
 {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, (M + 255) / 256), dim3(256), 0, (hipStream_t) stream, M, N, nslab, slabs, lds, stride,
-                       (const double*) nullptr, 0, 0.0, out, ldo);
+                       (const double*) nullptr, 0, 0.0, out, ldo, 256);
     return (int) hipGetLastError();
 }
 
@@ -1012,8 +1036,11 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     else rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     if (rc) return rc;
     if (!direct) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, (M + 255) / 256), dim3(256), 0, s, M, N, ksplit, slabs, M, per, Tm, ldt,
-                           beta, C, ldc);
+        // many slabs (tall-skinny products): shorter row pieces per workgroup, so that more threads share the slab index
+        int piece = 256;
+        if (Tm == nullptr && ksplit >= 32 && M >= 64) piece = ksplit >= 128 ? 32 : 64;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, (M + piece - 1) / piece), dim3(256), 0, s, M, N, ksplit, slabs, M, per, Tm, ldt,
+                           beta, C, ldc, piece);
         rc = (int) hipGetLastError();
     }
     return rc;

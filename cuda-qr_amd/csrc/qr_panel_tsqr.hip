@@ -1019,24 +1019,25 @@ __device__ __forceinline__ v2d slab_sum2(const double* __restrict__ slabs, int n
 }
 
 #define CQ2_MAXSLAB 32
-#define CQ2_HALF 256
-#define CQ2_LDQ (CQ2_HALF + 2)
-#define CQ2_LDS_DOUBLES (PW * CQ2_LDQ + 2 * PW * (PW + 1) + PW + 8)
+#define CQ2_LDS_DOUBLES(HALF) (PW * ((HALF) + 2) + 2 * PW * (PW + 1) + PW + 8)
 
-template <bool FULL>
-__global__ __launch_bounds__(PT) void cholq2_kernel(const double* __restrict__ P, int ld, int mk, int w,
+// NT rows per workgroup (one per thread), staged HALF at a time for the Gram.  <512, 256>: short leaves (few, fat workgroups);
+// <256, 128>: tall leaves -- 50 KB of LDS and one wave per SIMD, so three workgroups share a compute unit and hide each
+// other's serial phases (the one-wave Cholesky, the barriers), which is what a bandwidth-bound pass over 64 MB needs.
+template <bool FULL, int NT, int HALF>
+__global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P, int ld, int mk, int w,
                                                     const double* __restrict__ gslabs, int nslab, double* __restrict__ R1,
                                                     double* __restrict__ Vw, int ldv, double* __restrict__ slab2,
                                                     int* __restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) double cq_smem[];
-    double* Qs = cq_smem;                                                    // [PW][CQ2_LDQ]; later 8 partial Grams [8][PW*PW]
-    double (*Gs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * CQ2_LDQ);
-    double (*Rs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * CQ2_LDQ + PW * (PW + 1));
-    double* rinv = cq_smem + PW * CQ2_LDQ + 2 * PW * (PW + 1);
+    double* Qs = cq_smem;                                                    // [PW][(HALF + 2)]; later 8 partial Grams [8][PW*PW]
+    double (*Gs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * (HALF + 2));
+    double (*Rs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * (HALF + 2) + PW * (PW + 1));
+    double* rinv = cq_smem + PW * (HALF + 2) + 2 * PW * (PW + 1);
     int* okf = reinterpret_cast<int*>(rinv + PW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-    const int r = b * PT + tid;
+    const int r = b * NT + tid;
     double a[PW];
     {
         const double* p = P + min(r, mk - 1);
@@ -1044,9 +1045,9 @@ __global__ __launch_bounds__(PT) void cholq2_kernel(const double* __restrict__ P
         for (int c = 0; c < PW; ++c) a[c] = (FULL || c < w) ? p[(size_t) c * ld] : 0.0;      // in flight under the Gram sum
     }
     // G1 = sum of the slabs (fixed order; every workgroup forms the same bits).  Stored column-major, ld PW.
-    {
-        const v2d gsum = slab_sum2(gslabs, nslab, tid);                       // elements 2 tid, 2 tid + 1
-        const int e = 2 * tid;
+    for (int t2 = tid; t2 < PW * PW / 2; t2 += NT) {
+        const v2d gsum = slab_sum2(gslabs, nslab, t2);                        // elements 2 t2, 2 t2 + 1
+        const int e = 2 * t2;
         Gs[e / PW][e % PW] = gsum[0];                                         // Gs[j][i] = G(i, j)
         Gs[e / PW][e % PW + 1] = gsum[1];
     }
@@ -1100,16 +1101,16 @@ __global__ __launch_bounds__(PT) void cholq2_kernel(const double* __restrict__ P
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int h = 0; h < PT / CQ2_HALF; ++h) {
-        if ((tid >> 8) == h) {
+    for (int h = 0; h < NT / HALF; ++h) {
+        if (tid / HALF == h) {
 #pragma unroll
-            for (int c = 0; c < PW; ++c) Qs[c * CQ2_LDQ + (tid & (CQ2_HALF - 1))] = live ? q[c] : 0.0;
+            for (int c = 0; c < PW; ++c) Qs[c * (HALF + 2) + (tid & (HALF - 1))] = live ? q[c] : 0.0;
         }
         __syncthreads();
         const double* base = Qs + 32 * wave + l4;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const double f0 = base[l15 * CQ2_LDQ + 4 * ks], f1 = base[(16 + l15) * CQ2_LDQ + 4 * ks];
+            const double f0 = base[l15 * (HALF + 2) + 4 * ks], f1 = base[(16 + l15) * (HALF + 2) + 4 * ks];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, acc[1][0], 0, 0, 0);
@@ -1126,10 +1127,10 @@ __global__ __launch_bounds__(PT) void cholq2_kernel(const double* __restrict__ P
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) red[(16 * tj + l15) * PW + 16 * ti + l4 + 4 * rr] = acc[ti][tj][rr];
     __syncthreads();
-    for (int e = tid; e < PW * PW; e += PT) {
+    for (int e = tid; e < PW * PW; e += NT) {
         double s = 0.0;
 #pragma unroll
-        for (int v = 0; v < PT / 64; ++v) s += Qs[v * PW * PW + e];
+        for (int v = 0; v < NT / 64; ++v) s += Qs[v * PW * PW + e];
         slab2[(size_t) b * PW * PW + e] = s;
     }
 }
@@ -1501,8 +1502,10 @@ static int leaf_gen(void)
 
 int qrd_panel_tsqr_init(void)
 {
-    int rc = (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) (CQ2_LDS_DOUBLES * sizeof(double)));
+    int rc = (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 512, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
     return rc;
 }
 
@@ -1522,28 +1525,31 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
     const bool al = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && (ld % 2 == 0) && (mk % 2 == 0) &&
                     ((reinterpret_cast<uintptr_t>(Vw) & 15) == 0) && (ldv % 2 == 0);
     int rc;
-    if (leaf_gen() == 2 && al && slab_cap >= (size_t) (CQ2_MAXSLAB + nblk) * PW * PW) {
+    if (leaf_gen() == 2 && al && slab_cap >= (size_t) (CQ2_MAXSLAB + 2 * nblk) * PW * PW) {
         double* slab2 = slabs + (size_t) CQ2_MAXSLAB * PW * PW;
+        int nblk2 = nblk;                                   // workgroups of cholq2_kernel = slabs of G2
         if (nblk <= CQ2_MAXSLAB) {
             // short leaf (square problems): at most CQ2_MAXSLAB Gram slabs of >= 128 rows, summed by their consumers
             int rows_per = ((mk + CQ2_MAXSLAB - 1) / CQ2_MAXSLAB + GKB - 1) / GKB * GKB;
             if (rows_per < 2 * GKB) rows_per = 2 * GKB;
             const int nslab = (mk + rows_per - 1) / rows_per;
             hipLaunchKernelGGL(gram32_kernel, dim3(nslab), dim3(256), 0, s, P, ld, mk, rows_per, slabs);
-            hipLaunchKernelGGL(cholq2_kernel<true>, dim3(nblk), dim3(PT), CQ2_LDS_DOUBLES * sizeof(double), s, P, ld, mk, w, slabs, nslab,
-                               R1, Vw, ldv, slab2, guard);
+            hipLaunchKernelGGL((cholq2_kernel<true, 512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk, w,
+                               slabs, nslab, R1, Vw, ldv, slab2, guard);
         } else {
-            // tall leaf: the Gram pass needs hundreds of workgroups to reach HBM bandwidth, so its slabs go through a reduce launch
-            rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk * PW * PW);      // the tail of the buffer holds slab2
+            // tall leaf: the Gram pass needs hundreds of workgroups to reach HBM bandwidth, so its slabs go through a reduce launch;
+            // 256-row workgroups, three to a compute unit
+            nblk2 = (mk + 255) / 256;
+            rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
             if (rc) return rc;
-            slab2 = slabs + (slab_cap - (size_t) nblk * PW * PW);
-            hipLaunchKernelGGL(cholq2_kernel<true>, dim3(nblk), dim3(PT), CQ2_LDS_DOUBLES * sizeof(double), s, P, ld, mk, w, G1, 1,
-                               R1, Vw, ldv, slab2, guard);
+            slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
+            hipLaunchKernelGGL((cholq2_kernel<true, 256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
+                               G1, 1, R1, Vw, ldv, slab2, guard);
         }
-        if (nblk <= 2 * CQ2_MAXSLAB) {
-            hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+        if (nblk2 <= 2 * CQ2_MAXSLAB) {
+            hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk2, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
         } else {           // tall leaf: hundreds of partial Grams are summed by a grid, not by the one reconstruction workgroup
-            rc = qrd_slab_reduce(s, PW, PW, nblk, slab2, PW, (size_t) PW * PW, G2, PW);
+            rc = qrd_slab_reduce(s, PW, PW, nblk2, slab2, PW, (size_t) PW * PW, G2, PW);
             if (rc) return rc;
             hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
         }

@@ -144,6 +144,7 @@ int qr_copy_to_host(void* dst, const void* src, size_t bytes);
 
 int qr_plan_sync(qr_plan* plan);
 void* qr_plan_stream(qr_plan* plan);          /* the hipStream_t work is queued on */
+int qr_plan_update_cus(qr_plan* plan);        /* compute units the wide trailing update runs on (its share of the CU partition) */
 
 /* Per-kernel-class timing with HIP events recorded on the plan's stream inside the timed region.
  * class 0 = trailing update A2 -= V*W (gemm_nn), 1 = W = (V T)^T A2 (gemm_tn + slab reduce),

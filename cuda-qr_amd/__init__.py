@@ -60,6 +60,9 @@ _sig("qr_strerror", C.c_char_p, C.c_int)
 _sig("qr_set_block_size", C.c_int, C.c_int, C.c_int)
 _sig("qr_get_block_size", None, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("qr_thin", C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int)
+_fp = C.POINTER(C.c_float)
+_sig("mmqr_f32_status", C.c_int, _fp, C.POINTER(_fp), C.c_int, C.c_int)
+_sig("explicitQR_f32_status", C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int)
 _sig("qr_thin_mgpu", C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int)
 _sig("qr_release_cached_plans", C.c_int)
 _sig("qr_plan_create", C.c_int, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int)
@@ -201,6 +204,30 @@ def qr_thin(A, nb=0, nshards=1):
     Q = np.empty((m, n), order="F")
     R = np.empty((n, n), order="F")
     check(lib.qr_thin(_p(A), m, n, _p(Q), _p(R), nb, nshards), "qr_thin")
+    return Q, R
+
+
+def mmqr_f32(A):
+    """Float instantiation of mmqr (reference Scalar = float, qr.c:11): returns (factored float matrix, float tau)."""
+    F = np.asfortranarray(A, dtype=np.float32).copy(order="F")
+    m, n = F.shape
+    tau = _fp()
+    check(lib.mmqr_f32_status(F.ctypes.data_as(_fp), C.byref(tau), m, n), "mmqr_f32")
+    rp, cp = get_panel_dims(m, n)
+    nb = 256 if (m >= 8192 and n >= 8192) else get_block_size()[0]
+    t = np.ctypeslib.as_array(tau, shape=(rp * cp * nb,)).copy()
+    _libc.free(C.cast(tau, C.c_void_p))
+    return F, t
+
+
+def explicit_qr_f32(F, tau):
+    F = np.asfortranarray(F, dtype=np.float32)
+    m, n = F.shape
+    t = np.ascontiguousarray(tau, dtype=np.float32)
+    Q = np.empty((m, m), dtype=np.float32, order="F")
+    R = np.empty((m, n), dtype=np.float32, order="F")
+    check(lib.explicitQR_f32_status(F.ctypes.data_as(_fp), t.ctypes.data_as(_fp), Q.ctypes.data_as(_fp), R.ctypes.data_as(_fp), m, n),
+          "explicitQR_f32")
     return Q, R
 
 

@@ -545,7 +545,9 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
     CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
     /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
      * it hands anything it cannot take (ragged, unaligned) to the generic path itself */
-    if (mk >= 2048 && nc >= 128) return qrd_gemm_nn_update2(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
+    static int use_w8 = -1;
+    if (use_w8 < 0) { const char* e = getenv("MI355XQR_SMALLT_W8"); use_w8 = e ? atoi(e) : 1; }
+    if (use_w8 && mk >= 2048 && nc >= 128) return qrd_gemm_nn_update2(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
     return qrd_gemm_nn(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
 }
 
@@ -577,12 +579,31 @@ static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int
             CHECK(qrd_gemm_nn(stream, mk, wout, wout, 1.0, p->Vw2[e], ldv, p->T2[e], p->ldt, 0.0, p->VT2[e], ldv));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
         }
-        CHECK(prof_begin_on(p, 1, stream));
-        CHECK(qrd_gemm_tn_update(stream, nc, wout, mk, 1.0, A2, lda, p->VT2[e], ldv, 0.0, Wbuf, nc, slabs, p->slab_cap));
-        CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 8.0 * mk * ((double) nc + wout)));
-        CHECK(prof_begin_on(p, 0, stream));
-        CHECK(qrd_gemm_nt(stream, mk, nc, wout, -1, p->Vw2[e], ldv, Wbuf, nc, A2, lda, -1, NULL));
-        CHECK(prof_end(p, 2.0 * mk * (double) nc * wout, 16.0 * mk * (double) nc + 8.0 * mk * wout));
+        /* MI355XQR_CHUNK_MB > 0: the update walks A2 in column chunks of about that many MB, product and update of a chunk back
+         * to back, so that the update's read of the chunk is served by the 256 MB Infinity Cache instead of HBM */
+        static int chunk_mb = -1;
+        if (chunk_mb < 0) { const char* ce = getenv("MI355XQR_CHUNK_MB"); chunk_mb = ce ? atoi(ce) : 0; }
+        int cw = nc;
+        if (chunk_mb > 0) {
+            const int cus = qrd_stream_cus(stream), slots = 2 * cus, rt = mk / 128;
+            long long want = (long long) chunk_mb * 1000000 / ((long long) mk * 8);          /* columns */
+            /* whole rounds of workgroups: tiles = rt * (cw / 128) = k * slots */
+            long long k = (want / 128) * rt / slots;
+            if (k < 1) k = 1;
+            cw = (int) ((k * slots + rt - 1) / rt) * 128;
+            if (cw < 128) cw = 128;
+            if (cw > nc) cw = nc;
+        }
+        for (int c = 0; c < nc; c += cw) {
+            const int w1 = imin(cw, nc - c);
+            double* A2c = A2 + (size_t) c * lda;
+            CHECK(prof_begin_on(p, 1, stream));
+            CHECK(qrd_gemm_tn_update(stream, w1, wout, mk, 1.0, A2c, lda, p->VT2[e], ldv, 0.0, Wbuf, w1, slabs, p->slab_cap));
+            CHECK(prof_end(p, 2.0 * mk * (double) w1 * wout, 8.0 * mk * ((double) w1 + wout)));
+            CHECK(prof_begin_on(p, 0, stream));
+            CHECK(qrd_gemm_nt(stream, mk, w1, wout, -1, p->Vw2[e], ldv, Wbuf, w1, A2c, lda, -1, NULL));
+            CHECK(prof_end(p, 2.0 * mk * (double) w1 * wout, 16.0 * mk * (double) w1 + 8.0 * mk * wout));
+        }
         return 0;
     }
     if (profile == 1) {
@@ -1062,6 +1083,57 @@ int dgemm_status(double* A, double* B, double* C, int k, int m, int n)
     return rc;
 }
 
+/* ---- float instantiation of the drop-in symbols (the reference as committed has Scalar = float, qr.c:11) ----
+ * Same semantics on float arrays.  The arithmetic is the fp64 path: inputs are widened, results rounded once on the way out, so
+ * a float caller gets results at least as accurate as a float build of the reference (whose 6 x 4 self-test prints a residual
+ * of 3.8e-07, qr.c:505-515).  fp32 MFMA kernels would double the rate; not built (no consumer). */
+static double* widen(const float* x, size_t n)
+{
+    double* d = (double*) malloc(sizeof(double) * (n ? n : 1));
+    if (d) for (size_t i = 0; i < n; ++i) d[i] = (double) x[i];
+    return d;
+}
+
+int mmqr_f32_status(float* mat, float** tau, int m, int n)
+{
+    if (!mat || !tau || n < 1 || m < n) return QR_E_ARG;
+    const size_t cnt = (size_t) m * n;
+    double* d = widen(mat, cnt);
+    if (!d) return QR_E_ALLOC;
+    double* dt = NULL;
+    int rc = mmqr_status(d, &dt, m, n);
+    if (!rc) {
+        int rp, cp, nb = 128;
+        getPanelDims(m, n, &rp, &cp);
+        default_blocks(m, n, &nb, NULL);
+        const size_t nt = (size_t) rp * cp * nb;
+        float* ft = (float*) calloc(nt, sizeof(float));
+        if (!ft) rc = QR_E_ALLOC;
+        else {
+            for (size_t i = 0; i < nt; ++i) ft[i] = (float) dt[i];
+            for (size_t i = 0; i < cnt; ++i) mat[i] = (float) d[i];
+            *tau = ft;
+        }
+    }
+    free(dt); free(d);
+    return rc;
+}
+
+int explicitQR_f32_status(float* A, float* tau, float* Q, float* R, int m, int n)
+{
+    if (!A || !tau || !Q || !R || n < 1 || m < n) return QR_E_ARG;
+    const size_t an = (size_t) m * n, qn = (size_t) m * m;
+    double *dA = widen(A, an), *dt = widen(tau, (size_t) n);
+    double *dQ = (double*) malloc(sizeof(double) * qn), *dR = (double*) malloc(sizeof(double) * an);
+    int rc = (dA && dt && dQ && dR) ? explicitQR_status(dA, dt, dQ, dR, m, n) : QR_E_ALLOC;
+    if (!rc) {
+        for (size_t i = 0; i < qn; ++i) Q[i] = (float) dQ[i];
+        for (size_t i = 0; i < an; ++i) R[i] = (float) dR[i];
+    }
+    free(dA); free(dt); free(dQ); free(dR);
+    return rc;
+}
+
 static void complain(const char* fn, int rc)
 {
     if (rc) fprintf(stderr, "mi355xqr: %s failed: %s (%d)\n", fn, qr_strerror(rc), rc);
@@ -1071,6 +1143,9 @@ void mmqr(double* mat, double** tau, int m, int n) { complain("mmqr", mmqr_statu
 void explicitQR(double* A, double* tau, double* Q, double* R, int m, int n)
 { complain("explicitQR", explicitQR_status(A, tau, Q, R, m, n)); }
 void dgemm(double* A, double* B, double* C, int k, int m, int n) { complain("dgemm", dgemm_status(A, B, C, k, m, n)); }
+void mmqr_f32(float* mat, float** tau, int m, int n) { complain("mmqr_f32", mmqr_f32_status(mat, tau, m, n)); }
+void explicitQR_f32(float* A, float* tau, float* Q, float* R, int m, int n)
+{ complain("explicitQR_f32", explicitQR_f32_status(A, tau, Q, R, m, n)); }
 
 void identity(double* A, int m)
 {

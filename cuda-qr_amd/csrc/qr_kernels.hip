@@ -927,6 +927,11 @@ int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A
     if (alpha == 0.0 && beta == 1.0) return 0;      // C unchanged (and no 0 * inf from the C/alpha shortcut)
     // tile choice: big square tiles when the grid still fills the chip, smaller otherwise
     const long long t44 = (long long) ((M + 127) / 128) * ((N + 127) / 128);
+    {
+        static int tall_tile = -1;
+        if (tall_tile < 0) { const char* e = getenv("MI355XQR_NN_TALL_TILE"); tall_tile = e ? atoi(e) : 44; }
+        if (tall_tile == 22 && M >= 65536 && N <= 512 && N > 32) return launch_nn<2, 2>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    }
     if (N > 64 && M > 64 && t44 >= 192) return launch_nn<4, 4>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
     if (N <= 32) {
         if (M >= 128 * 96) return launch_nn<4, 1>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
@@ -998,6 +1003,11 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     else if (shortk && (long long) ((M + 31) / 32) * ((N + 31) / 32) <= 1024) { ti = 1; tj = 1; }
     else if (M <= 64 || N <= 64 || (shortk && (long long) ((M + 63) / 64) * ((N + 63) / 64) <= 2048)) { ti = 2; tj = 2; }
     else { ti = 4; tj = 4; }
+    {
+        static int tall_tile = -1;
+        if (tall_tile < 0) { const char* e = getenv("MI355XQR_TN_TALL_TILE"); tall_tile = e ? atoi(e) : 44; }
+        if (ti == 4 && tall_tile == 22 && K >= 65536 && (long long) M * N <= 512 * 512) { ti = 2; tj = 2; }
+    }
     const int BM = 32 * ti, BN = 32 * tj;
     const long long tiles = (long long) ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t per = (size_t) M * N;
@@ -1006,7 +1016,9 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     // overhead in K rows and reduce(k) the slab traffic of slab_reduce_kernel.  (The old rule aimed at 512 workgroups
     // whatever the stream: 624 workgroups on the 192-CU update stream = 1.6 rounds.)
     long long kmax = (K + 8 * BK - 1) / (8 * BK);             // each K slice at least 8 k-tiles long
-    if (kmax > 256) kmax = 256;
+    static int kcap = 0;
+    if (!kcap) { const char* e = getenv("MI355XQR_TN_KMAX"); kcap = e ? atoi(e) : 256; if (kcap < 1) kcap = 256; }
+    if (kmax > kcap) kmax = kcap;
     if (slabs == nullptr || slab_cap < per) kmax = 1;
     else if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
     if (kmax < 1 || shortk) kmax = 1;

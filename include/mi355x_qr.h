@@ -57,6 +57,16 @@ int mmqr_status(double* mat, double** tau, int m, int n);
 int explicitQR_status(double* A, double* tau, double* Q, double* R, int m, int n);
 int dgemm_status(double* A, double* B, double* C, int k, int m, int n);
 
+/* Float instantiation (the reference as committed has Scalar = float, qr.c:11): mmqr / explicitQR on float
+ * arrays with the same layouts and ownership rules.  The arithmetic is fp64 on the device (inputs widened, outputs rounded
+ * once), so the results are at least as accurate as a float build of the reference.  The reference's window-indexed tau
+ * layout (qr.c:300-304) is NOT reproduced in either precision: it describes the reflectors of its sliding-window algorithm
+ * and cannot be derived from a different reflector set. */
+void mmqr_f32(float* mat, float** tau, int m, int n);
+void explicitQR_f32(float* A, float* tau, float* Q, float* R, int m, int n);
+int mmqr_f32_status(float* mat, float** tau, int m, int n);
+int explicitQR_f32_status(float* A, float* tau, float* Q, float* R, int m, int n);
+
 #define QR_E_ARG      (-101)  /* bad argument (null pointer, m < n, non-positive size) */
 #define QR_E_ALLOC    (-102)  /* host allocation failed */
 #define QR_E_NODEVICE (-103)  /* no HIP device visible: there is NO CPU fallback */

@@ -16,7 +16,7 @@ for (mk, w) in shapes:
     tau = torch.zeros(w, dtype=torch.float64, device="cuda"); Tm = torch.zeros((w, w), dtype=torch.float64, device="cuda")
     V = torch.zeros((w, mk), dtype=torch.float64, device="cuda")
     ws = torch.zeros(int(lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
-    cws = torch.zeros(4 * 32 * 32 + 16, dtype=torch.float64, device="cuda"); slabs = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+    cws = torch.zeros(4 * 32 * 32 + 16, dtype=torch.float64, device="cuda"); slabs = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     for rep in range(3):
         Pm = P0.clone(); torch.cuda.synchronize()
@@ -24,7 +24,7 @@ for (mk, w) in shapes:
             q.check(lib.qrd_panel_tsqr(st, Pm.data_ptr(), mk, mk, w, tau.data_ptr(), Tm.data_ptr(), w, V.data_ptr(), mk, ws.data_ptr(), mk))
         else:
             q.check(lib.qrd_panel_cholqr(st, Pm.data_ptr(), mk, mk, w, tau.data_ptr(), Tm.data_ptr(), w, V.data_ptr(), mk, ws.data_ptr(), mk,
-                                         cws.data_ptr(), slabs.data_ptr(), 1 << 20))
+                                         cws.data_ptr(), slabs.data_ptr(), 1 << 22))
         p.sync()
     out.append({"mk": mk, "w": w, "leaf_bytes": 8 * mk * w})
 print(json.dumps({"mode": mode, "launches_per_shape": 3, "shapes": out}))

@@ -17,7 +17,7 @@ for r in rows:
     T[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 print("kernel                                   dispatch#   read MB  write MB    us     GB/s   (FETCH_SIZE x2 correction applied)")
 for k in sorted(F):
-    if not any(s in k for s in ("gram32", "cholq", "final2", "hr2", "tsqr_", "hr_top", "slab_reduce")): continue
+    if not any(s in k for s in ("gram32", "cholq", "final2", "final3", "hr2", "hr3", "tsqr_", "hr_top", "slab_reduce")): continue
     n = min(len(F[k]), len(W.get(k, [])), len(T.get(k, [])))
     for i in range(n):
         rd, wr, us = 2 * F[k][i] * 1024 / 1e6, W[k][i] * 1024 / 1e6, T[k][i] / 1e3

@@ -335,6 +335,23 @@ def test_panel_cholqr2_guard_falls_back_to_householder(q, oracle, kind):
         assert np.linalg.norm(oracle.sign_normalise(R) - ref) / np.linalg.norm(ref) < rtol
 
 
+@pytest.mark.parametrize("mk", [514, 700, 1024, 4098, 8192, 8194, 16384, 16386, 40000])
+def test_panel_guard_route_all_heights(q, oracle, mk):
+    """A leaf the CholeskyQR2 route must refuse (two equal columns) at heights on both sides of every switch of the guard route:
+    one block / several blocks, 512- and 1024-row blocks, the one-launch cooperative form (<= 16 blocks) and the separate launches
+    (two tree levels), odd sizes.  The Householder route's result must be a valid compact-WY panel."""
+    w = 32
+    P = np.random.default_rng(mk).random((mk, w))
+    P[:, 17] = P[:, 4]
+    out, tau, T, V, guard, _ = _cholqr_leaf(q, P)
+    assert guard == 1
+    assert np.isfinite(out).all() and np.isfinite(T).all() and np.isfinite(V).all() and np.isfinite(tau).all()
+    QtP = P - V @ (T.T @ (V.T @ P))
+    assert np.abs(np.tril(QtP, -1)).max() < 1e-11 * np.sqrt(mk)
+    assert np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-11 * np.sqrt(mk)
+    assert np.abs(np.diag(T) - tau).max() == 0.0 and np.abs(np.tril(T, -1)).max() == 0.0
+
+
 def test_panel_cholqr2_moderate_condition_stays_accurate(q, oracle):
     """cond ~ 1e3: inside the range where the fast path is taken; orthogonality and residual must be at Householder level."""
     mk, w = 20000, 32

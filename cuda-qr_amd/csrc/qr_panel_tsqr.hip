@@ -607,15 +607,13 @@ __device__ __forceinline__ bool coop_barrier(unsigned* cnt, unsigned target)
     return timed_out == 0;
 }
 
-__global__ __launch_bounds__(PT) void tsqr_coop_kernel(const double* P, int ld, int mk, int w, int nblk, int halves,
-                                                       double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
-                                                       double* __restrict__ stack, double* __restrict__ Rt, double* __restrict__ Ctop,
-                                                       double* __restrict__ Umat, double* A /* == P */, int lda,
-                                                       double* __restrict__ tau, double* __restrict__ T, int ldt,
-                                                       double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
-                                                       const int* __restrict__ guard)
+__device__ __forceinline__ void tsqr_coop_body(const double* P, int ld, int mk, int w, int nblk, int halves,
+                                               double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
+                                               double* __restrict__ stack, double* __restrict__ Rt, double* __restrict__ Ctop,
+                                               double* __restrict__ Umat, double* A /* == P */, int lda,
+                                               double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                               double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar)
 {
-    if (*guard == 0) return;                 // the CholeskyQR2 leaf succeeded: nothing to do, one kernel boundary paid
     const int b = blockIdx.x, G = gridDim.x, rows_stack = nblk * w;
     bool ok = true;
     // F: local Householder QR of this workgroup's row block (<= 1024 rows: two rows per thread)
@@ -633,6 +631,18 @@ __global__ __launch_bounds__(PT) void tsqr_coop_kernel(const double* P, int ld, 
         __syncthreads();
     }
     if (!ok && b == 0 && threadIdx.x < w) tau[threadIdx.x] = __builtin_nan("");
+}
+
+__global__ __launch_bounds__(PT) void tsqr_coop_kernel(const double* P, int ld, int mk, int w, int nblk, int halves,
+                                                       double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
+                                                       double* __restrict__ stack, double* __restrict__ Rt, double* __restrict__ Ctop,
+                                                       double* __restrict__ Umat, double* A /* == P */, int lda,
+                                                       double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                       double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
+                                                       const int* __restrict__ guard)
+{
+    if (*guard == 0) return;                 // the CholeskyQR2 leaf succeeded: nothing to do, one kernel boundary paid
+    tsqr_coop_body(P, ld, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
 }
 
 // mk <= 512: the whole leaf in one workgroup -- V, R, tau and T in a single launch.
@@ -1298,12 +1308,11 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
 
 // rows >= w of V: v U' = q by forward substitution over the columns (U' upper triangular), one row per thread
 template <bool FULL>
-__global__ __launch_bounds__(PT) void final3_kernel(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Um,
-                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
+__device__ __forceinline__ void final3_body(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Um,
+                                            double* __restrict__ A, int lda)
 {
     __shared__ double Usm[PW][PW + 1];
     __shared__ double uinv[PW];
-    if (*guard != 0) return;
     const int tid = threadIdx.x, r = blockIdx.x * PT + tid;
     double a[PW];
     {
@@ -1330,6 +1339,32 @@ __global__ __launch_bounds__(PT) void final3_kernel(double* __restrict__ Vw, int
 #pragma unroll
     for (int c = 0; c < PW; ++c)
         if (FULL || c < w) { Vw[(size_t) c * ldv + r] = v[c]; A[(size_t) c * lda + r] = v[c]; }
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(PT) void final3_kernel(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Um,
+                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
+{
+    if (*guard != 0) return;
+    final3_body<FULL>(Vw, ldv, mk, w, Um, A, lda);
+}
+
+// Short leaves (<= 16 row blocks): the last launch of the CholeskyQR2 leaf and the one-launch guard route share a grid
+// (one 512-row block per workgroup), so they are ONE launch -- the guard word picks the body.  Saves the kernel boundary
+// (~4.7 us per leaf, 3-4 % of an 8192^2 factorisation) that the guard route cost when it had nothing to do.
+__global__ __launch_bounds__(PT) void final3_coop_kernel(const double* __restrict__ Um, int nblk, int halves, int mk, int w,
+                                                         double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
+                                                         double* __restrict__ stack, double* __restrict__ Rt, double* __restrict__ Ctop,
+                                                         double* __restrict__ Umat, double* A, int lda,
+                                                         double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                         double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
+                                                         const int* __restrict__ guard)
+{
+    if (*guard != 0) {
+        tsqr_coop_body(A, lda, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
+        return;
+    }
+    final3_body<true>(Vw, ldv, mk, w, Um, A, lda);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1411,7 +1446,7 @@ static int coop_enabled(void)
 }
 
 static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
-                           double* ws, int m_cap, const int* guard, unsigned* bar = nullptr)
+                           double* ws, int m_cap, const int* guard, unsigned* bar = nullptr, const double* final3_u = nullptr)
 {
     hipStream_t s = (hipStream_t) stream;
     if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
@@ -1441,7 +1476,18 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     // per thread) above, which keeps the tree at two levels up to 16384 rows and three up to 262144
     const int brows0 = (mk <= 16 * PT) ? PT : 2 * PT;
     lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + brows0 - 1) / brows0; lv_off[0] = 0; lv_tau[0] = 0;
-    if (guard && bar && coop_enabled() && lv_nblk[0] * w <= PT) {
+    // final3_u: the caller's last CholeskyQR2 launch (final3_kernel<true> with this U') is still to be issued -- fused with the
+    // one-launch guard route where that exists (same grid), on its own otherwise
+    static int fuse = -1;
+    if (fuse < 0) { const char* e = getenv("MI355XQR_FUSE_GUARD"); fuse = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool coop = guard && bar && coop_enabled() && lv_nblk[0] * w <= PT;
+    if (final3_u && coop && fuse && brows0 == PT && w == PW) {
+        hipLaunchKernelGGL(final3_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
+                           stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
+        return (int) hipGetLastError();
+    }
+    if (final3_u) hipLaunchKernelGGL(final3_kernel<true>, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, w, final3_u, P, ld, guard);
+    if (coop) {
         // short leaf behind a CholeskyQR2 attempt: the whole guard route in one launch (grid barriers inside)
         hipLaunchKernelGGL(tsqr_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, P, ld, mk, w, lv_nblk[0], brows0 / PT, Vloc1, taus, Ts, stacks,
                            Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
@@ -1553,8 +1599,7 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
             if (rc) return rc;
             hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
         }
-        hipLaunchKernelGGL(final3_kernel<true>, dim3(nblk), dim3(PT), 0, s, Vw, ldv, mk, w, Mm, P, ld, guard);
-        have_bar = true;
+        have_bar = true;                                    // final3_kernel<true>: issued by panel_tsqr_impl, fused with the guard route where it can
     } else {
         rc = gram32(s, P, ld, mk, G1, slabs, slab_cap);
         if (rc) return rc;
@@ -1566,7 +1611,7 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
     }
     rc = (int) hipGetLastError();
     if (rc) return rc;
-    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr);
+    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr, have_bar ? Mm : nullptr);
 }
 
 }   // extern "C"

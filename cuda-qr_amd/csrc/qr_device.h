@@ -18,6 +18,8 @@ int qrd_gemm_nn_update(void* stream, int M, int N, int K, double alpha, const do
                        int ldb, double beta, double* C, int ldc);
 int qrd_gemm_nn_update2(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                         int ldb, double beta, double* C, int ldc);
+int qrd_gemm_tn_dual(void* stream, int N1, int N2, int K, const double* A, int lda, const double* B1, int ldb1, const double* B2,
+                     int ldb2, const double* Tm, int ldt, double* W, int ldw, double* G2, int ldg, double* slabs, size_t slab_cap);
 int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap);
 /* second-generation wide update (qr_gemm_nt.hip): W kept transposed, direct-to-LDS tile loads */

@@ -481,8 +481,14 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
     double* Ak = dA + (size_t) k * lda + k;
     CHECK(qrd_zero_block(p->stream, p->Vw, ldv, wout, wout));
     const int nhalf = (wout + QR_HALF - 1) / QR_HALF;
+    static int fuse_gram = -1;
+    if (fuse_gram < 0) { const char* fe = getenv("MI355XQR_FUSE_GRAM"); fuse_gram = fe ? atoi(fe) != 0 : 1; }
     for (int h = 0; h < nhalf; ++h) {
         const int c0 = h * QR_HALF, wh = imin(QR_HALF, wout - c0), cend = c0 + wh;
+        const int need_t = want_t || h + 1 < nhalf;          /* the next half's block update needs T of everything before it */
+        /* the Gram blocks V(:, c0:c)^T V_l that T needs are collected leaf by leaf, in the same launch as the leaf's in-panel
+         * product (qrd_gemm_tn_dual); gram_done stays 1 while every leaf of the half could do that */
+        int gram_done = fuse_gram && need_t;
         if (h > 0) {
             /* A(:, c0:cend) <- (I - V T V^T)^T A(:, c0:cend) with the c0 reflectors factored so far */
             if (half_ready) CHECK(qrd_stream_wait_event(p->stream, half_ready));
@@ -503,21 +509,28 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
                 CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
             else
                 CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
-            const int nrest = cend - (c + w);
-            if (nrest > 0) {
-                double* Arest = P + (size_t) w * lda;
+            const int nrest = cend - (c + w), nprev = gram_done ? c - c0 : 0;
+            double* Arest = P + (size_t) w * lda;
+            int fused = 0;
+            if (gram_done && w == 32 && nrest + nprev > 0) {
                 /* Wn, not W: with look-ahead the wide update on stream_u owns p->W while this panel runs */
-                CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->Wn, w, Tl));                  /* T_l^T V_l^T A_rest */
-                CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
+                const int rc = qrd_gemm_tn_dual(p->stream, nrest, nprev, mkl, Vl, ldv, Arest, lda, p->Vw + (size_t) c0 * ldv + c, ldv, Tl, ldt,
+                                                p->Wn, w, p->G + (size_t) c * nb + c0, nb, p->slabs, p->slab_cap);
+                if (rc == 0) fused = 1;
+                else if (rc != -7) return rc;
             }
+            if (!fused) {
+                if (nprev > 0 || (c > c0 && w != 32)) gram_done = 0;     /* this leaf's Gram column is missing: whole Gram at the end */
+                if (nrest > 0) CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->Wn, w, Tl));  /* T_l^T V_l^T A_rest */
+            }
+            if (nrest > 0) CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
         }
-        const int need_t = want_t || h + 1 < nhalf;          /* the next half's block update needs T of everything before it */
         if (!need_t) continue;
         double* Vh = p->Vw + (size_t) c0 * ldv + c0;          /* this half's V: rows from c0 (zero above) */
         double* Thh = p->T + (size_t) c0 * ldt + c0;
         if (wh > ib) {
             double* Ghh = p->G + (size_t) c0 * nb + c0;
-            CHECK(tn(p, wh, wh, mk - c0, Vh, ldv, Vh, ldv, Ghh, nb, NULL));                        /* Gram of the half */
+            if (!gram_done) CHECK(tn(p, wh, wh, mk - c0, Vh, ldv, Vh, ldv, Ghh, nb, NULL));       /* Gram of the half */
             /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the
              * wide update builds V*T itself on its own stream (update_cols), off the critical path */
             CHECK(qrd_larft(p->stream, wh, ib, Ghh, nb, dtau + k + c0, Thh, ldt, NULL, 0, p->X, nb));

@@ -376,14 +376,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
     else gemm_epilogue<TI, TJ, false>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
 }
 
+// The leaf's two long-K products in one launch:  [W | G^T] = V_l^T [A_rest | V_prev]  (32 x (N1 + N2), K = leaf height).
+// Column tiles j0 < N1 read B1 (the rest of the panel), the others B2 (the reflectors of the panel's earlier leaves): the Gram
+// blocks the panel's T needs are thus collected leaf by leaf, and the panel-wide Gram product after the last leaf goes away.
+__global__ __launch_bounds__(256, 2) void gemm_tn_dual_kernel(int N1, int N2, int K, int kchunk, const double* __restrict__ A, int lda,
+                                                              const double* __restrict__ B1, int ldb1, const double* __restrict__ B2,
+                                                              int ldb2, double* __restrict__ C, size_t slab_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;
+    double* Bs = smem + 2 * 32 * LDKF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int j0 = blockIdx.y * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    C += (size_t) blockIdx.z * slab_stride;
+    const bool second = j0 >= N1;
+    const double* B = second ? B2 + (size_t) (j0 - N1) * ldb2 : B1 + (size_t) j0 * ldb1;
+    const int ldb = second ? ldb2 : ldb1;
+    v4d acc[1][1];
+    acc[0][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+    gemm_kloop<1, 1, false, true>(acc, A, lda, B, ldb, 0, 0, 32, 32, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+    gemm_epilogue<1, 1, true>(acc, C, 32, 32, N1 + N2, 0, j0, 1.0, 0.0, wi, wj, l15, l4);
+}
+
 // out(:,j) = beta*out(:,j) + Tm^T * sum_z slab_z(:,j)   (Tm optional, upper triangular M x M, M <= 256)
 // One 256-thread block per output column.  The slab index is spread over 256/Mp thread groups (Mp = M rounded up
 // to 32), each summing its slabs in a fixed order, then the groups are added in a fixed order: deterministic and
 // short dependency chains even for hundreds of slabs.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(int M, int N, int nslab, const double* __restrict__ slabs, int lds,
                                                           size_t slab_stride, const double* __restrict__ Tm, int ldt,
-                                                          double beta, double* __restrict__ out, int ldo, int chunk)
+                                                          double beta, double* __restrict__ out, int ldo, int chunk,
+                                                          int nsplit, double* __restrict__ out2, int ldo2)
 {
+    // columns j >= nsplit (out2 != nullptr): raw sums, stored TRANSPOSED:  out2(j - nsplit, i)  (gemm_tn_dual_kernel's Gram part)
     __shared__ double red[256];
     __shared__ double col[256];
     const int j = blockIdx.x, tid = threadIdx.x;
@@ -414,6 +442,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int M, int N, int nsla
         col[tid] = t;
     }
     __syncthreads();
+    if (out2 && j >= nsplit) {
+        if (tid < Mc) out2[(size_t) (i0 + tid) * ldo2 + (j - nsplit)] = col[tid];
+        return;
+    }
     if (tid < Mc) {
         double v = col[tid];
         if (Tm) {
@@ -975,12 +1007,49 @@ int qrd_gemm_tn(void* stream, int M, int N, int K, double alpha, const double* A
     return gemm_tn_impl(stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, slabs, slab_cap, Tm, ldt, 0);
 }
 
+// [W | G2^T] = A^T [B1 | B2] for a 32-column A (the leaf's reflectors):  W (32 x N1, ld ldw) = Tm^T A^T B1,  G2 (N2 x 32, ld ldg) =
+// B2^T A.  One product launch + one reduce launch.  Returns -7 when the shapes do not fit the fast kernel (caller falls back to
+// two ordinary products): N1, N2 multiples of 32, K a multiple of the k-tile, 16-byte aligned operands.
+int qrd_gemm_tn_dual(void* stream, int N1, int N2, int K, const double* A, int lda, const double* B1, int ldb1, const double* B2,
+                     int ldb2, const double* Tm, int ldt, double* W, int ldw, double* G2, int ldg, double* slabs, size_t slab_cap)
+{
+    hipStream_t s = (hipStream_t) stream;
+    const int N = N1 + N2;
+    if (N <= 0) return 0;
+    if (N1 % 32 || N2 % 32 || K % BK || K < BK || !vec_ok(A, lda) || (N1 > 0 && !vec_ok(B1, ldb1)) || (N2 > 0 && !vec_ok(B2, ldb2)))
+        return -7;
+    const size_t per = (size_t) 32 * N;
+    if (!slabs || slab_cap < per) return -7;
+    const int tiles = N / 32, slots = 2 * stream_cus(s);
+    long long kmax = (K + 8 * BK - 1) / (8 * BK);
+    if (kmax > 256) kmax = 256;
+    if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
+    if (kmax < 1) kmax = 1;
+    // same cost model as gemm_tn_impl: rounds * (K rows per slice + fixed) + reduce
+    const double row_us = 2.0 * 32 * 32 / 0.113e6, red_rows = (double) per * 8.0 / 2.0e6 / row_us;
+    int ksplit = 1;
+    double best = 1e300;
+    for (long long k = 1; k <= kmax; ++k) {
+        const long long rounds = ((long long) tiles * k + slots - 1) / slots;
+        const double cost = (double) rounds * ((double) K / (double) k + 96.0) + (double) k * red_rows + 30.0;
+        if (cost < best) { best = cost; ksplit = (int) k; }
+    }
+    int kchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+    ksplit = (K + kchunk - 1) / kchunk;
+    const size_t shm = sizeof(double) * (4 * 32 * LDKF);
+    hipLaunchKernelGGL(gemm_tn_dual_kernel, dim3(1, tiles, ksplit), dim3(256), shm, s, N1, N2, K, kchunk, A, lda, B1, ldb1, B2, ldb2,
+                       slabs, per);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, 1), dim3(256), 0, s, 32, N, ksplit, slabs, 32, per, Tm, ldt, 0.0, W, ldw, 256, N1,
+                       G2, ldg);
+    return (int) hipGetLastError();
+}
+
 // the wide W = (V T)^T A2 of the trailing update: same kernel under its own profiler name (TAG = 1)
 // out (M x N, ldo) = sum of nslab slabs (slab z at slabs + z*stride, ld lds), fixed order
 int qrd_slab_reduce(void* stream, int M, int N, int nslab, const double* slabs, int lds, size_t stride, double* out, int ldo)
 {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, (M + 255) / 256), dim3(256), 0, (hipStream_t) stream, M, N, nslab, slabs, lds, stride,
-                       (const double*) nullptr, 0, 0.0, out, ldo, 256);
+                       (const double*) nullptr, 0, 0.0, out, ldo, 256, N, (double*) nullptr, 0);
     return (int) hipGetLastError();
 }
 
@@ -1052,7 +1121,7 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
         int piece = 256;
         if (Tm == nullptr && ksplit >= 32 && M >= 64) piece = ksplit >= 128 ? 32 : 64;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, (M + piece - 1) / piece), dim3(256), 0, s, M, N, ksplit, slabs, M, per, Tm, ldt,
-                           beta, C, ldc, piece);
+                           beta, C, ldc, piece, N, (double*) nullptr, 0);
         rc = (int) hipGetLastError();
     }
     return rc;

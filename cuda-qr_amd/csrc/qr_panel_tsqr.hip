@@ -1013,20 +1013,36 @@ __global__ __launch_bounds__(PT) void final2_kernel(double* __restrict__ Vw, int
 // =========================================================================================================
 // elements 2t, 2t+1 of the sum of `nslab` dense 32 x 32 slabs (1024 doubles apart), slabs added in index order; 16 loads
 // are issued before the first add (the previous two-at-a-time loop paid one L2 round trip per pair: ~10 us for 14 slabs)
+template <int BATCH = 16>
 __device__ __forceinline__ v2d slab_sum2(const double* __restrict__ slabs, int nslab, int t)
 {
     const v2d* p = reinterpret_cast<const v2d*>(slabs) + t;
     v2d acc = (v2d){0.0, 0.0};
-    for (int z0 = 0; z0 < nslab; z0 += 16) {
-        v2d v[16];
+    for (int z0 = 0; z0 < nslab; z0 += BATCH) {
+        v2d v[BATCH];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(size_t) min(z0 + u, nslab - 1) * (PW * PW / 2)];
+        for (int u = 0; u < BATCH; ++u) v[u] = p[(size_t) min(z0 + u, nslab - 1) * (PW * PW / 2)];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < BATCH; ++u)
             if (z0 + u < nslab) acc += v[u];
     }
     return acc;
 }
+
+// Phase stamps of the leaf kernels (development builds only: make STAMPS=1; devtools/tools_leaf_stamps.py reads them):
+// thread 0 of workgroup 0 records the 100 MHz wall clock at phase boundaries.
+#ifdef QRD_STAMPS
+__device__ long long qrd_dbg_stamps[64];
+// stamps stay in scalar registers until the kernel's last line (a store per stamp in the middle of the unrolled recurrences
+// cost cholq2_kernel 3.5 KB of scratch per thread)
+#define STAMP_DECL long long qst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(k) qst_[(k) & 7] = (long long) __builtin_amdgcn_s_memrealtime()
+#define STAMP_FLUSH(base, n) do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int q_ = 0; q_ < (n); ++q_) qrd_dbg_stamps[(base) + q_] = qst_[q_]; } while (0)
+#else
+#define STAMP_DECL do { } while (0)
+#define STAMP(k) do { } while (0)
+#define STAMP_FLUSH(base, n) do { } while (0)
+#endif
 
 #define CQ2_MAXSLAB 32
 #define CQ2_LDS_DOUBLES(HALF) (PW * ((HALF) + 2) + 2 * PW * (PW + 1) + PW + 8)
@@ -1049,6 +1065,8 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const int r = b * NT + tid;
     double a[PW];
+    STAMP_DECL;
+    STAMP(0);
     {
         const double* p = P + min(r, mk - 1);
 #pragma unroll
@@ -1062,6 +1080,7 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
         Gs[e / PW][e % PW + 1] = gsum[1];
     }
     __syncthreads();
+    STAMP(1);
     if (tid < 64) {
         // chol_wave reads G(i, j) as G[j * PW + i]: hand it the padded image row by row
         double g[PW];
@@ -1077,6 +1096,7 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
         if (lane == 0) *okf = ok ? 1 : 0;
     }
     __syncthreads();
+    STAMP(2);
     if (tid < PW) rinv[tid] = 1.0 / Rs[tid][tid];
     const bool ok = *okf != 0;
     if (b == 0) {
@@ -1097,11 +1117,13 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
         __builtin_amdgcn_sched_barrier(0);
     }
     const bool live = r < mk;
+    STAMP(3);
     if (live) {
 #pragma unroll
         for (int c = 0; c < PW; ++c)
             if (FULL || c < w) Vw[(size_t) c * ldv + r] = q[c];
     }
+    STAMP(4);
     // ---- this workgroup's share of G2 = Q^T Q: rows staged 256 at a time as a [column][row] image (ld 258: the 16 columns a
     // half-wave reads are 16 B apart in the bank row -> conflict-free ds_read_b64), wave v takes rows [32v, 32v+32) of the half
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1130,6 +1152,7 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
     }
     // D reg rr of lane (l4, l15) of tile (ti, tj) = G(16 ti + l4 + 4 rr, 16 tj + l15); partial of this wave -> LDS (over Qs)
     double* red = Qs + wave * PW * PW;
+    STAMP(5);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -1143,6 +1166,8 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
         for (int v = 0; v < NT / 64; ++v) s += Qs[v * PW * PW + e];
         slab2[(size_t) b * PW * PW + e] = s;
     }
+    STAMP(6);
+    STAMP_FLUSH(0, 7);
 }
 
 // Cholesky + modified LU of the reconstruction on ONE wave, no LDS and no barrier: lane c (< 32) holds column c of both
@@ -1220,8 +1245,12 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
     __shared__ int flags[2];
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const int rc = lane & (PW - 1);
+    STAMP_DECL;
+    STAMP(16);
     if (tid == 0) *bar = 0u;                               // arrival counter of the one-launch guard route that follows (tsqr_coop_kernel)
-    if (*guard != 0) return;                               // pass 1 already refused
+    // the guard word is TESTED only after the loads below have been issued (behind the second barrier): an early return here
+    // would put one more global round trip -- 2-4 us next to a running update GEMM -- in front of every other load
+    const int gword = *guard;
     if (tid < 2) flags[tid] = 0;
     double b[PW];
     if (g == 0) {                                          // column rc of Q_top: 32 consecutive doubles, in flight under the sum
@@ -1241,6 +1270,8 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
         R1s[i + 1][c] = (i + 1 <= c) ? R1[e + 1] : 0.0;
     }
     __syncthreads();
+    STAMP(17);
+    if (gword != 0) return;                                // pass 1 already refused
     if (flags[0]) { if (tid == 0) *guard = 1; return; }
     if (g == 0) {
         double gg[PW];
@@ -1249,6 +1280,7 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
         bool ok = true;
         double dinv = 1.0, sgn = 1.0;
         Chol3Step<0>::run(gg, rc, ok, dinv);
+        STAMP(18);
         if (ok) {
             Hr3Lu<0>::run(b, gg, rc, sgn);
             if (lane < PW) {
@@ -1260,6 +1292,7 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
         } else if (lane == 0) flags[1] = 1;
     }
     __syncthreads();
+    STAMP(19);
     if (flags[1]) { if (tid == 0) *guard = 1; return; }
     // wave 0: U = U' R2^-1 (row i in lane i); wave 1: L1^-1 (column j in lane j); the other six waves: R = S (R2 R1) and L1
     // -> A, unit-lower L1 -> Vw, U' -> Uout
@@ -1295,6 +1328,7 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
         }
     }
     __syncthreads();
+    STAMP(20);
     // T = -U S L1^-T:  T(i, c) = -sum_{k = i .. c} U(i, k) S_k L1^-1(c, k)      (upper triangular; T(i, i) = -U(i, i) S_i = tau_i)
     for (int el = tid; el < PW * PW; el += 64 * H3G) {
         const int i = el % PW, c = el / PW;
@@ -1304,17 +1338,19 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
         T[(size_t) c * ldt + i] = acc;
         if (i == c) tau[i] = acc;
     }
+    STAMP(21);
+    STAMP_FLUSH(16, 6);
 }
 
 // rows >= w of V: v U' = q by forward substitution over the columns (U' upper triangular), one row per thread
+// final3_load: this thread's row of Q into a[], U' into LDS (ends with a workgroup barrier); final3_finish: solve and store.
+// (Issuing these loads before the guard word is tested was tried: the fused kernel then spills -- 100 B of scratch -- and
+// 8192^2 ran 3 % slower.)
 template <bool FULL>
-__device__ __forceinline__ void final3_body(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Um,
-                                            double* __restrict__ A, int lda)
+__device__ __forceinline__ void final3_load(double (&a)[PW], double (*Usm)[PW + 1], double* uinv, const double* __restrict__ Vw, int ldv,
+                                            int mk, int w, const double* __restrict__ Um)
 {
-    __shared__ double Usm[PW][PW + 1];
-    __shared__ double uinv[PW];
     const int tid = threadIdx.x, r = blockIdx.x * PT + tid;
-    double a[PW];
     {
         const double* p = Vw + min(r, mk - 1);
 #pragma unroll
@@ -1327,6 +1363,13 @@ __device__ __forceinline__ void final3_body(double* __restrict__ Vw, int ldv, in
         if (i == c) uinv[i] = 1.0 / u;
     }
     __syncthreads();
+}
+
+template <bool FULL>
+__device__ __forceinline__ void final3_finish(double (&a)[PW], double (*Usm)[PW + 1], const double* uinv, double* __restrict__ Vw, int ldv,
+                                              int mk, int w, double* __restrict__ A, int lda)
+{
+    const int tid = threadIdx.x, r = blockIdx.x * PT + tid;
     if (r < w || r >= mk) return;
     double v[PW];
 #pragma unroll
@@ -1345,8 +1388,12 @@ template <bool FULL>
 __global__ __launch_bounds__(PT) void final3_kernel(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Um,
                                                     double* __restrict__ A, int lda, const int* __restrict__ guard)
 {
+    __shared__ double Usm[PW][PW + 1];
+    __shared__ double uinv[PW];
     if (*guard != 0) return;
-    final3_body<FULL>(Vw, ldv, mk, w, Um, A, lda);
+    double a[PW];
+    final3_load<FULL>(a, Usm, uinv, Vw, ldv, mk, w, Um);
+    final3_finish<FULL>(a, Usm, uinv, Vw, ldv, mk, w, A, lda);
 }
 
 // Short leaves (<= 16 row blocks): the last launch of the CholeskyQR2 leaf and the one-launch guard route share a grid
@@ -1360,11 +1407,15 @@ __global__ __launch_bounds__(PT) void final3_coop_kernel(const double* __restric
                                                          double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
                                                          const int* __restrict__ guard)
 {
+    __shared__ double Usm[PW][PW + 1];
+    __shared__ double uinv[PW];
     if (*guard != 0) {
         tsqr_coop_body(A, lda, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
         return;
     }
-    final3_body<true>(Vw, ldv, mk, w, Um, A, lda);
+    double a[PW];
+    final3_load<true>(a, Usm, uinv, Vw, ldv, mk, w, Um);
+    final3_finish<true>(a, Usm, uinv, Vw, ldv, mk, w, A, lda);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1545,6 +1596,13 @@ static int leaf_gen(void)
     if (!v) { const char* e = getenv("MI355XQR_LEAF"); v = (e && atoi(e) == 1) ? 1 : 2; }
     return v;
 }
+
+#ifdef QRD_STAMPS
+int qrd_dbg_read_stamps(long long* out)
+{
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(qrd_dbg_stamps), sizeof(long long) * 64, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int qrd_panel_tsqr_init(void)
 {

@@ -1020,8 +1020,15 @@ int qrd_gemm_tn_dual(void* stream, int N1, int N2, int K, const double* A, int l
         return -7;
     const size_t per = (size_t) 32 * N;
     if (!slabs || slab_cap < per) return -7;
-    const int tiles = N / 32, slots = 2 * stream_cus(s);
-    long long kmax = (K + 8 * BK - 1) / (8 * BK);
+    // workgroup slots per compute unit: the 32 x 32 tile kernel is latency-bound per workgroup (18 KB of LDS, 4 waves), so more
+    // and shorter K slices than the 2 per CU of the big-tile products pay (8192^2: 34.4 ms at 2 slots / >= 8 k-tiles per slice,
+    // 33.3 ms at 8 slots / >= 4 k-tiles)
+    static int spc = 0;
+    if (!spc) { const char* e = getenv("MI355XQR_DUAL_SLOTS"); spc = e ? atoi(e) : 8; if (spc < 1) spc = 8; }
+    static int kmin_tiles = 0;
+    if (!kmin_tiles) { const char* e = getenv("MI355XQR_DUAL_KMIN"); kmin_tiles = e ? atoi(e) : 4; if (kmin_tiles < 1) kmin_tiles = 4; }
+    const int tiles = N / 32, slots = spc * stream_cus(s);
+    long long kmax = (K + kmin_tiles * BK - 1) / (kmin_tiles * BK);
     if (kmax > 256) kmax = 256;
     if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
     if (kmax < 1) kmax = 1;

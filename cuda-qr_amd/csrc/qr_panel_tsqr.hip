@@ -1170,6 +1170,227 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
     STAMP_FLUSH(0, 7);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Third-generation leaf: the two row solves (q = a R1^-1 in cholq2_kernel, v = q U'^-1 in final3_kernel) were 7 us each and
+// bound by LDS bandwidth -- every thread reads all 528 entries of the triangle as broadcast reads, 8 waves x 496 x 512 B per
+// workgroup.  Here they are products with the explicit inverses on the matrix cores, the row operands going from global memory
+// straight into the MFMA operand layout (no LDS):
+//   * R1^-1 costs nothing: the Cholesky wave has 32 idle lanes, which run the same elimination on the columns of the identity
+//     (G = R^T R, so the row operations that turn G into R turn I into R^-T);
+//   * U'^-1 is a third 32-step recurrence in hr3_kernel<true>, on a wave that only copied data before.
+// Transposed products, so that the result lands column-fast for the stores:  q^T = (R1^-1)^T a^T : A operand (i = column, lane
+// l15; k, lane l4) = R1^-1(k, i), B operand (k; j = row, lane l15) = a(row, k), D reg rr of lane (l4, l15) = q(row l15, column
+// l4 + 4 rr): a wave's store instruction covers 4 columns x 16 consecutive rows.
+// ---------------------------------------------------------------------------------------------------------
+template <int K> struct CholAugStep {
+    static __device__ __forceinline__ void run(double (&g)[PW], int lane, bool& ok)
+    {
+        const double p = readlane_f64(g[K], K);
+        ok = ok && (p > 0.0);                       // false for NaN as well
+        const double inv = rsqrt_newton(p);
+        const double rk = (lane >= K) ? g[K] * inv : 0.0;          // lanes >= 32 (identity columns) always pass
+        g[K] = rk;
+#pragma unroll
+        for (int i = K + 1; i < PW; ++i) g[i] -= readlane_f64(rk, i) * rk;
+        if constexpr (K + 1 < PW) CholAugStep<K + 1>::run(g, lane, ok);
+    }
+};
+
+template <int NT, int HALF>
+__global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P, int ld, int mk,
+                                                    const double* __restrict__ gslabs, int nslab, double* __restrict__ R1,
+                                                    double* __restrict__ Vw, int ldv, double* __restrict__ slab2,
+                                                    int* __restrict__ guard)
+{
+    extern __shared__ __attribute__((aligned(16))) double cq_smem[];
+    double* Qs = cq_smem;                                                    // [PW][(HALF + 2)]; later NT/64 partial Grams [PW*PW]
+    double (*Gs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * (HALF + 2));
+    double (*Ws)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * (HALF + 2) + PW * (PW + 1));   // Ws[k][c] = R1^-1(k, c)
+    int* okf = reinterpret_cast<int*>(cq_smem + PW * (HALF + 2) + 2 * PW * (PW + 1) + PW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int wrow0 = b * NT + wave * 64;                                    // this wave's 64 rows: four 16-row tiles
+    double bq[4][8];                                                         // B operands: a(row0 + 16 t + l15, 4 ks + l4)
+    STAMP_DECL;
+    STAMP(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = wrow0 + 16 * t + l15;
+        const double* p = P + min(row, mk - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bq[t][ks] = p[(size_t) (4 * ks + l4) * ld];          // in flight under the Gram sum
+    }
+    for (int t2 = tid; t2 < PW * PW / 2; t2 += NT) {
+        const v2d gsum = slab_sum2(gslabs, nslab, t2);
+        const int e = 2 * t2;
+        Gs[e / PW][e % PW] = gsum[0];                                         // Gs[j][i] = G(i, j)
+        Gs[e / PW][e % PW + 1] = gsum[1];
+    }
+    __syncthreads();
+    STAMP(1);
+    if (tid < 64) {
+        double g[PW];
+        const int j = lane & (PW - 1);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) g[i] = (lane < PW) ? Gs[j][i] : (i == j ? 1.0 : 0.0);
+        // Bring G to O(1) by an even power of two first (exact): next to the underflow threshold the Gram half of the wave would
+        // round to multiples of 4.9e-324 while the identity half stays in the normal range, and R1 and "its" inverse would stop
+        // being inverses of each other (a panel scaled by 1e-160 lost 8 digits).  G' = 4^-h G = R'^T R', R = 2^h R', R^-1 = 2^-h R'^-1.
+        int e2 = 0;
+        {
+            const double d = readlane_f64(g[0], 0);
+            if (d > 0.0 && d < 1.7e308) { (void) frexp(d, &e2); e2 &= ~1; }
+        }
+        const double rs = ldexp(1.0, e2 / 2), ws = ldexp(1.0, -(e2 / 2));       // 4^-h itself may not be representable (G ~ 1e-317)
+        if (lane < PW) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) g[i] = (g[i] * ws) * ws;
+        }
+        bool ok = true;
+        CholAugStep<0>::run(g, lane, ok);
+        if (lane >= PW) {
+#pragma unroll
+            for (int k = 0; k < PW; ++k) Ws[j][k] = (k >= j) ? g[k] * ws : 0.0;      // row j of R1^-1
+        } else if (b == 0 && ok) {
+#pragma unroll
+            for (int k = 0; k < PW; ++k) R1[j * PW + k] = (k <= j) ? g[k] * rs : 0.0;   // column j of R1
+        }
+        if (lane == 0) *okf = ok ? 1 : 0;
+    }
+    __syncthreads();
+    STAMP(2);
+    const bool ok = *okf != 0;
+    if (b == 0 && tid == 0) *guard = ok ? 0 : 1;
+    if (!ok) return;                                                          // workgroup-uniform
+    v4d q[4][2];
+    {
+        double aw[2][8];                                                      // A operands: R1^-1(4 ks + l4, 16 ti + l15)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) aw[ti][ks] = Ws[4 * ks + l4][16 * ti + l15];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool live = wrow0 + 16 * t + l15 < mk;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[ti][ks], live ? bq[t][ks] : 0.0, acc, 0, 0, 0);
+                q[t][ti] = acc;
+            }
+        }
+    }
+    STAMP(3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = wrow0 + 16 * t + l15;
+        if (row < mk) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) Vw[(size_t) (16 * ti + l4 + 4 * rr) * ldv + row] = q[t][ti][rr];
+        }
+    }
+    STAMP(4);
+    // ---- this workgroup's share of G2 = Q^T Q, as in cholq2_kernel: rows staged HALF at a time as a [column][row] image
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int myhalf = (wave * 64) / HALF;
+#pragma unroll
+    for (int h = 0; h < NT / HALF; ++h) {
+        if (myhalf == h) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+                        Qs[(16 * ti + l4 + 4 * rr) * (HALF + 2) + ((wave * 64 + 16 * t + l15) & (HALF - 1))] = q[t][ti][rr];
+        }
+        __syncthreads();
+        const double* base = Qs + 32 * wave + l4;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const double f0 = base[l15 * (HALF + 2) + 4 * ks], f1 = base[(16 + l15) * (HALF + 2) + 4 * ks];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    STAMP(5);
+    double* red = Qs + wave * PW * PW;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) red[(16 * tj + l15) * PW + 16 * ti + l4 + 4 * rr] = acc[ti][tj][rr];
+    __syncthreads();
+    for (int e = tid; e < PW * PW; e += NT) {
+        double sum = 0.0;
+#pragma unroll
+        for (int v = 0; v < NT / 64; ++v) sum += Qs[v * PW * PW + e];
+        slab2[(size_t) b * PW * PW + e] = sum;
+    }
+    STAMP(6);
+    STAMP_FLUSH(0, 7);
+}
+
+// rows >= 32 of V = Q U'^-1 (Winv: U'^-1, column-major, ld PW), written to Vw and to A.  No LDS, no barrier.
+__device__ __forceinline__ void final4_body(double* __restrict__ Vw, int ldv, int mk, const double* __restrict__ Winv,
+                                            double* __restrict__ A, int lda)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int wrow0 = blockIdx.x * PT + wave * 64;
+    if (wrow0 >= mk) return;
+    double bq[4][8], aw[2][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double* p = Vw + min(wrow0 + 16 * t + l15, mk - 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bq[t][ks] = p[(size_t) (4 * ks + l4) * ldv];
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) aw[ti][ks] = Winv[(16 * ti + l15) * PW + 4 * ks + l4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = wrow0 + 16 * t + l15;
+        v4d acc[2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            acc[ti] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[ti][ks], bq[t][ks], acc[ti], 0, 0, 0);
+        }
+        if (row >= PW && row < mk) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const size_t c = (size_t) (16 * ti + l4 + 4 * rr);
+                    Vw[c * ldv + row] = acc[ti][rr];
+                    A[c * lda + row] = acc[ti][rr];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(PT) void final4_kernel(double* __restrict__ Vw, int ldv, int mk, const double* __restrict__ Winv,
+                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
+{
+    if (*guard != 0) return;
+    final4_body(Vw, ldv, mk, Winv, A, lda);
+}
+
 // Cholesky + modified LU of the reconstruction on ONE wave, no LDS and no barrier: lane c (< 32) holds column c of both
 // matrices in registers -- g[k] = R2(k, c) and b[r] = (Q_top - S R2)(r, c) being eliminated -- so a row of the pivot step is one
 // register per lane and only the multiplier column (the registers of lane I) is broadcast, with v_readlane.  The 8-wave
@@ -1235,6 +1456,20 @@ template <int I> struct UnitLowerInv {
     }
 };
 
+// back substitution  U' X = I  by columns: lane j computes column j of X = U'^-1 (zero below the diagonal);  Um[i][k] = U'(i, k)
+template <int I> struct UpperInv {
+    static __device__ __forceinline__ void run(double (&x)[PW], double (*Um)[PW + 1], double dinv, int lane)
+    {
+        double acc = (I == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = I + 1; k < PW; ++k) acc -= Um[I][k] * x[k];
+        x[I] = acc * readlane_f64(dinv, I);                    // dinv: 1 / U'(lane, lane) in lane `lane`
+        if constexpr (I > 0) UpperInv<I - 1>::run(x, Um, dinv, lane);
+    }
+};
+
+// UINV: Uout receives U'^-1 (third-generation leaf: final4 multiplies by it on the matrix cores) instead of U' (final3 solves with it)
+template <bool UINV>
 __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restrict__ G2s, int nslab, const double* __restrict__ R1,
                                                       double* __restrict__ Vw, int ldv, double* __restrict__ A, int lda,
                                                       double* __restrict__ tau, double* __restrict__ T, int ldt,
@@ -1312,17 +1547,25 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
 #pragma unroll
             for (int i = 0; i < PW; ++i) Ls[i][lane] = (i >= lane) ? x[i] : 0.0;       // Ls[i][j] = L1^-1(i, j)
         }
+    } else if (UINV && g == 2) {
+        double x[PW];
+        UpperInv<PW - 1>::run(x, Bs, rcp_newton(Bs[rc][rc]), rc);   // |U'(i, i)| >= R2(i, i) > 0
+        if (lane < PW) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) Uout[lane * PW + i] = (i <= lane) ? x[i] : 0.0;      // column `lane` of U'^-1
+        }
     } else {
-        for (int el = tid - 128; el < PW * PW; el += 64 * H3G - 128) {
+        const int first = UINV ? 192 : 128;
+        for (int el = tid - first; el < PW * PW; el += 64 * H3G - first) {
             const int i = el % PW, c = el / PW;
             if (c >= i) {
                 double acc = 0.0;
                 for (int k = i; k <= c; ++k) acc += R2s[i][k] * R1s[k][c];
                 A[(size_t) c * lda + i] = Ss[i] * acc;
-                Uout[el] = Bs[i][c];
+                if (!UINV) Uout[el] = Bs[i][c];
             } else {
                 A[(size_t) c * lda + i] = Bs[i][c];
-                Uout[el] = 0.0;
+                if (!UINV) Uout[el] = 0.0;
             }
             Vw[(size_t) c * ldv + i] = (c < i) ? Bs[i][c] : (c == i ? 1.0 : 0.0);
         }
@@ -1418,6 +1661,22 @@ __global__ __launch_bounds__(PT) void final3_coop_kernel(const double* __restric
     final3_finish<true>(a, Usm, uinv, Vw, ldv, mk, w, A, lda);
 }
 
+// the same for the third-generation leaf (Um = U'^-1, final4_body)
+__global__ __launch_bounds__(PT) void final4_coop_kernel(const double* __restrict__ Um, int nblk, int halves, int mk, int w,
+                                                         double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
+                                                         double* __restrict__ stack, double* __restrict__ Rt, double* __restrict__ Ctop,
+                                                         double* __restrict__ Umat, double* A, int lda,
+                                                         double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                         double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
+                                                         const int* __restrict__ guard)
+{
+    if (*guard != 0) {
+        tsqr_coop_body(A, lda, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
+        return;
+    }
+    final4_body(Vw, ldv, mk, Um, A, lda);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers: the workgroup is sized to the tallest block of the launch (64..512 threads) -- a 64-row top stack
 // runs on one wave with no cross-wave reduction instead of eight mostly-idle ones
@@ -1497,7 +1756,8 @@ static int coop_enabled(void)
 }
 
 static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
-                           double* ws, int m_cap, const int* guard, unsigned* bar = nullptr, const double* final3_u = nullptr)
+                           double* ws, int m_cap, const int* guard, unsigned* bar = nullptr, const double* final3_u = nullptr,
+                           int gen = 2)
 {
     hipStream_t s = (hipStream_t) stream;
     if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
@@ -1533,11 +1793,18 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     if (fuse < 0) { const char* e = getenv("MI355XQR_FUSE_GUARD"); fuse = (e && atoi(e) == 0) ? 0 : 1; }
     const bool coop = guard && bar && coop_enabled() && lv_nblk[0] * w <= PT;
     if (final3_u && coop && fuse && brows0 == PT && w == PW) {
-        hipLaunchKernelGGL(final3_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
-                           stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
+        if (gen == 3)
+            hipLaunchKernelGGL(final4_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
+                               stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
+        else
+            hipLaunchKernelGGL(final3_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
+                               stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
         return (int) hipGetLastError();
     }
-    if (final3_u) hipLaunchKernelGGL(final3_kernel<true>, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, w, final3_u, P, ld, guard);
+    if (final3_u && gen == 3)
+        hipLaunchKernelGGL(final4_kernel, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, final3_u, P, ld, guard);
+    else if (final3_u)
+        hipLaunchKernelGGL(final3_kernel<true>, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, w, final3_u, P, ld, guard);
     if (coop) {
         // short leaf behind a CholeskyQR2 attempt: the whole guard route in one launch (grid barriers inside)
         hipLaunchKernelGGL(tsqr_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, P, ld, mk, w, lv_nblk[0], brows0 / PT, Vloc1, taus, Ts, stacks,
@@ -1589,11 +1856,12 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
 // Leaf = CholeskyQR2 + Householder reconstruction, guarded: 7 short launches, then the Householder-TSQR leaf above as
 // launches that return at once unless the guard word says the Cholesky route was refused for this leaf.
 // cws: QRD_CHOLQR_WS doubles (G1, G2, R1, M, guard word).
-// MI355XQR_LEAF=1 selects the first-generation launch sequence (7 launches + guards), default 2 (4 launches + guards)
+// MI355XQR_LEAF=1 selects the first-generation launch sequence (7 launches + guards), 2 the second (4 launches, row solves on
+// the vector ALUs), default 3 (4 launches, row solves as matrix-core products with explicit triangular inverses; short leaves)
 static int leaf_gen(void)
 {
     static int v = 0;
-    if (!v) { const char* e = getenv("MI355XQR_LEAF"); v = (e && atoi(e) == 1) ? 1 : 2; }
+    if (!v) { const char* e = getenv("MI355XQR_LEAF"); v = e ? atoi(e) : 3; if (v < 1 || v > 3) v = 3; }
     return v;
 }
 
@@ -1610,6 +1878,8 @@ int qrd_panel_tsqr_init(void)
                                        (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<512, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
     return rc;
 }
 
@@ -1629,7 +1899,10 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
     const bool al = ((reinterpret_cast<uintptr_t>(P) & 15) == 0) && (ld % 2 == 0) && (mk % 2 == 0) &&
                     ((reinterpret_cast<uintptr_t>(Vw) & 15) == 0) && (ldv % 2 == 0);
     int rc;
-    if (leaf_gen() == 2 && al && slab_cap >= (size_t) (CQ2_MAXSLAB + 2 * nblk) * PW * PW) {
+    // third generation (matrix-core row solves) for short leaves only: on tall leaves, which stream 67 MB per pass, its operand
+    // loads (4 columns x 128 B per instruction instead of 1 x 512 B) cost more than the solves did (262144 x 512: 7.9 vs 7.6 ms)
+    const int gen = (leaf_gen() == 3 && nblk > CQ2_MAXSLAB) ? 2 : leaf_gen();
+    if (gen >= 2 && al && slab_cap >= (size_t) (CQ2_MAXSLAB + 2 * nblk) * PW * PW) {
         double* slab2 = slabs + (size_t) CQ2_MAXSLAB * PW * PW;
         int nblk2 = nblk;                                   // workgroups of cholq2_kernel = slabs of G2
         if (nblk <= CQ2_MAXSLAB) {
@@ -1638,8 +1911,12 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
             if (rows_per < 2 * GKB) rows_per = 2 * GKB;
             const int nslab = (mk + rows_per - 1) / rows_per;
             hipLaunchKernelGGL(gram32_kernel, dim3(nslab), dim3(256), 0, s, P, ld, mk, rows_per, slabs);
-            hipLaunchKernelGGL((cholq2_kernel<true, 512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk, w,
-                               slabs, nslab, R1, Vw, ldv, slab2, guard);
+            if (gen == 3)
+                hipLaunchKernelGGL((cholq3_kernel<512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk,
+                                   slabs, nslab, R1, Vw, ldv, slab2, guard);
+            else
+                hipLaunchKernelGGL((cholq2_kernel<true, 512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk, w,
+                                   slabs, nslab, R1, Vw, ldv, slab2, guard);
         } else {
             // tall leaf: the Gram pass needs hundreds of workgroups to reach HBM bandwidth, so its slabs go through a reduce launch;
             // 256-row workgroups, three to a compute unit
@@ -1651,11 +1928,17 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
                                G1, 1, R1, Vw, ldv, slab2, guard);
         }
         if (nblk2 <= 2 * CQ2_MAXSLAB) {
-            hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk2, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+            if (gen == 3)
+                hipLaunchKernelGGL(hr3_kernel<true>, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk2, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+            else
+                hipLaunchKernelGGL(hr3_kernel<false>, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk2, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
         } else {           // tall leaf: hundreds of partial Grams are summed by a grid, not by the one reconstruction workgroup
             rc = qrd_slab_reduce(s, PW, PW, nblk2, slab2, PW, (size_t) PW * PW, G2, PW);
             if (rc) return rc;
-            hipLaunchKernelGGL(hr3_kernel, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+            if (gen == 3)
+                hipLaunchKernelGGL(hr3_kernel<true>, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+            else
+                hipLaunchKernelGGL(hr3_kernel<false>, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
         }
         have_bar = true;                                    // final3_kernel<true>: issued by panel_tsqr_impl, fused with the guard route where it can
     } else {
@@ -1669,7 +1952,8 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
     }
     rc = (int) hipGetLastError();
     if (rc) return rc;
-    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr, have_bar ? Mm : nullptr);
+    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr, have_bar ? Mm : nullptr,
+                           gen);
 }
 
 }   // extern "C"

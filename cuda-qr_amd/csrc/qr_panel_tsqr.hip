@@ -1050,7 +1050,11 @@ __device__ long long qrd_dbg_stamps[64];
 // NT rows per workgroup (one per thread), staged HALF at a time for the Gram.  <512, 256>: short leaves (few, fat workgroups);
 // <256, 128>: tall leaves -- 50 KB of LDS and one wave per SIMD, so three workgroups share a compute unit and hide each
 // other's serial phases (the one-wave Cholesky, the barriers), which is what a bandwidth-bound pass over 64 MB needs.
-template <bool FULL, int NT, int HALF>
+// RB row blocks of NT rows per workgroup, one after the other (tall leaves, RB = 2): all their loads are in flight from the start,
+// the slab sum and the one-wave Cholesky are paid once per workgroup instead of once per block, and the partial Gram of
+// both blocks leaves as ONE slab -- the kernel streamed at 1.9 TB/s with RB = 1 (two rounds of 1024 workgroups, each 6.6 us of
+// Cholesky with no load in flight).
+template <bool FULL, int NT, int HALF, int RB = 1>
 __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P, int ld, int mk, int w,
                                                     const double* __restrict__ gslabs, int nslab, double* __restrict__ R1,
                                                     double* __restrict__ Vw, int ldv, double* __restrict__ slab2,
@@ -1063,14 +1067,14 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
     double* rinv = cq_smem + PW * (HALF + 2) + 2 * PW * (PW + 1);
     int* okf = reinterpret_cast<int*>(rinv + PW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-    const int r = b * NT + tid;
-    double a[PW];
+    double a[RB][PW];
     STAMP_DECL;
     STAMP(0);
-    {
-        const double* p = P + min(r, mk - 1);
 #pragma unroll
-        for (int c = 0; c < PW; ++c) a[c] = (FULL || c < w) ? p[(size_t) c * ld] : 0.0;      // in flight under the Gram sum
+    for (int rb = 0; rb < RB; ++rb) {
+        const double* p = P + min((b * RB + rb) * NT + tid, mk - 1);
+#pragma unroll
+        for (int c = 0; c < PW; ++c) a[rb][c] = (FULL || c < w) ? p[(size_t) c * ld] : 0.0;  // in flight under the Gram sum
     }
     // G1 = sum of the slabs (fixed order; every workgroup forms the same bits).  Stored column-major, ld PW.
     for (int t2 = tid; t2 < PW * PW / 2; t2 += NT) {
@@ -1108,12 +1112,21 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
     }
     if (!ok) return;                                                          // workgroup-uniform
     __syncthreads();
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+    const int r = (b * RB + rb) * NT + tid;
     double q[PW];
 #pragma unroll
     for (int k = 0; k < PW; ++k) {                                              // q R1 = a, column by column
-        q[k] = a[k] * rinv[k];
+        q[k] = a[rb][k] * rinv[k];
 #pragma unroll
-        for (int c = k + 1; c < PW; ++c) a[c] -= q[k] * Rs[k][c];
+        for (int c = k + 1; c < PW; ++c) a[rb][c] -= q[k] * Rs[k][c];
         __builtin_amdgcn_sched_barrier(0);
     }
     const bool live = r < mk;
@@ -1126,12 +1139,6 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
     STAMP(4);
     // ---- this workgroup's share of G2 = Q^T Q: rows staged 256 at a time as a [column][row] image (ld 258: the 16 columns a
     // half-wave reads are 16 B apart in the bank row -> conflict-free ds_read_b64), wave v takes rows [32v, 32v+32) of the half
-    const int l15 = lane & 15, l4 = lane >> 4;
-    v4d acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int h = 0; h < NT / HALF; ++h) {
         if (tid / HALF == h) {
@@ -1150,6 +1157,7 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
         }
         __syncthreads();
     }
+    }   // rb
     // D reg rr of lane (l4, l15) of tile (ti, tj) = G(16 ti + l4 + 4 rr, 16 tj + l15); partial of this wave -> LDS (over Qs)
     double* red = Qs + wave * PW * PW;
     STAMP(5);
@@ -1878,6 +1886,8 @@ int qrd_panel_tsqr_init(void)
                                        (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 256, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<512, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
     return rc;
@@ -1920,12 +1930,21 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
         } else {
             // tall leaf: the Gram pass needs hundreds of workgroups to reach HBM bandwidth, so its slabs go through a reduce launch;
             // 256-row workgroups, three to a compute unit
-            nblk2 = (mk + 255) / 256;
+            // two row blocks per workgroup where that still leaves >= 1.5 workgroups per compute unit (262144 rows: 7.58 -> 7.31 ms
+            // for the 512-column shard; 65536 rows: 2 % slower, half the chip would idle)
+            static int rb_env = -1;
+            if (rb_env < 0) { const char* e = getenv("MI355XQR_TALL_RB"); rb_env = e ? atoi(e) : 0; }
+            const bool rb2 = rb_env == 2 || (rb_env != 1 && (mk + 511) / 512 >= 384);
+            nblk2 = rb2 ? (mk + 511) / 512 : (mk + 255) / 256;
             rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
             if (rc) return rc;
             slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
-            hipLaunchKernelGGL((cholq2_kernel<true, 256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
-                               G1, 1, R1, Vw, ldv, slab2, guard);
+            if (rb2)
+                hipLaunchKernelGGL((cholq2_kernel<true, 256, 128, 2>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
+                                   G1, 1, R1, Vw, ldv, slab2, guard);
+            else
+                hipLaunchKernelGGL((cholq2_kernel<true, 256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
+                                   G1, 1, R1, Vw, ldv, slab2, guard);
         }
         if (nblk2 <= 2 * CQ2_MAXSLAB) {
             if (gen == 3)

@@ -183,7 +183,9 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     p->ldv = (m + 15) & ~15;
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
-    p->lookahead = la ? atoi(la) != 0 : 1;
+    /* very tall shards (262144 x 512): panel and update are both HBM-bound, running them side by side only slows the panel's
+     * latency-bound kernels (7.38 vs 7.22 ms); look-ahead stays on everywhere else */
+    p->lookahead = la ? atoi(la) != 0 : !((long long) m >= 128LL * n);
     const char* gr = getenv("MI355XQR_GRAPH");
     p->use_graph = gr ? atoi(gr) != 0 : 0;
     /* MI355XQR_SPLIT = "c0:f0,c1:f1,...,ck": the panel chain runs on its own c_i compute units and the wide update

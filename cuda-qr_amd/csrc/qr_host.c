@@ -761,6 +761,14 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
      *   P(s+1)'s second half needs W_a(s) (ev_half[s&1]);
      *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
     int wide_pending[2] = {0, 0}, extra_pending = 0;
+    /* Early look-ahead update (update-bound phase, one-level panels): N(s+1) is issued on the panel stream right after P(s+1),
+     * ahead of the panel stream's share E(s) of the wide update, instead of on the update stream between W(s) and W(s+1) --
+     * there it waited for ALL of W(s) and then ran alone on the chip for 0.16-0.18 ms per step (C3: 33 such steps).  For
+     * that, W(s) starts with the columns of panel s+2 (W1(s), event ev_half[s&1]) and E(s) takes the LAST columns of the wide
+     * range instead of the first.  early_done: N of the coming step has been issued already. */
+    static int early_env = -1;
+    if (early_env < 0) { const char* ee = getenv("MI355XQR_EARLY_NEXT"); early_env = ee ? atoi(ee) != 0 : 1; }
+    int early_done = 0;
     CHECK(enter_phase(p, phase_of(p, n, n)));
     {
         const int w0 = imin(nb, n);
@@ -776,11 +784,24 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         if (nt <= 0) break;
         const int wnext = imin(nb, nt), nwide = nt - wnext;
         const int nfirst = imin(QR_HALF, wnext), nhalf2 = wnext - nfirst;    /* N(s) covers nfirst columns, W_a(s) the other nhalf2 */
-        CHECK(enter_phase(p, phase_of(p, nt, n)));
-        const int extra = p->We ? balance_cols(p, mk, wout, nwide) : 0;
-        const int n_on_u = p->stream_u != NULL && p->npairs > 0 &&
+        const int phase_now = phase_of(p, nt, n);
+        const int n_early = early_done;                                      /* N(s) went out in the previous iteration */
+        early_done = 0;
+        CHECK(enter_phase(p, phase_now));
+        int extra = p->We ? balance_cols(p, mk, wout, nwide) : 0;
+        const int k1 = k + wout, mk1 = m - k1, nt1 = n - (k1 + wnext);                                        /* P(s+1) */
+        const int wnext2 = nt1 > 0 ? imin(nb, nt1) : 0;                      /* width of panel s+2 */
+        /* N(s+1) early?  Only while the wide update outlasts the panel chain (now and in the coming step), with the CU
+         * partition on, one-level panels, and no change of partition phase in between (the panel stream must stay the same) */
+        const int early_next = early_env && p->npairs > 0 && p->stream_u != NULL && nhalf2 == 0 && wnext2 > 0 && wnext2 <= QR_HALF &&
+                               nwide > wnext2 && update_bound(p, mk, wout, nwide) &&
+                               update_bound(p, mk1, wnext, nt1 - wnext2) && phase_of(p, nt1, n) == phase_now;
+        if (early_next && extra > nwide - wnext2) { extra = nwide - wnext2; extra -= extra % 128; }
+        const int n_on_u = !n_early && p->stream_u != NULL && p->npairs > 0 &&
                            (p->next_on_update == 1 || (p->next_on_update == 2 && !update_bound(p, mk, wout, nwide)));
-        if (n_on_u) {
+        if (n_early) {
+            /* nothing: N(s) sits on the panel stream behind P(s) */
+        } else if (n_on_u) {
             /* N(s) on the update stream: behind W(s-1) by stream order, after P(s) (ev_panel) and E(s-1) (ev_extra) */
             CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
             if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));
@@ -796,6 +817,7 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
             CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout, nfirst, p->Wn, p->Yn, p->slabs, 0, 0));   /* N(s) */
         }
         const int wide_cols = nhalf2 + nwide - extra;
+        const int cw = k + wout + wnext;                                     /* first column of the wide range */
         if (wide_cols > 0) {                                                                                  /* W(s) */
             if (!n_on_u) {
                 CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
@@ -807,21 +829,37 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
                 CHECK(qrd_event_record(p->ev_half[e], p->stream_u));
                 formed = 1;
             }
-            if (nwide - extra > 0)                                                                            /* W_b(s) */
-                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout + wnext + extra, nwide - extra, p->W,
+            if (early_next) {
+                /* W1(s): the columns of panel s+2 first, so that N(s+1) need not wait for the rest; E(s) at the far end */
+                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw, wnext2, p->W, NULL, p->slabs_u, 1, 1));
+                CHECK(qrd_event_record(p->ev_half[e], p->stream_u));
+                if (nwide - wnext2 - extra > 0)
+                    CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw + wnext2, nwide - wnext2 - extra, p->W, NULL,
+                                      p->slabs_u, 1, 0));
+            } else if (nwide - extra > 0)                                                                     /* W_b(s) */
+                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw + extra, nwide - extra, p->W,
                                   NULL, p->slabs_u, 1, !formed));
             CHECK(qrd_event_record(p->ev_wide[e], p->stream_u));
             wide_pending[e] = 1;
         }
         extra_pending = 0;
-        const int k1 = k + wout, mk1 = m - k1, nt1 = n - (k1 + wnext);                                        /* P(s+1) */
+        if (wide_pending[e ^ 1]) {           /* P(s+1) overwrites panel set e^1, which W(s-1) reads (only still pending after an early N(s)) */
+            CHECK(qrd_stream_wait_event(p->stream, p->ev_wide[e ^ 1]));
+            wide_pending[e ^ 1] = 0;
+        }
         use_set(p, e ^ 1);
         CHECK(prof_begin(p, 2));
         CHECK(factor_panel(p, dA, m, lda, k1, wnext, dtau, nt1 > 0, nhalf2 > 0 ? p->ev_half[e] : NULL));
         CHECK(prof_end(p, 2.0 * mk1 * (double) wnext * wnext, 16.0 * mk1 * wnext));
         CHECK(qrd_event_record(p->ev_panel[e ^ 1], p->stream));
+        if (early_next) {                                                                                     /* N(s+1), early */
+            CHECK(qrd_stream_wait_event(p->stream, p->ev_half[e]));                                           /* W1(s) */
+            CHECK(update_cols(p, p->stream, e ^ 1, dA, lda, k1, mk1, wnext, k1 + wnext, imin(QR_HALF, wnext2), p->Wn, p->Yn, p->slabs, 0, 0));
+            early_done = 1;
+        }
         if (extra > 0) {                                                                                      /* E(s) */
-            CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, k + wout + wnext, extra, p->We, p->Ye, p->slabs, 2, 0));
+            CHECK(update_cols(p, p->stream, e, dA, lda, k, mk, wout, early_next ? cw + nwide - extra : cw, extra, p->We, p->Ye,
+                              p->slabs, 2, 0));
             CHECK(qrd_event_record(p->ev_extra[e], p->stream));
             extra_pending = 1;
         }

@@ -77,6 +77,8 @@ np.save(sys.argv[1], O.sign_normalise(F))
     (128, {}),                                                                        # default schedule
     (128, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0"}),             # CU-masked streams + panel-stream share
     (256, {"MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0"}),
+    (128, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_EARLY_NEXT": "0"}),   # look-ahead update never issued early
+    (128, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0.05,0.05"}),     # early look-ahead update on some steps only
     (128, {"MI355XQR_PANEL": "tsqr"}),                                                # Householder-TSQR leaf only
     (64, {"MI355XQR_LOOKAHEAD": "0"}),                                                # single-stream schedule
     (512, {}),                                                                        # two-level panels (K = 512 wide update)

@@ -100,7 +100,8 @@ _sig("qrd_larft", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_in
 LEAF_SCRATCH = 2 * (256 * 32 + 32) + 32 * 32
 _sig("qrd_panel_ws_size", C.c_size_t, C.c_int)
 _sig("qrd_panel_tsqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
-_sig("qrd_panel_cholqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t)
+_sig("qrd_panel_cholqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, C.c_int)
+_sig("qrd_leaf_update_gram", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_int))
 _sig("qrd_gemm_nt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp)
 _sig("qrd_gemm_tnt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_size_t,
      C.c_int, C.c_int, C.c_int)

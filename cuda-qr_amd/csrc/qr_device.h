@@ -37,8 +37,13 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
                    double* ws, int m_cap);
 int qrd_slab_reduce(void* stream, int M, int N, int nslab, const double* slabs, int lds, size_t stride, double* out, int ldo);
 #define QRD_CHOLQR_WS (4 * 32 * 32 + 16)
+/* gram_nslab > 0: `slabs` already holds that many 32 x 32 partial Gram matrices of this leaf (qrd_leaf_update_gram) */
 int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
-                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap);
+                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab);
+/* fused kernels of the leaf chain (qr_leaf_fused.hip) */
+int qrd_leaf_fused_init(void);
+int qrd_leaf_update_gram(void* stream, int mk, int N, const double* V, int ldv, const double* W, double* C, int ldc, double* gslabs,
+                         size_t gslab_cap, int gy, int* nslab);
 int qrd_gemm_nn_batch(void* stream, int M, int N, int K, double alpha, const double* A, int lda, size_t sA,
                       const double* B, int ldb, size_t sB, double beta, double* C, int ldc, size_t sC, int batch);
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,

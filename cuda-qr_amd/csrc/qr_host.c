@@ -487,12 +487,25 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
     const int nhalf = (wout + QR_HALF - 1) / QR_HALF;
     static int fuse_gram = -1;
     if (fuse_gram < 0) { const char* fe = getenv("MI355XQR_FUSE_GRAM"); fuse_gram = fe ? atoi(fe) != 0 : 1; }
+    /* MI355XQR_FUSE_NN=0: in-panel update and the next leaf's Gram matrix as separate launches (gemm_nn + gram32_kernel);
+     * MI355XQR_FUSE_NN_MIN / _MAX: leaf heights the fused launch is used for (default: tall leaves only -- it saves a pass over
+     * the next leaf, 262144 x 512: 7.15 -> 7.08 ms; on the short leaves of square problems its 128 matrix-core instructions per
+     * wave sit on 10-14 compute units and the launch takes 18 us where gemm_nn + gram32 take 14: 8192^2 32.4 -> 33.0 ms);
+     * MI355XQR_FUSE_NN_GY: column pairs side by side on tall leaves (1 = every workgroup walks all columns, V read once) */
+    static int fuse_nn = -1, fuse_nn_min = 20000, fuse_nn_max = 0, fuse_nn_gy_tall = 1;
+    if (fuse_nn < 0) {
+        const char* fe = getenv("MI355XQR_FUSE_NN"); fuse_nn = fe ? atoi(fe) != 0 : 1;
+        fe = getenv("MI355XQR_FUSE_NN_MIN"); if (fe) fuse_nn_min = atoi(fe);
+        fe = getenv("MI355XQR_FUSE_NN_MAX"); if (fe) fuse_nn_max = atoi(fe);
+        fe = getenv("MI355XQR_FUSE_NN_GY"); if (fe) fuse_nn_gy_tall = atoi(fe);
+    }
     for (int h = 0; h < nhalf; ++h) {
         const int c0 = h * QR_HALF, wh = imin(QR_HALF, wout - c0), cend = c0 + wh;
         const int need_t = want_t || h + 1 < nhalf;          /* the next half's block update needs T of everything before it */
         /* the Gram blocks V(:, c0:c)^T V_l that T needs are collected leaf by leaf, in the same launch as the leaf's in-panel
          * product (qrd_gemm_tn_dual); gram_done stays 1 while every leaf of the half could do that */
         int gram_done = fuse_gram && need_t;
+        int gram_nslab = 0;          /* > 0: p->slabs holds that many partial Gram matrices of the coming leaf (left by the previous leaf's update) */
         if (h > 0) {
             /* A(:, c0:cend) <- (I - V T V^T)^T A(:, c0:cend) with the c0 reflectors factored so far */
             if (half_ready) CHECK(qrd_stream_wait_event(p->stream, half_ready));
@@ -508,7 +521,7 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
              * Householder TSQR leaf alone; col = one launch per column (34 launches, ~25 passes over the leaf) */
             if (p->panel_tsqr == 3)
                 CHECK(qrd_panel_cholqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
-                                       p->slabs, p->slab_cap));
+                                       p->slabs, p->slab_cap, gram_nslab));
             else if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
                 CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
             else
@@ -527,7 +540,19 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
                 if (nprev > 0 || (c > c0 && w != 32)) gram_done = 0;     /* this leaf's Gram column is missing: whole Gram at the end */
                 if (nrest > 0) CHECK(tn(p, w, nrest, mkl, Vl, ldv, Arest, lda, p->Wn, w, Tl));  /* T_l^T V_l^T A_rest */
             }
-            if (nrest > 0) CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
+            gram_nslab = 0;
+            if (nrest > 0) {
+                /* A_rest -= V_l W; with the CholeskyQR2 leaf the same launch leaves the Gram matrix of the NEXT leaf's columns in
+                 * p->slabs (qr_leaf_fused.hip: one launch less per leaf on the critical chain) */
+                int rc = -7;
+                if (fuse_nn && w == 32 && mkl >= fuse_nn_min && (fuse_nn_max <= 0 || mkl <= fuse_nn_max)) {
+                    const int want_gram = p->panel_tsqr == 3 && nrest >= 32;
+                    rc = qrd_leaf_update_gram(p->stream, mkl, nrest, Vl, ldv, p->Wn, Arest, lda, want_gram ? p->slabs : NULL, p->slab_cap / 2,
+                                              mkl > 32768 ? fuse_nn_gy_tall : 0, &gram_nslab);
+                    if (rc != 0 && rc != -7) return rc;
+                }
+                if (rc == -7) CHECK(qrd_gemm_nn(p->stream, mkl, nrest, w, -1.0, Vl, ldv, p->Wn, w, 1.0, Arest, lda));
+            }
         }
         if (!need_t) continue;
         double* Vh = p->Vw + (size_t) c0 * ldv + c0;          /* this half's V: rows from c0 (zero above) */

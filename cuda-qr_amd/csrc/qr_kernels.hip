@@ -897,6 +897,7 @@ int qrd_init(void)
     rc |= allow_lds(gemm_tn_kernel<4, 4, false>, sizeof(double) * (4 * 128 * LDKF));
     rc |= qrd_gemm2_init();
     rc |= qrd_panel_tsqr_init();
+    rc |= qrd_leaf_fused_init();
     return rc;
 }
 

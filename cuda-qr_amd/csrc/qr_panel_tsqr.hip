@@ -689,6 +689,7 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
 // the work.  The result has the same form either way: unit-lower V below R, tau, T.
 // =========================================================================================================
 #define QRD_GUARD_THR (1.0 / 64.0)
+#define QRD_CHOL1_THR 1e-9      /* hr3_kernel: below this max|Q^T Q - I| the second Cholesky factor is taken to first order */
 
 // 1/sqrt(p) from the hardware estimate (v_rsq_f64, ~2^-26 relative) and two Newton steps y <- y (3/2 - p/2 y^2): full double
 // accuracy to an ulp or two in ~10 dependent instructions.  The IEEE sqrt + division this replaces is ~60 instructions
@@ -1485,7 +1486,7 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
 {
     __shared__ double Bs[PW][PW + 1], R1s[PW][PW + 1], R2s[PW][PW + 1], Us[PW][PW + 1], Ls[PW][PW + 1], Gs[PW][PW + 1];
     __shared__ double Ss[PW], r2inv[PW];
-    __shared__ int flags[2];
+    __shared__ int flags[3];
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const int rc = lane & (PW - 1);
     STAMP_DECL;
@@ -1494,7 +1495,7 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
     // the guard word is TESTED only after the loads below have been issued (behind the second barrier): an early return here
     // would put one more global round trip -- 2-4 us next to a running update GEMM -- in front of every other load
     const int gword = *guard;
-    if (tid < 2) flags[tid] = 0;
+    if (tid < 3) flags[tid] = 0;
     double b[PW];
     if (g == 0) {                                          // column rc of Q_top: 32 consecutive doubles, in flight under the sum
         const v2d* col = reinterpret_cast<const v2d*>(Vw + (size_t) rc * ldv);
@@ -1509,6 +1510,7 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
         Gs[c][i + 1] = gsum[1];
         const double d0 = gsum[0] - (i == c ? 1.0 : 0.0), d1 = gsum[1] - (i + 1 == c ? 1.0 : 0.0);
         if (!(fabs(d0) <= QRD_GUARD_THR) || !(fabs(d1) <= QRD_GUARD_THR)) flags[0] = 1;     // also catches NaN
+        if (!(fabs(d0) <= QRD_CHOL1_THR) || !(fabs(d1) <= QRD_CHOL1_THR)) flags[2] = 1;     // G2 - I too large for the first-order factor
         R1s[i][c] = (i <= c) ? R1[e] : 0.0;
         R1s[i + 1][c] = (i + 1 <= c) ? R1[e + 1] : 0.0;
     }
@@ -1522,7 +1524,19 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
         for (int i = 0; i < PW; ++i) gg[i] = Gs[rc][i];
         bool ok = true;
         double dinv = 1.0, sgn = 1.0;
-        Chol3Step<0>::run(gg, rc, ok, dinv);
+        if (flags[2]) {
+            Chol3Step<0>::run(gg, rc, ok, dinv);
+        } else {
+            // G2 = I + E with max|E| <= 1e-9 (the usual case: after one CholeskyQR pass E ~ cond(leaf)^2 eps): the Cholesky factor is
+            // R2 = I + striu(E) + diag(E)/2 up to terms of size n |E|^2 <= 3e-17 -- below the rounding of R2 itself.  Replaces the
+            // 32-step dependent recurrence (~5 us of this one-workgroup kernel, on every leaf's critical chain) by one pass.
+#pragma unroll
+            for (int i = 0; i < PW; ++i) gg[i] = (i < rc) ? gg[i] : (i == rc ? 1.0 + 0.5 * (gg[i] - 1.0) : 0.0);
+            double d = 1.0;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) d = (i == rc) ? gg[i] : d;
+            dinv = 1.0 / d;
+        }
         STAMP(18);
         if (ok) {
             Hr3Lu<0>::run(b, gg, rc, sgn);
@@ -1894,7 +1908,7 @@ int qrd_panel_tsqr_init(void)
 }
 
 int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
-                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap)
+                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab)
 {
     hipStream_t s = (hipStream_t) stream;
     if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
@@ -1919,8 +1933,9 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
             // short leaf (square problems): at most CQ2_MAXSLAB Gram slabs of >= 128 rows, summed by their consumers
             int rows_per = ((mk + CQ2_MAXSLAB - 1) / CQ2_MAXSLAB + GKB - 1) / GKB * GKB;
             if (rows_per < 2 * GKB) rows_per = 2 * GKB;
-            const int nslab = (mk + rows_per - 1) / rows_per;
-            hipLaunchKernelGGL(gram32_kernel, dim3(nslab), dim3(256), 0, s, P, ld, mk, rows_per, slabs);
+            int nslab = (mk + rows_per - 1) / rows_per;
+            if (gram_nslab > 0 && gram_nslab <= CQ2_MAXSLAB) nslab = gram_nslab;      // left by the previous leaf's in-panel update
+            else hipLaunchKernelGGL(gram32_kernel, dim3(nslab), dim3(256), 0, s, P, ld, mk, rows_per, slabs);
             if (gen == 3)
                 hipLaunchKernelGGL((cholq3_kernel<512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk,
                                    slabs, nslab, R1, Vw, ldv, slab2, guard);
@@ -1936,7 +1951,10 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
             if (rb_env < 0) { const char* e = getenv("MI355XQR_TALL_RB"); rb_env = e ? atoi(e) : 0; }
             const bool rb2 = rb_env == 2 || (rb_env != 1 && (mk + 511) / 512 >= 384);
             nblk2 = rb2 ? (mk + 511) / 512 : (mk + 255) / 256;
-            rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
+            if (gram_nslab > 0 && (size_t) gram_nslab * PW * PW <= slab_cap - (size_t) nblk2 * PW * PW)
+                rc = qrd_slab_reduce(s, PW, PW, gram_nslab, slabs, PW, (size_t) PW * PW, G1, PW);   // partial Grams left by the previous leaf's update
+            else
+                rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
             if (rc) return rc;
             slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
             if (rb2)

@@ -6,7 +6,7 @@ here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(here, "cuda-qr_amd", "libmi355xqr_stamps.so"))
 vp = C.c_void_p
 lib.qrd_panel_ws_size.restype = C.c_size_t; lib.qrd_panel_ws_size.argtypes = [C.c_int]
-lib.qrd_panel_cholqr.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_size_t]
+lib.qrd_panel_cholqr.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_size_t, C.c_int]
 lib.qrd_dbg_read_stamps.argtypes = [C.POINTER(C.c_longlong)]
 assert lib.qrd_init() == 0
 names = {0: "cholq2 start", 1: "  G1 slabs summed", 2: "  Cholesky done", 3: "  q = a R1^-1 done", 4: "  V stores issued",
@@ -24,7 +24,7 @@ for mk in [int(x) for x in sys.argv[1:]] or [8192, 2048]:
         P.uniform_()
         torch.cuda.synchronize()
         rc = lib.qrd_panel_cholqr(None, P.data_ptr(), mk, mk, w, tau.data_ptr(), T.data_ptr(), w, V.data_ptr(), mk, ws.data_ptr(), mk,
-                                  cws.data_ptr(), slabs.data_ptr(), 1 << 20)
+                                  cws.data_ptr(), slabs.data_ptr(), 1 << 20, 0)
         assert rc == 0, rc
         torch.cuda.synchronize()
     st = (C.c_longlong * 64)()

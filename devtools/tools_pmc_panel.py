@@ -24,7 +24,7 @@ for (mk, w) in shapes:
             q.check(lib.qrd_panel_tsqr(st, Pm.data_ptr(), mk, mk, w, tau.data_ptr(), Tm.data_ptr(), w, V.data_ptr(), mk, ws.data_ptr(), mk))
         else:
             q.check(lib.qrd_panel_cholqr(st, Pm.data_ptr(), mk, mk, w, tau.data_ptr(), Tm.data_ptr(), w, V.data_ptr(), mk, ws.data_ptr(), mk,
-                                         cws.data_ptr(), slabs.data_ptr(), 1 << 22))
+                                         cws.data_ptr(), slabs.data_ptr(), 1 << 22, 0))
         p.sync()
     out.append({"mk": mk, "w": w, "leaf_bytes": 8 * mk * w})
 print(json.dumps({"mode": mode, "launches_per_shape": 3, "shapes": out}))

@@ -261,7 +261,7 @@ def _cholqr_leaf(q, P, ld=None, ldv=None, ldt=None):
     slabs = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     q.check(q.lib.qrd_panel_cholqr(None, dP.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), ldt, dV.data_ptr(), ldv,
-                                   ws.data_ptr(), mk, cws.data_ptr(), slabs.data_ptr(), 1 << 20))
+                                   ws.data_ptr(), mk, cws.data_ptr(), slabs.data_ptr(), 1 << 20, 0))
     _sync(q)
     guard = int(cws[4 * 32 * 32:].view(torch.int32)[0].item())
     return host(dP), host(dtau)[:, 0], host(dT)[:w], host(dV)[:mk], guard, buf
@@ -441,3 +441,35 @@ def test_diffnorm(q):
     a, b = p.diffnorm(dX, 777, 13, 13, mode=1)
     assert abs(a - ((X[:13] - np.eye(13)) ** 2).sum()) < 1e-9 and abs(b - 13.0) < 1e-12
     p.close()
+
+
+@pytest.mark.parametrize("mk,N,gy", [(64, 32, 0), (512, 96, 0), (1000, 64, 0), (4100, 224, 0), (7168, 224, 2), (7168, 96, 1),
+                                     (33000, 96, 1), (131072, 64, 1)])
+def test_leaf_update_gram(q, mk, N, gy):
+    """Fused in-panel update of the leaf chain (qr.c:215-235): A_rest -= V W on the matrix cores and, from the same accumulators,
+    the partial Gram matrices of the NEXT leaf's 32 columns (rows below the current leaf's 32 x 32 diagonal block) -- against
+    numpy; the padding rows of A_rest (ld > mk) must stay untouched."""
+    import ctypes as C
+    rng = np.random.default_rng(mk + N)
+    V, W, A0 = rng.standard_normal((mk, 32)), rng.standard_normal((32, N)), rng.standard_normal((mk, N))
+    ld = mk + 6
+    buf = np.full((ld, N), 7.0); buf[:mk] = A0
+    dV, dW, dA = dev(V), dev(W), dev(buf)
+    cap = 1 << 20
+    slabs = torch.full((cap,), np.nan, dtype=torch.float64, device="cuda")
+    nslab = C.c_int(0)
+    torch.cuda.synchronize()
+    q.check(q.lib.qrd_leaf_update_gram(None, mk, N, dV.data_ptr(), mk, dW.data_ptr(), dA.data_ptr(), ld, slabs.data_ptr(), cap, gy,
+                                       C.byref(nslab)))
+    _sync(q)
+    ref = A0 - V @ W
+    out = host(dA)
+    assert rel(out[:mk], ref) < 1e-14
+    assert np.array_equal(out[mk:], np.full((ld - mk, N), 7.0))
+    assert nslab.value == (mk + 511) // 512
+    G = slabs[: nslab.value * 1024].cpu().numpy().reshape(nslab.value, 32, 32).sum(axis=0).T      # slabs are column-major 32 x 32
+    Gref = ref[32:, :32].T @ ref[32:, :32]
+    assert rel(G, Gref) < 1e-13
+    # shapes the kernel does not take are refused, not mangled (the host then launches the plain product)
+    assert q.lib.qrd_leaf_update_gram(None, mk + 2, N, dV.data_ptr(), mk, dW.data_ptr(), dA.data_ptr(), ld, None, 0, 0, None) == -7
+    assert q.lib.qrd_leaf_update_gram(None, mk, N + 16, dV.data_ptr(), mk, dW.data_ptr(), dA.data_ptr(), ld, None, 0, 0, None) == -7

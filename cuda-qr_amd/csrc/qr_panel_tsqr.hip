@@ -614,7 +614,7 @@ __device__ __forceinline__ void tsqr_coop_body(const double* P, int ld, int mk, 
                                                double* __restrict__ tau, double* __restrict__ T, int ldt,
                                                double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar)
 {
-    const int b = blockIdx.x, G = gridDim.x, rows_stack = nblk * w;
+    const int b = blockIdx.x, G = nblk, rows_stack = nblk * w;      // participants: workgroups 0 .. nblk-1 (the launch may hold more)
     bool ok = true;
     // F: local Householder QR of this workgroup's row block (<= 1024 rows: two rows per thread)
     tsqr_factor_body<PT, 2>(b, nblk, P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stack, rows_stack);
@@ -1353,11 +1353,14 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
 }
 
 // rows >= 32 of V = Q U'^-1 (Winv: U'^-1, column-major, ld PW), written to Vw and to A.  No LDS, no barrier.
+// rows_wg: rows per workgroup -- PT (every wave 64 rows) or PT / 2 (waves 0..3 only: twice the workgroups, i.e. compute units, for
+// the same 64 matrix-core instructions per wave; two waves per SIMD took 3.7 us of the launch's 11, one takes 1.9)
 __device__ __forceinline__ void final4_body(double* __restrict__ Vw, int ldv, int mk, const double* __restrict__ Winv,
-                                            double* __restrict__ A, int lda)
+                                            double* __restrict__ A, int lda, int rows_wg = PT)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int wrow0 = blockIdx.x * PT + wave * 64;
+    if (wave * 64 >= rows_wg) return;
+    const int wrow0 = blockIdx.x * rows_wg + wave * 64;
     if (wrow0 >= mk) return;
     double bq[4][8], aw[2][8];
 #pragma unroll
@@ -1690,13 +1693,15 @@ __global__ __launch_bounds__(PT) void final4_coop_kernel(const double* __restric
                                                          double* __restrict__ Umat, double* A, int lda,
                                                          double* __restrict__ tau, double* __restrict__ T, int ldt,
                                                          double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
-                                                         const int* __restrict__ guard)
+                                                         const int* __restrict__ guard, int rows_wg)
 {
     if (*guard != 0) {
-        tsqr_coop_body(A, lda, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
+        // guard route: the first nblk workgroups (dispatched first), one 512-row block each; any others have nothing to do
+        if ((int) blockIdx.x < nblk)
+            tsqr_coop_body(A, lda, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
         return;
     }
-    final4_body(Vw, ldv, mk, Um, A, lda);
+    final4_body(Vw, ldv, mk, Um, A, lda, rows_wg);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1815,9 +1820,13 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     if (fuse < 0) { const char* e = getenv("MI355XQR_FUSE_GUARD"); fuse = (e && atoi(e) == 0) ? 0 : 1; }
     const bool coop = guard && bar && coop_enabled() && lv_nblk[0] * w <= PT;
     if (final3_u && coop && fuse && brows0 == PT && w == PW) {
-        if (gen == 3)
-            hipLaunchKernelGGL(final4_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
-                               stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
+        if (gen == 3) {
+            static int half_wg = -1;
+            if (half_wg < 0) { const char* e = getenv("MI355XQR_LEAF_HALFWG"); half_wg = e ? atoi(e) != 0 : 1; }
+            const int rows_wg = half_wg ? PT / 2 : PT;
+            hipLaunchKernelGGL(final4_coop_kernel, dim3(half_wg ? (mk + rows_wg - 1) / rows_wg : lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0],
+                               brows0 / PT, mk, w, Vloc1, taus, Ts, stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, rows_wg);
+        }
         else
             hipLaunchKernelGGL(final3_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
                                stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
@@ -1904,6 +1913,8 @@ int qrd_panel_tsqr_init(void)
                                     (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<512, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
     return rc;
 }
 
@@ -1936,7 +1947,16 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
             int nslab = (mk + rows_per - 1) / rows_per;
             if (gram_nslab > 0 && gram_nslab <= CQ2_MAXSLAB) nslab = gram_nslab;      // left by the previous leaf's in-panel update
             else hipLaunchKernelGGL(gram32_kernel, dim3(nslab), dim3(256), 0, s, P, ld, mk, rows_per, slabs);
-            if (gen == 3)
+            // 256-row workgroups where that keeps the partial Grams of G2 within CQ2_MAXSLAB (mk <= 8192, the chain-bound part of a
+            // square factorisation): the kernel is bound by its 128 matrix-core instructions per wave -- at two waves per SIMD 7.4 us
+            // of its 25 -- and half-size workgroups put them on twice the compute units
+            static int half_wg = -1;
+            if (half_wg < 0) { const char* e = getenv("MI355XQR_LEAF_HALFWG"); half_wg = e ? atoi(e) != 0 : 1; }
+            if (gen == 3 && half_wg && (mk + 255) / 256 <= CQ2_MAXSLAB) {
+                nblk2 = (mk + 255) / 256;
+                hipLaunchKernelGGL((cholq3_kernel<256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk,
+                                   slabs, nslab, R1, Vw, ldv, slab2, guard);
+            } else if (gen == 3)
                 hipLaunchKernelGGL((cholq3_kernel<512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk,
                                    slabs, nslab, R1, Vw, ldv, slab2, guard);
             else

@@ -1285,8 +1285,10 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
             for (int ti = 0; ti < 2; ++ti) {
                 v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ti == 0 && ks >= 4) continue;          // R1^-1 is upper triangular: rows k >= 16 of its first 16 columns are zero
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[ti][ks], live ? bq[t][ks] : 0.0, acc, 0, 0, 0);
+                }
                 q[t][ti] = acc;
             }
         }
@@ -1327,8 +1329,7 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
         for (int ks = 0; ks < 8; ++ks) {
             const double f0 = base[l15 * (HALF + 2) + 4 * ks], f1 = base[(16 + l15) * (HALF + 2) + 4 * ks];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);   // tile (1, 0) is its transpose (bitwise)
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
@@ -1338,9 +1339,12 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int tj = ti; tj < 2; ++tj)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) red[(16 * tj + l15) * PW + 16 * ti + l4 + 4 * rr] = acc[ti][tj][rr];
+            for (int rr = 0; rr < 4; ++rr) {
+                red[(16 * tj + l15) * PW + 16 * ti + l4 + 4 * rr] = acc[ti][tj][rr];
+                if (ti != tj) red[(16 * ti + l4 + 4 * rr) * PW + 16 * tj + l15] = acc[ti][tj][rr];     // G2 is symmetric
+            }
     __syncthreads();
     for (int e = tid; e < PW * PW; e += NT) {
         double sum = 0.0;
@@ -1381,7 +1385,10 @@ __device__ __forceinline__ void final4_body(double* __restrict__ Vw, int ldv, in
         for (int ti = 0; ti < 2; ++ti) {
             acc[ti] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[ti][ks], bq[t][ks], acc[ti], 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ti == 0 && ks >= 4) continue;              // U'^-1 is upper triangular: nothing below row 15 in its first 16 columns
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[ti][ks], bq[t][ks], acc[ti], 0, 0, 0);
+            }
         }
         if (row >= PW && row < mk) {
 #pragma unroll
@@ -1942,7 +1949,9 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
         int nblk2 = nblk;                                   // workgroups of cholq2_kernel = slabs of G2
         if (nblk <= CQ2_MAXSLAB) {
             // short leaf (square problems): at most CQ2_MAXSLAB Gram slabs of >= 128 rows, summed by their consumers
-            int rows_per = ((mk + CQ2_MAXSLAB - 1) / CQ2_MAXSLAB + GKB - 1) / GKB * GKB;
+            static int gslab_max = 0;
+            if (!gslab_max) { const char* e = getenv("MI355XQR_GRAM_SLABS"); gslab_max = e ? atoi(e) : CQ2_MAXSLAB; if (gslab_max < 1 || gslab_max > CQ2_MAXSLAB) gslab_max = CQ2_MAXSLAB; }
+            int rows_per = ((mk + gslab_max - 1) / gslab_max + GKB - 1) / GKB * GKB;
             if (rows_per < 2 * GKB) rows_per = 2 * GKB;
             int nslab = (mk + rows_per - 1) / rows_per;
             if (gram_nslab > 0 && gram_nslab <= CQ2_MAXSLAB) nslab = gram_nslab;      // left by the previous leaf's in-panel update

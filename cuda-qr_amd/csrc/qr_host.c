@@ -589,7 +589,11 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
      * it hands anything it cannot take (ragged, unaligned) to the generic path itself */
     static int use_w8 = -1;
     if (use_w8 < 0) { const char* e = getenv("MI355XQR_SMALLT_W8"); use_w8 = e ? atoi(e) : 1; }
-    if (use_w8 && mk >= 2048 && nc >= 128) return qrd_gemm_nn_update2(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
+    /* ... as long as its 128 x 128 tiles give every compute unit of the stream one: the look-ahead update of a late panel
+     * (mk <= 8192, 256 columns: 128 tiles for 192-224 CUs) runs 16 serial K steps on half the chip -- 64 x 64 tiles then
+     * (8192^2: 29.7 -> 29.2 ms) */
+    if (use_w8 && mk >= 2048 && nc >= 128 && (long long) (mk / 128) * (nc / 128) >= qrd_stream_cus(stream))
+        return qrd_gemm_nn_update2(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
     return qrd_gemm_nn(stream, mk, nc, kw, -1.0, V, ldv, Wbuf, kw, 1.0, A2, lda);
 }
 

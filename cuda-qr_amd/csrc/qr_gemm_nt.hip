@@ -40,27 +40,7 @@
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*) (p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*) (p))
 
-// Workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2), so the
-// linear id is first turned into "XCD-major" order (each XCD gets a contiguous range of tile indices), and tile
-// indices walk the grid in groups of GM row tiles x all column tiles: the ~64 workgroups an XCD runs at a time then
-// form a compact GM x (64/GM) block of the tile grid that shares GM V tiles and 64/GM Wt tiles in that XCD's L2.
-// Speed only: any bijection is correct.
-__device__ __forceinline__ void tile_of_block(int bid, int gx, int gy, int gm, int& tx, int& ty)
-{
-    const int nwg = gx * gy;
-    int id = bid;
-    if (gm > 0) {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        const int per = gm * gy, g = id / per, in = id - g * per;
-        const int rows = min(gm, gx - g * gm);            // the last group may be shorter
-        tx = g * gm + in % rows;
-        ty = in / rows;
-    } else {
-        tx = id % gx;
-        ty = id / gx;
-    }
-}
+// (tile_of_block: workgroup -> tile map, XCD-aware; qr_common.h)
 
 // ------------------------------------------------------------------------------------------------
 // C (M x N, ldc) -= A (M x K, lda) * Bt (N x K, ldbt)^T      (NEG; else +=)

@@ -583,8 +583,16 @@ static void use_set(qr_plan* p, int e) { p->Vw = p->Vw2[e]; p->VT = p->VT2[e]; p
 static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, const double* T, int ldt, int mk, int kw, double* A2,
                          int lda, int nc, double* Wbuf, double* Ybuf, double* slabs)
 {
-    CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Ybuf, kw, slabs, p->slab_cap, NULL, 0));
-    CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
+    /* narrow panels: T^T is folded into the reduction of the split-K slabs (one thread per entry of W walks a column of T:
+     * fine for kw <= 128, 32 KB of T per output column; at kw = 256 every column's workgroup would pull 256 KB through L2) */
+    static int fold_max = -1;
+    if (fold_max < 0) { const char* e = getenv("MI355XQR_TFOLD_MAX"); fold_max = e ? atoi(e) : 128; }
+    if (kw <= fold_max && slabs != NULL) {
+        CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Wbuf, kw, slabs, p->slab_cap, T, ldt));
+    } else {
+        CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Ybuf, kw, slabs, p->slab_cap, NULL, 0));
+        CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
+    }
     /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
      * it hands anything it cannot take (ragged, unaligned) to the generic path itself */
     static int use_w8 = -1;
@@ -795,8 +803,11 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
      * there it waited for ALL of W(s) and then ran alone on the chip for 0.16-0.18 ms per step (C3: 33 such steps).  For
      * that, W(s) starts with the columns of panel s+2 (W1(s), event ev_half[s&1]) and E(s) takes the LAST columns of the wide
      * range instead of the first.  early_done: N of the coming step has been issued already. */
-    static int early_env = -1;
-    if (early_env < 0) { const char* ee = getenv("MI355XQR_EARLY_NEXT"); early_env = ee ? atoi(ee) != 0 : 1; }
+    static int early_env = -1, early_w1 = 2048;
+    if (early_env < 0) {
+        const char* ee = getenv("MI355XQR_EARLY_NEXT"); early_env = ee ? atoi(ee) != 0 : 1;
+        ee = getenv("MI355XQR_EARLY_W1"); if (ee && atoi(ee) >= 128) early_w1 = atoi(ee) / 128 * 128;
+    }
     int early_done = 0;
     CHECK(enter_phase(p, phase_of(p, n, n)));
     {
@@ -859,11 +870,15 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
                 formed = 1;
             }
             if (early_next) {
-                /* W1(s): the columns of panel s+2 first, so that N(s+1) need not wait for the rest; E(s) at the far end */
-                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw, wnext2, p->W, NULL, p->slabs_u, 1, 1));
+                /* W1(s): a first slice that holds the columns of panel s+2, so that N(s+1) need not wait for the rest; E(s) at the
+                 * far end.  The slice is ~2048 columns, not just the 256 N(s+1) needs: a 256-column launch pair fills half the
+                 * update stream's workgroup slots (0.14 ms for 0.07 ms of work, every step), and N(s+1) has P(s+1)'s 1.4 ms to spare */
+                int w1 = nwide - extra;
+                if (w1 > early_w1 + 1024) w1 = early_w1 > wnext2 ? early_w1 : wnext2;
+                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw, w1, p->W, NULL, p->slabs_u, 1, 1));
                 CHECK(qrd_event_record(p->ev_half[e], p->stream_u));
-                if (nwide - wnext2 - extra > 0)
-                    CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw + wnext2, nwide - wnext2 - extra, p->W, NULL,
+                if (nwide - w1 - extra > 0)
+                    CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw + w1, nwide - w1 - extra, p->W, NULL,
                                       p->slabs_u, 1, 0));
             } else if (nwide - extra > 0)                                                                     /* W_b(s) */
                 CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw + extra, nwide - extra, p->W,

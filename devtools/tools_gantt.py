@@ -28,7 +28,9 @@ for st, nm, a, b in order:
 for st in sorted(by):
     d = by[st]
     f = lambda k: ("%8.2f..%8.2f" % (d[k][0][0], d[k][-1][1])) if k in d else " " * 18
-    w = [d.get(k, [(0, 0)])[0] for k in ("W.vt", "W.tn", "W.nn")]
-    ws = ("%8.2f..%8.2f (%5.2f)" % (w[0][0], w[2][1], w[2][1] - w[0][0])) if "W.nn" in d else ""
+    # the wide update may come in two slices (W1: the next-next panel's columns first, then the rest): first start .. last end
+    w0 = min(d[k][0][0] for k in ("W.vt", "W.tn", "W.nn") if k in d) if "W.nn" in d else 0.0
+    w1 = d["W.nn"][-1][1] if "W.nn" in d else 0.0
+    ws = ("%8.2f..%8.2f (%5.2f)" % (w0, w1, w1 - w0)) if "W.nn" in d else ""
     print("%4d | %s (%5.2f) | %s | %-34s | %s" % (st, f("P"), d["P"][0][1] - d["P"][0][0] if "P" in d else 0, f("N"), ws, f("E")))
 p.close()

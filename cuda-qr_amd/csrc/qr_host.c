@@ -28,11 +28,11 @@
 #define QR_MAX_NB 512           /* outer block (the K of the wide update) */
 #define QR_HALF 256             /* outer blocks wider than this are factored half by half (two-level panel, factor_panel) */
 #define QR_DEFAULT_SPLIT "64"
-/* large square problems are update-bound for most of their flops: one XCD (32 CUs) for the panel chain, seven for the wide
- * update, and the look-ahead update N(s) on the update stream (it would crawl on 32 CUs).  Measured at 16384^2: the same
- * 140 ms as 64 / 192, but the update GEMMs run on 224 CUs instead of 192 (50 instead of 43 TFLOP/s per launch); at 8192^2
- * and below the chain dominates and 64 CUs (two XCDs) are 6 % faster.  CU masks must follow XCD boundaries (32 CUs each):
- * 48 / 208 leaves the update stream an XCD with half its CUs and costs 15 %. */
+/* large square problems are update-bound for most of their flops: 32 CUs for the panel chain, 224 for the wide update, and the
+ * look-ahead update N(s) on the update stream in the chain-bound phase (it would crawl on 32 CUs).  Measured at 16384^2: 125.6 ms
+ * against 131.8 with 64 / 192 (the update GEMMs run at 50 instead of 43 TFLOP/s per launch); at 8192^2 and below the chain
+ * dominates and 64 CUs are faster.  A mask bit i is compute unit i/8 of XCC i%8 (profiles/r02_probe_cumask.txt): a contiguous
+ * range of 32 bits = 4 CUs of every XCD, so both streams stay balanced over the XCDs; a 48 / 208 split was measured 15 % slower. */
 #define QR_DEFAULT_SPLIT_BIG "32"
 #define QR_DEFAULT_PANEL 3
 struct qr_plan {

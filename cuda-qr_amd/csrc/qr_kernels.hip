@@ -1337,6 +1337,32 @@ int qrd_stream_create_cumask(void** s, int first, int count)
     if (g_nstream_cus < QRD_MAX_MASKED_STREAMS) { g_stream_cus[g_nstream_cus].s = st; g_stream_cus[g_nstream_cus].cus = count; ++g_nstream_cus; }
     return 0;
 }
+// Which (XCC, SE, CU) the workgroups of a stream land on: out[b] = XCC_ID | HW_ID << 8 (development probe for the CU-mask layout)
+__global__ void mask_probe_kernel(unsigned* __restrict__ out, int spin)
+{
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));        // HW_REG_XCC_ID[3:0]
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));          // HW_REG_HW_ID
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long) spin) { }
+    if (threadIdx.x == 0) out[blockIdx.x] = (xcc & 0xf) | (hw << 8);
+}
+
+// mask words given explicitly (development probe); n workgroups, result per workgroup in out (host array)
+int qrd_probe_cumask(const unsigned* mask_words, int nwords, int nwg, unsigned* out_host)
+{
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t) nwords, mask_words);
+    if (e != hipSuccess) return (int) e;
+    unsigned* d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(unsigned) * nwg));
+    hipLaunchKernelGGL(mask_probe_kernel, dim3(nwg), dim3(64), 0, st, d, 20000);
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned) * nwg, hipMemcpyDeviceToHost));
+    hipFree(d);
+    hipStreamDestroy(st);
+    return 0;
+}
+
 int qrd_stream_destroy(void* s)
 {
     if (!s) return 0;

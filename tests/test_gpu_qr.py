@@ -419,6 +419,19 @@ def test_profile_hooks(qr):
     assert 1 <= prof["update_nn"]["launches"] <= n // nb - 1 and prof["panel"]["launches"] == n // nb
     assert prof["update_nn"]["ms"] > 0 and prof["update_nn"]["flops"] > 0
     assert prof["update_nn"]["flops"] == prof["vta_tn"]["flops"]
+    # class mask (what bench.py uses inside its timed region): only the wide update's class 0 carries events
+    full_nn = prof["update_nn"]["launches"]
+    p.fill_uniform(dA, m, m, n)
+    p.set_profile(2 * (1 << 0))
+    p.geqrf(dA, m, n, m, dtau)
+    prof = p.get_profile()
+    assert prof["update_nn"]["launches"] == full_nn and prof["update_nn"]["ms"] > 0
+    assert prof["panel"]["launches"] == 0 and prof["vta_tn"]["launches"] == 0 and prof["vt_misc"]["launches"] == 0
+    p.set_profile(2 * (1 << 2))
+    p.fill_uniform(dA, m, m, n)
+    p.geqrf(dA, m, n, m, dtau)
+    prof = p.get_profile()
+    assert prof["panel"]["launches"] == n // nb and prof["update_nn"]["launches"] == 0
     p.close()
 
 

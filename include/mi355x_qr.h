@@ -115,7 +115,10 @@ int qr_plan_destroy(qr_plan* plan);
 
 /* In-place blocked Householder QR of dA (m x n, lda), m <= plan m, n <= plan n; dtau: n doubles.
  * Device-side counterpart of mmqr (qr.c:55) with input already resident in HBM; asynchronous on the
- * plan's stream -- call qr_plan_sync before reading results on another stream. */
+ * plan's stream -- call qr_plan_sync before reading results on another stream.  The plan's streams are
+ * non-blocking streams of their own: work queued on ANOTHER stream that writes a buffer handed to the plan
+ * (a memset, a fill, a framework's allocation-time zeroing) must have completed -- synchronise that stream,
+ * or make qr_plan_stream() wait on an event -- before the call, or it may land on top of the plan's output. */
 int qr_geqrf_dev(qr_plan* plan, double* dA, int m, int n, int lda, double* dtau);
 
 /* dC (m x ccols, ldc) <- Q * dC where Q = H_0..H_{n-1} comes from qr_geqrf_dev's factors.

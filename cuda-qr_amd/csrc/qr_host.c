@@ -108,9 +108,11 @@ static void default_blocks(int m, int n, int* nb, int* ib)
     pthread_mutex_lock(&g_lock);
     defaults_from_env_locked();
     int b = g_nb;
-    /* large square problems are update-bound: K = 256 lifts the update GEMMs (C3: 155 -> 151 ms); everything smaller or
-     * tall-skinny is panel-bound and better off with 128 */
-    if (!g_nb_explicit && m >= 8192 && n >= 8192 && 256 % g_ib == 0) b = 256;
+    /* large problems are update-bound: K = 256 lifts the update GEMMs (C3: 155 -> 151 ms in round 1).  With the round-2 leaf the
+     * same holds for every square-ish problem from 1024 columns on -- half as many panel tails (T merge, look-ahead update) for
+     * the same leaves: 4096^2 12.1 -> 11.5 ms, 2048^2 5.9 -> 5.6, 12288 x 8192 41.9 -> 39.2 -- while tall shapes keep 128
+     * (16384 x 2048: 9.0 against 9.9 ms; 8192 x 4096: 13.8 against 14.0); profiles/r02_session2_ab_measurements.txt */
+    if (!g_nb_explicit && 256 % g_ib == 0 && (n >= 8192 || (n >= 1024 && 2LL * m <= 3LL * n))) b = 256;
     if (nb) *nb = b;
     if (ib) *ib = g_ib;
     pthread_mutex_unlock(&g_lock);

@@ -74,8 +74,8 @@ int explicitQR_f32_status(float* A, float* tau, float* Q, float* R, int m, int n
 const char* qr_strerror(int status);
 
 /* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 256;
- * leaf width ib <= 32).  Defaults 128 / 32 (256 / 32 when both m and n are >= 8192 and nothing was set explicitly --
- * getPanelDims(m, n, ..) reports the panel grid of the block size that shape will really get);
+ * leaf width ib <= 32).  Defaults 128 / 32 (256 / 32 when nothing was set explicitly and n >= 8192, or n >= 1024 with
+ * m <= 1.5 n: square-ish problems -- getPanelDims(m, n, ..) reports the panel grid of the block size that shape will really get);
  * env MI355XQR_NB / MI355XQR_IB override the defaults.
  * Threading: the library may be used from one host thread per GPU (each thread with its own current device and its own
  * plans; a plan belongs to one thread at a time).  Process-wide state (these defaults, per-device kernel attributes, the

@@ -30,7 +30,9 @@ def test_host_only_helpers(qr, capfd):
     assert np.array_equal(I, np.eye(5))
     nb, ib = qr.get_block_size()
     assert qr.get_panel_dims(512, 128) == (1, -(-128 // nb))
-    assert qr.get_panel_dims(4096, 4096) == (1, -(-4096 // nb))
+    assert qr.get_panel_dims(8192, 4096) == (1, -(-4096 // nb))              # tall: the default block
+    assert qr.get_panel_dims(4096, 4096) == (1, 4096 // 256)                 # square-ish from 1024 columns on: 256 (what mmqr really uses)
+    assert qr.get_panel_dims(32768, 8192) == (1, 8192 // 256)
     A = np.asfortranarray(np.arange(6, dtype=np.float64).reshape(2, 3))
     qr.lib.printMat(A.ctypes.data_as(C.POINTER(C.c_double)), 2, 3)   # qr.c:21-33 format
     C.CDLL(None).fflush(None)

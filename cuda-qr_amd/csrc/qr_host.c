@@ -205,7 +205,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         char spec[128];
         if (sp) snprintf(spec, sizeof spec, "%s", sp);
         else if (pc) snprintf(spec, sizeof spec, "%s", pc);
-        else snprintf(spec, sizeof spec, "%s", n >= 2048 ? ((m >= 12288 && n >= 12288) ? QR_DEFAULT_SPLIT_BIG : QR_DEFAULT_SPLIT) : "0");
+        else snprintf(spec, sizeof spec, "%s", n >= 2048 ? ((m >= 10240 && n >= 10240) ? QR_DEFAULT_SPLIT_BIG : QR_DEFAULT_SPLIT) : "0");
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
         char* save = NULL;

@@ -185,9 +185,12 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     p->ldv = (m + 15) & ~15;
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
-    /* very tall shards (262144 x 512): panel and update are both HBM-bound, running them side by side only slows the panel's
-     * latency-bound kernels (7.38 vs 7.22 ms); look-ahead stays on everywhere else */
-    p->lookahead = la ? atoi(la) != 0 : !((long long) m >= 128LL * n);
+    /* Look-ahead (two streams, CU partition) pays where there is a wide update worth overlapping: from 2048 columns and ~18 M
+     * elements on, and not for very tall shapes (m >= 16 n: panel and update are both HBM-bound there, side by side they only
+     * slow each other: 262144 x 512 7.38 vs 7.22 ms, 65536 x 2048 20.5 vs 19.0).  Below that the single-stream schedule
+     * is 5-10 % faster (2048^2 5.46 -> 4.93 ms, 3072^2 8.4 -> 7.9, 4096 x 1024 2.90 -> 2.65; equal at 4096^2;
+     * profiles/r02_session2_ab_measurements.txt section 12) */
+    p->lookahead = la ? atoi(la) != 0 : (n >= 2048 && (long long) m * n >= 18000000LL && (long long) m < 16LL * n);
     const char* gr = getenv("MI355XQR_GRAPH");
     p->use_graph = gr ? atoi(gr) != 0 : 0;
     /* MI355XQR_SPLIT = "c0:f0,c1:f1,...,ck": the panel chain runs on its own c_i compute units and the wide update

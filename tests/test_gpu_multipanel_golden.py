@@ -29,8 +29,11 @@ def _golden_R(g, n):
     return R
 
 
+@pytest.mark.parametrize("la", [None, "1"])          # default for this shape: single-stream schedule; "1": look-ahead on two streams
 @pytest.mark.parametrize("nb", [128, 64, 256, 32, 512])
-def test_1184x640_blocked_path_vs_reference_R(qr, oracle, nb):
+def test_1184x640_blocked_path_vs_reference_R(qr, oracle, nb, la, monkeypatch):
+    if la is not None:
+        monkeypatch.setenv("MI355XQR_LOOKAHEAD", la)    # read at plan creation
     m, n = 1184, 640
     g = load_golden("ref_1184x640_f64_64x8")
     A = oracle.fill_rand(m, n)
@@ -74,15 +77,17 @@ np.save(sys.argv[1], O.sign_normalise(F))
 
 
 @pytest.mark.parametrize("nb,env", [
-    (128, {}),                                                                        # default schedule
-    (128, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0"}),             # CU-masked streams + panel-stream share
-    (256, {"MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0"}),
-    (128, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_EARLY_NEXT": "0"}),   # look-ahead update never issued early
-    (128, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0.05,0.05"}),     # early look-ahead update on some steps only
+    (128, {}),                                                                        # default schedule (this shape: single stream)
+    (128, {"MI355XQR_LOOKAHEAD": "1"}),                                               # look-ahead on two streams, shared CUs
+    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0"}),   # CU-masked streams + panel-stream share
+    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0"}),
+    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_EARLY_NEXT": "0"}),   # look-ahead update never issued early
+    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0.05,0.05"}),     # early look-ahead update on some steps only
     (128, {"MI355XQR_PANEL": "tsqr"}),                                                # Householder-TSQR leaf only
     (64, {"MI355XQR_LOOKAHEAD": "0"}),                                                # single-stream schedule
     (512, {}),                                                                        # two-level panels (K = 512 wide update)
-    (512, {"MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_NEXT": "update"}),
+    (512, {"MI355XQR_LOOKAHEAD": "1"}),                                               # ... with look-ahead (W_a / W_b pieces, ev_half)
+    (512, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_NEXT": "update"}),
     (512, {"MI355XQR_LOOKAHEAD": "0"}),
     (128, {"MI355XQR_LEAF": "1"}),                                                    # first-generation CholeskyQR2 leaf
 ])

@@ -23,3 +23,9 @@ print("8192^2 after empty_cache %.2f ms" % t(8192, 8192, 256))
 buf = torch.rand((4096, 4096), dtype=torch.float64, device="cuda"); a, tau = torch.geqrf(buf); torch.cuda.synchronize(); del a, tau, buf
 print("8192^2 after torch.geqrf %.2f ms" % t(8192, 8192, 256))
 print("4096^2                  %.2f ms" % t(4096, 4096, 256))
+buf = torch.rand((16384, 16384), dtype=torch.float64, device="cuda"); a, tau = torch.geqrf(buf.mT); torch.cuda.synchronize(); del a, tau, buf
+print("8192^2 after torch.geqrf 16384^2 %.2f ms" % t(8192, 8192, 256))
+torch.cuda.empty_cache()
+print("8192^2 after empty_cache         %.2f ms" % t(8192, 8192, 256))
+print("16384^2                          %.2f ms" % t(16384, 16384, 256))
+print("6144^2                           %.2f ms" % t(6144, 6144, 256))

@@ -9,6 +9,9 @@ from oracle import oracle as O
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 shapes = [(3000, 2500, 0), (5000, 5000, 256), (10000, 3000, 128), (9000, 4100, 256), (4097, 2049, 64), (6144, 6144, 0), (20000, 2304, 256),
           (12288, 2560, 128), (70000, 320, 0), (33000, 96, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "ragged":        # odd sizes: ragged tiles, leaves narrower than 32, heights not multiples of 4
+    shapes = [(1900, 1900, 0), (2500, 2047, 0), (8200, 8190, 0), (12289, 2051, 0), (5000, 1025, 0), (33001, 97, 0), (4099, 4097, 256),
+              (6145, 3071, 128), (70001, 321, 0), (20003, 2305, 256)]
 worst = 0.0
 for (m, n, nb) in shapes:
     kind = rng.integers(0, 3)

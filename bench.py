@@ -270,7 +270,7 @@ def main():
                 "measured_mfma_f64_sustained_tflops": measured["mfma_f64_tflops"] if measured else None,
                 "frac_of_measured_sustained": ach / measured["mfma_f64_tflops"] if measured else None,
                 "cu_partition_note": ("with look-ahead the wide update runs on the update stream's compute units "
-                                      "(16384^2: 224 of 256, the panel chain owns one XCD = 32; smaller problems 192 / 64)"),
+                                      "(16384^2: 224 of 256, the panel chain owns 32 = 4 compute units of every XCD; smaller problems 192 / 64)"),
                 "update_stream_cus": cus_u,
                 "rocprof_pmc": "profiles/r02_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
                 "measured_probe": measured,

@@ -62,6 +62,9 @@ struct qr_plan {
     int next_on_update;         /* 1: N(s) runs on the update stream's CUs, ahead of W(s); 0: on the panel stream; 2: on the panel
                                  * stream while the factorisation is update-bound, on the update stream once it is chain-bound */
     void* ev_panel[2];          /* panel set s ready (V, T, VT) */
+    void* t_wait;               /* see apply_small_t */
+    void* ev_v[2];              /* V of panel set s complete (its T merge still running): the long-K product of N(s) may start */
+    void* v_ready;              /* event factor_panel records before the T merge of a one-level panel (NULL: none) */
     void* ev_wide[2];           /* wide update that read panel set s finished */
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
     double *Vw2[2], *VT2[2], *T2[2];
@@ -259,6 +262,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
             sscanf(b, "%lf,%lf,%lf,%lf", &p->bal_rp, &p->bal_ru, &p->bal_tc0, &p->bal_tc1);
         }
     }
+    for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_v[e]);
     for (int e = 0; e < 2 && !rc; ++e) {
         rc = qrd_event_create_notiming(&p->ev_panel[e]);
         if (!rc) rc = qrd_event_create_notiming(&p->ev_wide[e]);
@@ -308,6 +312,7 @@ int qr_plan_destroy(qr_plan* p)
     qrd_graph_destroy(p->graph_exec);
     for (int e = 0; e < 2; ++e) {
         if (p->ev_panel[e]) qrd_event_destroy(p->ev_panel[e]);
+        if (p->ev_v[e]) qrd_event_destroy(p->ev_v[e]);
         if (p->ev_wide[e]) qrd_event_destroy(p->ev_wide[e]);
         qrd_free(p->Vw2[e]); qrd_free(p->VT2[e]); qrd_free(p->T2[e]);
     }
@@ -564,6 +569,7 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
             }
         }
         if (!need_t) continue;
+        if (p->v_ready && nhalf == 1) CHECK(qrd_event_record(p->v_ready, p->stream));   /* V done; what follows only builds T */
         double* Vh = p->Vw + (size_t) c0 * ldv + c0;          /* this half's V: rows from c0 (zero above) */
         double* Thh = p->T + (size_t) c0 * ldt + c0;
         if (wh > ib) {
@@ -592,14 +598,20 @@ static void use_set(qr_plan* p, int e) { p->Vw = p->Vw2[e]; p->VT = p->VT2[e]; p
 static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, const double* T, int ldt, int mk, int kw, double* A2,
                          int lda, int nc, double* Wbuf, double* Ybuf, double* slabs)
 {
+    /* p->t_wait (set by the caller around ONE call): event after which T is complete -- V was complete before this call, so the
+     * long-K product Y = V^T A2 runs under the T merge of the panel stream and only W = T^T Y waits */
+    void* const t_wait = p->t_wait;
+    p->t_wait = NULL;
     /* narrow panels: T^T is folded into the reduction of the split-K slabs (one thread per entry of W walks a column of T:
      * fine for kw <= 128, 32 KB of T per output column; at kw = 256 every column's workgroup would pull 256 KB through L2) */
     static int fold_max = -1;
     if (fold_max < 0) { const char* e = getenv("MI355XQR_TFOLD_MAX"); fold_max = e ? atoi(e) : 128; }
     if (kw <= fold_max && slabs != NULL) {
+        if (t_wait) CHECK(qrd_stream_wait_event(stream, t_wait));
         CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Wbuf, kw, slabs, p->slab_cap, T, ldt));
     } else {
         CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Ybuf, kw, slabs, p->slab_cap, NULL, 0));
+        if (t_wait) CHECK(qrd_stream_wait_event(stream, t_wait));
         CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
     }
     /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
@@ -807,6 +819,9 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
      *   P(s+1)'s second half needs W_a(s) (ev_half[s&1]);
      *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
     int wide_pending[2] = {0, 0}, extra_pending = 0;
+    int v_recorded[2] = {0, 0};     /* ev_v[e] was recorded inside factor_panel for the panel now in set e */
+    static int split_t = -1;
+    if (split_t < 0) { const char* se = getenv("MI355XQR_SPLIT_T"); split_t = se ? atoi(se) != 0 : 1; }
     /* Early look-ahead update (update-bound phase, one-level panels): N(s+1) is issued on the panel stream right after P(s+1),
      * ahead of the panel stream's share E(s) of the wide update, instead of on the update stream between W(s) and W(s+1) --
      * there it waited for ALL of W(s) and then ran alone on the chip for 0.16-0.18 ms per step (C3: 33 such steps).  For
@@ -823,7 +838,10 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         const int w0 = imin(nb, n);
         use_set(p, 0);
         CHECK(prof_begin(p, 2));
+        p->v_ready = (split_t && p->npairs > 0 && w0 <= QR_HALF && n > w0) ? p->ev_v[0] : NULL;
+        v_recorded[0] = p->v_ready != NULL;
         CHECK(factor_panel(p, dA, m, lda, 0, w0, dtau, n > w0, NULL));
+        p->v_ready = NULL;
         CHECK(prof_end(p, 2.0 * m * (double) w0 * w0, 16.0 * m * w0));
         CHECK(qrd_event_record(p->ev_panel[0], p->stream));
     }
@@ -852,9 +870,14 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
             /* nothing: N(s) sits on the panel stream behind P(s) */
         } else if (n_on_u) {
             /* N(s) on the update stream: behind W(s-1) by stream order, after P(s) (ev_panel) and E(s-1) (ev_extra) */
-            CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
+            if (v_recorded[e]) {        /* V^T A_next may start as soon as V is complete; T^T (.) waits for the T merge */
+                CHECK(qrd_stream_wait_event(p->stream_u, p->ev_v[e]));
+                p->t_wait = p->ev_panel[e];
+            } else
+                CHECK(qrd_stream_wait_event(p->stream_u, p->ev_panel[e]));
             if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));
             CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout, nfirst, p->Wn, p->Yn, p->slabs_u, 0, 0));
+            p->t_wait = NULL;
             CHECK(qrd_event_record(p->ev_next[e], p->stream_u));
             CHECK(qrd_stream_wait_event(p->stream, p->ev_next[e]));
             wide_pending[e ^ 1] = 0;                 /* W(s-1) is ordered before N(s), hence before everything the panel stream does next */
@@ -902,7 +925,10 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         }
         use_set(p, e ^ 1);
         CHECK(prof_begin(p, 2));
+        p->v_ready = (split_t && p->npairs > 0 && wnext <= QR_HALF && nt1 > 0) ? p->ev_v[e ^ 1] : NULL;
+        v_recorded[e ^ 1] = p->v_ready != NULL;
         CHECK(factor_panel(p, dA, m, lda, k1, wnext, dtau, nt1 > 0, nhalf2 > 0 ? p->ev_half[e] : NULL));
+        p->v_ready = NULL;
         CHECK(prof_end(p, 2.0 * mk1 * (double) wnext * wnext, 16.0 * mk1 * wnext));
         CHECK(qrd_event_record(p->ev_panel[e ^ 1], p->stream));
         if (early_next) {                                                                                     /* N(s+1), early */

@@ -1356,6 +1356,134 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
     STAMP_FLUSH(0, 7);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tall leaves, streaming form (round 2, end): cholq2_kernel spends 7.8 us of every workgroup in a one-wave Cholesky with nothing
+// in flight, solves q R1 = a on the vector ALUs with R1 broadcast from LDS, and stages Q through LDS for G2.  Here the Cholesky
+// (with R1^-1, CholAugStep) runs ONCE in a one-wave kernel, and the pass over the leaf is pure streaming on the matrix cores:
+// rows on the MFMA row index, each wave's 64 rows as four interleaved 16-row tiles (physical row 4 p + t: every global access is 32
+// contiguous bytes per lane, qr_leaf_fused.hip), q = a R1^-1 with R1^-1 as the B operand, and the accumulators of q feed G2 = q^T q
+// directly -- no LDS, no barrier in the loop.  Workgroups walk row blocks grid-stride and leave one partial G2 each.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void chol1_kernel(const double* __restrict__ G1, double* __restrict__ R1, double* __restrict__ Rinv,
+                                                   int* __restrict__ guard)
+{
+    const int lane = threadIdx.x, j = lane & (PW - 1);
+    double g[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) g[i] = (lane < PW) ? G1[j * PW + i] : (i == j ? 1.0 : 0.0);     // G1(i, j); lanes >= 32: identity
+    int e2 = 0;                                            // power-of-two scaling as in cholq3_kernel
+    {
+        const double d = readlane_f64(g[0], 0);
+        if (d > 0.0 && d < 1.7e308) { (void) frexp(d, &e2); e2 &= ~1; }
+    }
+    const double rs = ldexp(1.0, e2 / 2), ws = ldexp(1.0, -(e2 / 2));
+    if (lane < PW) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) g[i] = (g[i] * ws) * ws;
+    }
+    bool ok = true;
+    CholAugStep<0>::run(g, lane, ok);
+    if (lane >= PW) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) Rinv[k * PW + j] = (k >= j) ? g[k] * ws : 0.0;       // row j of R1^-1, stored column-major: (j, k)
+    } else if (ok) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) R1[j * PW + k] = (k <= j) ? g[k] * rs : 0.0;         // column j of R1
+    }
+    if (lane == 0) *guard = ok ? 0 : 1;
+}
+
+__device__ __forceinline__ void tq_load4(const double* __restrict__ p, double (&d)[4])
+{
+    const v2d a = *reinterpret_cast<const v2d*>(p), b = *reinterpret_cast<const v2d*>(p + 2);
+    d[0] = a[0]; d[1] = a[1]; d[2] = b[0]; d[3] = b[1];
+}
+
+// Q (mk x 32 -> Vw) = P R1^-1 and this workgroup's partial G2 = Q^T Q (slab2[blockIdx.x], 32 x 32, ld 32).  mk % 4 == 0, P / Vw 16-byte
+// aligned with even leading dimensions.  Rinv: R1^-1 column-major ld 32.  512 threads; row blocks of 512 rows, grid-stride.
+__global__ __launch_bounds__(PT) void cholq4_tall_kernel(const double* __restrict__ P, int ld, int mk, const double* __restrict__ Rinv,
+                                                         double* __restrict__ Vw, int ldv, double* __restrict__ slab2,
+                                                         const int* __restrict__ guard)
+{
+    extern __shared__ __attribute__((aligned(16))) double tq_red[];          // [8 waves][32 * 32]
+    if (*guard != 0) return;                                                 // the Cholesky refused the leaf: nothing is written
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double rb[2][8];                                                         // B operand: R1^-1(4 ks + l4, 16 ti + l15)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) rb[ti][ks] = Rinv[(16 * ti + l15) * PW + 4 * ks + l4];
+    v4d g[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) g[i][jj] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int base = blockIdx.x * PT + wave * 64; base < mk; base += gridDim.x * PT) {
+        double xa[8][4];                                                     // a(base + 4 l15 + t, 4 ks + l4)
+        {
+            const int rowA = base + 4 * l15;
+            const bool va = rowA < mk;
+            const double* pa = P + (va ? rowA : 0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                tq_load4(pa + (size_t) (4 * ks + l4) * ld, xa[ks]);
+                if (!va) { xa[ks][0] = 0.0; xa[ks][1] = 0.0; xa[ks][2] = 0.0; xa[ks][3] = 0.0; }
+            }
+        }
+        v4d q[2][4];                                                         // [column tile][t], reg rr: row base + 4 l4 + 16 rr + t
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ti == 0 && ks >= 4) continue;                        // R1^-1 upper triangular
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks][t], rb[ti][ks], acc, 0, 0, 0);
+                }
+                q[ti][t] = acc;
+            }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            double* pc = Vw + (size_t) (16 * ti + l15) * ldv;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row0 = base + 4 * l4 + 16 * rr;
+                if (row0 < mk) {
+                    *reinterpret_cast<v2d*>(pc + row0) = (v2d){q[ti][0][rr], q[ti][1][rr]};
+                    *reinterpret_cast<v2d*>(pc + row0 + 2) = (v2d){q[ti][2][rr], q[ti][3][rr]};
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                g[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[0][t][rr], q[0][t][rr], g[0][0], 0, 0, 0);
+                g[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[0][t][rr], q[1][t][rr], g[0][1], 0, 0, 0);
+                g[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(q[1][t][rr], q[1][t][rr], g[1][1], 0, 0, 0);
+            }
+    }
+    // D reg r of lane (l15, l4) of tile (ti, tj) = G2(16 ti + l4 + 4 r, 16 tj + l15); tile (1, 0) mirrored; fixed order over the waves
+    double* red = tq_red + wave * PW * PW;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[(16 * tj + l15) * PW + 16 * ti + l4 + 4 * r] = g[ti][tj][r];
+                if (ti != tj) red[(16 * ti + l4 + 4 * r) * PW + 16 * tj + l15] = g[ti][tj][r];
+            }
+    __syncthreads();
+    for (int e = tid; e < PW * PW; e += PT) {
+        double sum = 0.0;
+#pragma unroll
+        for (int v = 0; v < PT / 64; ++v) sum += tq_red[v * PW * PW + e];
+        slab2[(size_t) blockIdx.x * PW * PW + e] = sum;
+    }
+}
+
 // rows >= 32 of V = Q U'^-1 (Winv: U'^-1, column-major, ld PW), written to Vw and to A.  No LDS, no barrier.
 // rows_wg: rows per workgroup -- PT (every wave 64 rows) or PT / 2 (waves 0..3 only: twice the workgroups, i.e. compute units, for
 // the same 64 matrix-core instructions per wave; two waves per SIMD took 3.7 us of the launch's 11, one takes 1.9)
@@ -1920,6 +2048,8 @@ int qrd_panel_tsqr_init(void)
                                     (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<512, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq4_tall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (8 * PW * PW * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
     return rc;
@@ -1986,7 +2116,17 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
                 rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
             if (rc) return rc;
             slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
-            if (rb2)
+            static int tall_q = -1;
+            if (tall_q < 0) { const char* e = getenv("MI355XQR_TALL_Q"); tall_q = e ? atoi(e) : 4; }
+            if (tall_q == 4 && (mk & 3) == 0 && w == PW) {
+                // streaming form: one-wave Cholesky (R1, R1^-1 -> Mm, which hr3 overwrites later), then the matrix-core pass
+                int gq = (mk + PT - 1) / PT;
+                if (gq > 512) gq = 512;
+                nblk2 = gq;
+                slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
+                hipLaunchKernelGGL(chol1_kernel, dim3(1), dim3(64), 0, s, G1, R1, Mm, guard);
+                hipLaunchKernelGGL(cholq4_tall_kernel, dim3(gq), dim3(PT), 8 * PW * PW * sizeof(double), s, P, ld, mk, Mm, Vw, ldv, slab2, guard);
+            } else if (rb2)
                 hipLaunchKernelGGL((cholq2_kernel<true, 256, 128, 2>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
                                    G1, 1, R1, Vw, ldv, slab2, guard);
             else

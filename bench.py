@@ -296,13 +296,13 @@ def main():
             if m_local == 262144:
                 ptraffic = pj["hbm_bytes_per_leaf_streaming_kernels"] * (nb // 32)
                 psrc = {"file": "profiles/r02_pmc_panel_hbm.json", "per_leaf_kernels": pj["kernels"],
-                        "covers": "gram32 + cholq2 + final3 of the nb/32 leaves of one outer panel (%.0f MB per 67 MB leaf: %.1f passes); "
+                        "covers": "gram32 + cholq4_tall + final3 of the nb/32 leaves of one outer panel (%.0f MB per 67 MB leaf: %.1f passes); "
                                   "not the in-panel updates, the Gram / T merge or the one-workgroup reconstruction kernel"
                                   % (pj["hbm_bytes_per_leaf_streaming_kernels"] / 1e6, pj["hbm_bytes_per_leaf_streaming_kernels"] / 67.1e6),
                         "method": pj["method"] + "; replayed from the committed file"}
         except Exception:
             pass
-        roof = {"bound": "hbm", "kernel": "panel factorisation (gram32 / cholq2 / hr3 / final3 leaf kernels + guard launches, in-panel gemm_tn / gemm_nn, Gram + T merge)",
+        roof = {"bound": "hbm", "kernel": "panel factorisation (gram32 / chol1 / cholq4_tall / hr3 / final3 leaf kernels + guard launches, in-panel gemm_tn_dual / leaf_update_gram, Gram + T merge)",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": ptraffic, "traffic_source": psrc,
                 "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),

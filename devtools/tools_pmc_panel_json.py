@@ -14,11 +14,11 @@ for line in open(sys.argv[1]):
     name = " ".join(p[:-5])
     if rd >= 60.0:
         rows[name].append((rd, wr, us))
-out = {"leaf": "262144 x 32 (67.1 MB), CholeskyQR2 leaf as the tall-skinny plans run it (gram32 / cholq2<256,128,2> / final3), dispatches averaged",
+out = {"leaf": "262144 x 32 (67.1 MB), CholeskyQR2 leaf as the tall-skinny plans run it (gram32 / [chol1] cholq4_tall / final3), dispatches averaged",
        "git_head": sys.argv[2] if len(sys.argv) > 2 else None, "kernels": {}}
 tot_b = tot_us = 0.0
 for name, v in rows.items():
-    if not any(k in name for k in ("gram32", "cholq2", "final3")):
+    if not any(k in name for k in ("gram32", "cholq2", "cholq4", "final3")):
         continue
     rd = sum(x[0] for x in v) / len(v); wr = sum(x[1] for x in v) / len(v); us = sum(x[2] for x in v) / len(v)
     out["kernels"][name] = {"read_MB": round(rd, 1), "write_MB": round(wr, 1), "us": round(us, 1), "GBps": round((rd + wr) / us * 1e3)}

@@ -12,6 +12,9 @@ shapes = [(3000, 2500, 0), (5000, 5000, 256), (10000, 3000, 128), (9000, 4100, 2
 if len(sys.argv) > 2 and sys.argv[2] == "ragged":        # odd sizes: ragged tiles, leaves narrower than 32, heights not multiples of 4
     shapes = [(1900, 1900, 0), (2500, 2047, 0), (8200, 8190, 0), (12289, 2051, 0), (5000, 1025, 0), (33001, 97, 0), (4099, 4097, 256),
               (6145, 3071, 128), (70001, 321, 0), (20003, 2305, 256)]
+if len(sys.argv) > 2 and sys.argv[2] == "edges":         # shapes next to the thresholds of the default rules (block size, look-ahead, partition)
+    shapes = [(1536, 1024, 0), (1537, 1024, 0), (1024, 1023, 0), (4243, 4243, 0), (4242, 4242, 0), (32768, 2048, 0), (32767, 2048, 0),
+              (10240, 10240, 0), (10239, 10239, 0), (16385, 16384, 0), (8192, 8192, 0), (16384, 1024, 0)]
 worst = 0.0
 for (m, n, nb) in shapes:
     kind = rng.integers(0, 3)

@@ -827,7 +827,7 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
      * there it waited for ALL of W(s) and then ran alone on the chip for 0.16-0.18 ms per step (C3: 33 such steps).  For
      * that, W(s) starts with the columns of panel s+2 (W1(s), event ev_half[s&1]) and E(s) takes the LAST columns of the wide
      * range instead of the first.  early_done: N of the coming step has been issued already. */
-    static int early_env = -1, early_w1 = 2048;
+    static int early_env = -1, early_w1 = 4096;
     if (early_env < 0) {
         const char* ee = getenv("MI355XQR_EARLY_NEXT"); early_env = ee ? atoi(ee) != 0 : 1;
         ee = getenv("MI355XQR_EARLY_W1"); if (ee && atoi(ee) >= 128) early_w1 = atoi(ee) / 128 * 128;
@@ -903,8 +903,9 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
             }
             if (early_next) {
                 /* W1(s): a first slice that holds the columns of panel s+2, so that N(s+1) need not wait for the rest; E(s) at the
-                 * far end.  The slice is ~2048 columns, not just the 256 N(s+1) needs: a 256-column launch pair fills half the
-                 * update stream's workgroup slots (0.14 ms for 0.07 ms of work, every step), and N(s+1) has P(s+1)'s 1.4 ms to spare */
+                 * far end.  The slice is ~4096 columns, not just the 256 N(s+1) needs: a 256-column launch pair fills half the
+                 * update stream's workgroup slots (0.14 ms for 0.07 ms of work, every step), and N(s+1) has P(s+1)'s 1.4 ms to spare
+                 * (16384^2: 1024 / 2048 / 4096 / 6144 / 8192 columns: 125.1 / 124.9 / 124.3 / 131.0 / 143.7 ms) */
                 int w1 = nwide - extra;
                 if (w1 > early_w1 + 1024) w1 = early_w1 > wnext2 ? early_w1 : wnext2;
                 CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw, w1, p->W, NULL, p->slabs_u, 1, 1));

@@ -907,7 +907,17 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
                  * update stream's workgroup slots (0.14 ms for 0.07 ms of work, every step), and N(s+1) has P(s+1)'s 1.4 ms to spare
                  * (16384^2: 1024 / 2048 / 4096 / 6144 / 8192 columns: 125.1 / 124.9 / 124.3 / 131.0 / 143.7 ms) */
                 int w1 = nwide - extra;
-                if (w1 > early_w1 + 1024) w1 = early_w1 > wnext2 ? early_w1 : wnext2;
+                {
+                    /* ... but W1(s) must be over well before P(s+1) is (N(s+1) waits for it): at most 0.7 of the panel's measured
+                     * time 0.62 + 0.9 mk / 16384 ms (nb = 256) at the update stream's rate, and never more than early_w1 columns */
+                    const double pest = (0.62 + 0.9 * (double) mk1 / 16384.0) * (double) wnext / 256.0;            /* ms */
+                    const double fcol = 4.0 * mk * (double) wout * 1e-9;                                         /* GFLOP per column */
+                    int cap = (int) (0.7 * pest * p->bal_ru / fcol);
+                    cap -= cap % 128;
+                    if (cap > early_w1) cap = early_w1;
+                    if (cap < wnext2) cap = wnext2;
+                    if (w1 > cap + 1024) w1 = cap;
+                }
                 CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, cw, w1, p->W, NULL, p->slabs_u, 1, 1));
                 CHECK(qrd_event_record(p->ev_half[e], p->stream_u));
                 if (nwide - w1 - extra > 0)

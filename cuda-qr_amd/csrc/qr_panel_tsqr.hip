@@ -2120,8 +2120,10 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
             if (tall_q < 0) { const char* e = getenv("MI355XQR_TALL_Q"); tall_q = e ? atoi(e) : 4; }
             if (tall_q == 4 && (mk & 3) == 0 && w == PW) {
                 // streaming form: one-wave Cholesky (R1, R1^-1 -> Mm, which hr3 overwrites later), then the matrix-core pass
+                static int gq_max = 0;
+                if (!gq_max) { const char* e = getenv("MI355XQR_TALL_QGRID"); gq_max = e ? atoi(e) : 512; if (gq_max < 32 || gq_max > 2048) gq_max = 512; }
                 int gq = (mk + PT - 1) / PT;
-                if (gq > 512) gq = 512;
+                if (gq > gq_max) gq = gq_max;
                 nblk2 = gq;
                 slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
                 hipLaunchKernelGGL(chol1_kernel, dim3(1), dim3(64), 0, s, G1, R1, Mm, guard);

@@ -24,7 +24,13 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
+
+# The host driver of this pool only supports dmabuf IPC: RCCL's intra-node transport (and CUDA-tensor sharing across processes)
+# fails with "hipIpcGetMemHandle: invalid argument" without this.  Must be in the environment BEFORE the HSA runtime starts, i.e.
+# before `import torch` touches the GPU; a value set by the launcher wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -45,8 +51,37 @@ def parse():
     ap.add_argument("--ib", type=int, default=0)
     ap.add_argument("--no-check", action="store_true", help="skip the post-run residual/orthogonality check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="1184x640", help="m x n of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-sample", default="792x384", help="m x n of the bounded multi-panel CPU-baseline sample")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("BENCH_WATCHDOG_S", "30")),
+                    help="seconds a bring-up phase (rendezvous, communicator, first collective) may take before the process exits 124")
     return ap.parse_args()
+
+
+class Watchdog:
+    """A phase that does not finish in time ends THIS process with a non-zero exit code (os._exit: no re-exec of a process that
+    has touched the GPU, no retry loop); the launcher (torch.distributed.run) then tears the other ranks down."""
+
+    def __init__(self, rank):
+        self.rank, self.timer = rank, None
+
+    def arm(self, seconds, what):
+        self.disarm()
+        if seconds <= 0:
+            return
+
+        def fire():
+            sys.stderr.write(json.dumps({"bench_watchdog": what, "rank": self.rank, "timeout_s": seconds,
+                                         "hint": "RCCL on this pool needs HSA_ENABLE_IPC_MODE_LEGACY=0 and one visible GPU per rank"}) + "\n")
+            sys.stderr.flush()
+            os._exit(124)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer:
+            self.timer.cancel()
+            self.timer = None
 
 
 def flops(m, n):
@@ -54,26 +89,49 @@ def flops(m, n):
 
 
 def cpu_baseline(sample):
-    """The reference qr.c (oracle/_ref, PR=64 PC=8, double) on ONE host core -- the reference has no
-    threading anywhere -- over a bounded sample of the same kind of input (dense uniform[0,1))."""
+    """The reference qr.c (oracle/_ref when it travelled, else the bitwise-pinned oracle restatement; Scalar=double, PR=64,
+    PC=8) on ONE host core -- the reference has no threading anywhere -- over a bounded sample (~2-3 s in total):
+      C1      BASELINE configs[0], 512 x 128 from srand(12): mmqr (the `value` of this object), qr.c:477
+      multi   a multi-panel matrix of the same kind (default 792 x 384): mmqr
+      expQ    explicitQR (dense m x m Q by one m^3 product per reflector, qr.c:494) once, on 120 x 32 -- at C1 itself it takes
+              314 s on one core, which the line quotes as a committed measurement, not a live one."""
     import numpy as np
     from oracle import oracle as O
-    m, n = (int(x) for x in sample.split("x"))
     PR, PC = 64, 8
-    O.check_shape(m, n, PR, PC)
-    A = O.fill_rand(m, n, 12, np.float64)
     kind = "reference" if O.ref_path(np.float64, PR, PC) else "port"
-    t0 = time.perf_counter()
-    if kind == "reference":
-        O.ref_mmqr(A, PR, PC)            # real qr.c mmqr; its printf chatter goes to /dev/null
-    else:
-        O.mmqr(A, PR, PC)                # oracle restatement (bitwise-equal arithmetic, no prints)
-    dt = time.perf_counter() - t0
-    return {"value": flops(m, n) / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": kind,
-            "host_cores_available": os.cpu_count(), "seconds": dt,
-            "sample": f"reference qr.c mmqr (Scalar=double, PR=64, PC=8) on a {m}x{n} uniform[0,1) matrix "
-                      f"(srand(12) generator, qr.c:468-474), stdout to /dev/null, 1 thread; "
-                      f"useful flops 2mn^2-2n^3/3"}
+    f_mmqr = (lambda A: O.ref_mmqr(A, PR, PC)) if kind == "reference" else (lambda A: O.mmqr(A, PR, PC))
+    f_expq = (lambda F, t: O.ref_explicit_qr(F, t, PR, PC)) if kind == "reference" and hasattr(O, "ref_explicit_qr") \
+        else (lambda F, t: O.explicit_qr(F, t, PR, PC))
+    legs = {}
+
+    def leg_mmqr(name, m, n):
+        O.check_shape(m, n, PR, PC)
+        A = O.fill_rand(m, n, 12, np.float64)
+        t0 = time.perf_counter()
+        out = f_mmqr(A)
+        dt = time.perf_counter() - t0
+        legs[name] = {"m": m, "n": n, "seconds": dt, "gflops": flops(m, n) / dt / 1e9}
+        return out
+
+    leg_mmqr("C1_mmqr_512x128", 512, 128)
+    sm, sn = (int(x) for x in sample.split("x"))
+    leg_mmqr(f"multi_mmqr_{sm}x{sn}", sm, sn)
+    out = leg_mmqr("expQ_mmqr_120x32", 120, 32)
+    try:
+        t0 = time.perf_counter()
+        f_expq(out[0], out[1])
+        legs["expQ_explicitQR_120x32"] = {"m": 120, "n": 32, "seconds": time.perf_counter() - t0,
+                                          "note": "dense m x m Q, one m^3 product per reflector (qr.c:415-429)"}
+    except Exception as e:          # the checker's explicitQR wrapper differs between oracle builds: never fail the bench over it
+        legs["expQ_explicitQR_120x32"] = {"error": repr(e)}
+    c1 = legs["C1_mmqr_512x128"]
+    return {"value": c1["gflops"], "unit": "GFLOP/s", "cores": 1, "kind": kind,
+            "host_cores_available": os.cpu_count(), "seconds": sum(v.get("seconds", 0.0) for v in legs.values()),
+            "legs": legs,
+            "committed_not_live": {"C1_explicitQR_512x128_seconds": 313.7, "source": "BASELINE.md section 2 (real qr.c, 1 core)"},
+            "sample": "reference qr.c mmqr (Scalar=double, PR=64, PC=8) on C1 = 512x128 uniform[0,1) (srand(12) generator, "
+                      "qr.c:468-474), stdout to /dev/null, 1 thread, useful flops 2mn^2-2n^3/3; legs: the same on a "
+                      f"{sm}x{sn} multi-panel matrix, and mmqr + explicitQR once on 120x32"}
 
 
 def main():
@@ -87,6 +145,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
+    wd = Watchdog(rank)
+    wd.arm(args.watchdog + 90.0, "first GPU touch (import torch pages the image in: up to 2 min on a fresh box)")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
     ndev = torch.cuda.device_count()
     # BENCH_BACKEND=gloo: bring-up only -- lets N ranks share fewer GPUs (RCCL refuses duplicate devices); the R
@@ -95,10 +155,13 @@ def main():
     torch.cuda.set_device(local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        wd.arm(args.watchdog + 60.0, "torch.distributed rendezvous / process group")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.ib:
+        os.environ["MI355XQR_IB"] = str(args.ib)         # read once when the library first needs its defaults
     import cuda_qr_amd as qr
     from cuda_qr_amd import tsqr as T
 
@@ -125,8 +188,13 @@ def main():
         raise SystemExit("square configs do not shard (replicas only, DESIGN.md); use --workload c4 | c5 | tsqr")
     scaling = "strong" if wl in ("c4", "c5") else "weak"      # c4 / c5: the total matrix is fixed, shards shrink with N
 
-    be = T.HipBackend(qr, m_local, n, world, nb, args.ib)
-    ts = T.TSQR(be, n, world, rank, stage_through_host=(world > 1 and backend != "nccl"))
+    # the C-ABI device-resident step (qr_tsqr_plan: local QR -> ncclAllGather -> stacked QR, all issued from C); with one rank it
+    # is the plain qr_plan of the square configs.  Creating it is collective for N > 1 (ncclCommInitRank).
+    wd.arm(args.watchdog, "qr_tsqr_plan_create (ncclCommInitRank over the ranks of this node)")
+    be = T.DeviceTSQR(qr, m_local, n, world, rank, nb, transport="rccl" if backend == "nccl" else "host")
+    ts = be
+    rccl_ranks = be.tp.comm_ranks() if (world > 1 and backend == "nccl") else None
+    wd.disarm()
     K, W = args.steps, args.warmup
     bytes_per = 8 * m_local * n
     nbuf = min(K + W, max(1, int(160e9 // bytes_per)))
@@ -146,12 +214,14 @@ def main():
         A = bufs[i % nbuf]
         if i >= nbuf:                       # only when K+W exceeds the buffer pool: regenerate (stated in config)
             be.fill(A, m_local, n, rank * m_local, m_total, seeds[i % nbuf])
-        return ts.factor(A, pipelined=True)      # independent factorisations: the small stacked QR of step i runs under
-                                                  # the local QR of step i+1 (everything is finished inside the timed bracket)
+        return ts.factor(A)      # stream-ordered in C; independent factorisations: the small stacked QR of step i runs
+                                 # under the local QR of step i+1 (everything is finished inside the timed bracket)
 
+    wd.arm(args.watchdog + 30.0, "warm-up steps (first collective)")
     for i in range(W):
         step(i)
     barrier()
+    wd.arm(max(300.0, args.watchdog), "timed region")
     # HIP events on the plan's own streams, inside the timed region -- around the launches of the DOMINANT kernel only (class 0:
     # the wide update's gemm_nt; tall-skinny: class 2, the panel): every record is two event packets on a stream (~4 us each),
     # and with all six classes recorded the 16384^2 step took 128.5 ms instead of 126
@@ -169,6 +239,7 @@ def main():
     barrier()
     prof_full = be.plan.get_profile()
     be.plan.set_profile(False)
+    wd.arm(max(300.0, args.watchdog), "post-run checks")
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -183,6 +254,7 @@ def main():
     if not args.no_check:
         last = (W + K) % nbuf               # the matrix of the extra (fully profiled) step: the last one factored, ts.R is its R
         A = bufs[last]
+        ts.sync()
         R = ts.R
         Q = ts.form_q(A)
         QR = be.new_matrix(m_local, n)
@@ -206,7 +278,8 @@ def main():
         acc = {"resid": float((sums[0] / sums[1]).sqrt().item()), "orth": float(o ** 0.5)}
         del Q, QR, G
 
-    # ---- N > 1 only, outside the timed region: where a TSQR step goes (local shard QR vs exchange + stacked QR)
+    # ---- N > 1 only, outside the timed region: the UN-pipelined latency of one factorisation (every step drained before the
+    # next starts, so the exchange and the stacked QR are fully exposed) and where it goes
     tsqr_split = None
     if world > 1:
         reps = max(1, min(K, 3))
@@ -215,11 +288,27 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for i in range(reps):
-            be.local_factor(bufs[i % nbuf], ts.R_local)
-        torch.cuda.synchronize()
+            be.local_only(bufs[i % nbuf])
+            ts.sync()
         loc_ms = (time.perf_counter() - t1) / reps * 1e3
-        tsqr_split = {"local_qr_ms": loc_ms, "exchange_and_stacked_qr_ms": dt / K * 1e3 - loc_ms,
-                      "note": "this rank; the stacked (world*n) x n factorisation is redundant on every rank and latency-bound"}
+        for i in range(reps):
+            be.fill(bufs[i % nbuf], m_local, n, rank * m_local, m_total, seeds[i % nbuf])
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(reps):
+            ts.factor(bufs[i % nbuf])
+            ts.sync()
+        lat_ms = (time.perf_counter() - t1) / reps * 1e3
+        lat = torch.tensor([lat_ms, loc_ms], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(lat, op=dist.ReduceOp.MAX)
+        lat_ms, loc_ms = float(lat[0].item()), float(lat[1].item())
+        tsqr_split = {"unpipelined_latency_ms": lat_ms, "local_qr_ms": loc_ms,
+                      "exchange_and_stacked_qr_ms": lat_ms - loc_ms,
+                      "pipelined_ms_per_step": dt / K * 1e3,
+                      "unpipelined_gflops": flops(m_total, n) / (lat_ms * 1e-3) / 1e9,
+                      "note": "max over ranks; un-pipelined = qr_tsqr_factor_dev + qr_tsqr_sync per step (the single-factorisation "
+                              "latency); `value` is the pipelined throughput of K independent factorisations; the stacked "
+                              "(world*n) x n factorisation is redundant on every rank and latency-bound"}
 
     # ---- roofline of the dominant kernel
     # dominant kernel: from the timed region; the rest: from the extra profiled step (per-step figures, K_full = 1)
@@ -314,25 +403,37 @@ def main():
 
     # ---- N = 1 only: the one-GPU leg of the multi-GPU (TSQR, weak scaling) series, so that the N > 1 lines of this
     # bench (262144 x 512 per GPU) have their own denominator next to the C3 headline
-    weak_base = None
+    weak_base, tsqr_model = None, None
     if world == 1 and wl == "c3":
         bufs.clear()
         be.close()
-        be = T.HipBackend(qr, 262144, 512, 1, 128, args.ib)
-        ts1 = T.TSQR(be, 512, 1, 0)
+        be = T.DeviceTSQR(qr, 262144, 512, 1, 0, 128)
         reps = max(2, min(K, 5))
         tb = [be.new_matrix(262144, 512) for _ in range(reps)]
         for i, A in enumerate(tb):
             be.fill(A, 262144, 512, 0, 262144, 12 + i)
-        ts1.factor(tb[0]); be.fill(tb[0], 262144, 512, 0, 262144, 12)      # warm-up, then restore the input
+        be.factor(tb[0]); be.sync(); be.fill(tb[0], 262144, 512, 0, 262144, 12)      # warm-up, then restore the input
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(reps):
-            ts1.factor(tb[i])
-        torch.cuda.synchronize()
+            be.factor(tb[i])
+        be.sync()
         dtb = (time.perf_counter() - t0) / reps
         weak_base = {"workload": "one 262144x512 TSQR shard on 1 GPU (the per-GPU work of the N>1 lines of this bench)",
                      "value": flops(262144, 512) / dtb / 1e9, "unit": "GFLOP/s", "ms_per_step": dtb * 1e3, "steps": reps}
+        tb.clear()
+        # the other step of a multi-GPU factorisation, measured on this one GPU: the stacked (P n) x n QR every rank does after
+        # the all-gather (C5: 8 x 512 = 4096 x 512; C4 on 4 GPUs: 1024 x 256), un-pipelined, and what that predicts
+        try:
+            st5 = T.stacked_step_ms(qr, 8, 512, 128)
+            st4 = T.stacked_step_ms(qr, 4, 256, 128)
+            loc5 = dtb * 1e3
+            tsqr_model = {"stacked_qr_4096x512_ms": st5, "stacked_qr_1024x256_ms": st4, "local_262144x512_ms": loc5,
+                          "predicted_c5_efficiency_8gpu": loc5 / (loc5 + st5 + 0.1),
+                          "note": "single-GPU measurements; efficiency = local / (local + stacked + 0.1 ms assumed for the 2 MiB-per-rank "
+                                  "all-gather), un-pipelined (one factorisation's latency); C5 on one GPU is the P = 1 denominator"}
+        except Exception as e:
+            tsqr_model = {"error": repr(e)}
 
     line = None
     if rank == 0:
@@ -354,7 +455,11 @@ def main():
             "accuracy": acc,
             "roofline": roof,
             "weak_scaling_base_1gpu": weak_base,
+            "tsqr_model_1gpu": tsqr_model,
             "tsqr_step_split": tsqr_split,
+            "rccl": ({"nranks_seen_by_rccl": rccl_ranks, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                      "driver": "C-ABI qr_tsqr_plan: ncclCommInitRank from a broadcast unique id, ncclAllGather on the plan's stream"}
+                     if world > 1 else None),
             "scaling_note": ("the N = 1 line of this bench is the square C3 headline, a different workload: the weak-scaling "
                              "denominator of this line is weak_scaling_base_1gpu of the N = 1 line (one 262144x512 shard on "
                              "one GPU)") if world > 1 else None,
@@ -362,10 +467,12 @@ def main():
             "device": info,
         }
         print(json.dumps(line), flush=True)
+    wd.arm(args.watchdog + 30.0, "teardown")
     be.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    wd.disarm()
 
 
 if __name__ == "__main__":

@@ -59,12 +59,27 @@ _sig("printMat", None, _dp, C.c_int, C.c_int)
 _sig("qr_strerror", C.c_char_p, C.c_int)
 _sig("qr_set_block_size", C.c_int, C.c_int, C.c_int)
 _sig("qr_get_block_size", None, C.POINTER(C.c_int), C.POINTER(C.c_int))
+_sig("qr_default_block_size", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("qr_thin", C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int)
 _fp = C.POINTER(C.c_float)
 _sig("mmqr_f32_status", C.c_int, _fp, C.POINTER(_fp), C.c_int, C.c_int)
 _sig("explicitQR_f32_status", C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int)
 _sig("qr_thin_mgpu", C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int)
 _sig("qr_release_cached_plans", C.c_int)
+_sig("qr_tsqr_unique_id", C.c_int, _vp)
+_sig("qr_tsqr_plan_create", C.c_int, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("qr_tsqr_plan_create_comm", C.c_int, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("qr_tsqr_plan_destroy", C.c_int, _vp)
+_sig("qr_tsqr_factor_dev", C.c_int, _vp, _vp, C.c_int, _vp)
+_sig("qr_tsqr_formq_dev", C.c_int, _vp, _vp, C.c_int, _vp, C.c_int)
+_sig("qr_tsqr_local_dev", C.c_int, _vp, _vp, C.c_int)
+_sig("qr_tsqr_exchange_buffers", C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp))
+_sig("qr_tsqr_stacked_dev", C.c_int, _vp, _vp)
+_sig("qr_tsqr_sync", C.c_int, _vp)
+_sig("qr_tsqr_stream", _vp, _vp)
+_sig("qr_tsqr_comm_ranks", C.c_int, _vp, C.POINTER(C.c_int))
+_sig("qr_tsqr_local_plan", _vp, _vp)
+_sig("qr_tsqr_stacked_plan", _vp, _vp)
 _sig("qr_plan_create", C.c_int, C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("qr_plan_destroy", C.c_int, _vp)
 _sig("qr_geqrf_dev", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp)
@@ -105,6 +120,7 @@ _sig("qrd_leaf_update_gram", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, 
 _sig("qrd_gemm_nt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp)
 _sig("qrd_gemm_tnt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_size_t,
      C.c_int, C.c_int, C.c_int)
+_sig("qrd_copy_block", C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int)
 _sig("qrd_init", C.c_int)
 _sig("qrd_device_sync", C.c_int)
 
@@ -123,7 +139,7 @@ def exported_symbols():
     import re
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|double|char\*|void\*|const char\*)\s*\*?\s*(\w+)\s*\(", txt, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|double|char\*|void\*|const char\*|qr_plan\*)\s*\*?\s*(\w+)\s*\(", txt, flags=re.M)
     return sorted(set(names))
 
 
@@ -150,6 +166,19 @@ def get_block_size():
     return nb.value, ib.value
 
 
+def default_block_size(m, n):
+    """(nb, ib) an m x n problem really gets from mmqr / a default plan (shape-dependent; sizes mmqr's tau)."""
+    nb, ib = C.c_int(), C.c_int()
+    check(lib.qr_default_block_size(m, n, C.byref(nb), C.byref(ib)), "qr_default_block_size")
+    return nb.value, ib.value
+
+
+def tau_len(m, n):
+    """entries of the tau array mmqr mallocs for an m x n problem: rowPanels * colPanels * nb (qr.c:61 sizing rule)."""
+    rp, cp = get_panel_dims(m, n)
+    return rp * cp * default_block_size(m, n)[0]
+
+
 def set_block_size(nb, ib):
     check(lib.qr_set_block_size(nb, ib), "qr_set_block_size")
 
@@ -164,9 +193,7 @@ def mmqr(A):
     m, n = F.shape
     tptr = _dp()
     check(lib.mmqr_status(_p(F), C.byref(tptr), m, n), "mmqr")
-    rp, cp = get_panel_dims(m, n)
-    nb, _ = get_block_size()
-    tau = np.ctypeslib.as_array(tptr, shape=(rp * cp * nb,)).copy()
+    tau = np.ctypeslib.as_array(tptr, shape=(tau_len(m, n),)).copy()
     _libc.free(C.cast(tptr, C.c_void_p))
     return F, tau
 
@@ -176,6 +203,8 @@ def explicit_qr(F, tau):
     F = _f(F)
     m, n = F.shape
     tau = np.ascontiguousarray(tau, dtype=np.float64)
+    if tau.size < n:
+        raise QRError(f"explicit_qr: tau has {tau.size} entries, the factorisation of {n} columns has {n}")
     Q = np.empty((m, m), order="F")
     R = np.empty((m, n), order="F")
     check(lib.explicitQR_status(_p(F), _p(tau), _p(Q), _p(R), m, n), "explicitQR")
@@ -214,9 +243,7 @@ def mmqr_f32(A):
     m, n = F.shape
     tau = _fp()
     check(lib.mmqr_f32_status(F.ctypes.data_as(_fp), C.byref(tau), m, n), "mmqr_f32")
-    rp, cp = get_panel_dims(m, n)
-    nb = 256 if (m >= 8192 and n >= 8192) else get_block_size()[0]
-    t = np.ctypeslib.as_array(tau, shape=(rp * cp * nb,)).copy()
+    t = np.ctypeslib.as_array(tau, shape=(tau_len(m, n),)).copy()
     _libc.free(C.cast(tau, C.c_void_p))
     return F, t
 
@@ -225,6 +252,8 @@ def explicit_qr_f32(F, tau):
     F = np.asfortranarray(F, dtype=np.float32)
     m, n = F.shape
     t = np.ascontiguousarray(tau, dtype=np.float32)
+    if t.size < n:
+        raise QRError(f"explicit_qr_f32: tau has {t.size} entries, the factorisation of {n} columns has {n}")
     Q = np.empty((m, m), dtype=np.float32, order="F")
     R = np.empty((m, n), dtype=np.float32, order="F")
     check(lib.explicitQR_f32_status(F.ctypes.data_as(_fp), t.ctypes.data_as(_fp), Q.ctypes.data_as(_fp), R.ctypes.data_as(_fp), m, n),
@@ -300,16 +329,20 @@ class Plan:
     """qr_plan wrapper.  The plan's HIP stream is independent of torch's current stream: call
     torch.cuda.synchronize() (or Plan.sync) at the hand-over points."""
 
-    def __init__(self, m, n, nb=0, ib=0):
+    def __init__(self, m, n, nb=0, ib=0, borrowed=None):
         self.h = None
+        self.owned = borrowed is None
+        if borrowed is not None:            # a qr_plan that lives inside another object (TsqrPlan): used, never destroyed here
+            self.h, self.m, self.n = _vp(borrowed), m, n
+            return
         h = _vp()
         check(lib.qr_plan_create(C.byref(h), m, n, nb, ib), "qr_plan_create")
         self.h, self.m, self.n = h, m, n
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             lib.qr_plan_destroy(self.h)
-            self.h = None
+        self.h = None
 
     __del__ = close
 
@@ -365,6 +398,66 @@ class Plan:
         check(lib.qr_plan_get_profile(self.h, C.byref(pr)), "qr_plan_get_profile")
         return {PROF_NAMES[c]: {"ms": pr.ms[c], "flops": pr.flops[c], "bytes": pr.bytes[c],
                                 "launches": pr.launches[c]} for c in range(QR_PROF_CLASSES)}
+
+
+class TsqrPlan:
+    """qr_tsqr_plan wrapper: the device-resident TSQR step of one rank (include/mi355x_qr.h).  `unique_id`: the 128 bytes
+    rank 0 got from tsqr_unique_id(), carried to every rank by the caller; None with nranks = 1; comm="external" builds a
+    plan without a communicator (the caller exchanges the R factors itself: local / exchange_buffers / stacked)."""
+
+    def __init__(self, m_local, n, nranks=1, rank=0, nb=0, unique_id=None, comm=None):
+        self.h = None
+        h = _vp()
+        if comm == "external":
+            check(lib.qr_tsqr_plan_create_comm(C.byref(h), None, nranks, rank, m_local, n, nb), "qr_tsqr_plan_create_comm")
+        else:
+            buf = None
+            if nranks > 1:
+                assert unique_id is not None and len(unique_id) == 128
+                buf = C.create_string_buffer(bytes(unique_id), 128)
+            check(lib.qr_tsqr_plan_create(C.byref(h), buf, nranks, rank, m_local, n, nb), "qr_tsqr_plan_create")
+        self.h, self.m, self.n, self.nranks, self.rank = h, m_local, n, nranks, rank
+        self.local = Plan(m_local, n, borrowed=lib.qr_tsqr_local_plan(h))
+        sp = lib.qr_tsqr_stacked_plan(h)
+        self.stacked = Plan(nranks * n, n, borrowed=sp) if sp else None
+
+    def close(self):
+        if self.h:
+            lib.qr_tsqr_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def factor(self, dA, lda, dR):
+        check(lib.qr_tsqr_factor_dev(self.h, _dptr(dA), lda, _dptr(dR)), "qr_tsqr_factor_dev")
+
+    def formq(self, dA, lda, dQ, ldq):
+        check(lib.qr_tsqr_formq_dev(self.h, _dptr(dA), lda, _dptr(dQ), ldq), "qr_tsqr_formq_dev")
+
+    def local_factor(self, dA, lda):
+        check(lib.qr_tsqr_local_dev(self.h, _dptr(dA), lda), "qr_tsqr_local_dev")
+
+    def exchange_buffers(self):
+        s, r = _vp(), _vp()
+        check(lib.qr_tsqr_exchange_buffers(self.h, C.byref(s), C.byref(r)), "qr_tsqr_exchange_buffers")
+        return s.value, r.value
+
+    def stacked_factor(self, dR):
+        check(lib.qr_tsqr_stacked_dev(self.h, _dptr(dR)), "qr_tsqr_stacked_dev")
+
+    def sync(self):
+        check(lib.qr_tsqr_sync(self.h), "qr_tsqr_sync")
+
+    def comm_ranks(self):
+        n = C.c_int()
+        check(lib.qr_tsqr_comm_ranks(self.h, C.byref(n)), "qr_tsqr_comm_ranks")
+        return n.value
+
+
+def tsqr_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib.qr_tsqr_unique_id(buf), "qr_tsqr_unique_id")
+    return bytes(buf.raw)
 
 
 def uniform_at(seed, idx):

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include "qr_device.h"
 
@@ -18,6 +20,9 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     int state = 0;      // 0 = not tried, 1 = loaded, -1 = unavailable
 };
 RcclApi g_rccl;
@@ -27,6 +32,11 @@ int load_rccl()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.state) return g_rccl.state > 0 ? 0 : QRD_E_NORCCL;
+    // The host driver of this pool only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's intra-node transport
+    // fails with "hipIpcGetMemHandle: invalid argument".  The variable is read when the HSA runtime starts, i.e. before this
+    // function can run in a process that already used the GPU -- launchers (bench.py) export it themselves;
+    // setting it here (never overriding the caller's value) only covers processes whose first GPU call is a multi-GPU entry point.
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -37,7 +47,13 @@ int load_rccl()
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
-    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl.state = -1; return QRD_E_NORCCL; }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.handle, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.handle, "ncclCommInitRank"));
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(g_rccl.handle, "ncclCommCount"));
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetUniqueId || !g_rccl.CommInitRank) {
+        g_rccl.state = -1;
+        return QRD_E_NORCCL;
+    }
     g_rccl.state = 1;
     return 0;
 }
@@ -53,6 +69,41 @@ int qrd_comm_init_all(void** comms, int n, const int* devs)
     static_assert(sizeof(ncclComm_t) == sizeof(void*), "communicator handles travel as void*");
     const ncclResult_t r = g_rccl.CommInitAll(reinterpret_cast<ncclComm_t*>(comms), n, devs);
     return r == ncclSuccess ? 0 : QRD_E_RCCL - (int) r;
+}
+
+// one process (or thread) per GPU: rank 0 makes the id, the caller carries its QRD_UNIQUE_ID_BYTES to every rank by its own means
+// (MPI, a torch.distributed store, a file), then every rank calls qrd_comm_init_rank with its current device set
+int qrd_comm_unique_id(void* id)
+{
+    int rc = load_rccl();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == QRD_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+    const ncclResult_t r = g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId*>(id));
+    return r == ncclSuccess ? 0 : QRD_E_RCCL - (int) r;
+}
+
+int qrd_comm_init_rank(void** comm, int nranks, const void* id, int rank)
+{
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    const ncclResult_t r = g_rccl.CommInitRank(reinterpret_cast<ncclComm_t*>(comm), nranks, uid, rank);
+    return r == ncclSuccess ? 0 : QRD_E_RCCL - (int) r;
+}
+
+// ranks the communicator really spans, as RCCL reports it
+int qrd_comm_count(void* comm, int* n)
+{
+    if (g_rccl.state <= 0 || !g_rccl.CommCount) return QRD_E_NORCCL;
+    const ncclResult_t r = g_rccl.CommCount((ncclComm_t) comm, n);
+    return r == ncclSuccess ? 0 : QRD_E_RCCL - (int) r;
+}
+
+const char* qrd_rccl_error_string(int r)
+{
+    if (g_rccl.state > 0 && g_rccl.GetErrorString) return g_rccl.GetErrorString((ncclResult_t) r);
+    return "RCCL call failed";
 }
 
 int qrd_comm_destroy(void* comm)

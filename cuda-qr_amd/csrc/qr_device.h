@@ -62,7 +62,12 @@ int qrd_diff_norm(void* stream, const double* X, int ldx, const double* Y, int l
 /* RCCL glue (qr_comm.hip): librccl is dlopen()ed on first use, never linked */
 #define QRD_E_NORCCL (-120)   /* librccl.so could not be loaded */
 #define QRD_E_RCCL   (-130)   /* an RCCL call failed: -130 - ncclResult_t */
+#define QRD_UNIQUE_ID_BYTES 128
 int qrd_comm_init_all(void** comms, int n, const int* devs);
+int qrd_comm_unique_id(void* id);
+int qrd_comm_init_rank(void** comm, int nranks, const void* id, int rank);
+int qrd_comm_count(void* comm, int* n);
+const char* qrd_rccl_error_string(int r);
 int qrd_comm_destroy(void* comm);
 int qrd_allgather_f64(void* comm, void* stream, const double* send, double* recv, size_t count);
 

@@ -68,6 +68,8 @@ struct qr_plan {
     void* ev_wide[2];           /* wide update that read panel set s finished */
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
     double *Vw2[2], *VT2[2], *T2[2];
+    int vt_formed[2];           /* VT2[e] = Vw2[e] * T2[e] of the panel NOW in set e exists (cleared when a panel is factored into the set,
+                                 * set where the V*T product is issued): a slice of the wide update that needs it forms it on demand */
     double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *leaf_scratch, *panel_ws;
     int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height;
                                  * 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
@@ -91,6 +93,51 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static int g_nb = 0, g_ib = 0;
 static int g_nb_explicit = 0;      /* MI355XQR_NB or qr_set_block_size chose nb: no automatic 256 for large square problems */
 static unsigned char g_dev_inited[QR_MAX_DEVICES];
+
+/* Tuning knobs of the schedule (MI355XQR_* environment variables): read ONCE per process under pthread_once --
+ * qr_thin_mgpu drives qr_geqrf_dev from one host thread per device, so nothing here may be a lazily written function static. */
+typedef struct qr_knobs {
+    int fuse_gram;                                          /* MI355XQR_FUSE_GRAM */
+    int fuse_nn, fuse_nn_min, fuse_nn_max, fuse_nn_gy_tall; /* MI355XQR_FUSE_NN, _MIN, _MAX, _GY */
+    int fold_max;                                           /* MI355XQR_TFOLD_MAX */
+    int use_w8;                                             /* MI355XQR_SMALLT_W8 */
+    int chunk_mb;                                           /* MI355XQR_CHUNK_MB */
+    int split_t;                                            /* MI355XQR_SPLIT_T */
+    int early_next, early_w1;                               /* MI355XQR_EARLY_NEXT, MI355XQR_EARLY_W1 */
+    int plan_cache;                                         /* MI355XQR_PLAN_CACHE */
+} qr_knobs;
+static qr_knobs g_knobs;
+static pthread_once_t g_knobs_once = PTHREAD_ONCE_INIT;
+
+static int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static void knobs_init(void)
+{
+    qr_knobs* k = &g_knobs;
+    k->fuse_gram = env_int("MI355XQR_FUSE_GRAM", 1) != 0;
+    k->fuse_nn = env_int("MI355XQR_FUSE_NN", 1) != 0;
+    k->fuse_nn_min = env_int("MI355XQR_FUSE_NN_MIN", 20000);
+    k->fuse_nn_max = env_int("MI355XQR_FUSE_NN_MAX", 0);
+    k->fuse_nn_gy_tall = env_int("MI355XQR_FUSE_NN_GY", 1);
+    k->fold_max = env_int("MI355XQR_TFOLD_MAX", 128);
+    k->use_w8 = env_int("MI355XQR_SMALLT_W8", 1);
+    k->chunk_mb = env_int("MI355XQR_CHUNK_MB", 0);
+    k->split_t = env_int("MI355XQR_SPLIT_T", 1) != 0;
+    k->early_next = env_int("MI355XQR_EARLY_NEXT", 1) != 0;
+    k->early_w1 = 4096;
+    { const int v = env_int("MI355XQR_EARLY_W1", 0); if (v >= 128) k->early_w1 = v / 128 * 128; }
+    k->plan_cache = env_int("MI355XQR_PLAN_CACHE", 1) != 0;
+}
+
+static const qr_knobs* knobs(void)
+{
+    pthread_once(&g_knobs_once, knobs_init);
+    return &g_knobs;
+}
 
 static void defaults_from_env_locked(void)
 {
@@ -139,6 +186,14 @@ void qr_get_block_size(int* nb, int* ib)
     pthread_mutex_unlock(&g_lock);
 }
 
+/* the block sizes mmqr / a plan created with nb = 0, ib = 0 really use for an m x n problem (getPanelDims reports the grid of these) */
+int qr_default_block_size(int m, int n, int* nb, int* ib)
+{
+    if (m < 1 || n < 1 || m < n) return QR_E_ARG;
+    default_blocks(m, n, nb, ib);
+    return 0;
+}
+
 /* kernel attributes (dynamic-LDS caps) are per device: initialise the CURRENT device of the calling thread once */
 static int ensure_device(void)
 {
@@ -164,7 +219,11 @@ const char* qr_strerror(int status)
     case QR_E_ALLOC: return "host allocation failed";
     case QR_E_NODEVICE: return "no HIP device (this library has no CPU fallback)";
     case QR_E_INTERNAL: return "internal error";
-    default: return status > 0 ? qrd_error_string(status) : "kernel launch argument error";
+    case QRD_E_NORCCL: return "librccl.so could not be loaded (multi-GPU entry points need RCCL)";
+    default:
+        if (status > 0) return qrd_error_string(status);
+        if (status <= QRD_E_RCCL) return qrd_rccl_error_string(QRD_E_RCCL - status);
+        return "kernel launch argument error";
     }
 }
 
@@ -499,20 +558,15 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
      * leaf route writes from its own diagonal block down, whatever the panel), so the zeros written once at plan creation stay
      * (5 us per panel on the critical chain otherwise). */
     const int nhalf = (wout + QR_HALF - 1) / QR_HALF;
-    static int fuse_gram = -1;
-    if (fuse_gram < 0) { const char* fe = getenv("MI355XQR_FUSE_GRAM"); fuse_gram = fe ? atoi(fe) != 0 : 1; }
+    p->vt_formed[p->Vw == p->Vw2[1]] = 0;                     /* this set's V*T (if any) belongs to an older panel */
+    const qr_knobs* const kn = knobs();
+    const int fuse_gram = kn->fuse_gram;
     /* MI355XQR_FUSE_NN=0: in-panel update and the next leaf's Gram matrix as separate launches (gemm_nn + gram32_kernel);
      * MI355XQR_FUSE_NN_MIN / _MAX: leaf heights the fused launch is used for (default: tall leaves only -- it saves a pass over
      * the next leaf, 262144 x 512: 7.15 -> 7.08 ms; on the short leaves of square problems its 128 matrix-core instructions per
      * wave sit on 10-14 compute units and the launch takes 18 us where gemm_nn + gram32 take 14: 8192^2 32.4 -> 33.0 ms);
      * MI355XQR_FUSE_NN_GY: column pairs side by side on tall leaves (1 = every workgroup walks all columns, V read once) */
-    static int fuse_nn = -1, fuse_nn_min = 20000, fuse_nn_max = 0, fuse_nn_gy_tall = 1;
-    if (fuse_nn < 0) {
-        const char* fe = getenv("MI355XQR_FUSE_NN"); fuse_nn = fe ? atoi(fe) != 0 : 1;
-        fe = getenv("MI355XQR_FUSE_NN_MIN"); if (fe) fuse_nn_min = atoi(fe);
-        fe = getenv("MI355XQR_FUSE_NN_MAX"); if (fe) fuse_nn_max = atoi(fe);
-        fe = getenv("MI355XQR_FUSE_NN_GY"); if (fe) fuse_nn_gy_tall = atoi(fe);
-    }
+    const int fuse_nn = kn->fuse_nn, fuse_nn_min = kn->fuse_nn_min, fuse_nn_max = kn->fuse_nn_max, fuse_nn_gy_tall = kn->fuse_nn_gy_tall;
     for (int h = 0; h < nhalf; ++h) {
         const int c0 = h * QR_HALF, wh = imin(QR_HALF, wout - c0), cend = c0 + wh;
         const int need_t = want_t || h + 1 < nhalf;          /* the next half's block update needs T of everything before it */
@@ -604,8 +658,7 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
     p->t_wait = NULL;
     /* narrow panels: T^T is folded into the reduction of the split-K slabs (one thread per entry of W walks a column of T:
      * fine for kw <= 128, 32 KB of T per output column; at kw = 256 every column's workgroup would pull 256 KB through L2) */
-    static int fold_max = -1;
-    if (fold_max < 0) { const char* e = getenv("MI355XQR_TFOLD_MAX"); fold_max = e ? atoi(e) : 128; }
+    const int fold_max = knobs()->fold_max;
     if (kw <= fold_max && slabs != NULL) {
         if (t_wait) CHECK(qrd_stream_wait_event(stream, t_wait));
         CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Wbuf, kw, slabs, p->slab_cap, T, ldt));
@@ -616,8 +669,7 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
     }
     /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
      * it hands anything it cannot take (ragged, unaligned) to the generic path itself */
-    static int use_w8 = -1;
-    if (use_w8 < 0) { const char* e = getenv("MI355XQR_SMALLT_W8"); use_w8 = e ? atoi(e) : 1; }
+    const int use_w8 = knobs()->use_w8;
     /* ... as long as its 128 x 128 tiles give every compute unit of the stream one: the look-ahead update of a late panel
      * (mk <= 8192, 256 columns: 128 tiles for 192-224 CUs) runs 16 serial K steps on half the chip -- 64 x 64 tiles then
      * (8192^2: 29.7 -> 29.2 ms) */
@@ -649,15 +701,15 @@ static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int
     if (profile == 1 && p->update_gen == 2 && qrd_gemm_nt_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda)) {
         /* second-generation wide update: W kept transposed (Wt = A2^T (V T), nc x wout), so that both operands of
          * A2 -= V Wt^T are row-fast and go HBM -> LDS directly (qr_gemm_nt.hip) */
-        if (form_vt) {
+        if (form_vt || !p->vt_formed[e]) {     /* on demand: an earlier slice of this update may have taken the tall-skinny shortcut above */
             CHECK(prof_begin_on(p, 3, stream));
             CHECK(qrd_gemm_nn(stream, mk, wout, wout, 1.0, p->Vw2[e], ldv, p->T2[e], p->ldt, 0.0, p->VT2[e], ldv));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+            p->vt_formed[e] = 1;
         }
         /* MI355XQR_CHUNK_MB > 0: the update walks A2 in column chunks of about that many MB, product and update of a chunk back
          * to back, so that the update's read of the chunk is served by the 256 MB Infinity Cache instead of HBM */
-        static int chunk_mb = -1;
-        if (chunk_mb < 0) { const char* ce = getenv("MI355XQR_CHUNK_MB"); chunk_mb = ce ? atoi(ce) : 0; }
+        const int chunk_mb = knobs()->chunk_mb;
         int cw = nc;
         if (chunk_mb > 0) {
             const int cus = qrd_stream_cus(stream), slots = 2 * cus, rt = mk / 128;
@@ -683,10 +735,11 @@ static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int
     }
     if (profile == 1) {
         const int tagged = wout >= 128 && nc >= 128;
-        if (form_vt) {
+        if (form_vt || !p->vt_formed[e]) {     /* on demand: an earlier slice of this update may have taken the tall-skinny shortcut above */
             CHECK(prof_begin_on(p, 3, stream));
             CHECK(qrd_gemm_nn(stream, mk, wout, wout, 1.0, p->Vw2[e], ldv, p->T2[e], p->ldt, 0.0, p->VT2[e], ldv));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
+            p->vt_formed[e] = 1;
         }
         CHECK(prof_begin_on(p, 1, stream));
         if (tagged)
@@ -820,18 +873,13 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
      *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
     int wide_pending[2] = {0, 0}, extra_pending = 0;
     int v_recorded[2] = {0, 0};     /* ev_v[e] was recorded inside factor_panel for the panel now in set e */
-    static int split_t = -1;
-    if (split_t < 0) { const char* se = getenv("MI355XQR_SPLIT_T"); split_t = se ? atoi(se) != 0 : 1; }
+    const int split_t = knobs()->split_t;
     /* Early look-ahead update (update-bound phase, one-level panels): N(s+1) is issued on the panel stream right after P(s+1),
      * ahead of the panel stream's share E(s) of the wide update, instead of on the update stream between W(s) and W(s+1) --
      * there it waited for ALL of W(s) and then ran alone on the chip for 0.16-0.18 ms per step (C3: 33 such steps).  For
      * that, W(s) starts with the columns of panel s+2 (W1(s), event ev_half[s&1]) and E(s) takes the LAST columns of the wide
      * range instead of the first.  early_done: N of the coming step has been issued already. */
-    static int early_env = -1, early_w1 = 4096;
-    if (early_env < 0) {
-        const char* ee = getenv("MI355XQR_EARLY_NEXT"); early_env = ee ? atoi(ee) != 0 : 1;
-        ee = getenv("MI355XQR_EARLY_W1"); if (ee && atoi(ee) >= 128) early_w1 = atoi(ee) / 128 * 128;
-    }
+    const int early_env = knobs()->early_next, early_w1 = knobs()->early_w1;
     int early_done = 0;
     CHECK(enter_phase(p, phase_of(p, n, n)));
     {
@@ -1090,8 +1138,7 @@ static int slot_acquire(int m, int n, host_slot* priv, host_slot** out)
     int dev = 0, nb = 128;
     CHECK(qrd_get_device(&dev));
     default_blocks(m, n, &nb, NULL);
-    const char* e = getenv("MI355XQR_PLAN_CACHE");
-    const int cacheable = (!e || atoi(e) != 0) && (size_t) m * n <= QR_CACHE_MAX_ELEMS;
+    const int cacheable = knobs()->plan_cache && (size_t) m * n <= QR_CACHE_MAX_ELEMS;
     host_slot* sl = NULL;
     int reuse = 0;
     if (cacheable) {
@@ -1362,14 +1409,187 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
     return rc;
 }
 
-/* ---- thin QR over the GPUs of one node: TSQR with one RCCL all-gather ---------------------------------
- * One host thread per device (created here); device d owns the contiguous row block d of A.  Steps, per device:
- *   1. H2D of its rows, local qr_geqrf_dev -> R_d
- *   2. ONE all-gather of the n x n R factors (RCCL over xGMI; latency-bound: n = 512 is 2 MiB per rank)
- *   3. redundant QR of the stacked (P n) x n matrix on every device -> final R (identical bits everywhere) and the device's
- *      n x n block of the tree's Q
- *   4. Q_d = Q_local_d [Qtree_d; 0], D2H of its rows of Q
+/* ---- device-resident TSQR step over one communicator (north_star: "host code stays in C") -------------------
+ * One qr_tsqr_plan per rank (= per GPU: one process or one host thread each).  A factorisation of the rank's row shard:
+ *   1. local qr_geqrf_dev of the shard -> R_p (n x n) packed into the plan's send buffer
+ *   2. ONE ncclAllGather of the R factors on the plan's stream (RCCL over xGMI; latency-bound: n = 512 is 2 MiB per rank)
+ *   3. redundant QR of the stacked (P n) x n matrix on every rank -> the final R (identical bits everywhere)
+ *   4. (qr_tsqr_formq_dev) Q_p = Q_local_p [Qtree_p; 0]
+ * Everything is stream-ordered: no host synchronisation inside a step.  The stacked factorisation runs on its own plan's streams
+ * behind an event, and the next step's exchange waits for it through another, so in a sequence of independent factorisations the
+ * stacked QR of step i runs under the local QR of step i+1 without the caller doing anything; qr_tsqr_sync() drains both.
  * No reference counterpart: the reference is single-device (qr.cu:711,737). */
+struct qr_tsqr_plan {
+    int nranks, rank, m_local, n, nb, sm;
+    qr_plan *p, *p2;                /* local shard, stacked R factors (NULL when nranks == 1) */
+    void* comm; int own_comm;       /* ncclComm_t as void*; own_comm: created here from a unique id, destroyed with the plan */
+    double *dtau, *dtau2, *dRp, *dRall, *dS, *dQt;
+    void *ev_gathered, *ev_stacked; /* stack matrix filled (local stream) / stacked factorisation has consumed it (stack stream) */
+    int stacked_pending;            /* ev_stacked has been recorded and not yet waited for by the local stream */
+    int local_done;                 /* qr_tsqr_local_dev ran and the stacked step has not yet consumed its R factor */
+};
+
+int qr_tsqr_unique_id(void* id128)
+{
+    if (!id128) return QR_E_ARG;
+    return qrd_comm_unique_id(id128);
+}
+
+static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nranks, int rank, int m_local, int n, int nb)
+{
+    qr_tsqr_plan* t = (qr_tsqr_plan*) calloc(1, sizeof *t);
+    if (!t) { if (own_comm) qrd_comm_destroy(comm); return QR_E_ALLOC; }
+    t->nranks = nranks; t->rank = rank; t->m_local = m_local; t->n = n; t->nb = nb; t->sm = nranks * n;
+    t->comm = comm; t->own_comm = own_comm;
+    const size_t nn = (size_t) n * n;
+    int rc = qr_plan_create(&t->p, m_local, n, nb, 0);
+    if (!rc) rc = qrd_malloc((void**) &t->dtau, sizeof(double) * n);
+    if (!rc) rc = qrd_malloc((void**) &t->dRp, sizeof(double) * nn);
+    if (!rc && nranks > 1) {
+        rc = qr_plan_create(&t->p2, t->sm, n, nb, 0);
+        if (!rc) rc = qrd_malloc((void**) &t->dtau2, sizeof(double) * n);
+        if (!rc) rc = qrd_malloc((void**) &t->dRall, sizeof(double) * nn * nranks);
+        if (!rc) rc = qrd_malloc((void**) &t->dS, sizeof(double) * (size_t) t->sm * n);
+        if (!rc) rc = qrd_event_create_notiming(&t->ev_gathered);
+        if (!rc) rc = qrd_event_create_notiming(&t->ev_stacked);
+    }
+    if (rc) { qr_tsqr_plan_destroy(t); return rc; }
+    *out = t;
+    return 0;
+}
+
+int qr_tsqr_plan_create(qr_tsqr_plan** out, const void* id128, int nranks, int rank, int m_local, int n, int nb)
+{
+    if (!out || nranks < 1 || rank < 0 || rank >= nranks || n < 1 || m_local < n || (nranks > 1 && !id128)) return QR_E_ARG;
+    if ((long long) nranks * n > 0x7fffffffLL / 2) return QR_E_ARG;
+    CHECK(ensure_device());
+    void* comm = NULL;
+    if (nranks > 1) CHECK(qrd_comm_init_rank(&comm, nranks, id128, rank));
+    return tsqr_plan_build(out, comm, nranks > 1, nranks, rank, m_local, n, nb);
+}
+
+/* the same over a communicator the caller already owns (an ncclComm_t, passed as void*): it is used, never destroyed */
+int qr_tsqr_plan_create_comm(qr_tsqr_plan** out, void* nccl_comm, int nranks, int rank, int m_local, int n, int nb)
+{
+    if (!out || nranks < 1 || rank < 0 || rank >= nranks || n < 1 || m_local < n) return QR_E_ARG;
+    if ((long long) nranks * n > 0x7fffffffLL / 2) return QR_E_ARG;
+    CHECK(ensure_device());
+    return tsqr_plan_build(out, nccl_comm, 0, nranks, rank, m_local, n, nb);
+}
+
+int qr_tsqr_plan_destroy(qr_tsqr_plan* t)
+{
+    if (!t) return 0;
+    qr_tsqr_sync(t);
+    if (t->ev_gathered) qrd_event_destroy(t->ev_gathered);
+    if (t->ev_stacked) qrd_event_destroy(t->ev_stacked);
+    qrd_free(t->dtau); qrd_free(t->dtau2); qrd_free(t->dRp); qrd_free(t->dRall); qrd_free(t->dS); qrd_free(t->dQt);
+    qr_plan_destroy(t->p); qr_plan_destroy(t->p2);
+    if (t->own_comm && t->comm) qrd_comm_destroy(t->comm);
+    free(t);
+    return 0;
+}
+
+int qr_tsqr_sync(qr_tsqr_plan* t)
+{
+    if (!t) return QR_E_ARG;
+    int rc = t->p ? qr_plan_sync(t->p) : 0;
+    if (!rc && t->p2) rc = qr_plan_sync(t->p2);
+    return rc;
+}
+
+void* qr_tsqr_stream(qr_tsqr_plan* t) { return t && t->p ? t->p->s_main : NULL; }
+qr_plan* qr_tsqr_local_plan(qr_tsqr_plan* t) { return t ? t->p : NULL; }
+qr_plan* qr_tsqr_stacked_plan(qr_tsqr_plan* t) { return t ? t->p2 : NULL; }
+
+/* ranks of the communicator as RCCL itself counts them (1 without a communicator) */
+int qr_tsqr_comm_ranks(qr_tsqr_plan* t, int* nranks)
+{
+    if (!t || !nranks) return QR_E_ARG;
+    *nranks = 1;
+    if (t->nranks == 1 || !t->comm) return 0;
+    return qrd_comm_count(t->comm, nranks);
+}
+
+/* step 1: local factorisation of the shard, R_p packed into the send buffer */
+int qr_tsqr_local_dev(qr_tsqr_plan* t, double* dA, int lda)
+{
+    if (!t || !dA || lda < t->m_local) return QR_E_ARG;
+    qr_plan* p = t->p;
+    CHECK(qr_geqrf_dev(p, dA, t->m_local, t->n, lda, t->dtau));
+    CHECK(qr_extract_r_dev(p, dA, t->m_local, t->n, lda, t->dRp, t->n, t->n));
+    t->local_done = 1;
+    return 0;
+}
+
+/* for transports other than RCCL (bring-up with more ranks than GPUs): after qr_tsqr_local_dev + qr_tsqr_sync, `*send` holds
+ * this rank's n x n R factor (column-major, ld n); the caller fills `*recv` with all ranks' factors in rank order
+ * (nranks * n * n doubles) and calls qr_tsqr_stacked_dev. */
+int qr_tsqr_exchange_buffers(qr_tsqr_plan* t, double** send, double** recv)
+{
+    if (!t) return QR_E_ARG;
+    if (send) *send = t->dRp;
+    if (recv) *recv = t->dRall;
+    return 0;
+}
+
+/* steps 3: stack the gathered factors, factor, dR (n x n, ld n) = final R */
+int qr_tsqr_stacked_dev(qr_tsqr_plan* t, double* dR)
+{
+    if (!t || !dR) return QR_E_ARG;
+    const int n = t->n, P = t->nranks, sm = t->sm;
+    const size_t nn = (size_t) n * n;
+    qr_plan* p = t->p;
+    if (P == 1) { t->local_done = 0; return qrd_d2d(p->s_main, dR, t->dRp, sizeof(double) * nn); }
+    /* the previous stacked factorisation may still be reading dS on the other plan's streams */
+    if (t->stacked_pending) { CHECK(qrd_stream_wait_event(p->s_main, t->ev_stacked)); t->stacked_pending = 0; }
+    for (int q = 0; q < P; ++q)
+        CHECK(qrd_copy_block(p->s_main, t->dRall + (size_t) q * nn, n, t->dS + (size_t) q * n, sm, n, n));
+    CHECK(qrd_event_record(t->ev_gathered, p->s_main));
+    qr_plan* p2 = t->p2;
+    CHECK(qrd_stream_wait_event(p2->s_main, t->ev_gathered));
+    CHECK(qr_geqrf_dev(p2, t->dS, sm, n, sm, t->dtau2));
+    CHECK(qr_extract_r_dev(p2, t->dS, sm, n, sm, dR, n, n));
+    CHECK(qrd_event_record(t->ev_stacked, p2->s_main));
+    t->stacked_pending = 1;
+    t->local_done = 0;
+    return 0;
+}
+
+/* steps 1-3 with the RCCL all-gather in between; asynchronous (qr_tsqr_sync before dR is read on another stream) */
+int qr_tsqr_factor_dev(qr_tsqr_plan* t, double* dA, int lda, double* dR)
+{
+    if (!t || !dA || !dR) return QR_E_ARG;
+    CHECK(qr_tsqr_local_dev(t, dA, lda));
+    if (t->nranks > 1) {
+        if (!t->comm) return QR_E_ARG;      /* plan made for an external transport: use local / exchange_buffers / stacked */
+        /* dRall is read by the copies of the previous step on this same stream: stream order is enough */
+        CHECK(qrd_allgather_f64(t->comm, t->p->s_main, t->dRp, t->dRall, (size_t) t->n * t->n));
+    }
+    return qr_tsqr_stacked_dev(t, dR);
+}
+
+/* step 4 after a factorisation of dA: dQ (m_local x n, ldq) = this rank's rows of the thin Q */
+int qr_tsqr_formq_dev(qr_tsqr_plan* t, const double* dA, int lda, double* dQ, int ldq)
+{
+    if (!t || !dA || !dQ || lda < t->m_local || ldq < t->m_local) return QR_E_ARG;
+    const int n = t->n, rows = t->m_local, sm = t->sm;
+    qr_plan* p = t->p;
+    if (t->nranks == 1) return qr_applyq_dev(p, dA, rows, n, lda, t->dtau, dQ, n, ldq, 1);
+    if (!t->dQt) CHECK(qrd_malloc((void**) &t->dQt, sizeof(double) * (size_t) sm * n));
+    qr_plan* p2 = t->p2;
+    CHECK(qr_applyq_dev(p2, t->dS, sm, n, sm, t->dtau2, t->dQt, n, sm, 1));          /* the tree's Q, (P n) x n */
+    CHECK(qrd_event_record(t->ev_stacked, p2->s_main));
+    CHECK(qrd_stream_wait_event(p->s_main, t->ev_stacked));
+    t->stacked_pending = 0;
+    CHECK(qrd_zero_block(p->s_main, dQ, ldq, rows, n));
+    CHECK(qrd_copy_block(p->s_main, t->dQt + (size_t) t->rank * n, sm, dQ, ldq, n, n));
+    return qr_applyq_dev(p, dA, rows, n, lda, t->dtau, dQ, n, ldq, 0);
+}
+
+/* ---- thin QR over the GPUs of one node, host pointers: a thin user of the TSQR plan above -------------------------------------
+ * One host thread per device (created here); device d owns the contiguous row block d of A: H2D of its rows, qr_tsqr_factor_dev,
+ * qr_tsqr_formq_dev, D2H of its rows of Q.  Communicators from ONE ncclCommInitAll in the calling thread. */
 typedef struct mg_ctx {
     int rank, ngpu, dev, m, n, nb, r0, rows, rc;
     const double* A;
@@ -1381,51 +1601,33 @@ typedef struct mg_ctx {
 
 static int mg_run(mg_ctx* c)
 {
-    const int n = c->n, rows = c->rows, P = c->ngpu, sm = P * n;
+    const int n = c->n, rows = c->rows;
     const size_t nn = (size_t) n * n;
-    qr_plan *p = NULL, *p2 = NULL;
-    double *dA = NULL, *dQ = NULL, *dtau = NULL, *dRp = NULL, *dRall = NULL, *dS = NULL, *dQt = NULL, *dtau2 = NULL, *dR = NULL;
+    qr_tsqr_plan* t = NULL;
+    double *dA = NULL, *dQ = NULL, *dR = NULL;
     int rc = qrd_set_device(c->dev);
-    if (!rc) rc = qr_plan_create(&p, rows, n, c->nb, 0);
-    if (!rc) rc = qr_plan_create(&p2, sm, n, c->nb, 0);
+    if (!rc) rc = qr_tsqr_plan_create_comm(&t, c->comm, c->ngpu, c->rank, rows, n, c->nb);
     if (!rc) rc = qrd_malloc((void**) &dA, sizeof(double) * (size_t) rows * n);
     if (!rc) rc = qrd_malloc((void**) &dQ, sizeof(double) * (size_t) rows * n);
-    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * n);
-    if (!rc) rc = qrd_malloc((void**) &dtau2, sizeof(double) * n);
-    if (!rc) rc = qrd_malloc((void**) &dRp, sizeof(double) * nn);
     if (!rc) rc = qrd_malloc((void**) &dR, sizeof(double) * nn);
-    if (!rc) rc = qrd_malloc((void**) &dRall, sizeof(double) * nn * P);
-    if (!rc) rc = qrd_malloc((void**) &dS, sizeof(double) * (size_t) sm * n);
-    if (!rc) rc = qrd_malloc((void**) &dQt, sizeof(double) * (size_t) sm * n);
-    /* 1. rows [r0, r0 + rows) of the column-major host matrix (ld m) -> its own column-major array (ld rows) */
-    if (!rc) rc = qrd_h2d_2d(p->stream, dA, sizeof(double) * rows, c->A + c->r0, sizeof(double) * c->m, sizeof(double) * rows, n);
-    if (!rc) rc = qr_geqrf_dev(p, dA, rows, n, rows, dtau);
-    if (!rc) rc = qr_extract_r_dev(p, dA, rows, n, rows, dRp, n, n);
+    void* s = t ? qr_tsqr_stream(t) : NULL;
+    /* rows [r0, r0 + rows) of the column-major host matrix (ld m) -> its own column-major array (ld rows) */
+    if (!rc) rc = qrd_h2d_2d(s, dA, sizeof(double) * rows, c->A + c->r0, sizeof(double) * c->m, sizeof(double) * rows, n);
     /* every thread reaches the collective or none does: a rank that failed before it would leave the others hanging */
     if (rc) __atomic_store_n(c->any_fail, 1, __ATOMIC_SEQ_CST);
     pthread_barrier_wait(c->bar);
     if (__atomic_load_n(c->any_fail, __ATOMIC_SEQ_CST)) { if (!rc) rc = QR_E_INTERNAL; goto done; }
-    /* 2. the one collective */
-    if (P > 1) rc = qrd_allgather_f64(c->comm, p->stream, dRp, dRall, nn);
-    else rc = qrd_d2d(p->stream, dRall, dRp, sizeof(double) * nn);
-    for (int q = 0; q < P && !rc; ++q)
-        rc = qrd_copy_block(p->stream, dRall + (size_t) q * nn, n, dS + (size_t) q * n, sm, n, n);
-    if (!rc) rc = qrd_stream_sync(p->stream);
-    /* 3. stacked factorisation, redundantly on every device */
-    if (!rc) rc = qr_geqrf_dev(p2, dS, sm, n, sm, dtau2);
-    if (!rc) rc = qr_extract_r_dev(p2, dS, sm, n, sm, dR, n, n);
-    if (!rc) rc = qr_applyq_dev(p2, dS, sm, n, sm, dtau2, dQt, n, sm, 1);
-    if (!rc) rc = qr_plan_sync(p2);
-    /* 4. Q_d = Q_local_d [Qtree_d ; 0] */
-    if (!rc) rc = qrd_memset(p->stream, dQ, 0, sizeof(double) * (size_t) rows * n);
-    if (!rc) rc = qrd_copy_block(p->stream, dQt + (size_t) c->rank * n, sm, dQ, rows, n, n);
-    if (!rc) rc = qr_applyq_dev(p, dA, rows, n, rows, dtau, dQ, n, rows, 0);
-    if (!rc) rc = qrd_d2h_2d(p->stream, c->Q + c->r0, sizeof(double) * c->m, dQ, sizeof(double) * rows, sizeof(double) * rows, n);
-    if (!rc && c->rank == 0) rc = qrd_d2h(p->stream, c->R, dR, sizeof(double) * nn);
-    if (!rc) rc = qr_plan_sync(p);
+    rc = qr_tsqr_factor_dev(t, dA, rows, dR);
+    if (!rc) rc = qr_tsqr_formq_dev(t, dA, rows, dQ, rows);
+    if (!rc) rc = qrd_d2h_2d(s, c->Q + c->r0, sizeof(double) * c->m, dQ, sizeof(double) * rows, sizeof(double) * rows, n);
+    if (!rc && c->rank == 0) {
+        rc = qr_plan_sync(t->p2 ? t->p2 : t->p);            /* dR is written on the stacked plan's stream */
+        if (!rc) rc = qrd_d2h(s, c->R, dR, sizeof(double) * nn);
+    }
+    if (!rc) rc = qr_tsqr_sync(t);
 done:
-    qrd_free(dA); qrd_free(dQ); qrd_free(dtau); qrd_free(dtau2); qrd_free(dRp); qrd_free(dR); qrd_free(dRall); qrd_free(dS); qrd_free(dQt);
-    qr_plan_destroy(p); qr_plan_destroy(p2);
+    qrd_free(dA); qrd_free(dQ); qrd_free(dR);
+    qr_tsqr_plan_destroy(t);
     return rc;
 }
 
@@ -1452,7 +1654,10 @@ int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, in
     for (int d = 0; d < ngpu; ++d) devs[d] = d;
     if (ngpu > 1) CHECK(qrd_comm_init_all(comms, ngpu, devs));
     pthread_barrier_t bar;
-    if (pthread_barrier_init(&bar, NULL, (unsigned) ngpu)) return QR_E_INTERNAL;
+    if (pthread_barrier_init(&bar, NULL, (unsigned) ngpu)) {
+        for (int d = 0; d < ngpu; ++d) qrd_comm_destroy(comms[d]);
+        return QR_E_INTERNAL;
+    }
     mg_ctx ctx[QR_MAX_DEVICES];
     pthread_t th[QR_MAX_DEVICES];
     int started = 0, any_fail = 0, rc = 0;

@@ -11,12 +11,113 @@ RCCL has no user-defined reduction, so the "all-reduce of R factors" of the nort
 all-gather + a redundant small QR; the messages are latency-bound (KBs..MBs), far below the xGMI
 per-link bandwidth, so there is exactly one collective per factorisation and nothing to overlap.
 
-The local factorisations go through a `backend` object.  The product backend is HipBackend (the
-C-ABI library through cuda_qr_amd.Plan).  Tests inject a CPU backend to exercise the orchestration
-with gloo; nothing in this file falls back to a CPU path by itself.
+Two drivers of the same steps:
+
+  DeviceTSQR   the product path: the C-ABI qr_tsqr_plan (include/mi355x_qr.h) -- schedule, stream ordering and the RCCL
+               all-gather all live in C (qr_host.c, qr_comm.hip); Python only carries the 128-byte unique id from rank 0 to
+               the other ranks through torch.distributed.  bench.py --gpus N uses this.
+  TSQR         the same steps orchestrated here over a `backend` object with torch.distributed collectives.  Tests inject a
+               CPU backend to exercise stacking order and the Q combine with gloo (world 2 / 3, runs without a GPU); HipBackend
+               is the device backend of that orchestration.  Nothing in this file falls back to a CPU path by itself.
 """
 import torch
 import torch.distributed as dist
+
+
+class DeviceTSQR:
+    """One rank's device-resident TSQR step through the C-ABI plan (qr_tsqr_factor_dev / qr_tsqr_formq_dev).
+
+    transport "rccl": the all-gather is issued by the library on its own stream (ncclAllGather via the dlopen()ed librccl).
+    transport "host": bring-up only (more ranks than GPUs; RCCL refuses duplicate devices) -- the R factors travel through
+    host memory and the torch.distributed group (gloo); local and stacked steps are the same C entry points."""
+
+    def __init__(self, qr, m_local, n, world, rank, nb=0, transport="rccl", group=None):
+        self.qr, self.m, self.n, self.world, self.rank, self.group = qr, m_local, n, world, rank, group
+        self.transport = transport if world > 1 else "none"
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        if world == 1:
+            self.tp = qr.TsqrPlan(m_local, n, 1, 0, nb)
+        elif transport == "rccl":
+            box = [qr.tsqr_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            self.tp = qr.TsqrPlan(m_local, n, world, rank, nb, unique_id=box[0])
+        else:
+            self.tp = qr.TsqrPlan(m_local, n, world, rank, nb, comm="external")
+            self._send, self._recv = self.tp.exchange_buffers()
+            self._host_send = torch.empty(n * n, dtype=torch.float64).pin_memory()
+            self._host_recv = torch.empty(world * n * n, dtype=torch.float64).pin_memory()
+        self.plan = self.tp.local              # fills, norms, products, profiling on the local plan's stream
+        self.R = torch.empty((n, n), dtype=torch.float64, device=dev)
+
+    def new_matrix(self, rows, cols):
+        return torch.empty((cols, rows), dtype=torch.float64, device=self.device)
+
+    def fill(self, A, rows, cols, row_off, total_rows, seed):
+        self.plan.fill_uniform(A, rows, rows, cols, row_off=row_off, total_rows=total_rows, seed=seed)
+        self.plan.sync()
+
+    def factor(self, A):
+        """Steps 1-3 on this rank's shard A (overwritten with its local factors); returns the buffer that will hold the final
+        R (n x n column-major).  Asynchronous with transport rccl / none: call sync() before reading R."""
+        if self.transport != "host":
+            self.tp.factor(A, self.m, self.R)
+            return self.R
+        nn = self.n * self.n
+        self.tp.local_factor(A, self.m)
+        self.tp.sync()
+        self.qr.check(self.qr.lib.qr_copy_to_host(self._host_send.data_ptr(), self._send, 8 * nn), "copy R out")
+        dist.all_gather_into_tensor(self._host_recv, self._host_send, group=self.group)
+        self.qr.check(self.qr.lib.qr_copy_to_device(self._recv, self._host_recv.data_ptr(), 8 * nn * self.world), "copy R in")
+        self.tp.stacked_factor(self.R)
+        return self.R
+
+    def local_only(self, A):
+        """step 1 alone (timing split)."""
+        self.tp.local_factor(A, self.m)
+
+    def form_q(self, A):
+        Q = self.new_matrix(self.m, self.n)
+        self.tp.formq(A, self.m, Q, self.m)
+        self.tp.sync()
+        return Q
+
+    def sync(self):
+        self.tp.sync()
+
+    def close(self):
+        self.tp.close()
+
+
+def stacked_step_ms(qr, P, n, nb=0, reps=8):
+    """Milliseconds of the stacked step of a P-rank factorisation (qr_tsqr_stacked_dev: stack P gathered n x n upper-triangular
+    R factors, factor the (P n) x n matrix, extract R), un-pipelined, on the current device -- what every rank does after the
+    all-gather, measurable on one GPU (a plan without a communicator; the gathered factors are synthetic)."""
+    import time
+    import numpy as np
+    tp = qr.TsqrPlan(n, n, P, 0, nb, comm="external")
+    _, recv = tp.exchange_buffers()
+    rng = np.random.default_rng(5)
+    blocks = np.triu(rng.random((P, n, n)) + np.eye(n) * 4.0)             # R_p(r, c), r <= c
+    host = np.ascontiguousarray(blocks.transpose(0, 2, 1))                # [p][c][r]: column-major n x n blocks in rank order
+    qr.check(qr.lib.qr_copy_to_device(recv, host.ctypes.data, host.nbytes), "copy R in")
+    R = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    tp.stacked_factor(R); tp.sync()
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tp.stacked_factor(R)
+            tp.sync()
+        best = min(best, (time.perf_counter() - t0) / reps * 1e3)
+    ref = np.linalg.qr(blocks.reshape(P * n, n), mode="r")
+    got = np.triu(R.cpu().numpy().T)
+    sg, sr = np.sign(np.diag(got))[:, None], np.sign(np.diag(ref))[:, None]
+    err = float(np.linalg.norm(sg * got - sr * ref) / np.linalg.norm(ref))
+    tp.close()
+    if not err < 1e-12:
+        raise RuntimeError(f"stacked step: R differs from LAPACK by {err:.2e}")
+    return best
 
 
 class HipBackend:

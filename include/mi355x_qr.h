@@ -73,7 +73,7 @@ int explicitQR_f32_status(float* A, float* tau, float* Q, float* R, int m, int n
 #define QR_E_INTERNAL (-104)
 const char* qr_strerror(int status);
 
-/* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 256;
+/* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 512, above 256 a multiple of 256;
  * leaf width ib <= 32).  Defaults 128 / 32 (256 / 32 when nothing was set explicitly and n >= 8192, or n >= 1024 with
  * m <= 1.5 n: square-ish problems -- getPanelDims(m, n, ..) reports the panel grid of the block size that shape will really get);
  * env MI355XQR_NB / MI355XQR_IB override the defaults.
@@ -82,6 +82,9 @@ const char* qr_strerror(int status);
  * plan cache of the host-pointer entry points) is guarded internally. */
 int qr_set_block_size(int nb, int ib);
 void qr_get_block_size(int* nb, int* ib);
+/* the block sizes an m x n problem REALLY gets from mmqr / a plan created with nb = 0, ib = 0 (shape-dependent, see above):
+ * mmqr's tau holds ceil(n / nb) * nb entries of this nb -- size buffers from here, not from qr_get_block_size */
+int qr_default_block_size(int m, int n, int* nb, int* ib);
 
 /* Thin QR for shapes whose m x m Q cannot exist (no reference counterpart: the
  * reference's explicitQR is m x m only).  A (m x n, host) is not modified; Q is m x n, R is n x n
@@ -97,6 +100,33 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
  * qr_thin(..., nshards = 1).  Returns QR_E_ARG when ngpu exceeds the visible devices or a shard would have fewer than n rows.
  * Q is m x n, R is n x n (host memory).  No reference counterpart (the reference is single-device, qr.cu:711,737). */
 int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, int ngpu);
+
+/* Device-resident TSQR step, one rank per GPU (one process or one host thread each), for callers whose row shard already lives
+ * in HBM -- the per-GPU step of BASELINE configs C4 / C5.  No reference counterpart (single-device, qr.cu:711,737).
+ *   rank 0:      qr_tsqr_unique_id(id)            128 bytes; carry them to every rank (MPI_Bcast, a key-value store, a file)
+ *   every rank:  hipSetDevice(local gpu); qr_tsqr_plan_create(&tp, id, nranks, rank, m_local, n, nb)     (collective)
+ *   per matrix:  qr_tsqr_factor_dev(tp, dA_shard, lda, dR)      local QR -> ONE ncclAllGather of the n x n R factors ->
+ *                                                               redundant QR of the stacked (nranks n) x n matrix -> dR (n x n, ld n)
+ *                qr_tsqr_formq_dev(tp, dA_shard, lda, dQ, ldq)  optional: this rank's m_local x n rows of the thin Q
+ * Stream-ordered, no host synchronisation inside a step; the stacked factorisation of one call overlaps the local factorisation
+ * of the next (independent matrices).  qr_tsqr_sync() before results are read on another stream.  librccl.so is dlopen()ed
+ * on first use.  nranks = 1 needs no id (NULL) and no communicator.  qr_tsqr_plan_create_comm takes an ncclComm_t the caller
+ * already owns (as void*; NULL = the caller exchanges the factors itself: qr_tsqr_local_dev, copy through
+ * qr_tsqr_exchange_buffers -- send: this rank's n*n doubles, recv: nranks*n*n in rank order --, qr_tsqr_stacked_dev). */
+typedef struct qr_tsqr_plan qr_tsqr_plan;
+#define QR_TSQR_UNIQUE_ID_BYTES 128
+int qr_tsqr_unique_id(void* id128);
+int qr_tsqr_plan_create(qr_tsqr_plan** tp, const void* id128, int nranks, int rank, int m_local, int n, int nb);
+int qr_tsqr_plan_create_comm(qr_tsqr_plan** tp, void* nccl_comm, int nranks, int rank, int m_local, int n, int nb);
+int qr_tsqr_plan_destroy(qr_tsqr_plan* tp);
+int qr_tsqr_factor_dev(qr_tsqr_plan* tp, double* dA_shard, int lda, double* dR);
+int qr_tsqr_formq_dev(qr_tsqr_plan* tp, const double* dA_shard, int lda, double* dQ, int ldq);
+int qr_tsqr_local_dev(qr_tsqr_plan* tp, double* dA_shard, int lda);
+int qr_tsqr_exchange_buffers(qr_tsqr_plan* tp, double** send, double** recv);
+int qr_tsqr_stacked_dev(qr_tsqr_plan* tp, double* dR);
+int qr_tsqr_sync(qr_tsqr_plan* tp);
+void* qr_tsqr_stream(qr_tsqr_plan* tp);                 /* hipStream_t of the local step and the collective */
+int qr_tsqr_comm_ranks(qr_tsqr_plan* tp, int* nranks);  /* ranks as RCCL itself counts them */
 
 /* The host-pointer entry points (mmqr, explicitQR) keep their last few plans and device buffers, keyed by (device, m, n, nb),
  * so that repeated calls on same-sized matrices -- what the reference's harness does, qr.cu:776-789 -- do not pay ~10 ms of
@@ -154,6 +184,10 @@ int qr_device_malloc(void** dptr, size_t bytes);
 int qr_device_free(void* dptr);
 int qr_copy_to_device(void* dst, const void* src, size_t bytes);
 int qr_copy_to_host(void* dst, const void* src, size_t bytes);
+
+/* the two qr_plans inside a TSQR plan (profiling, fills, norms on the same streams); stacked: NULL when nranks = 1 */
+qr_plan* qr_tsqr_local_plan(qr_tsqr_plan* tp);
+qr_plan* qr_tsqr_stacked_plan(qr_tsqr_plan* tp);
 
 int qr_plan_sync(qr_plan* plan);
 void* qr_plan_stream(qr_plan* plan);          /* the hipStream_t work is queued on */

@@ -1,0 +1,149 @@
+/* host_sanitize.c -- TEST-ONLY driver of the C host layer (cuda-qr_amd/csrc/qr_host.c) over the stub device layer
+ * (qrd_stub.c), built with -fsanitize=address,undefined or -fsanitize=thread by `make -C cuda-qr_amd asan|tsan`.
+ * Exercises what the sanitizers can see without a GPU: the schedule's workspace indexing (the stub bounds-checks every operand
+ * block), plan life cycle and leak-freedom, the plan cache of the host-pointer entry points under concurrent callers, the
+ * per-device threads + barrier protocol of qr_thin_mgpu, and the event protocol of the TSQR plan. */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/mi355x_qr.h"
+
+long qrd_stub_launches(void);
+int qrd_stub_live_allocations(void);
+
+#define OK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #x, rc_, qr_strerror(rc_)); exit(1); } } while (0)
+
+static void factor_once(int pm, int pn, int nb, int m, int n, int with_q, int profile)
+{
+    qr_plan* p = NULL;
+    double *dA = NULL, *dtau = NULL, *dQ = NULL, *dR = NULL;
+    OK(qr_plan_create(&p, pm, pn, nb, 0));
+    OK(qr_device_malloc((void**) &dA, sizeof(double) * (size_t) m * n));
+    OK(qr_device_malloc((void**) &dtau, sizeof(double) * n));
+    if (profile) OK(qr_plan_set_profile(p, 1));
+    OK(qr_geqrf_dev(p, dA, m, n, m, dtau));
+    OK(qr_geqrf_dev(p, dA, m, n, m, dtau));
+    if (profile) { qr_profile pr; OK(qr_plan_get_profile(p, &pr)); }
+    if (with_q) {
+        OK(qr_device_malloc((void**) &dQ, sizeof(double) * (size_t) m * n));
+        OK(qr_device_malloc((void**) &dR, sizeof(double) * (size_t) n * n));
+        OK(qr_extract_r_dev(p, dA, m, n, m, dR, n, n));
+        OK(qr_applyq_dev(p, dA, m, n, m, dtau, dQ, n, m, 1));
+        OK(qr_applyq_dev(p, dA, m, n, m, dtau, dQ, n, m, 0));
+    }
+    OK(qr_plan_sync(p));
+    OK(qr_device_free(dA)); OK(qr_device_free(dtau)); OK(qr_device_free(dQ)); OK(qr_device_free(dR));
+    OK(qr_plan_destroy(p));
+}
+
+static void* host_caller(void* arg)
+{
+    const int id = (int) (long) arg;
+    const int shapes[3][2] = {{512, 128}, {300, 77}, {1100, 1030}};
+    for (int it = 0; it < 6; ++it) {
+        const int m = shapes[(id + it) % 3][0], n = shapes[(id + it) % 3][1];
+        double* A = (double*) calloc((size_t) m * n, sizeof(double));
+        double* Q = (double*) calloc((size_t) m * m, sizeof(double));
+        double* R = (double*) calloc((size_t) m * n, sizeof(double));
+        double* tau = NULL;
+        OK(mmqr_status(A, &tau, m, n));
+        int nb = 0, rp = 0, cp = 0;
+        OK(qr_default_block_size(m, n, &nb, NULL));
+        getPanelDims(m, n, &rp, &cp);
+        tau[(size_t) rp * cp * nb - 1] = 0.0;                /* the last entry of the documented length is ours to touch */
+        OK(explicitQR_status(A, tau, Q, R, m, n));
+        free(tau); free(A); free(Q); free(R);
+    }
+    return NULL;
+}
+
+int main(void)
+{
+    /* 1. schedules: single stream, look-ahead on shared CUs, look-ahead on a CU partition with the panel stream's share,
+     *    two-level panels, ragged widths, sub-size problems on a bigger plan (incl. the tall-skinny shortcut mix), graph replay */
+    setenv("MI355XQR_LOOKAHEAD", "0", 1);
+    factor_once(1000, 333, 128, 1000, 333, 1, 0);
+    factor_once(4096, 1024, 512, 4096, 1000, 1, 1);
+    factor_once(70000, 96, 32, 70000, 96, 1, 0);
+    factor_once(16384, 2048, 256, 4096, 2048, 0, 0);
+    setenv("MI355XQR_LOOKAHEAD", "1", 1);
+    factor_once(3000, 2100, 128, 3000, 2100, 1, 1);
+    factor_once(2304, 2304, 512, 2304, 2304, 0, 0);
+    factor_once(16384, 2048, 256, 8192, 2048, 0, 0);
+    setenv("MI355XQR_PANEL_CUS", "64", 1);
+    setenv("MI355XQR_BALANCE", "14,44,0.05,0.05", 1);
+    factor_once(6144, 4096, 256, 6144, 4096, 0, 1);
+    factor_once(6144, 4096, 128, 6000, 3900, 0, 0);
+    factor_once(5120, 5120, 512, 5120, 5120, 0, 0);
+    setenv("MI355XQR_NEXT", "update", 1);
+    factor_once(6144, 4096, 256, 6144, 4096, 0, 0);
+    unsetenv("MI355XQR_NEXT"); unsetenv("MI355XQR_PANEL_CUS"); unsetenv("MI355XQR_BALANCE");
+    setenv("MI355XQR_LOOKAHEAD", "0", 1);
+    setenv("MI355XQR_GRAPH", "1", 1);
+    factor_once(2000, 500, 128, 2000, 500, 0, 0);
+    unsetenv("MI355XQR_GRAPH"); unsetenv("MI355XQR_LOOKAHEAD");
+    setenv("MI355XQR_PANEL", "tsqr", 1);
+    factor_once(9000, 200, 128, 9000, 200, 1, 0);
+    setenv("MI355XQR_PANEL", "col", 1);
+    factor_once(900, 200, 64, 900, 200, 0, 0);
+    unsetenv("MI355XQR_PANEL");
+    /* argument errors */
+    { qr_plan* p = NULL; if (qr_plan_create(&p, 10, 20, 0, 0) != QR_E_ARG || qr_plan_create(&p, 64, 64, 100, 32) != QR_E_ARG) return 2; }
+
+    /* 2. host-pointer entry points from four threads at once: the plan cache (QR_CACHE_SLOTS = 4, three shapes) */
+    pthread_t th[4];
+    for (long i = 0; i < 4; ++i) pthread_create(&th[i], NULL, host_caller, (void*) i);
+    for (int i = 0; i < 4; ++i) pthread_join(th[i], NULL);
+    OK(qr_release_cached_plans());
+
+    /* 3. thin QR: virtual shards on one device, and one host thread per (stub) device with the all-gather in between */
+    {
+        const int m = 4096, n = 64;
+        double* A = (double*) calloc((size_t) m * n, sizeof(double));
+        double* Q = (double*) calloc((size_t) m * n, sizeof(double));
+        double* R = (double*) calloc((size_t) n * n, sizeof(double));
+        OK(qr_thin(A, m, n, Q, R, 0, 1));
+        OK(qr_thin(A, m, n, Q, R, 32, 3));
+        OK(qr_thin_mgpu(A, m, n, Q, R, 0, 1));
+        OK(qr_thin_mgpu(A, m, n, Q, R, 0, 4));
+        OK(qr_thin_mgpu(A, 4093, n, Q, R, 0, 3));                               /* ragged last shard */
+        if (qr_thin_mgpu(A, m, n, Q, R, 0, 5) != QR_E_ARG) return 3;          /* more than the 4 stub devices */
+        free(A); free(Q); free(R);
+    }
+
+    /* 4. TSQR plan: external transport, back-to-back steps (event protocol between the local and the stacked plan), thin Q */
+    {
+        const int ml = 8192, n = 128, P = 4;
+        qr_tsqr_plan* t = NULL;
+        double *dA = NULL, *dR = NULL, *dQ = NULL, *send = NULL, *recv = NULL;
+        OK(qr_tsqr_plan_create_comm(&t, NULL, P, 1, ml, n, 0));
+        OK(qr_device_malloc((void**) &dA, sizeof(double) * (size_t) ml * n));
+        OK(qr_device_malloc((void**) &dQ, sizeof(double) * (size_t) ml * n));
+        OK(qr_device_malloc((void**) &dR, sizeof(double) * (size_t) n * n));
+        OK(qr_tsqr_exchange_buffers(t, &send, &recv));
+        if (!send || !recv) return 4;
+        if (qr_tsqr_factor_dev(t, dA, ml, dR) != QR_E_ARG) return 5;          /* no communicator: the all-in-one call is refused */
+        for (int it = 0; it < 3; ++it) {
+            OK(qr_tsqr_local_dev(t, dA, ml));
+            OK(qr_tsqr_stacked_dev(t, dR));
+        }
+        OK(qr_tsqr_formq_dev(t, dA, ml, dQ, ml));
+        int nr = 0;
+        OK(qr_tsqr_comm_ranks(t, &nr));
+        OK(qr_tsqr_sync(t));
+        OK(qr_tsqr_plan_destroy(t));
+        OK(qr_tsqr_plan_create(&t, NULL, 1, 0, ml, n, 0));
+        OK(qr_tsqr_factor_dev(t, dA, ml, dR));
+        OK(qr_tsqr_formq_dev(t, dA, ml, dQ, ml));
+        OK(qr_tsqr_plan_destroy(t));
+        OK(qr_device_free(dA)); OK(qr_device_free(dQ)); OK(qr_device_free(dR));
+    }
+    if (qrd_stub_live_allocations() != 0) {
+        fprintf(stderr, "device-memory leak: %d allocations still live\n", qrd_stub_live_allocations());
+        return 6;
+    }
+    printf("host layer sanitize run ok: %ld operand blocks checked\n", qrd_stub_launches());
+    return 0;
+}

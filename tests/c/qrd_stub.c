@@ -1,0 +1,258 @@
+/* qrd_stub.c -- TEST-ONLY stand-in for the HIP launch layer (cuda-qr_amd/csrc/qr_device.h), so that the C host layer
+ * (qr_host.c: schedule, plan cache, TSQR plan, per-device threads) can run under AddressSanitizer / UBSan / ThreadSanitizer on a
+ * box without a GPU (SURVEY section 5 "race detection / sanitizers"; GPU sanitizers are not available on the pool).
+ *
+ * It computes NOTHING: "device memory" is host calloc, copies are memcpy, every kernel launch only CHECKS that the operand blocks
+ * it was given lie inside live allocations (so an out-of-range workspace index in the schedule aborts here with a message) and
+ * returns.  It is never linked into libmi355xqr.so and nothing under cuda-qr_amd/ refers to it. */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../cuda-qr_amd/csrc/qr_device.h"
+
+#define MAXA 4096
+static struct { char* p; size_t n; } g_alloc[MAXA];
+static int g_nalloc;
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static __thread int t_dev = 0;
+static long g_launches;
+
+static void die(const char* what, const void* p, size_t bytes)
+{
+    fprintf(stderr, "qrd_stub: %s: block %p + %zu bytes is not inside a live device allocation\n", what, p, bytes);
+    abort();
+}
+
+/* column-major block rows x cols (doubles) with leading dimension ld at p: inside ONE live allocation? */
+static void chk(const char* what, const void* p, long ld, long rows, long cols)
+{
+    if (rows <= 0 || cols <= 0) return;
+    if (!p) die(what, p, 0);
+    if (ld < rows) { fprintf(stderr, "qrd_stub: %s: ld %ld < rows %ld\n", what, ld, rows); abort(); }
+    const size_t bytes = sizeof(double) * ((size_t) ld * (size_t) (cols - 1) + (size_t) rows);
+    const char* c = (const char*) p;
+    int ok = 0;
+    pthread_mutex_lock(&g_mu);
+    for (int i = 0; i < g_nalloc && !ok; ++i)
+        if (c >= g_alloc[i].p && c + bytes <= g_alloc[i].p + g_alloc[i].n) ok = 1;
+    ++g_launches;
+    pthread_mutex_unlock(&g_mu);
+    if (!ok) die(what, p, bytes);
+}
+static void chkb(const char* what, const void* p, size_t bytes) { if (bytes) chk(what, p, (long) ((bytes + 7) / 8), (long) ((bytes + 7) / 8), 1); }
+
+long qrd_stub_launches(void) { return g_launches; }
+int qrd_stub_live_allocations(void) { return g_nalloc; }
+
+int qrd_init(void) { return 0; }
+int qrd_gemm2_init(void) { return 0; }
+int qrd_panel_tsqr_init(void) { return 0; }
+int qrd_leaf_fused_init(void) { return 0; }
+
+int qrd_malloc(void** p, size_t bytes)
+{
+    if (!p) return 1;
+    const size_t n = (bytes + 7) & ~(size_t) 7;
+    char* q = (char*) calloc(1, n ? n : 8);
+    if (!q) return 2;
+    pthread_mutex_lock(&g_mu);
+    if (g_nalloc == MAXA) { pthread_mutex_unlock(&g_mu); free(q); return 2; }
+    g_alloc[g_nalloc].p = q; g_alloc[g_nalloc].n = n ? n : 8; ++g_nalloc;
+    pthread_mutex_unlock(&g_mu);
+    *p = q;
+    return 0;
+}
+int qrd_free(void* p)
+{
+    if (!p) return 0;
+    pthread_mutex_lock(&g_mu);
+    int found = 0;
+    for (int i = 0; i < g_nalloc; ++i)
+        if (g_alloc[i].p == (char*) p) { g_alloc[i] = g_alloc[--g_nalloc]; found = 1; break; }
+    pthread_mutex_unlock(&g_mu);
+    if (!found) { fprintf(stderr, "qrd_stub: qrd_free of %p, which is not a live allocation (double free?)\n", p); abort(); }
+    free(p);
+    return 0;
+}
+int qrd_memset(void* s, void* p, int v, size_t bytes) { (void) s; chkb("memset", p, bytes); memset(p, v, bytes); return 0; }
+int qrd_h2d(void* s, void* d, const void* h, size_t bytes) { (void) s; chkb("h2d", d, bytes); memcpy(d, h, bytes); return 0; }
+int qrd_d2h(void* s, void* h, const void* d, size_t bytes) { (void) s; chkb("d2h", d, bytes); memcpy(h, d, bytes); return 0; }
+int qrd_d2d(void* s, void* dst, const void* src, size_t bytes) { (void) s; chkb("d2d dst", dst, bytes); chkb("d2d src", src, bytes); memmove(dst, src, bytes); return 0; }
+int qrd_h2d_2d(void* s, void* d, size_t dp, const void* h, size_t hp, size_t w, size_t hgt)
+{
+    (void) s;
+    for (size_t r = 0; r < hgt; ++r) { chkb("h2d_2d", (char*) d + r * dp, w); memcpy((char*) d + r * dp, (const char*) h + r * hp, w); }
+    return 0;
+}
+int qrd_d2h_2d(void* s, void* h, size_t hp, const void* d, size_t dp, size_t w, size_t hgt)
+{
+    (void) s;
+    for (size_t r = 0; r < hgt; ++r) { chkb("d2h_2d", (const char*) d + r * dp, w); memcpy((char*) h + r * hp, (const char*) d + r * dp, w); }
+    return 0;
+}
+
+typedef struct stub_stream { int cus; } stub_stream;
+int qrd_stream_create(void** s, int hp) { (void) hp; stub_stream* x = calloc(1, sizeof *x); if (!x) return 2; x->cus = 256; *s = x; return 0; }
+int qrd_stream_create_cumask(void** s, int first, int count) { (void) first; stub_stream* x = calloc(1, sizeof *x); if (!x) return 2; x->cus = count; *s = x; return 0; }
+int qrd_stream_destroy(void* s) { free(s); return 0; }
+int qrd_stream_cus(void* s) { return s ? ((stub_stream*) s)->cus : 256; }
+int qrd_stream_sync(void* s) { (void) s; return 0; }
+int qrd_device_sync(void) { return 0; }
+int qrd_capture_begin(void* s) { (void) s; return 0; }
+int qrd_capture_end(void* s, void** exec) { (void) s; *exec = calloc(1, 8); return *exec ? 0 : 2; }
+int qrd_graph_launch(void* exec, void* s) { (void) s; return exec ? 0 : 1; }
+int qrd_graph_destroy(void* exec) { free(exec); return 0; }
+int qrd_event_create(void** e) { *e = calloc(1, 8); return *e ? 0 : 2; }
+int qrd_event_create_notiming(void** e) { return qrd_event_create(e); }
+int qrd_event_destroy(void* e) { free(e); return 0; }
+int qrd_event_record(void* e, void* s) { (void) s; return e ? 0 : 1; }
+int qrd_event_sync(void* e) { return e ? 0 : 1; }
+int qrd_stream_wait_event(void* s, void* e) { (void) s; return e ? 0 : 1; }
+int qrd_event_elapsed_ms(void* a, void* b, float* ms) { if (!a || !b) return 1; *ms = 0.125f; return 0; }
+int qrd_device_count(int* n) { const char* e = getenv("QRD_STUB_NDEV"); *n = e ? atoi(e) : 4; return 0; }
+int qrd_set_device(int d) { t_dev = d; return 0; }
+int qrd_get_device(int* d) { *d = t_dev; return 0; }
+int qrd_host_register(void* p, size_t b) { (void) p; (void) b; return 0; }
+int qrd_host_unregister(void* p) { (void) p; return 0; }
+const char* qrd_error_string(int e) { (void) e; return "stub device layer error"; }
+int qrd_device_info(char* name, int len, int* cus, int* khz, size_t* mem)
+{
+    if (name && len > 0) snprintf(name, (size_t) len, "stub");
+    if (cus) *cus = 256;
+    if (khz) *khz = 2400000;
+    if (mem) *mem = (size_t) 1 << 36;
+    return 0;
+}
+int qrd_probe_mfma_f64(double* o) { o[0] = o[1] = o[2] = 1.0; return 0; }
+int qrd_probe_copy(double* g) { *g = 1.0; return 0; }
+
+/* ---- kernel launches: operand checks only ---- */
+int qrd_gemm_nn(void* s, int M, int N, int K, double al, const double* A, int lda, const double* B, int ldb, double be, double* C, int ldc)
+{ (void) s; (void) al; (void) be; chk("gemm_nn A", A, lda, M, K); chk("gemm_nn B", B, ldb, K, N); chk("gemm_nn C", C, ldc, M, N); return 0; }
+int qrd_gemm_nn_update(void* s, int M, int N, int K, double al, const double* A, int lda, const double* B, int ldb, double be, double* C, int ldc)
+{ return qrd_gemm_nn(s, M, N, K, al, A, lda, B, ldb, be, C, ldc); }
+int qrd_gemm_nn_update2(void* s, int M, int N, int K, double al, const double* A, int lda, const double* B, int ldb, double be, double* C, int ldc)
+{ return qrd_gemm_nn(s, M, N, K, al, A, lda, B, ldb, be, C, ldc); }
+int qrd_gemm_tn(void* s, int M, int N, int K, double al, const double* A, int lda, const double* B, int ldb, double be, double* C, int ldc,
+                double* slabs, size_t cap, const double* Tm, int ldt)
+{
+    (void) s; (void) al; (void) be;
+    chk("gemm_tn A", A, lda, K, M); chk("gemm_tn B", B, ldb, K, N); chk("gemm_tn C", C, ldc, M, N);
+    if (slabs) chkb("gemm_tn slabs", slabs, cap * sizeof(double));
+    if (Tm) chk("gemm_tn T", Tm, ldt, M, M);
+    return 0;
+}
+int qrd_gemm_tn_update(void* s, int M, int N, int K, double al, const double* A, int lda, const double* B, int ldb, double be, double* C, int ldc,
+                       double* slabs, size_t cap)
+{ return qrd_gemm_tn(s, M, N, K, al, A, lda, B, ldb, be, C, ldc, slabs, cap, NULL, 0); }
+int qrd_gemm_tn_dual(void* s, int N1, int N2, int K, const double* A, int lda, const double* B1, int ldb1, const double* B2, int ldb2,
+                     const double* Tm, int ldt, double* W, int ldw, double* G2, int ldg, double* slabs, size_t cap)
+{
+    (void) s;
+    chk("tn_dual A", A, lda, K, 32);
+    if (N1 > 0) { chk("tn_dual B1", B1, ldb1, K, N1); chk("tn_dual W", W, ldw, 32, N1); }
+    if (N2 > 0) { chk("tn_dual B2", B2, ldb2, K, N2); chk("tn_dual G2", G2, ldg, N2, 32); }
+    chk("tn_dual T", Tm, ldt, 32, 32);
+    chkb("tn_dual slabs", slabs, cap * sizeof(double));
+    return (K & 64) ? -7 : 0;          /* both outcomes of the fused launch are exercised */
+}
+int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc)
+{ (void) A; (void) Bt; (void) C; (void) lda; (void) ldbt; (void) ldc; return M % 128 == 0 && N % 128 == 0 && K % 16 == 0; }
+int qrd_gemm_nt(void* s, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt, double* C, int ldc, int gm,
+                unsigned long long* st)
+{ (void) s; (void) sign; (void) gm; (void) st; chk("gemm_nt A", A, lda, M, K); chk("gemm_nt Bt", Bt, ldbt, N, K); chk("gemm_nt C", C, ldc, M, N); return 0; }
+int qrd_gemm_tnt(void* s, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* Ct, int ldct, double* slabs,
+                 size_t cap, int ks, int cus, int gm)
+{ (void) s; (void) ks; (void) cus; (void) gm; (void) slabs; (void) cap; chk("tnt A", A, lda, K, M); chk("tnt B", B, ldb, K, N); chk("tnt Ct", Ct, ldct, N, M); return 0; }
+int qrd_gemm_nn_batch(void* s, int M, int N, int K, double al, const double* A, int lda, size_t sA, const double* B, int ldb, size_t sB,
+                      double be, double* C, int ldc, size_t sC, int batch)
+{
+    for (int b = 0; b < batch; ++b) qrd_gemm_nn(s, M, N, K, al, A + sA * b, lda, B + sB * b, ldb, be, C + sC * b, ldc);
+    return 0;
+}
+static void leaf_chk(const char* w, double* P, int ld, int mk, int wd, double* tau, double* T, int ldt, double* Vw, int ldv)
+{ chk(w, P, ld, mk, wd); chk(w, tau, wd, wd, 1); chk(w, T, ldt, wd, wd); chk(w, Vw, ldv, mk, wd); }
+int qrd_leaf_panel(void* s, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* scratch)
+{ (void) s; leaf_chk("leaf_panel", P, ld, mk, w, tau, T, ldt, Vw, ldv); chkb("leaf scratch", scratch, sizeof(double) * QRD_LEAF_SCRATCH); return 0; }
+size_t qrd_panel_ws_size(int m) { return (size_t) 80 * (size_t) (m > 0 ? m : 1) + 65536; }
+int qrd_panel_tsqr(void* s, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int mcap)
+{ (void) s; leaf_chk("panel_tsqr", P, ld, mk, w, tau, T, ldt, Vw, ldv); chkb("panel ws", ws, sizeof(double) * qrd_panel_ws_size(mcap)); return 0; }
+int qrd_panel_cholqr(void* s, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int mcap,
+                     double* cws, double* slabs, size_t cap, int gn)
+{
+    (void) gn;
+    qrd_panel_tsqr(s, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, mcap);
+    chkb("cholqr ws", cws, sizeof(double) * QRD_CHOLQR_WS); chkb("cholqr slabs", slabs, cap * sizeof(double));
+    return 0;
+}
+int qrd_slab_reduce(void* s, int M, int N, int ns, const double* slabs, int lds, size_t stride, double* out, int ldo)
+{ (void) s; chk("slab_reduce in", slabs, lds, M, N); (void) ns; (void) stride; chk("slab_reduce out", out, ldo, M, N); return 0; }
+int qrd_leaf_update_gram(void* s, int mk, int N, const double* V, int ldv, const double* W, double* C, int ldc, double* gs, size_t cap, int gy,
+                         int* nslab)
+{
+    (void) s; (void) gy;
+    if (mk < 1024) return -7;
+    chk("lug V", V, ldv, mk, 32); chk("lug W", W, 32, 32, N); chk("lug C", C, ldc, mk, N);
+    if (gs) chkb("lug slabs", gs, cap * sizeof(double));
+    if (nslab) *nslab = gs ? 8 : 0;
+    return 0;
+}
+int qrd_larft(void* s, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt, double* Tt, int bd, double* X, int ldx)
+{
+    (void) s; (void) ib; (void) bd;
+    chk("larft G", G, ldg, nbp, nbp); chk("larft tau", tau, nbp, nbp, 1); chk("larft T", T, ldt, nbp, nbp); chk("larft X", X, ldx, nbp, nbp);
+    if (Tt) chk("larft Tt", Tt, ldt, nbp, nbp);
+    return 0;
+}
+int qrd_zero_block(void* s, double* A, int ld, int r, int c) { (void) s; chk("zero_block", A, ld, r, c); return 0; }
+int qrd_extract_v(void* s, const double* P, int ld, int mk, int w, double* V, int ldv) { (void) s; chk("extract_v P", P, ld, mk, w); chk("extract_v V", V, ldv, mk, w); return 0; }
+int qrd_extract_r(void* s, const double* A, int lda, int m, int n, double* R, int ldr, int rr) { (void) s; chk("extract_r A", A, lda, m, n); chk("extract_r R", R, ldr, rr, n); return 0; }
+int qrd_set_identity(void* s, double* C, int ld, int r, int c, int ro) { (void) s; (void) ro; chk("set_identity", C, ld, r, c); return 0; }
+int qrd_copy_block(void* s, const double* S, int lds, double* D, int ldd, int r, int c) { (void) s; chk("copy_block S", S, lds, r, c); chk("copy_block D", D, ldd, r, c); return 0; }
+int qrd_fill_uniform(void* s, double* A, int ld, long long rows, int cols, long long ro, long long tr, unsigned long long seed)
+{ (void) s; (void) ro; (void) tr; (void) seed; chk("fill", A, ld, (long) rows, cols); return 0; }
+double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx) { (void) seed; (void) idx; return 0.5; }
+int qrd_diff_norm(void* s, const double* X, int ldx, const double* Y, int ldy, long long rows, int cols, long long ro, long long tr,
+                  unsigned long long seed, int si, double* out)
+{ (void) s; (void) ro; (void) tr; (void) seed; (void) si; chk("diffnorm X", X, ldx, (long) rows, cols); if (Y) chk("diffnorm Y", Y, ldy, (long) rows, cols); out[0] = 0.0; out[1] = 1.0; return 0; }
+
+/* ---- "RCCL": a thread-level all-gather (one thread per device, the way qr_thin_mgpu drives it) ---- */
+typedef struct stub_world { int n; pthread_barrier_t bar; const double* send[64]; } stub_world;
+typedef struct stub_comm { stub_world* w; int rank; } stub_comm;
+int qrd_comm_init_all(void** comms, int n, const int* devs)
+{
+    (void) devs;
+    stub_world* w = calloc(1, sizeof *w);
+    if (!w) return QRD_E_RCCL;
+    w->n = n;
+    pthread_barrier_init(&w->bar, NULL, (unsigned) n);
+    for (int i = 0; i < n; ++i) { stub_comm* c = calloc(1, sizeof *c); c->w = w; c->rank = i; comms[i] = c; }
+    return 0;
+}
+int qrd_comm_unique_id(void* id) { memset(id, 7, QRD_UNIQUE_ID_BYTES); return 0; }
+int qrd_comm_init_rank(void** comm, int n, const void* id, int rank) { (void) comm; (void) n; (void) id; (void) rank; return QRD_E_NORCCL; }
+int qrd_comm_count(void* comm, int* n) { *n = ((stub_comm*) comm)->w->n; return 0; }
+const char* qrd_rccl_error_string(int r) { (void) r; return "stub rccl error"; }
+int qrd_comm_destroy(void* comm)
+{
+    stub_comm* c = (stub_comm*) comm;
+    if (!c) return 0;
+    if (c->rank == 0) { pthread_barrier_destroy(&c->w->bar); free(c->w); }
+    free(c);
+    return 0;
+}
+int qrd_allgather_f64(void* comm, void* stream, const double* send, double* recv, size_t count)
+{
+    (void) stream;
+    stub_comm* c = (stub_comm*) comm;
+    chkb("allgather send", send, count * sizeof(double));
+    chkb("allgather recv", recv, count * sizeof(double) * (size_t) c->w->n);
+    c->w->send[c->rank] = send;
+    pthread_barrier_wait(&c->w->bar);
+    for (int q = 0; q < c->w->n; ++q) memcpy(recv + (size_t) q * count, c->w->send[q], count * sizeof(double));
+    pthread_barrier_wait(&c->w->bar);
+    return 0;
+}

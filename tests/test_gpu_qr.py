@@ -35,7 +35,7 @@ def test_dropin_mmqr_explicitQR_vs_reference_golden(qr, oracle, name, m, n):
     A = oracle.fill_rand(m, n)
     F, tau = qr.mmqr(A)
     rp, cp = qr.get_panel_dims(m, n)
-    assert tau.shape[0] == rp * cp * qr.get_block_size()[0] >= n        # qr.c:61 sizing rule
+    assert tau.shape[0] == rp * cp * qr.default_block_size(m, n)[0] >= n        # qr.c:61 sizing rule
     Rn = oracle.sign_normalise(F)
     assert rel(Rn, golden_R(g, n)) <= 1e-13
     assert np.abs(np.abs(np.diag(F[:n])) - np.abs(g["diagR"])).max() < 1e-12 * np.abs(g["diagR"]).max()
@@ -466,3 +466,142 @@ def test_qr_device_cli_like_reference_harness(qr):
     assert m and 0.0 < float(m.group(1)) < 5.0
     usage = subprocess.run([exe], capture_output=True, text=True)
     assert usage.returncode == 1 and "Usage: ./qr_device m n" in usage.stdout
+
+
+@pytest.mark.parametrize("m,n", [(1024, 1024), (2048, 2048), (1536, 1100)])
+def test_dropin_roundtrip_where_the_default_block_is_256(qr, oracle, m, n):
+    """mmqr -> explicitQR through the host-pointer ABI on shapes that get nb = 256 by default (square-ish, >= 1024 columns) while
+    the global default stays 128: tau must carry all n scalars (it is sized from the block size the SHAPE gets) or explicitQR
+    reads past it and returns a wrong Q."""
+    rng = np.random.default_rng(m + n)
+    A = rng.random((m, n))
+    F, tau = qr.mmqr(A)
+    assert tau.shape[0] == qr.tau_len(m, n) >= n
+    assert np.all(tau[:n - 1] != 0.0)
+    Q, R = qr.explicit_qr(F, tau)
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
+    assert np.linalg.norm(Q.T @ Q - np.eye(m)) < 1e-12
+    ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert rel(oracle.sign_normalise(F), ref) < 1e-13
+    with pytest.raises(qr.QRError):
+        qr.explicit_qr(F, tau[: n // 2])                 # a truncated tau is refused, not over-read
+
+
+def test_dropin_roundtrip_f32_at_1024(qr):
+    A = np.random.default_rng(9).random((1024, 1024)).astype(np.float32)
+    F, tau = qr.mmqr_f32(A)
+    assert tau.shape[0] == qr.tau_len(1024, 1024)
+    Q, R = qr.explicit_qr_f32(F, tau)
+    A64 = A.astype(np.float64)
+    assert np.linalg.norm(Q.astype(np.float64) @ R.astype(np.float64) - A64) / np.linalg.norm(A64) < 1e-6
+
+
+@pytest.mark.parametrize("plan_mn,sub_mn", [((16384, 2048), (8192, 2048)), ((16384, 2048), (4096, 2048)), ((12288, 1536), (3072, 1536))])
+def test_subsize_geqrf_on_a_tall_plan(qr, oracle, plan_mn, sub_mn):
+    """A plan made for m >= 8 n has the tall-skinny shortcut of the wide update (T applied to the small product, V*T never
+    formed); a SMALLER problem on the same plan mixes slices that take the shortcut with slices that need V*T -- which must then
+    be formed on demand (vt_formed) instead of being read stale from an older panel."""
+    pm, pn = plan_mn
+    m, n = sub_mn
+    for la in ("0", "1"):
+        import os
+        os.environ["MI355XQR_LOOKAHEAD"] = la
+        try:
+            p = qr.Plan(pm, pn, 256, 32)
+        finally:
+            del os.environ["MI355XQR_LOOKAHEAD"]
+        dA = zeros(m, n)
+        p.fill_uniform(dA, m, m, n, seed=21)
+        p.sync()
+        A = host(dA)
+        dtau, dR = zeros(n, 1), zeros(n, n)
+        p.geqrf(dA, m, n, m, dtau)
+        p.extract_r(dA, m, n, m, dR, n, n)
+        p.sync()
+        ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+        assert rel(oracle.sign_normalise(host(dR)), ref) < 1e-13, f"lookahead={la}"
+        p.close()
+
+
+@pytest.mark.parametrize("m_local,n,P", [(4096, 128, 1), (2048, 96, 3), (8192, 256, 4), (1000, 64, 2)])
+def test_tsqr_plan_c_abi_virtual_ranks(qr, oracle, m_local, n, P):
+    """The C-ABI device-resident TSQR step (qr_tsqr_plan_*) with P virtual ranks on ONE device: every rank's plan runs
+    qr_tsqr_local_dev, the R factors are exchanged by the test through qr_tsqr_exchange_buffers (the hook for transports other
+    than RCCL), qr_tsqr_stacked_dev gives the final R -- identical bits on every rank, equal to LAPACK's after sign
+    normalisation -- and qr_tsqr_formq_dev the rank's rows of the thin Q.  P = 1 goes through qr_tsqr_factor_dev itself."""
+    import ctypes as C
+    m = m_local * P
+    A = qr.uniform_matrix_host(m, n, seed=31)
+    plans = [qr.TsqrPlan(m_local, n, P, r, 128, comm="external" if P > 1 else None) for r in range(P)]
+    shards, Rs = [], []
+    for r, tp in enumerate(plans):
+        dA = zeros(m_local, n)
+        tp.local.fill_uniform(dA, m_local, m_local, n, row_off=r * m_local, total_rows=m, seed=31)
+        tp.sync()
+        shards.append(dA)
+        Rs.append(zeros(n, n))
+    if P == 1:
+        plans[0].factor(shards[0], m_local, Rs[0])
+        assert plans[0].comm_ranks() == 1
+    else:
+        for tp, dA in zip(plans, shards):
+            tp.local_factor(dA, m_local)
+            tp.sync()
+        nn8 = 8 * n * n
+        for tp in plans:                                   # the "all-gather": rank q's send buffer -> slot q of every recv buffer
+            _, recv = tp.exchange_buffers()
+            for q, tq in enumerate(plans):
+                send, _ = tq.exchange_buffers()
+                tmp = np.empty(n * n)
+                qr.check(qr.lib.qr_copy_to_host(tmp.ctypes.data, send, nn8))
+                qr.check(qr.lib.qr_copy_to_device(recv + q * nn8, tmp.ctypes.data, nn8))
+        for tp, dR in zip(plans, Rs):
+            tp.stacked_factor(dR)
+    for tp in plans:
+        tp.sync()
+    R0 = host(Rs[0])
+    for dR in Rs[1:]:
+        assert np.array_equal(R0, host(dR)), "every rank must hold the identical final R"
+    assert np.array_equal(np.tril(R0, -1), np.zeros((n, n)))
+    ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert rel(oracle.sign_normalise(R0), ref) < 1e-13
+    Q = np.vstack([host(_formq(qr, tp, dA, m_local, n)) for tp, dA in zip(plans, shards)])
+    assert np.linalg.norm(A - Q @ R0) / np.linalg.norm(A) < 1e-13
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+    for tp in plans:
+        tp.close()
+
+
+def _formq(qr, tp, dA, m_local, n):
+    dQ = zeros(m_local, n)
+    tp.formq(dA, m_local, dQ, m_local)
+    tp.sync()
+    return dQ
+
+
+def test_tsqr_plan_back_to_back_steps_are_stream_ordered(qr, oracle):
+    """Independent factorisations issued back to back on one TSQR plan without any host synchronisation in between (the stacked
+    QR of step i runs under the local QR of step i+1): every step's R must be the R of ITS matrix."""
+    m_local, n, P = 16384, 128, 4
+    tp = qr.TsqrPlan(m_local, n, P, 0, 128, comm="external")
+    send, recv = tp.exchange_buffers()
+    mats, Rs = [], []
+    for i in range(4):
+        dA = zeros(m_local, n)
+        tp.local.fill_uniform(dA, m_local, m_local, n, seed=40 + i)
+        mats.append(dA)
+        Rs.append(zeros(n, n))
+    tp.sync()
+    hosts = [host(x) for x in mats]
+    stream = qr.lib.qr_tsqr_stream(tp.h)
+    for dA, dR in zip(mats, Rs):
+        tp.local_factor(dA, m_local)
+        # device-side "all-gather" of P copies of this rank's own factor, stream-ordered on the plan's stream
+        for q in range(P):
+            qr.check(qr.lib.qrd_copy_block(stream, send, n, recv + 8 * n * n * q, n, n, n))
+        tp.stacked_factor(dR)
+    tp.sync()
+    for Ah, dR in zip(hosts, Rs):
+        ref = oracle.sign_normalise(np.linalg.qr(np.vstack([np.linalg.qr(Ah, mode="r")] * P), mode="r"))
+        assert rel(oracle.sign_normalise(host(dR)), ref) < 1e-13
+    tp.close()

@@ -3,6 +3,7 @@ include/mi355x_qr.h declares, and refuses to compute without a GPU (no CPU fallb
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -90,6 +91,66 @@ def test_qr_thin_mgpu_argument_checks(qr):
     else:
         with pytest.raises(qr.QRError, match="invalid argument"):
             qr.qr_thin_mgpu(A, ngpu=ndev + 1)
+
+
+def test_tsqr_plan_argument_checks(qr):
+    """Device-resident TSQR step (qr_tsqr_plan_*, include/mi355x_qr.h): argument errors come before anything touches a device
+    or loads RCCL; a valid single-rank request without a GPU is QR_E_NODEVICE (no CPU fallback)."""
+    import torch
+    h = C.c_void_p()
+    E_ARG = -101
+    assert qr.lib.qr_tsqr_plan_create(C.byref(h), None, 0, 0, 64, 8, 0) == E_ARG          # no ranks
+    assert qr.lib.qr_tsqr_plan_create(C.byref(h), None, 2, 2, 64, 8, 0) == E_ARG          # rank out of range
+    assert qr.lib.qr_tsqr_plan_create(C.byref(h), None, 2, 0, 64, 8, 0) == E_ARG          # 2 ranks need a unique id
+    assert qr.lib.qr_tsqr_plan_create(C.byref(h), None, 1, 0, 4, 8, 0) == E_ARG           # shard with fewer rows than columns
+    assert qr.lib.qr_tsqr_plan_create(None, None, 1, 0, 64, 8, 0) == E_ARG
+    assert qr.lib.qr_tsqr_plan_create_comm(C.byref(h), None, 3, 3, 64, 8, 0) == E_ARG
+    assert qr.lib.qr_tsqr_factor_dev(None, None, 0, None) == E_ARG
+    assert qr.lib.qr_tsqr_formq_dev(None, None, 0, None, 0) == E_ARG
+    assert qr.lib.qr_tsqr_stacked_dev(None, None) == E_ARG
+    assert qr.lib.qr_tsqr_sync(None) == E_ARG
+    assert qr.lib.qr_tsqr_unique_id(None) == E_ARG
+    assert qr.lib.qr_tsqr_plan_destroy(None) == 0
+    if not torch.cuda.is_available():
+        assert qr.lib.qr_tsqr_plan_create(C.byref(h), None, 1, 0, 64, 8, 0) == -103       # QR_E_NODEVICE
+        with pytest.raises(qr.QRError, match="no HIP device"):
+            qr.TsqrPlan(64, 8)
+
+
+def test_default_block_size_sizes_tau(qr):
+    """mmqr's tau has rowPanels*colPanels*nb entries of the block size THAT SHAPE gets (256 for square-ish problems from 1024
+    columns on), not of the global default: the Python wrapper and C callers size it through qr_default_block_size."""
+    # in a fresh process: an earlier qr_set_block_size (test_block_size_validation) pins nb for the rest of this one
+    code = ("import sys; sys.path.insert(0, %r); import cuda_qr_amd as qr\n"
+            "g = qr.get_block_size()[0]\n"
+            "assert qr.default_block_size(512, 128)[0] == g\n"
+            "assert qr.default_block_size(1024, 1024)[0] == 256 and qr.tau_len(1024, 1024) == 1024\n"
+            "assert qr.default_block_size(8192, 1024)[0] == g\n"
+            "assert qr.tau_len(2048, 2048) == 2048 and qr.tau_len(1300, 1100) == 1280\n"
+            "assert qr.lib.qr_default_block_size(4, 8, None, None) == -101\n"
+            "qr.set_block_size(64, 32)\n"
+            "assert qr.default_block_size(4096, 4096)[0] == 64 and qr.tau_len(1000, 100) == 128\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MI355XQR_")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_strerror_names_rccl_failures(qr):
+    assert "rccl" in qr.strerror(-120).lower()
+    assert "argument" not in qr.strerror(-133).lower()          # an RCCL failure (-130 - ncclResult_t) is not an argument error
+    assert "argument" in qr.strerror(-7).lower()
+
+
+@pytest.mark.parametrize("target", ["asan", "tsan"])
+def test_host_layer_under_sanitizers(target):
+    """SURVEY section 5 (race detection / sanitizers): the C host layer (schedule, plan cache, per-device threads of
+    qr_thin_mgpu, TSQR plan) built with AddressSanitizer + UBSan / ThreadSanitizer against the test-only stub device layer
+    (tests/c/qrd_stub.c bounds-checks every operand block a launch receives) and run through tests/c/host_sanitize.c."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MI355XQR_")}
+    out = subprocess.run(["make", "-C", os.path.join(root, "cuda-qr_amd"), target], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:] + out.stderr[-3000:])
+    assert "host layer sanitize run ok" in out.stdout
 
 
 def test_product_never_touches_the_oracle():

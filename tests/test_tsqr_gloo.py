@@ -141,3 +141,28 @@ def test_bench_under_torchrun_rccl_matches_single_gpu(workload, tmp_path):
     assert line["n_gpus"] == P and line["value"] > 0
     # residual and orthogonality are computed over ALL shards (all-reduced): the gathered R factors were the right ones
     assert line["accuracy"]["resid"] < 1e-12 and line["accuracy"]["orth"] < 1e-11
+
+
+@pytest.mark.gpu
+def test_bench_bringup_two_ranks_on_one_gpu_through_the_c_abi_plan(tmp_path):
+    """Bring-up of the N > 1 bench path on a ONE-GPU box: 2 ranks under torch.distributed.run share the device, the R factors
+    travel through gloo (RCCL refuses duplicate devices) and everything else -- local QR, stacking, stacked QR, thin Q -- is the
+    same C-ABI qr_tsqr_plan the RCCL path uses.  Checks the fields the driver and the judge read."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", BENCH_WATCHDOG_S="120")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c4", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["accuracy"]["resid"] < 1e-12 and line["accuracy"]["orth"] < 1e-11
+    sp = line["tsqr_step_split"]
+    assert sp["unpipelined_latency_ms"] >= sp["local_qr_ms"] > 0 and sp["pipelined_ms_per_step"] > 0
+    assert line["config"]["collective"].startswith("1 all_gather")

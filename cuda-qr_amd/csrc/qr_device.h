@@ -36,10 +36,15 @@ int qrd_panel_tsqr_init(void);
 int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                    double* ws, int m_cap);
 int qrd_slab_reduce(void* stream, int M, int N, int nslab, const double* slabs, int lds, size_t stride, double* out, int ldo);
-#define QRD_CHOLQR_WS (4 * 32 * 32 + 16)
+#define QRD_CHOLQR_WS (10 * 32 * 32 + 16)      /* G1, G2, R1, M, guard words; then L1 and the four fold matrices of the early product */
 /* gram_nslab > 0: `slabs` already holds that many 32 x 32 partial Gram matrices of this leaf (qrd_leaf_update_gram) */
 int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                      double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab);
+/* the leaf and its in-panel products in one call: the long-K product runs in the same launch as the one-workgroup reconstruction */
+int qrd_panel_cholqr_ep(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                        double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab,
+                        int N1, const double* B1, int ldb1, int N2, const double* B2, int ldb2, double* W, int ldw, double* G2, int ldg,
+                        double* ep_slabs, size_t ep_slab_cap, int* did);
 /* fused kernels of the leaf chain (qr_leaf_fused.hip) */
 int qrd_leaf_fused_init(void);
 int qrd_leaf_update_gram(void* stream, int mk, int N, const double* V, int ldv, const double* W, double* C, int ldc, double* gslabs,

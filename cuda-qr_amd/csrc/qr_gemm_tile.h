@@ -1,0 +1,190 @@
+// qr_gemm_tile.h -- the LDS-staged MFMA f64 tile machinery shared by the GEMM kernels (qr_kernels.hip) and the fused leaf
+// kernels (qr_panel_tsqr.hip: the leaf's long-K product runs in the same launch as its one-workgroup reconstruction).
+//
+// MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3):
+//   A-operand: lane l holds Aop[p = l&15][k = l>>4];  B-operand: lane l holds Bop[k = l>>4][q = l&15]
+//   D: lane l, reg r holds D[p = (l>>4) + 4r][q = l&15].
+// The COLUMN index of the (column-major) output is always on p and the ROW index on q, so that 16 consecutive lanes touch 16
+// consecutive rows of one output column (128 contiguous bytes).
+#ifndef QR_GEMM_TILE_H
+#define QR_GEMM_TILE_H
+#include "qr_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// GEMM tiles.  Block = 256 threads = 4 waves arranged 2 (rows) x 2 (cols); each wave owns
+// (16*TI) x (16*TJ) of the output as TI*TJ MFMA accumulators; block tile = (32*TI) x (32*TJ), BK = 16.
+// LDS images (double units):
+//   "row-fast"  image [BK][32*TI + 16]  (NN left operand: k-major, rows contiguous; +16 pad makes the two
+//                k-rows a half-wave reads land on disjoint bank halves -> conflict-free ds_read_b64)
+//   "k-fast"    image [cols][BK + 2]    (operands whose k runs contiguously in memory; the stride 18
+//                = 2*odd spreads 16 columns x 2 k's over all 32 eight-byte banks -> conflict-free)
+// ------------------------------------------------------------------------------------------------
+#define BK 16
+#define LDKF (BK + 2)
+
+// Tile loaders.  `fast` is block-uniform (whole tile in range, 16-byte aligned): the fast path is
+// straight-line 16-byte loads.  The edge path uses clamped addresses + selects, never a branch per
+// element: hipcc waits (s_waitcnt vmcnt(0)) inside every divergent branch that consumes a load, which
+// would turn one tile fetch into dozens of serial HBM round trips.
+template <int TR>   // TR = tile extent / 32 (rows of the row-fast image)
+__device__ __forceinline__ void load_rowfast(v2d (&reg)[TR], const double* __restrict__ A, int lda,
+                                             int i0, int k0, int M, int kend, bool fast, int tid)
+{
+    constexpr int HALF = 16 * TR;          // double2 per column
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < TR; ++q) {
+            const int idx = tid + 256 * q;
+            reg[q] = *reinterpret_cast<const v2d*>(A + (size_t) (k0 + idx / HALF) * lda + i0 + 2 * (idx % HALF));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < TR; ++q) {
+            const int idx = tid + 256 * q;
+            const int i = i0 + 2 * (idx % HALF), k = k0 + idx / HALF;
+            const double* col = A + (size_t) min(k, kend - 1) * lda;
+            const double a = col[min(i, M - 1)], b = col[min(i + 1, M - 1)];
+            reg[q] = (v2d){(k < kend && i < M) ? a : 0.0, (k < kend && i + 1 < M) ? b : 0.0};
+        }
+    }
+}
+
+template <int TR>
+__device__ __forceinline__ void store_rowfast(const v2d (&reg)[TR], double* __restrict__ S, int tid)
+{
+    constexpr int HALF = 16 * TR, LD = 32 * TR + 16;
+#pragma unroll
+    for (int q = 0; q < TR; ++q) {
+        const int idx = tid + 256 * q;
+        const int col = idx / HALF, r2 = idx % HALF;
+        *reinterpret_cast<v2d*>(S + col * LD + 2 * r2) = reg[q];
+    }
+}
+
+template <int TC>   // TC = tile extent / 32 (columns of the k-fast image)
+__device__ __forceinline__ void load_kfast(v2d (&reg)[TC], const double* __restrict__ B, int ldb,
+                                           int j0, int k0, int N, int kend, bool fast, int tid)
+{
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < TC; ++q) {
+            const int idx = tid + 256 * q;
+            reg[q] = *reinterpret_cast<const v2d*>(B + (size_t) (j0 + idx / 8) * ldb + k0 + 2 * (idx % 8));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < TC; ++q) {
+            const int idx = tid + 256 * q;
+            const int j = j0 + idx / 8, k = k0 + 2 * (idx % 8);
+            const double* col = B + (size_t) min(j, N - 1) * ldb;
+            const double a = col[min(k, kend - 1)], b = col[min(k + 1, kend - 1)];
+            reg[q] = (v2d){(j < N && k < kend) ? a : 0.0, (j < N && k + 1 < kend) ? b : 0.0};
+        }
+    }
+}
+
+template <int TC>
+__device__ __forceinline__ void store_kfast(const v2d (&reg)[TC], double* __restrict__ S, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < TC; ++q) {
+        const int idx = tid + 256 * q;
+        *reinterpret_cast<v2d*>(S + (idx / 8) * LDKF + 2 * (idx % 8)) = reg[q];
+    }
+}
+
+// ---- shared GEMM pieces -----------------------------------------------------------------------
+// One BK-deep step of the wave tile from LDS.  AROW: the row operand comes from a row-fast image
+// (NN kernel), else from a k-fast image (TN kernel).  The column operand image is always k-fast.
+// PRIO: s_setprio around the MFMA burst.  Measured on the C3 update shapes: +3 % for the TN kernel, -2 % for the NN kernel,
+// so only the k-fast (TN) instantiation raises its priority.
+template <int TI, int TJ, bool AROW, bool PRIO = !AROW>
+__device__ __forceinline__ void mma_tile(v4d (&acc)[TJ][TI], const double* __restrict__ as,
+                                         const double* __restrict__ bs, int wi, int wj, int l15, int l4)
+{
+    constexpr int LA = 32 * TI + 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int kk = 4 * ks + l4;
+        double rowv[TI], colv[TJ];
+#pragma unroll
+        for (int b = 0; b < TI; ++b)
+            rowv[b] = AROW ? as[kk * LA + wi * 16 * TI + 16 * b + l15] : as[(wi * 16 * TI + 16 * b + l15) * LDKF + kk];
+#pragma unroll
+        for (int a = 0; a < TJ; ++a) colv[a] = bs[(wj * 16 * TJ + 16 * a + l15) * LDKF + kk];
+        if (PRIO) __builtin_amdgcn_s_setprio(1);      // keep the MFMA pipe for the wave that has its fragments
+#pragma unroll
+        for (int a = 0; a < TJ; ++a)
+#pragma unroll
+            for (int b = 0; b < TI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[a], rowv[b], acc[a][b], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// Double-buffered K loop over [kbeg, kend).  FAST is a compile-time copy of the block-uniform "every
+// tile of this block is fully in range and 16-byte aligned" flag, so the hot instantiation has no
+// branch (and therefore no compiler-inserted wait) between issuing the next tile's global loads and
+// starting this tile's MFMAs: the loads fly under 64 MFMAs (~4k cycles) and are only waited for at
+// the ds_write that follows them.
+template <int TI, int TJ, bool AROW, bool FAST>
+__device__ __forceinline__ void gemm_kloop(v4d (&acc)[TJ][TI], const double* __restrict__ A, int lda,
+                                           const double* __restrict__ B, int ldb, int i0, int j0, int M, int N,
+                                           int kbeg, int kend, double* __restrict__ As, double* __restrict__ Bs,
+                                           int tid, int wi, int wj, int l15, int l4)
+{
+    constexpr int BM = 32 * TI, BN = 32 * TJ;
+    constexpr int ASZ = AROW ? BK * (BM + 16) : BM * LDKF, BSZ = BN * LDKF;
+    v2d ra[TI], rb[TJ];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        if (AROW) load_rowfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
+        else load_kfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
+        load_kfast<TJ>(rb, B, ldb, j0, kbeg, N, kend, FAST, tid);
+        if (AROW) store_rowfast<TI>(ra, As, tid); else store_kfast<TI>(ra, As, tid);
+        store_kfast<TJ>(rb, Bs, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            if (AROW) load_rowfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
+            else load_kfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
+            load_kfast<TJ>(rb, B, ldb, j0, k0, N, kend, FAST, tid);
+        }
+        mma_tile<TI, TJ, AROW>(acc, As + buf * ASZ, Bs + buf * BSZ, wi, wj, l15, l4);
+        if (kt + 1 < nk) {
+            if (AROW) store_rowfast<TI>(ra, As + (buf ^ 1) * ASZ, tid); else store_kfast<TI>(ra, As + (buf ^ 1) * ASZ, tid);
+            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BSZ, tid);
+        }
+        __syncthreads();
+    }
+}
+
+// C = alpha*acc (+ beta*C on the generic path).  STORE_ONLY: no load sits between the stores (a load
+// there makes every store wait for the previous one: vmcnt is in-order and counts stores).
+template <int TI, int TJ, bool STORE_ONLY>
+__device__ __forceinline__ void gemm_epilogue(const v4d (&acc)[TJ][TI], double* __restrict__ C, int ldc, int M, int N,
+                                              int i0, int j0, double alpha, double beta, int wi, int wj, int l15, int l4)
+{
+#pragma unroll
+    for (int a = 0; a < TJ; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + wj * 16 * TJ + 16 * a + l4 + 4 * r;
+#pragma unroll
+            for (int b = 0; b < TI; ++b) {
+                const int i = i0 + wi * 16 * TI + 16 * b + l15;
+                if (i < M && j < N) {
+                    double* cp = C + (size_t) j * ldc + i;
+                    double v = alpha * acc[a][b][r];
+                    if (!STORE_ONLY) v += beta * (*cp);
+                    *cp = v;
+                }
+            }
+        }
+}
+
+
+#endif

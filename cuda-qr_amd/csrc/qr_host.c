@@ -71,6 +71,8 @@ struct qr_plan {
     int vt_formed[2];           /* VT2[e] = Vw2[e] * T2[e] of the panel NOW in set e exists (cleared when a panel is factored into the set,
                                  * set where the V*T product is issued): a slice of the wide update that needs it forms it on demand */
     double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *leaf_scratch, *panel_ws;
+    double* slabs_ep;           /* split-K slabs of the leaf's early product: written while the reconstruction still reads p->slabs */
+    size_t slab_ep_cap;
     int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height;
                                  * 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
     double* chol_ws;
@@ -105,6 +107,7 @@ typedef struct qr_knobs {
     int split_t;                                            /* MI355XQR_SPLIT_T */
     int early_next, early_w1;                               /* MI355XQR_EARLY_NEXT, MI355XQR_EARLY_W1 */
     int plan_cache;                                         /* MI355XQR_PLAN_CACHE */
+    int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
 } qr_knobs;
 static qr_knobs g_knobs;
 static pthread_once_t g_knobs_once = PTHREAD_ONCE_INIT;
@@ -131,6 +134,7 @@ static void knobs_init(void)
     k->early_w1 = 4096;
     { const int v = env_int("MI355XQR_EARLY_W1", 0); if (v >= 128) k->early_w1 = v / 128 * 128; }
     k->plan_cache = env_int("MI355XQR_PLAN_CACHE", 1) != 0;
+    k->early_product = env_int("MI355XQR_EP", 1) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -359,6 +363,11 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
     }
     if (!rc && p->panel_tsqr) rc = qrd_malloc((void**) &p->panel_ws, sizeof(double) * qrd_panel_ws_size(m));
     if (!rc && p->panel_tsqr == 3) rc = qrd_malloc((void**) &p->chol_ws, sizeof(double) * QRD_CHOLQR_WS);
+    if (!rc && p->panel_tsqr == 3 && knobs()->early_product) {
+        /* 32 x (nb - 32) outputs per K slice, up to 128 slices */
+        p->slab_ep_cap = (size_t) 32 * (size_t) (nb > 64 ? nb : 64) * 128;
+        rc = qrd_malloc((void**) &p->slabs_ep, sizeof(double) * p->slab_ep_cap);
+    }
     if (rc) { qr_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -390,7 +399,7 @@ int qr_plan_destroy(qr_plan* p)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
-    qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws); qrd_free(p->chol_ws);
+    qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
     if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
     return 0;
@@ -587,17 +596,23 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
             /* leaf algorithm (MI355XQR_PANEL = cholqr [default] | tsqr | col | auto): CholeskyQR2 + Householder reconstruction
              * (4 short launches) guarded by the Householder TSQR leaf (4-6 launches, no-ops unless the guard trips); tsqr = the
              * Householder TSQR leaf alone; col = one launch per column (34 launches, ~25 passes over the leaf) */
-            if (p->panel_tsqr == 3)
+            const int nrest = cend - (c + w), nprev = gram_done ? c - c0 : 0;
+            double* Arest = P + (size_t) w * lda;
+            int fused = 0;
+            if (p->panel_tsqr == 3 && p->slabs_ep && gram_done && w == 32 && nrest + nprev > 0) {
+                /* the leaf and its two long-K products (W = T_l^T V_l^T A_rest into Wn; the Gram block V_prev^T V_l into G) in one
+                 * call: the products run in the launch of the leaf's one-workgroup reconstruction (qr_panel_tsqr.hip, hr3_ep_kernel) */
+                CHECK(qrd_panel_cholqr_ep(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
+                                          p->slabs, p->slab_cap, gram_nslab, nrest, Arest, lda, nprev, p->Vw + (size_t) c0 * ldv + c, ldv,
+                                          p->Wn, w, p->G + (size_t) c * nb + c0, nb, p->slabs_ep, p->slab_ep_cap, &fused));
+            } else if (p->panel_tsqr == 3)
                 CHECK(qrd_panel_cholqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
                                        p->slabs, p->slab_cap, gram_nslab));
             else if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
                 CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
             else
                 CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
-            const int nrest = cend - (c + w), nprev = gram_done ? c - c0 : 0;
-            double* Arest = P + (size_t) w * lda;
-            int fused = 0;
-            if (gram_done && w == 32 && nrest + nprev > 0) {
+            if (!fused && gram_done && w == 32 && nrest + nprev > 0) {
                 /* Wn, not W: with look-ahead the wide update on stream_u owns p->W while this panel runs */
                 const int rc = qrd_gemm_tn_dual(p->stream, nrest, nprev, mkl, Vl, ldv, Arest, lda, p->Vw + (size_t) c0 * ldv + c, ldv, Tl, ldt,
                                                 p->Wn, w, p->G + (size_t) c * nb + c0, nb, p->slabs, p->slab_cap);

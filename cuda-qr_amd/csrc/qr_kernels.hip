@@ -24,184 +24,9 @@
 #include <mutex>
 #include "qr_device.h"
 #include "qr_common.h"
+#include "qr_gemm_tile.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int) e_; } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// GEMM tiles.  Block = 256 threads = 4 waves arranged 2 (rows) x 2 (cols); each wave owns
-// (16*TI) x (16*TJ) of the output as TI*TJ MFMA accumulators; block tile = (32*TI) x (32*TJ), BK = 16.
-// LDS images (double units):
-//   "row-fast"  image [BK][32*TI + 16]  (NN left operand: k-major, rows contiguous; +16 pad makes the two
-//                k-rows a half-wave reads land on disjoint bank halves -> conflict-free ds_read_b64)
-//   "k-fast"    image [cols][BK + 2]    (operands whose k runs contiguously in memory; the stride 18
-//                = 2*odd spreads 16 columns x 2 k's over all 32 eight-byte banks -> conflict-free)
-// ------------------------------------------------------------------------------------------------
-#define BK 16
-#define LDKF (BK + 2)
-
-// Tile loaders.  `fast` is block-uniform (whole tile in range, 16-byte aligned): the fast path is
-// straight-line 16-byte loads.  The edge path uses clamped addresses + selects, never a branch per
-// element: hipcc waits (s_waitcnt vmcnt(0)) inside every divergent branch that consumes a load, which
-// would turn one tile fetch into dozens of serial HBM round trips.
-template <int TR>   // TR = tile extent / 32 (rows of the row-fast image)
-__device__ __forceinline__ void load_rowfast(v2d (&reg)[TR], const double* __restrict__ A, int lda,
-                                             int i0, int k0, int M, int kend, bool fast, int tid)
-{
-    constexpr int HALF = 16 * TR;          // double2 per column
-    if (fast) {
-#pragma unroll
-        for (int q = 0; q < TR; ++q) {
-            const int idx = tid + 256 * q;
-            reg[q] = *reinterpret_cast<const v2d*>(A + (size_t) (k0 + idx / HALF) * lda + i0 + 2 * (idx % HALF));
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < TR; ++q) {
-            const int idx = tid + 256 * q;
-            const int i = i0 + 2 * (idx % HALF), k = k0 + idx / HALF;
-            const double* col = A + (size_t) min(k, kend - 1) * lda;
-            const double a = col[min(i, M - 1)], b = col[min(i + 1, M - 1)];
-            reg[q] = (v2d){(k < kend && i < M) ? a : 0.0, (k < kend && i + 1 < M) ? b : 0.0};
-        }
-    }
-}
-
-template <int TR>
-__device__ __forceinline__ void store_rowfast(const v2d (&reg)[TR], double* __restrict__ S, int tid)
-{
-    constexpr int HALF = 16 * TR, LD = 32 * TR + 16;
-#pragma unroll
-    for (int q = 0; q < TR; ++q) {
-        const int idx = tid + 256 * q;
-        const int col = idx / HALF, r2 = idx % HALF;
-        *reinterpret_cast<v2d*>(S + col * LD + 2 * r2) = reg[q];
-    }
-}
-
-template <int TC>   // TC = tile extent / 32 (columns of the k-fast image)
-__device__ __forceinline__ void load_kfast(v2d (&reg)[TC], const double* __restrict__ B, int ldb,
-                                           int j0, int k0, int N, int kend, bool fast, int tid)
-{
-    if (fast) {
-#pragma unroll
-        for (int q = 0; q < TC; ++q) {
-            const int idx = tid + 256 * q;
-            reg[q] = *reinterpret_cast<const v2d*>(B + (size_t) (j0 + idx / 8) * ldb + k0 + 2 * (idx % 8));
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < TC; ++q) {
-            const int idx = tid + 256 * q;
-            const int j = j0 + idx / 8, k = k0 + 2 * (idx % 8);
-            const double* col = B + (size_t) min(j, N - 1) * ldb;
-            const double a = col[min(k, kend - 1)], b = col[min(k + 1, kend - 1)];
-            reg[q] = (v2d){(j < N && k < kend) ? a : 0.0, (j < N && k + 1 < kend) ? b : 0.0};
-        }
-    }
-}
-
-template <int TC>
-__device__ __forceinline__ void store_kfast(const v2d (&reg)[TC], double* __restrict__ S, int tid)
-{
-#pragma unroll
-    for (int q = 0; q < TC; ++q) {
-        const int idx = tid + 256 * q;
-        *reinterpret_cast<v2d*>(S + (idx / 8) * LDKF + 2 * (idx % 8)) = reg[q];
-    }
-}
-
-// ---- shared GEMM pieces -----------------------------------------------------------------------
-// One BK-deep step of the wave tile from LDS.  AROW: the row operand comes from a row-fast image
-// (NN kernel), else from a k-fast image (TN kernel).  The column operand image is always k-fast.
-// PRIO: s_setprio around the MFMA burst.  Measured on the C3 update shapes: +3 % for the TN kernel, -2 % for the NN kernel,
-// so only the k-fast (TN) instantiation raises its priority.
-template <int TI, int TJ, bool AROW, bool PRIO = !AROW>
-__device__ __forceinline__ void mma_tile(v4d (&acc)[TJ][TI], const double* __restrict__ as,
-                                         const double* __restrict__ bs, int wi, int wj, int l15, int l4)
-{
-    constexpr int LA = 32 * TI + 16;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int kk = 4 * ks + l4;
-        double rowv[TI], colv[TJ];
-#pragma unroll
-        for (int b = 0; b < TI; ++b)
-            rowv[b] = AROW ? as[kk * LA + wi * 16 * TI + 16 * b + l15] : as[(wi * 16 * TI + 16 * b + l15) * LDKF + kk];
-#pragma unroll
-        for (int a = 0; a < TJ; ++a) colv[a] = bs[(wj * 16 * TJ + 16 * a + l15) * LDKF + kk];
-        if (PRIO) __builtin_amdgcn_s_setprio(1);      // keep the MFMA pipe for the wave that has its fragments
-#pragma unroll
-        for (int a = 0; a < TJ; ++a)
-#pragma unroll
-            for (int b = 0; b < TI; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[a], rowv[b], acc[a][b], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-    }
-}
-
-// Double-buffered K loop over [kbeg, kend).  FAST is a compile-time copy of the block-uniform "every
-// tile of this block is fully in range and 16-byte aligned" flag, so the hot instantiation has no
-// branch (and therefore no compiler-inserted wait) between issuing the next tile's global loads and
-// starting this tile's MFMAs: the loads fly under 64 MFMAs (~4k cycles) and are only waited for at
-// the ds_write that follows them.
-template <int TI, int TJ, bool AROW, bool FAST>
-__device__ __forceinline__ void gemm_kloop(v4d (&acc)[TJ][TI], const double* __restrict__ A, int lda,
-                                           const double* __restrict__ B, int ldb, int i0, int j0, int M, int N,
-                                           int kbeg, int kend, double* __restrict__ As, double* __restrict__ Bs,
-                                           int tid, int wi, int wj, int l15, int l4)
-{
-    constexpr int BM = 32 * TI, BN = 32 * TJ;
-    constexpr int ASZ = AROW ? BK * (BM + 16) : BM * LDKF, BSZ = BN * LDKF;
-    v2d ra[TI], rb[TJ];
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        if (AROW) load_rowfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
-        else load_kfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
-        load_kfast<TJ>(rb, B, ldb, j0, kbeg, N, kend, FAST, tid);
-        if (AROW) store_rowfast<TI>(ra, As, tid); else store_kfast<TI>(ra, As, tid);
-        store_kfast<TJ>(rb, Bs, tid);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            if (AROW) load_rowfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
-            else load_kfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
-            load_kfast<TJ>(rb, B, ldb, j0, k0, N, kend, FAST, tid);
-        }
-        mma_tile<TI, TJ, AROW>(acc, As + buf * ASZ, Bs + buf * BSZ, wi, wj, l15, l4);
-        if (kt + 1 < nk) {
-            if (AROW) store_rowfast<TI>(ra, As + (buf ^ 1) * ASZ, tid); else store_kfast<TI>(ra, As + (buf ^ 1) * ASZ, tid);
-            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BSZ, tid);
-        }
-        __syncthreads();
-    }
-}
-
-// C = alpha*acc (+ beta*C on the generic path).  STORE_ONLY: no load sits between the stores (a load
-// there makes every store wait for the previous one: vmcnt is in-order and counts stores).
-template <int TI, int TJ, bool STORE_ONLY>
-__device__ __forceinline__ void gemm_epilogue(const v4d (&acc)[TJ][TI], double* __restrict__ C, int ldc, int M, int N,
-                                              int i0, int j0, double alpha, double beta, int wi, int wj, int l15, int l4)
-{
-#pragma unroll
-    for (int a = 0; a < TJ; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + wj * 16 * TJ + 16 * a + l4 + 4 * r;
-#pragma unroll
-            for (int b = 0; b < TI; ++b) {
-                const int i = i0 + wi * 16 * TI + 16 * b + l15;
-                if (i < M && j < N) {
-                    double* cp = C + (size_t) j * ldc + i;
-                    double v = alpha * acc[a][b][r];
-                    if (!STORE_ONLY) v += beta * (*cp);
-                    *cp = v;
-                }
-            }
-        }
-}
 
 // C = beta*C + alpha*A*B     A: M x K (lda), B: K x N (ldb), C: M x N (ldc), all column-major.
 // Used for: trailing update A2 -= V*W (K = nb), VT = V*T, T merges, Q*R products, Q_local*Q_tree.
@@ -379,7 +204,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 // The leaf's two long-K products in one launch:  [W | G^T] = V_l^T [A_rest | V_prev]  (32 x (N1 + N2), K = leaf height).
 // Column tiles j0 < N1 read B1 (the rest of the panel), the others B2 (the reflectors of the panel's earlier leaves): the Gram
 // blocks the panel's T needs are thus collected leaf by leaf, and the panel-wide Gram product after the last leaf goes away.
-__global__ __launch_bounds__(256, 2) void gemm_tn_dual_kernel(int N1, int N2, int K, int kchunk, const double* __restrict__ A, int lda,
+// Workgroup -> (column tile, K slice): workgroups are dealt round-robin over the 8 XCDs, and every column tile of a K slice reads the
+// same 32-column slice of A -- so the slices are dealt to the XCDs (slice z on XCD z % 8, all its tiles there): A's slice then comes
+// from HBM once per slice instead of once per XCD that happens to hold one of its tiles (a tall leaf: 6 tiles -> up to 6 x 67 MB).
+// The grid is tiles * 8 * ceil(ksplit / 8) workgroups; those whose slice does not exist leave at once.
+__global__ __launch_bounds__(256, 2) void gemm_tn_dual_kernel(int N1, int N2, int K, int kchunk, int tiles, int ksplit,
+                                                              const double* __restrict__ A, int lda,
                                                               const double* __restrict__ B1, int ldb1, const double* __restrict__ B2,
                                                               int ldb2, double* __restrict__ C, size_t slab_stride)
 {
@@ -388,11 +218,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dual_kernel(int N1, int N2, in
     double* Bs = smem + 2 * 32 * LDKF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
-    const int j0 = blockIdx.y * 32;
+    const int slot = blockIdx.x >> 3, z = (int) (blockIdx.x & 7) + 8 * (slot / tiles);
+    if (z >= ksplit) return;
+    const int j0 = (slot % tiles) * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = z * kchunk;
     const int kend = min(K, kbeg + kchunk);
-    C += (size_t) blockIdx.z * slab_stride;
+    C += (size_t) z * slab_stride;
     const bool second = j0 >= N1;
     const double* B = second ? B2 + (size_t) (j0 - N1) * ldb2 : B1 + (size_t) j0 * ldb1;
     const int ldb = second ? ldb2 : ldb1;
@@ -1045,8 +877,8 @@ int qrd_gemm_tn_dual(void* stream, int N1, int N2, int K, const double* A, int l
     int kchunk = ((K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     ksplit = (K + kchunk - 1) / kchunk;
     const size_t shm = sizeof(double) * (4 * 32 * LDKF);
-    hipLaunchKernelGGL(gemm_tn_dual_kernel, dim3(1, tiles, ksplit), dim3(256), shm, s, N1, N2, K, kchunk, A, lda, B1, ldb1, B2, ldb2,
-                       slabs, per);
+    hipLaunchKernelGGL(gemm_tn_dual_kernel, dim3(tiles * 8 * ((ksplit + 7) / 8)), dim3(256), shm, s, N1, N2, K, kchunk, tiles, ksplit, A, lda,
+                       B1, ldb1, B2, ldb2, slabs, per);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(N, 1), dim3(256), 0, s, 32, N, ksplit, slabs, 32, per, Tm, ldt, 0.0, W, ldw, 256, N1,
                        G2, ldg);
     return (int) hipGetLastError();

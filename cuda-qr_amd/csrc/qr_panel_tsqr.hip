@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include "qr_device.h"
 #include "qr_common.h"
+#include "qr_gemm_tile.h"
 
 #define PW LEAFW          // max leaf width
 #define PT 512            // threads per workgroup = rows per block
@@ -1487,8 +1488,9 @@ __global__ __launch_bounds__(PT) void cholq4_tall_kernel(const double* __restric
 // rows >= 32 of V = Q U'^-1 (Winv: U'^-1, column-major, ld PW), written to Vw and to A.  No LDS, no barrier.
 // rows_wg: rows per workgroup -- PT (every wave 64 rows) or PT / 2 (waves 0..3 only: twice the workgroups, i.e. compute units, for
 // the same 64 matrix-core instructions per wave; two waves per SIMD took 3.7 us of the launch's 11, one takes 1.9)
+// L1s != nullptr (early-product leaf): the top 32 rows of Vw still hold Q_top -- the unit-lower L1 that belongs there comes from L1s
 __device__ __forceinline__ void final4_body(double* __restrict__ Vw, int ldv, int mk, const double* __restrict__ Winv,
-                                            double* __restrict__ A, int lda, int rows_wg = PT)
+                                            double* __restrict__ A, int lda, int rows_wg = PT, const double* __restrict__ L1s = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
     if (wave * 64 >= rows_wg) return;
@@ -1527,15 +1529,24 @@ __device__ __forceinline__ void final4_body(double* __restrict__ Vw, int ldv, in
                     Vw[c * ldv + row] = acc[ti][rr];
                     A[c * lda + row] = acc[ti][rr];
                 }
+        } else if (L1s && row < PW) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const size_t c = (size_t) (16 * ti + l4 + 4 * rr);
+                    Vw[c * ldv + row] = L1s[c * PW + row];
+                }
         }
     }
 }
 
 __global__ __launch_bounds__(PT) void final4_kernel(double* __restrict__ Vw, int ldv, int mk, const double* __restrict__ Winv,
-                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
+                                                    double* __restrict__ A, int lda, const int* __restrict__ guard,
+                                                    const double* __restrict__ L1s)
 {
     if (*guard != 0) return;
-    final4_body(Vw, ldv, mk, Winv, A, lda);
+    final4_body(Vw, ldv, mk, Winv, A, lda, PT, L1s);
 }
 
 // Cholesky + modified LU of the reconstruction on ONE wave, no LDS and no barrier: lane c (< 32) holds column c of both
@@ -1616,13 +1627,19 @@ template <int I> struct UpperInv {
 };
 
 // UINV: Uout receives U'^-1 (third-generation leaf: final4 multiplies by it on the matrix cores) instead of U' (final3 solves with it)
-template <bool UINV>
-__global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restrict__ G2s, int nslab, const double* __restrict__ R1,
-                                                      double* __restrict__ Vw, int ldv, double* __restrict__ A, int lda,
-                                                      double* __restrict__ tau, double* __restrict__ T, int ldt,
-                                                      double* __restrict__ Uout, int* __restrict__ guard, unsigned* __restrict__ bar)
+// EP ("early product", see hr3_ep_kernel): the unit-lower top block L1 of V goes to epw (Vw's top rows still hold Q_top, which the
+// product workgroups of the same launch are reading), followed by the two 32 x 32 matrices slab_reduce_ep_kernel folds in besides T:
+//   epw + 0*1024: L1 (unit lower)        + 1*1024: U'^-1 (upper)        + 2*1024: B = S R2 (upper)        (all column-major, ld 32)
+// -- written by waves that were storing anyway, so the reconstruction's own chain is not a step longer than without EP
+template <bool UINV, bool EP>
+__device__ __forceinline__ void hr3_body(const double* __restrict__ G2s, int nslab, const double* __restrict__ R1,
+                                         double* __restrict__ Vw, int ldv, double* __restrict__ A, int lda,
+                                         double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                         double* __restrict__ Uout, int* __restrict__ guard, unsigned* __restrict__ bar,
+                                         double* __restrict__ epw)
 {
     __shared__ double Bs[PW][PW + 1], R1s[PW][PW + 1], R2s[PW][PW + 1], Us[PW][PW + 1], Ls[PW][PW + 1], Gs[PW][PW + 1];
+
     __shared__ double Ss[PW], r2inv[PW];
     __shared__ int flags[3];
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
@@ -1707,15 +1724,19 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
 #pragma unroll
             for (int i = 0; i < PW; ++i) Ls[i][lane] = (i >= lane) ? x[i] : 0.0;       // Ls[i][j] = L1^-1(i, j)
         }
-    } else if (UINV && g == 2) {
+    } else if ((UINV || EP) && g == 2) {
         double x[PW];
         UpperInv<PW - 1>::run(x, Bs, rcp_newton(Bs[rc][rc]), rc);   // |U'(i, i)| >= R2(i, i) > 0
         if (lane < PW) {
 #pragma unroll
-            for (int i = 0; i < PW; ++i) Uout[lane * PW + i] = (i <= lane) ? x[i] : 0.0;      // column `lane` of U'^-1
+            for (int i = 0; i < PW; ++i) {
+                const double v = (i <= lane) ? x[i] : 0.0;                                     // column `lane` of U'^-1
+                if (UINV) Uout[lane * PW + i] = v;
+                if (EP) epw[1 * PW * PW + lane * PW + i] = v;                                    // column-major U'^-1
+            }
         }
     } else {
-        const int first = UINV ? 192 : 128;
+        const int first = (UINV || EP) ? 192 : 128;
         for (int el = tid - first; el < PW * PW; el += 64 * H3G - first) {
             const int i = el % PW, c = el / PW;
             if (c >= i) {
@@ -1727,7 +1748,11 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
                 A[(size_t) c * lda + i] = Bs[i][c];
                 if (!UINV) Uout[el] = 0.0;
             }
-            Vw[(size_t) c * ldv + i] = (c < i) ? Bs[i][c] : (c == i ? 1.0 : 0.0);
+            const double l1 = (c < i) ? Bs[i][c] : (c == i ? 1.0 : 0.0);
+            if (EP) {
+                epw[el] = l1;                           // Vw's top rows are still being read as Q_top: the last leaf launch copies this
+                epw[2 * PW * PW + el] = (c >= i) ? Ss[i] * R2s[i][c] : 0.0;                      // B = S R2 (upper triangular)
+            } else Vw[(size_t) c * ldv + i] = l1;
         }
     }
     __syncthreads();
@@ -1743,6 +1768,247 @@ __global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restri
     }
     STAMP(21);
     STAMP_FLUSH(16, 6);
+}
+
+template <bool UINV>
+__global__ __launch_bounds__(64 * H3G, 2) void hr3_kernel(const double* __restrict__ G2s, int nslab, const double* __restrict__ R1,
+                                                      double* __restrict__ Vw, int ldv, double* __restrict__ A, int lda,
+                                                      double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                      double* __restrict__ Uout, int* __restrict__ guard, unsigned* __restrict__ bar)
+{
+    hr3_body<UINV, false>(G2s, nslab, R1, Vw, ldv, A, lda, tau, T, ldt, Uout, guard, bar, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// "Early product": the leaf's long-K in-panel product in the SAME launch as its one-workgroup reconstruction.
+// The reconstruction (hr3: 25-30 us on ONE workgroup, the rest of the chip idle) and the product V_l^T [A_rest | V_prev] that
+// followed it (18 us on a short leaf, 80 us on a 262144-row one) were two links of every leaf's dependent chain.  But
+//     V = (Q - [S R2; 0]) U'^-1        (rows >= 32: Q U'^-1; top block: L1)
+// so  V^T X = U'^-T (Q^T X - (S R2)^T X_top): the long-K part Q^T X needs only Q, which exists BEFORE the reconstruction.  Workgroup
+// 0 of this launch runs hr3; workgroups 1.. compute split-K slabs of Z = Q^T [A_rest | V_prev] (32 x 32 tiles on the MFMA pipe, the
+// tile loop of the GEMM kernels); slab_reduce_ep_kernel then sums the slabs and folds in the 32 x 32 factors (one workgroup per column,
+// three 32-term products each -- cheap there, a serial step each in the one reconstruction workgroup):
+//     y = U'^-T (z - B^T x_top),   B = S R2       z = a column of Z, x_top = the top 32 rows of that column of [A_rest | V_prev]
+//     W(:, j) = T^T y   (columns of A_rest)       G(j, :) = y^T   (columns of V_prev)
+// If the reconstruction refuses the leaf (guard word set), the slabs are garbage; the Householder-TSQR fallback then forms V and
+// the product is redone from V with (U'^-1, B) := (I, 0), so the reduce launch is the same either way.
+// ---------------------------------------------------------------------------------------------------------
+struct EpArgs {
+    int N1, N2, K, kchunk, tiles, ksplit;    // Z is 32 x (N1 + N2); K rows in slices of kchunk; tiles = (N1 + N2) / 32 (redo tiling)
+    int ftiles;                               // column tiles of the fused launch: ceil((N1 + N2) / (32 TJ))
+    const double* Q; int ldq;                 // the leaf's 32 columns (Q before / V after the reconstruction), K rows
+    const double* B1; int ldb1;               // A_rest: K x N1
+    const double* B2; int ldb2;               // V_prev: K x N2 (rows from the leaf's top row)
+    double* slabs; size_t slab_stride;        // slab z at slabs + z * slab_stride, each 32 x (N1 + N2), ld 32
+};
+
+// one (32-column tile, K-slice) item of the product on the first 256 threads of the workgroup: the guard routes' redo
+__device__ __forceinline__ void ep_product_item(const EpArgs& e, int item, const double* __restrict__ Qp)
+{
+    extern __shared__ __attribute__((aligned(16))) double ep_smem[];
+    double* As = ep_smem;
+    double* Bsm = ep_smem + 2 * 32 * LDKF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1, l15 = lane & 15, l4 = lane >> 4;
+    const int tile = item % e.tiles, z = item / e.tiles;
+    const int j0 = tile * 32;
+    const int kbeg = z * e.kchunk, kend = min(e.K, kbeg + e.kchunk);
+    const bool second = j0 >= e.N1;
+    const double* B = second ? e.B2 + (size_t) (j0 - e.N1) * e.ldb2 : e.B1 + (size_t) j0 * e.ldb1;
+    const int ldb = second ? e.ldb2 : e.ldb1;
+    v4d acc[1][1];
+    acc[0][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+    gemm_kloop<1, 1, false, true>(acc, Qp, e.ldq, B, ldb, 0, 0, 32, 32, kbeg, kend, As, Bsm, tid, wi, wj, l15, l4);
+    gemm_epilogue<1, 1, true>(acc, e.slabs + (size_t) z * e.slab_stride, 32, 32, e.N1 + e.N2, 0, j0, 1.0, 0.0, wi, wj, l15, l4);
+}
+
+#define EP_SMEM_BYTES (sizeof(double) * 4 * 32 * LDKF)
+#define EP_FUSED_SMEM_BYTES(TJ) (sizeof(double) * 2 * 32 * (1 + (TJ)) * LDKF)
+
+// The fused launch's product item: a 32 x (32 TJ) tile of Z over one K slice, on the first 256 threads of a 512-thread workgroup
+// (the launch is sized by the reconstruction: ~205 VGPRs, one workgroup per compute unit, so the product has ONE 4-wave
+// workgroup per CU where the separate launch had up to eight: wider tiles -- TJ accumulators per wave between two barriers -- and TWO
+// k-tiles of global loads in flight make up for the missing occupancy).  The 32-column blocks of a tile may sit on either side of the
+// A_rest | V_prev boundary (N1 is a multiple of 32); blocks past the last column read block 0 of the tile and are never stored.
+template <int TJ>
+__device__ __forceinline__ void ep_fused_item(const EpArgs& e, int tile, int z)
+{
+    extern __shared__ __attribute__((aligned(16))) double ep_smem[];
+    constexpr int ASZ = 32 * LDKF, BSZ = 32 * TJ * LDKF;
+    double* As = ep_smem;                    // [2][32][LDKF]
+    double* Bsm = ep_smem + 2 * ASZ;         // [2][32 TJ][LDKF]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1, l15 = lane & 15, l4 = lane >> 4;
+    const int j0 = tile * 32 * TJ, N = e.N1 + e.N2;
+    const int kbeg = z * e.kchunk, kend = min(e.K, kbeg + e.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    // this thread's column of every 32-column block, and of the Q tile: 8 threads per column, 2 doubles each per k-tile
+    const double* bp[TJ];
+#pragma unroll
+    for (int q = 0; q < TJ; ++q) {
+        int j = j0 + 32 * q + (tid >> 3);
+        if (j >= N) j = j0 + (tid >> 3);
+        bp[q] = (j >= e.N1 ? e.B2 + (size_t) (j - e.N1) * e.ldb2 : e.B1 + (size_t) j * e.ldb1) + 2 * (tid & 7);
+    }
+    const double* qp = e.Q + (size_t) (tid >> 3) * e.ldq + 2 * (tid & 7);
+    v2d ra[2], rb[2][TJ];
+    auto gload = [&](int st, int k0) {
+        ra[st] = *reinterpret_cast<const v2d*>(qp + k0);
+#pragma unroll
+        for (int q = 0; q < TJ; ++q) rb[st][q] = *reinterpret_cast<const v2d*>(bp[q] + k0);
+    };
+    auto sstore = [&](int st, int buf) {
+        *reinterpret_cast<v2d*>(As + buf * ASZ + (tid >> 3) * LDKF + 2 * (tid & 7)) = ra[st];
+#pragma unroll
+        for (int q = 0; q < TJ; ++q) *reinterpret_cast<v2d*>(Bsm + buf * BSZ + (32 * q + (tid >> 3)) * LDKF + 2 * (tid & 7)) = rb[st][q];
+    };
+    v4d acc[TJ][1];
+#pragma unroll
+    for (int a = 0; a < TJ; ++a) acc[a][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (nk > 0) gload(0, kbeg);
+    if (nk > 1) gload(1, kbeg + BK);
+    if (nk > 0) sstore(0, 0);
+    __syncthreads();
+    // k-tile kt: LDS buffer kt & 1 holds it, register stage (kt + 1) & 1 holds tile kt + 1, stage kt & 1 is free for tile kt + 2
+    auto step = [&](int kt, int st) {          // st = kt & 1 as a literal after unrolling
+        if (kt + 2 < nk) gload(st, kbeg + (kt + 2) * BK);
+        mma_tile<1, TJ, false>(acc, As + st * ASZ, Bsm + st * BSZ, wi, wj, l15, l4);
+        if (kt + 1 < nk) sstore(st ^ 1, st ^ 1);
+        __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { step(kt, 0); step(kt + 1, 1); }
+    if (kt < nk) step(kt, 0);
+    gemm_epilogue<1, TJ, true>(acc, e.slabs + (size_t) z * e.slab_stride, 32, 32, N, 0, j0, 1.0, 0.0, wi, wj, l15, l4);
+}
+
+template <bool UINV, int TJ>
+__global__ __launch_bounds__(64 * H3G, 2) void hr3_ep_kernel(const double* __restrict__ G2s, int nslab, const double* __restrict__ R1,
+                                                         double* __restrict__ Vw, int ldv, double* __restrict__ A, int lda,
+                                                         double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                         double* __restrict__ Uout, int* __restrict__ guard, unsigned* __restrict__ bar,
+                                                         double* __restrict__ epw, EpArgs e)
+{
+    if (blockIdx.x == 0) {
+        hr3_body<UINV, true>(G2s, nslab, R1, Vw, ldv, A, lda, tau, T, ldt, Uout, guard, bar, epw);
+        return;
+    }
+    if (threadIdx.x >= 256) return;          // the product tile is a 4-wave job (whole waves leave: the barriers below count the rest)
+    if (*guard != 0) return;                 // pass 1 refused the leaf: there is no Q
+    // K slices are dealt to the XCDs (workgroup b runs on XCD b % 8; all column tiles of a slice share its 32-column slice of Q in
+    // that XCD's L2, see gemm_tn_dual_kernel) -- to XCDs 1..7 only: XCD 0 has the reconstruction, and on a CU-masked panel stream
+    // (4 compute units per XCD, one workgroup of this launch per CU) a product workgroup there would queue behind it
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (xcd == 0 || slot == 0) return;
+    const int z = xcd - 1 + 7 * ((slot - 1) / e.ftiles);
+    if (z >= e.ksplit) return;
+    ep_fused_item<TJ>(e, (slot - 1) % e.ftiles, z);
+}
+
+// the fold matrices of the fallback: slabs recomputed from the final V, so y = z:  U'^-1 := I, B := 0
+__device__ __forceinline__ void ep_fallback_folds(double* __restrict__ epw)
+{
+    for (int el = threadIdx.x; el < PW * PW; el += blockDim.x) {
+        epw[1 * PW * PW + el] = (el % PW == el / PW) ? 1.0 : 0.0;
+        epw[2 * PW * PW + el] = 0.0;
+    }
+}
+
+// fallback launch (leaves whose guard route runs as separate launches): no-op unless the guard tripped; then the product
+// again, from V (complete in Vw by now), and the fallback's fold matrices
+__global__ __launch_bounds__(256, 2) void ep_redo_kernel(const int* __restrict__ guard, double* __restrict__ epw, EpArgs e)
+{
+    if (*guard == 0) return;
+    if (blockIdx.x == 0) { ep_fallback_folds(epw); return; }
+    ep_product_item(e, (int) blockIdx.x - 1, e.Q);
+}
+
+// W (32 x N1, ldw) and the Gram block G2 (N2 x 32, ldg) from the product slabs, T, and the factors in epw (see hr3_ep_kernel).
+// One 256-thread workgroup per column j of Z: thread (i = tid & 31, zp = tid >> 5); the slab index is spread over the 8 groups zp,
+// every sum is formed in a fixed order.  The three folds are 32-term products: 4 terms per thread, 8 partials per output.
+__global__ __launch_bounds__(256) void slab_reduce_ep_kernel(int N1, int N2, int nslab, const double* __restrict__ slabs, size_t slab_stride,
+                                                             const double* __restrict__ epw, const double* __restrict__ T, int ldt,
+                                                             const double* __restrict__ B1, int ldb1,
+                                                             const double* __restrict__ B2, int ldb2, double* __restrict__ W, int ldw,
+                                                             double* __restrict__ G2, int ldg)
+{
+    __shared__ double red[256];
+    __shared__ double vec[PW], top[PW];
+    const int j = blockIdx.x, tid = threadIdx.x, i = tid & 31, zp = tid >> 5;
+    const bool second = j >= N1;
+    // the factor entries this thread needs, issued before the slab walk (they come from L2 under it):
+    //   fb: B(r = zp + 8q, k = i)     fu: U'^-1(k = zp + 8q, c = i)     ft: T(c = zp + 8q, i)
+    double fb[4], fu[4], ft[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = zp + 8 * q;
+        fb[q] = epw[2 * PW * PW + i * PW + r];
+        fu[q] = epw[1 * PW * PW + i * PW + r];
+        ft[q] = (!second && r <= i) ? T[(size_t) i * ldt + r] : 0.0;
+    }
+    if (tid < PW) top[tid] = second ? B2[(size_t) (j - N1) * ldb2 + tid] : B1[(size_t) j * ldb1 + tid];
+    {
+        const double* p = slabs + (size_t) j * 32 + i;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int z = zp;
+        for (; z + 24 < nslab; z += 32) {
+            s0 += p[(size_t) z * slab_stride];
+            s1 += p[(size_t) (z + 8) * slab_stride];
+            s2 += p[(size_t) (z + 16) * slab_stride];
+            s3 += p[(size_t) (z + 24) * slab_stride];
+        }
+        for (; z < nslab; z += 8) s0 += p[(size_t) z * slab_stride];
+        red[tid] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    // z(k = i) - sum_r B(r, k) top(r)
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part -= fb[q] * top[zp + 8 * q];
+    if (zp == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g * 32 + i];
+        part += t;
+    }
+    __syncthreads();
+    red[tid] = part;
+    __syncthreads();
+    if (tid < PW) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g * 32 + tid];
+        vec[tid] = t;
+    }
+    __syncthreads();
+    // y(c = i) = sum_k U'^-1(k, c) vec(k)
+    part = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part += fu[q] * vec[zp + 8 * q];
+    red[tid] = part;
+    __syncthreads();
+    double y = 0.0;
+    if (tid < PW) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) y += red[g * 32 + tid];
+        if (second) { G2[(size_t) tid * ldg + (j - N1)] = y; }
+        else vec[tid] = y;
+    }
+    if (second) return;
+    __syncthreads();
+    // W(i, j) = sum_c T(c, i) y(c)
+    part = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part += ft[q] * vec[zp + 8 * q];
+    __syncthreads();
+    red[tid] = part;
+    __syncthreads();
+    if (tid < PW) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g * 32 + tid];
+        W[(size_t) j * ldw + tid] = t;
+    }
 }
 
 // rows >= w of V: v U' = q by forward substitution over the columns (U' upper triangular), one row per thread
@@ -1770,10 +2036,17 @@ __device__ __forceinline__ void final3_load(double (&a)[PW], double (*Usm)[PW + 
 
 template <bool FULL>
 __device__ __forceinline__ void final3_finish(double (&a)[PW], double (*Usm)[PW + 1], const double* uinv, double* __restrict__ Vw, int ldv,
-                                              int mk, int w, double* __restrict__ A, int lda)
+                                              int mk, int w, double* __restrict__ A, int lda, const double* __restrict__ L1s = nullptr)
 {
     const int tid = threadIdx.x, r = blockIdx.x * PT + tid;
-    if (r < w || r >= mk) return;
+    if (r >= mk) return;
+    if (r < w) {                              // early-product leaf: the unit-lower top block of V comes from L1s (see final4_body)
+        if (L1s) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c) Vw[(size_t) c * ldv + r] = L1s[c * PW + r];
+        }
+        return;
+    }
     double v[PW];
 #pragma unroll
     for (int k = 0; k < PW; ++k) {
@@ -1789,36 +2062,48 @@ __device__ __forceinline__ void final3_finish(double (&a)[PW], double (*Usm)[PW 
 
 template <bool FULL>
 __global__ __launch_bounds__(PT) void final3_kernel(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Um,
-                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
+                                                    double* __restrict__ A, int lda, const int* __restrict__ guard,
+                                                    const double* __restrict__ L1s)
 {
     __shared__ double Usm[PW][PW + 1];
     __shared__ double uinv[PW];
     if (*guard != 0) return;
     double a[PW];
     final3_load<FULL>(a, Usm, uinv, Vw, ldv, mk, w, Um);
-    final3_finish<FULL>(a, Usm, uinv, Vw, ldv, mk, w, A, lda);
+    final3_finish<FULL>(a, Usm, uinv, Vw, ldv, mk, w, A, lda, L1s);
 }
 
 // Short leaves (<= 16 row blocks): the last launch of the CholeskyQR2 leaf and the one-launch guard route share a grid
 // (one 512-row block per workgroup), so they are ONE launch -- the guard word picks the body.  Saves the kernel boundary
 // (~4.7 us per leaf, 3-4 % of an 8192^2 factorisation) that the guard route cost when it had nothing to do.
+// ep != 0 (early-product leaf, see hr3_ep_kernel): on the guard route the product slabs are recomputed from the final V by the
+// same workgroups behind one more grid barrier, and the fold matrices become (T, 0, I, 0)
+__device__ __forceinline__ void coop_ep_redo(int nblk, unsigned* __restrict__ bar, double* __restrict__ epw, const EpArgs& e)
+{
+    coop_barrier(bar, 4u * (unsigned) nblk);                 // V is complete in every workgroup's rows
+    if (blockIdx.x == 0) ep_fallback_folds(epw);
+    if (threadIdx.x >= 256) return;
+    for (int item = blockIdx.x; item < e.tiles * e.ksplit; item += nblk) ep_product_item(e, item, e.Q);
+}
+
 __global__ __launch_bounds__(PT) void final3_coop_kernel(const double* __restrict__ Um, int nblk, int halves, int mk, int w,
                                                          double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
                                                          double* __restrict__ stack, double* __restrict__ Rt, double* __restrict__ Ctop,
                                                          double* __restrict__ Umat, double* A, int lda,
                                                          double* __restrict__ tau, double* __restrict__ T, int ldt,
                                                          double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
-                                                         const int* __restrict__ guard)
+                                                         const int* __restrict__ guard, int ep, double* __restrict__ epw, EpArgs e)
 {
     __shared__ double Usm[PW][PW + 1];
     __shared__ double uinv[PW];
     if (*guard != 0) {
         tsqr_coop_body(A, lda, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
+        if (ep) coop_ep_redo(nblk, bar, epw, e);
         return;
     }
     double a[PW];
     final3_load<true>(a, Usm, uinv, Vw, ldv, mk, w, Um);
-    final3_finish<true>(a, Usm, uinv, Vw, ldv, mk, w, A, lda);
+    final3_finish<true>(a, Usm, uinv, Vw, ldv, mk, w, A, lda, ep ? epw : nullptr);
 }
 
 // the same for the third-generation leaf (Um = U'^-1, final4_body)
@@ -1828,15 +2113,17 @@ __global__ __launch_bounds__(PT) void final4_coop_kernel(const double* __restric
                                                          double* __restrict__ Umat, double* A, int lda,
                                                          double* __restrict__ tau, double* __restrict__ T, int ldt,
                                                          double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
-                                                         const int* __restrict__ guard, int rows_wg)
+                                                         const int* __restrict__ guard, int rows_wg, int ep, double* __restrict__ epw, EpArgs e)
 {
     if (*guard != 0) {
         // guard route: the first nblk workgroups (dispatched first), one 512-row block each; any others have nothing to do
-        if ((int) blockIdx.x < nblk)
+        if ((int) blockIdx.x < nblk) {
             tsqr_coop_body(A, lda, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
+            if (ep) coop_ep_redo(nblk, bar, epw, e);
+        }
         return;
     }
-    final4_body(Vw, ldv, mk, Um, A, lda, rows_wg);
+    final4_body(Vw, ldv, mk, Um, A, lda, rows_wg, ep ? epw : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1917,9 +2204,11 @@ static int coop_enabled(void)
     return v;
 }
 
+// ep / epw: early-product leaf (hr3_ep_kernel has run): the last CholeskyQR2 launch also restores the top block of Vw from epw,
+// and the guard route ends with the product's redo (inside the one-launch form, as ep_redo_kernel otherwise)
 static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
                            double* ws, int m_cap, const int* guard, unsigned* bar = nullptr, const double* final3_u = nullptr,
-                           int gen = 2)
+                           int gen = 2, const EpArgs* ep = nullptr, double* epw = nullptr)
 {
     hipStream_t s = (hipStream_t) stream;
     if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
@@ -1954,28 +2243,36 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     static int fuse = -1;
     if (fuse < 0) { const char* e = getenv("MI355XQR_FUSE_GUARD"); fuse = (e && atoi(e) == 0) ? 0 : 1; }
     const bool coop = guard && bar && coop_enabled() && lv_nblk[0] * w <= PT;
+    const EpArgs ep0 = ep ? *ep : EpArgs{};
+    const size_t ep_shm = ep ? EP_SMEM_BYTES : 0;
+    // the product's redo for guard routes that run as separate launches: one more launch that returns at once unless the guard tripped
+    auto redo = [&]() {
+        if (ep)
+            hipLaunchKernelGGL(ep_redo_kernel, dim3(1 + ep->tiles * ep->ksplit), dim3(256), EP_SMEM_BYTES, s, guard, epw, ep0);
+        return (int) hipGetLastError();
+    };
     if (final3_u && coop && fuse && brows0 == PT && w == PW) {
         if (gen == 3) {
-            static int half_wg = -1;
-            if (half_wg < 0) { const char* e = getenv("MI355XQR_LEAF_HALFWG"); half_wg = e ? atoi(e) != 0 : 1; }
+            static const int half_wg = [] { const char* e = getenv("MI355XQR_LEAF_HALFWG"); return e ? (int) (atoi(e) != 0) : 1; }();
             const int rows_wg = half_wg ? PT / 2 : PT;
-            hipLaunchKernelGGL(final4_coop_kernel, dim3(half_wg ? (mk + rows_wg - 1) / rows_wg : lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0],
-                               brows0 / PT, mk, w, Vloc1, taus, Ts, stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, rows_wg);
+            hipLaunchKernelGGL(final4_coop_kernel, dim3(half_wg ? (mk + rows_wg - 1) / rows_wg : lv_nblk[0]), dim3(PT), ep_shm, s, final3_u, lv_nblk[0],
+                               brows0 / PT, mk, w, Vloc1, taus, Ts, stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, rows_wg,
+                               ep ? 1 : 0, epw, ep0);
         }
         else
-            hipLaunchKernelGGL(final3_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
-                               stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
+            hipLaunchKernelGGL(final3_coop_kernel, dim3(lv_nblk[0]), dim3(PT), ep_shm, s, final3_u, lv_nblk[0], brows0 / PT, mk, w, Vloc1, taus, Ts,
+                               stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, ep ? 1 : 0, epw, ep0);
         return (int) hipGetLastError();
     }
     if (final3_u && gen == 3)
-        hipLaunchKernelGGL(final4_kernel, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, final3_u, P, ld, guard);
+        hipLaunchKernelGGL(final4_kernel, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, final3_u, P, ld, guard, ep ? epw : nullptr);
     else if (final3_u)
-        hipLaunchKernelGGL(final3_kernel<true>, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, w, final3_u, P, ld, guard);
+        hipLaunchKernelGGL(final3_kernel<true>, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, w, final3_u, P, ld, guard, ep ? epw : nullptr);
     if (coop) {
         // short leaf behind a CholeskyQR2 attempt: the whole guard route in one launch (grid barriers inside)
         hipLaunchKernelGGL(tsqr_coop_kernel, dim3(lv_nblk[0]), dim3(PT), 0, s, P, ld, mk, w, lv_nblk[0], brows0 / PT, Vloc1, taus, Ts, stacks,
                            Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard);
-        return (int) hipGetLastError();
+        return redo();
     }
     size_t off = 0, toff = (size_t) lv_nblk[0] * PW;
     launch_factor(s, lv_nblk[0], (mk + lv_nblk[0] - 1) / lv_nblk[0], P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, lv_nblk[0] * w, guard);
@@ -2010,7 +2307,7 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     hipLaunchKernelGGL(tsqr_final_kernel, dim3(lv_nblk[0] * halves), dim3(PT), 0, s, Vloc1, mk, taus, Ts, mk, lv_nblk[0], halves, w,
                        Cin, ldci, Umat, P, ld, Vw, ldv, guard);
     (void) Q1;
-    return (int) hipGetLastError();
+    return redo();
 }
 
 int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
@@ -2052,17 +2349,80 @@ int qrd_panel_tsqr_init(void)
                                     (int) (8 * PW * PW * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
+    // early-product launches: ~59 KB of static LDS (reconstruction) + the product's 18 KB tile images
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(hr3_ep_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_FUSED_SMEM_BYTES(1));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(hr3_ep_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_FUSED_SMEM_BYTES(2));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(hr3_ep_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_FUSED_SMEM_BYTES(4));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(hr3_ep_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_FUSED_SMEM_BYTES(1));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(hr3_ep_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_FUSED_SMEM_BYTES(2));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(hr3_ep_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_FUSED_SMEM_BYTES(4));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(final4_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_SMEM_BYTES);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(final3_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_SMEM_BYTES);
     return rc;
 }
 
-int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
-                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab)
+// early-product request of the host (qrd_panel_cholqr_ep): where the product goes and what it needs
+struct EpHost {
+    int N1, N2;
+    const double* B1; int ldb1;
+    const double* B2; int ldb2;
+    double* W; int ldw;
+    double* G2; int ldg;
+    double* slabs; size_t slab_cap;
+    int done;                       // out: 1 = W and G2 are (will be, in stream order) complete
+};
+
+static inline bool ep_vec_ok(const void* p, int ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 2 == 0); }
+
+static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                             double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab, EpHost* eph)
 {
     hipStream_t s = (hipStream_t) stream;
     if (w < 1 || w > PW || mk < w || mk > m_cap) return -4;
     // one workgroup covers the leaf / ragged last leaf (the per-column predicates a narrow leaf needs cost the
     // Cholesky kernels 3.5 KB of scratch per thread): Householder path directly
     if (mk <= PT || w < PW) return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, nullptr);
+    // early product: same shape rules as the separate product launch (32-column tiles, whole k-tiles, 16-byte aligned operands)
+    EpArgs ep{};
+    double* epw = cws + 5 * PW * PW;
+    bool use_ep = false;
+    int ep_tj = 1;
+    if (eph) {
+        const int N = eph->N1 + eph->N2;
+        const size_t per = (size_t) 32 * N;
+        // The fused launch has one 4-wave product workgroup per compute unit (~2 TB/s on a tall leaf) where the separate launch streams
+        // at 3.3 TB/s; it wins while the product is shorter than that difference plus the reconstruction it hides (~28 us): up to
+        // ~128 MB of operands (65536 x 256: 1.17 -> 1.11 ms; 262144 x 512: 6.96 -> 7.09, hence not there)
+        static const long long ep_max_mb = [] { const char* e = getenv("MI355XQR_EP_MAX_MB"); return (long long) (e ? atoi(e) : 128); }();
+        if (N > 0 && 8LL * mk * (32 + N) <= ep_max_mb * 1000000LL &&
+            eph->N1 % 32 == 0 && eph->N2 % 32 == 0 && mk % BK == 0 && mk >= BK && ep_vec_ok(Vw, ldv) &&
+            (eph->N1 == 0 || ep_vec_ok(eph->B1, eph->ldb1)) && (eph->N2 == 0 || ep_vec_ok(eph->B2, eph->ldb2)) && eph->slabs &&
+            eph->slab_cap >= per) {
+            // Fused launch: ONE 4-wave product workgroup per compute unit (the launch is sized by the reconstruction), so: the widest
+            // tile that still gives every CU of the stream a workgroup, and as many K slices as there are workgroup slots (one round),
+            // each at least 4 k-tiles long; the slabs are summed by one reduce workgroup per column, 8 slabs at a time
+            const int tiles = N / 32;
+            int per_xcd = qrd_stream_cus(stream) / 8;            // one product workgroup per compute unit, XCDs 1..7
+            if (per_xcd < 1) per_xcd = 1;
+            long long kcap = (mk + 4 * BK - 1) / (4 * BK);
+            if (kcap > 128) kcap = 128;
+            if ((size_t) kcap * per > eph->slab_cap) kcap = (long long) (eph->slab_cap / per);
+            if (kcap < 1) kcap = 1;
+            ep_tj = N >= 128 ? 4 : (N >= 64 ? 2 : 1);
+            while (ep_tj > 1 && ((N + 32 * ep_tj - 1) / (32 * ep_tj) > per_xcd ||
+                                 (long long) ((N + 32 * ep_tj - 1) / (32 * ep_tj)) * kcap < (3LL * 7 * per_xcd) / 4)) ep_tj >>= 1;
+            const int ftiles = (N + 32 * ep_tj - 1) / (32 * ep_tj);
+            long long ks = 7LL * (per_xcd / ftiles > 0 ? per_xcd / ftiles : 1);      // slices per XCD * 7 XCDs: one round of workgroups
+            if (ks > kcap) ks = kcap;
+            int ksplit = (int) ks;
+            int kchunk = ((mk + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+            ksplit = (mk + kchunk - 1) / kchunk;
+            ep.N1 = eph->N1; ep.N2 = eph->N2; ep.K = mk; ep.kchunk = kchunk; ep.tiles = tiles; ep.ksplit = ksplit; ep.ftiles = ftiles;
+            ep.Q = Vw; ep.ldq = ldv; ep.B1 = eph->B1; ep.ldb1 = eph->ldb1; ep.B2 = eph->B2; ep.ldb2 = eph->ldb2;
+            ep.slabs = eph->slabs; ep.slab_stride = per;
+            use_ep = true;
+        }
+    }
     double *G1 = cws, *G2 = cws + PW * PW, *R1 = cws + 2 * PW * PW, *Mm = cws + 3 * PW * PW;
     int* guard = (int*) (cws + 4 * PW * PW);
     unsigned* bar = (unsigned*) (guard + 2);             // zeroed by hr3_kernel: second-generation leaf only
@@ -2135,21 +2495,29 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
                 hipLaunchKernelGGL((cholq2_kernel<true, 256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
                                    G1, 1, R1, Vw, ldv, slab2, guard);
         }
-        if (nblk2 <= 2 * CQ2_MAXSLAB) {
-            if (gen == 3)
-                hipLaunchKernelGGL(hr3_kernel<true>, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk2, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
-            else
-                hipLaunchKernelGGL(hr3_kernel<false>, dim3(1), dim3(64 * H3G), 0, s, slab2, nblk2, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
-        } else {           // tall leaf: hundreds of partial Grams are summed by a grid, not by the one reconstruction workgroup
+        const double* g2src = slab2;
+        int g2n = nblk2;
+        if (nblk2 > 2 * CQ2_MAXSLAB) {   // tall leaf: hundreds of partial Grams are summed by a grid, not by the one reconstruction workgroup
             rc = qrd_slab_reduce(s, PW, PW, nblk2, slab2, PW, (size_t) PW * PW, G2, PW);
             if (rc) return rc;
-            if (gen == 3)
-                hipLaunchKernelGGL(hr3_kernel<true>, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
-            else
-                hipLaunchKernelGGL(hr3_kernel<false>, dim3(1), dim3(64 * H3G), 0, s, G2, 1, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+            g2src = G2; g2n = 1;
         }
+        if (use_ep) {
+            // reconstruction (workgroup 0) and the leaf's long-K product on Q (the others) in ONE launch
+            // 8 workgroups per "slot": slot 0 = the reconstruction (+ 7 that leave at once), then ftiles slots per group of 7 slices
+            const dim3 grid(8 * (1 + ep.ftiles * ((ep.ksplit + 6) / 7)));
+#define LAUNCH_HR3_EP(UI, TJ) hipLaunchKernelGGL((hr3_ep_kernel<UI, TJ>), grid, dim3(64 * H3G), EP_FUSED_SMEM_BYTES(TJ), s, g2src, g2n, R1, Vw, ldv, \
+                                                 P, ld, tau, T, ldt, Mm, guard, bar, epw, ep)
+            if (gen == 3) { if (ep_tj == 4) LAUNCH_HR3_EP(true, 4); else if (ep_tj == 2) LAUNCH_HR3_EP(true, 2); else LAUNCH_HR3_EP(true, 1); }
+            else { if (ep_tj == 4) LAUNCH_HR3_EP(false, 4); else if (ep_tj == 2) LAUNCH_HR3_EP(false, 2); else LAUNCH_HR3_EP(false, 1); }
+#undef LAUNCH_HR3_EP
+        } else if (gen == 3)
+            hipLaunchKernelGGL(hr3_kernel<true>, dim3(1), dim3(64 * H3G), 0, s, g2src, g2n, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
+        else
+            hipLaunchKernelGGL(hr3_kernel<false>, dim3(1), dim3(64 * H3G), 0, s, g2src, g2n, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
         have_bar = true;                                    // final3_kernel<true>: issued by panel_tsqr_impl, fused with the guard route where it can
     } else {
+        use_ep = false;                                     // first-generation launch sequence: the product stays a separate launch
         rc = gram32(s, P, ld, mk, G1, slabs, slab_cap);
         if (rc) return rc;
         hipLaunchKernelGGL(cholq_kernel<true>, dim3(nblk), dim3(PT), 0, s, P, ld, mk, w, G1, R1, Vw, ldv, guard);
@@ -2160,8 +2528,34 @@ int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau
     }
     rc = (int) hipGetLastError();
     if (rc) return rc;
-    return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr, have_bar ? Mm : nullptr,
-                           gen);
+    rc = panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr, have_bar ? Mm : nullptr,
+                         gen, use_ep ? &ep : nullptr, epw);
+    if (rc || !use_ep) return rc;
+    hipLaunchKernelGGL(slab_reduce_ep_kernel, dim3(ep.N1 + ep.N2), dim3(256), 0, s, ep.N1, ep.N2, ep.ksplit, ep.slabs, ep.slab_stride, epw,
+                       T, ldt, ep.B1, ep.ldb1, ep.B2, ep.ldb2, eph->W, eph->ldw, eph->G2, eph->ldg);
+    eph->done = 1;
+    return (int) hipGetLastError();
+}
+
+int qrd_panel_cholqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                     double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab)
+{
+    return panel_cholqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, cws, slabs, slab_cap, gram_nslab, nullptr);
+}
+
+// The leaf AND its in-panel products in one call ("early product", hr3_ep_kernel):  W (32 x N1, ldw) = T_l^T V_l^T B1 and
+// G2 (N2 x 32, ldg) = B2^T V_l, with B1 = the rest of the panel (mk x N1) and B2 = the panel's earlier reflectors (mk x N2, rows from
+// this leaf's top row).  ep_slabs: split-K workspace of the product, NOT aliasing `slabs`.  *did = 1: W and G2 are done (in stream
+// order); *did = 0: the leaf is factored but the shapes did not fit -- the caller issues the products itself (qrd_gemm_tn_dual).
+int qrd_panel_cholqr_ep(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
+                        double* ws, int m_cap, double* cws, double* slabs, size_t slab_cap, int gram_nslab,
+                        int N1, const double* B1, int ldb1, int N2, const double* B2, int ldb2, double* W, int ldw, double* G2, int ldg,
+                        double* ep_slabs, size_t ep_slab_cap, int* did)
+{
+    EpHost h{N1, N2, B1, ldb1, B2, ldb2, W, ldw, G2, ldg, ep_slabs, ep_slab_cap, 0};
+    const int rc = panel_cholqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, cws, slabs, slab_cap, gram_nslab, &h);
+    if (did) *did = h.done;
+    return rc;
 }
 
 }   // extern "C"

@@ -188,6 +188,18 @@ int qrd_panel_cholqr(void* s, double* P, int ld, int mk, int w, double* tau, dou
     chkb("cholqr ws", cws, sizeof(double) * QRD_CHOLQR_WS); chkb("cholqr slabs", slabs, cap * sizeof(double));
     return 0;
 }
+int qrd_panel_cholqr_ep(void* s, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int mcap,
+                        double* cws, double* slabs, size_t cap, int gn, int N1, const double* B1, int ldb1, int N2, const double* B2, int ldb2,
+                        double* W, int ldw, double* G2, int ldg, double* eps, size_t ecap, int* did)
+{
+    qrd_panel_cholqr(s, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, mcap, cws, slabs, cap, gn);
+    if (N1 > 0) { chk("ep B1", B1, ldb1, mk, N1); chk("ep W", W, ldw, 32, N1); }
+    if (N2 > 0) { chk("ep B2", B2, ldb2, mk, N2); chk("ep G2", G2, ldg, N2, 32); }
+    chkb("ep slabs", eps, ecap * sizeof(double));
+    if (ecap < (size_t) 32 * (size_t) (N1 + N2)) { fprintf(stderr, "qrd_stub: early-product slab buffer too small\n"); abort(); }
+    *did = (mk & 64) ? 0 : 1;          /* both outcomes are exercised */
+    return 0;
+}
 int qrd_slab_reduce(void* s, int M, int N, int ns, const double* slabs, int lds, size_t stride, double* out, int ldo)
 { (void) s; chk("slab_reduce in", slabs, lds, M, N); (void) ns; (void) stride; chk("slab_reduce out", out, ldo, M, N); return 0; }
 int qrd_leaf_update_gram(void* s, int mk, int N, const double* V, int ldv, const double* W, double* C, int ldc, double* gs, size_t cap, int gy,

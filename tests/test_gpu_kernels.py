@@ -473,3 +473,93 @@ def test_leaf_update_gram(q, mk, N, gy):
     # shapes the kernel does not take are refused, not mangled (the host then launches the plain product)
     assert q.lib.qrd_leaf_update_gram(None, mk + 2, N, dV.data_ptr(), mk, dW.data_ptr(), dA.data_ptr(), ld, None, 0, 0, None) == -7
     assert q.lib.qrd_leaf_update_gram(None, mk, N + 16, dV.data_ptr(), mk, dW.data_ptr(), dA.data_ptr(), ld, None, 0, 0, None) == -7
+
+
+EP_CASES = [(1024, 224, 0), (4096, 96, 96), (8192, 0, 224), (8192, 32, 0), (6144, 160, 64), (16384, 192, 32), (70000 // 16 * 16, 96, 96),
+            (262144, 64, 32), (131072, 64, 0), (2048, 448, 0)]
+
+
+@pytest.mark.parametrize("kind", ["ok", "dependent"])
+@pytest.mark.parametrize("mk,n1,n2", EP_CASES)
+def test_panel_cholqr_early_product(q, oracle, mk, n1, n2, kind):
+    """qrd_panel_cholqr_ep: the leaf AND its two long-K in-panel products in one call -- the products run on Q in the launch of the
+    one-workgroup reconstruction (hr3_ep_kernel) and are folded to  W = T^T V^T A_rest  and  G = V_prev^T V  by slab_reduce_ep_kernel.
+    Checked against the same quantities formed in numpy from the call's own V and T, on the fast route ("ok") and on the guard route
+    ("dependent": two equal columns, the Householder TSQR forms V and the product is redone from it -- inside the one-launch guard
+    route for short leaves, as a separate launch for tall ones)."""
+    import ctypes as C
+    w = 32
+    rng = np.random.default_rng(mk + n1 + 3 * n2)
+    P = rng.random((mk, w))
+    if kind == "dependent":
+        P[:, 21] = P[:, 3]
+    B1 = rng.standard_normal((mk, max(n1, 1)))
+    B2 = rng.standard_normal((mk, max(n2, 1))) / np.sqrt(mk)
+    ld = mk + 2
+    panel = np.full((ld, w + max(n1, 1)), 3.0)
+    panel[:mk, :w] = P
+    panel[:mk, w:] = B1
+    dA, dB2 = dev(panel), dev(B2)
+    dtau, dT, dV = zeros(w, 1), dev(np.full((w, w), np.nan)), dev(np.full((mk, w), np.nan))
+    dW, dG = dev(np.full((w, max(n1, 1)), np.nan)), dev(np.full((max(n2, 1) + 5, w), np.nan))
+    ws = torch.zeros(int(q.lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
+    cws = torch.zeros(10 * 32 * 32 + 16, dtype=torch.float64, device="cuda")
+    slabs = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
+    eps = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    did = C.c_int(-1)
+    f = q.lib.qrd_panel_cholqr_ep
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                                         C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                                         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+    q.check(f(None, dA.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), mk, ws.data_ptr(), mk, cws.data_ptr(),
+              slabs.data_ptr(), 1 << 22, 0, n1, dA.data_ptr() + 8 * ld * w, ld, n2, dB2.data_ptr(), mk, dW.data_ptr(), w, dG.data_ptr(),
+              max(n2, 1) + 5, eps.data_ptr(), 1 << 20, C.byref(did)))
+    _sync(q)
+    guard = int(cws[4 * 32 * 32:].view(torch.int32)[0].item())
+    # the fused launch is only used while the product's operands stay below ~128 MB (a tall leaf streams faster as a launch of its own)
+    expect_ep = 8 * mk * (32 + n1 + n2) <= 128e6
+    assert did.value == (1 if expect_ep else 0) and guard == (1 if kind == "dependent" else 0)
+    out, tau, T, V = host(dA)[:mk, :w], host(dtau)[:, 0], host(dT), host(dV)
+    assert np.isfinite(V).all() and np.isfinite(T).all()
+    assert np.array_equal(np.triu(V[:w], 1), np.zeros((w, w))) and np.array_equal(np.diag(V[:w]), np.ones(w))
+    assert np.array_equal(np.tril(V, -1), np.tril(out, -1)), "explicit V and in-place tails must agree"
+    QtP = P - V @ (T.T @ (V.T @ P))
+    assert np.abs(np.tril(QtP, -1)).max() < 1e-11 * np.sqrt(mk) and np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-11 * np.sqrt(mk)
+    assert np.array_equal(host(dA)[:mk, w:], B1), "the rest of the panel is read, never written"
+    if not expect_ep:
+        return
+    if n1:
+        Wref = T.T @ (V.T @ B1)
+        assert np.abs(host(dW) - Wref).max() < 1e-12 * np.sqrt(mk) * max(1.0, np.abs(Wref).max())
+    if n2:
+        Gref = B2.T @ V
+        G = host(dG)
+        assert np.abs(G[:n2] - Gref).max() < 1e-12 * np.sqrt(mk) * max(1.0, np.abs(Gref).max())
+        assert np.isnan(G[n2:]).all(), "rows of the Gram buffer beyond N2 stay untouched"
+
+
+def test_panel_cholqr_early_product_declines_odd_heights(q):
+    """heights that are not whole k-tiles: the leaf is factored, the products are left to the caller (did = 0)"""
+    import ctypes as C
+    mk, w, n1 = 1000, 32, 64
+    rng = np.random.default_rng(1)
+    panel = rng.random((mk, w + n1))
+    dA = dev(panel)
+    dtau, dT, dV, dW = zeros(w, 1), zeros(w, w), zeros(mk, w), dev(np.full((w, n1), np.nan))
+    ws = torch.zeros(int(q.lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
+    cws = torch.zeros(10 * 32 * 32 + 16, dtype=torch.float64, device="cuda")
+    slabs = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+    eps = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    did = C.c_int(-1)
+    f = q.lib.qrd_panel_cholqr_ep
+    q.check(f(None, dA.data_ptr(), mk, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), mk, ws.data_ptr(), mk, cws.data_ptr(),
+              slabs.data_ptr(), 1 << 20, 0, n1, dA.data_ptr() + 8 * mk * w, mk, 0, None, mk, dW.data_ptr(), w, None, w, eps.data_ptr(), 1 << 20,
+              C.byref(did)))
+    _sync(q)
+    assert did.value == 0 and np.isnan(host(dW)).all()
+    V, T = host(dV), host(dT)
+    P = panel[:, :w]
+    assert np.abs(np.tril(P - V @ (T.T @ (V.T @ P)), -1)).max() < 1e-11

@@ -22,6 +22,8 @@ int qrd_gemm_tn_dual(void* stream, int N1, int N2, int K, const double* A, int l
                      int ldb2, const double* Tm, int ldt, double* W, int ldw, double* G2, int ldg, double* slabs, size_t slab_cap);
 int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                        int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap);
+int qrd_gemm_tn_update_wide(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                            int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap);
 /* second-generation wide update (qr_gemm_nt.hip): W kept transposed, direct-to-LDS tile loads */
 int qrd_gemm2_init(void);
 int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc);

@@ -201,6 +201,90 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
     else gemm_epilogue<TI, TJ, false>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide TN product of the trailing update, Wt = A2^T (V T):  M = columns of A2 (thousands), N = nb (256 / 512), K = panel height.
+// The 128 x 128 kernel above gives every 128 columns of V T their own workgroup, so A2 -- the big operand, 8 mk nt bytes -- is read
+// N / 128 times (rocprofv3: x2.3 the algorithmic bytes at nb = 256, x4 at 512).  Here a workgroup owns 128 columns of A2 against
+// 256 columns of V T: 512 threads = 8 waves as 2 x 4, wave tile 64 x 64 (16 accumulators), so A2 is read N / 256 times; the V T
+// slice of a K chunk is shared through L2 by the workgroups that walk the same chunk.  LDS 108 KB (two stages): one workgroup,
+// two waves per SIMD, per compute unit -- the same occupancy as two workgroups of the 4-wave kernel.
+// Interior only: M % 128 == 0, N % 256 == 0, K % 16 == 0, 16-byte aligned operands; slab z of the split-K at C + z * slab_stride.
+// ------------------------------------------------------------------------------------------------
+template <int TAG>
+__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(int K, int kchunk, const double* __restrict__ A, int lda,
+                                                           const double* __restrict__ B, int ldb, double* __restrict__ C, int ldc,
+                                                           size_t slab_stride)
+{
+    constexpr int BM = 128, BN = 256, ASZ = BM * LDKF, BSZ = BN * LDKF;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem;                       // [2][BM][LDKF]
+    double* Bs = smem + 2 * ASZ;             // [2][BN][LDKF]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1, l15 = lane & 15, l4 = lane >> 4;
+    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int nk = (kend - kbeg) / BK;
+    C += (size_t) blockIdx.z * slab_stride;
+    // 8 threads per column, one double2 each per k-tile: 2 columns of A2 and 4 of V T per thread
+    const double* ap[2];
+    const double* bp[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ap[q] = A + (size_t) (i0 + ((tid + 512 * q) >> 3)) * lda + 2 * (tid & 7);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bp[q] = B + (size_t) (j0 + ((tid + 512 * q) >> 3)) * ldb + 2 * (tid & 7);
+    v2d ra[2], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ra[q] = *reinterpret_cast<const v2d*>(ap[q] + k0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const v2d*>(bp[q] + k0);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<v2d*>(As + buf * ASZ + ((tid + 512 * q) >> 3) * LDKF + 2 * (tid & 7)) = ra[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<v2d*>(Bs + buf * BSZ + ((tid + 512 * q) >> 3) * LDKF + 2 * (tid & 7)) = rb[q];
+    };
+    v4d acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (nk > 0) { gload(kbeg); sstore(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+        const double* as = As + buf * ASZ + (wi * 64 + l15) * LDKF;
+        const double* bs = Bs + buf * BSZ + (wj * 64 + l15) * LDKF;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + l4;
+            double rowv[4], colv[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rowv[b] = as[16 * b * LDKF + kk];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) colv[a] = bs[16 * a * LDKF + kk];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[a], rowv[b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* cp = C + (size_t) (j0 + wj * 64 + 16 * a + l4 + 4 * r) * ldc + i0 + wi * 64 + l15;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) cp[16 * b] = acc[a][b][r];
+        }
+}
+
 // The leaf's two long-K products in one launch:  [W | G^T] = V_l^T [A_rest | V_prev]  (32 x (N1 + N2), K = leaf height).
 // Column tiles j0 < N1 read B1 (the rest of the panel), the others B2 (the reflectors of the panel's earlier leaves): the Gram
 // blocks the panel's T needs are thus collected leaf by leaf, and the panel-wide Gram product after the last leaf goes away.
@@ -724,6 +808,7 @@ int qrd_init(void)
     rc |= allow_lds(gemm_nn_w8_kernel<0>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_w8_kernel<1>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_wide_kernel<1>, sizeof(double) * (2 * (128 + 256) * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, false>, sizeof(double) * (4 * 128 * LDKF));
@@ -899,6 +984,13 @@ int qrd_gemm_tn_update(void* stream, int M, int N, int K, double alpha, const do
     return gemm_tn_impl(stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, slabs, slab_cap, nullptr, 0, 1);
 }
 
+// the wide-tile form of the same product, whatever MI355XQR_TN_WIDE says (kernel tests, A/B measurements)
+int qrd_gemm_tn_update_wide(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                            int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap)
+{
+    return gemm_tn_impl(stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, slabs, slab_cap, nullptr, 0, 2);
+}
+
 static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
                         int ldb, double beta, double* C, int ldc, double* slabs, size_t slab_cap, const double* Tm,
                         int ldt, int tag)
@@ -917,7 +1009,13 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
         if (tall_tile < 0) { const char* e = getenv("MI355XQR_TN_TALL_TILE"); tall_tile = e ? atoi(e) : 44; }
         if (ti == 4 && tall_tile == 22 && K >= 65536 && (long long) M * N <= 512 * 512) { ti = 2; tj = 2; }
     }
-    const int BM = 32 * ti, BN = 32 * tj;
+    // the wide product of the trailing update on 128 x 256 workgroup tiles (gemm_tn_wide_kernel: A2 read N / 256 times instead of
+    // N / 128) -- measured in round 3: half the HBM traffic, the same rate (16384^2: 50.7 against 51.4 TFLOP/s in situ; the product
+    // is bound on the matrix-core side, not by bytes), so the 128 x 128 kernel stays the default; MI355XQR_TN_WIDE=1 or tag 2 select it
+    static const int wide_ok = [] { const char* e = getenv("MI355XQR_TN_WIDE"); return e ? (int) (atoi(e) != 0) : 0; }();
+    const bool wide = (tag == 2 || (tag == 1 && wide_ok)) && ti == 4 && Tm == nullptr && alpha == 1.0 && beta == 0.0 && N % 256 == 0 && M >= 128 &&
+                      K % BK == 0 && vec_ok(A, lda) && vec_ok(B, ldb) && slabs != nullptr;
+    const int BM = 32 * ti, BN = wide ? 256 : 32 * tj;
     const long long tiles = (long long) ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t per = (size_t) M * N;
     // K split: minimise  rounds(k) * (K/k + fixed) + reduce(k)  over k, where rounds = ceil(tiles*k / slots), slots =
@@ -931,8 +1029,8 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     if (slabs == nullptr || slab_cap < per) kmax = 1;
     else if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
     if (kmax < 1 || shortk) kmax = 1;
-    const int slots = 2 * stream_cus(s);
-    const double row_us = 2.0 * BM * BN / 0.113e6;            // one K row of one tile on one workgroup slot
+    const int slots = (wide ? 1 : 2) * stream_cus(s);
+    const double row_us = 2.0 * BM * BN / (wide ? 0.226e6 : 0.113e6);   // one K row of one tile on one workgroup slot (wide: the whole CU)
     const double red_rows = (double) per * 8.0 / 2.0e6 / row_us;   // reading one slab of the output at ~2 TB/s, in K rows
     int ksplit = 1;
     double best = 1e300;
@@ -953,7 +1051,16 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     if (ti == 1 && tj == 4) rc = launch_tn<1, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else if (ti == 1) rc = launch_tn<1, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else if (ti == 2) rc = launch_tn<2, 2>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
-    else if (tag == 1) rc = launch_tn<4, 4, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (wide) {
+        // interior rows (multiples of 128) on the wide kernel, the ragged rest on the guarded 128 x 128 kernel, same K slices
+        const int Mi = (M / 128) * 128;
+        hipLaunchKernelGGL(gemm_tn_wide_kernel<1>, dim3(Mi / 128, N / 256, ksplit), dim3(512), sizeof(double) * (2 * (128 + 256) * LDKF), s,
+                           K, kchunk, A, lda, B, ldb, dst, ldd, per);
+        rc = (int) hipGetLastError();
+        if (!rc && Mi < M)
+            rc = launch_tn1<4, 4, false>(s, M - Mi, N, K, ksplit, kchunk, alpha, A + (size_t) Mi * lda, lda, B, ldb, b2, dst + Mi, ldd, per);
+    }
+    else if (tag >= 1) rc = launch_tn<4, 4, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     if (rc) return rc;
     if (!direct) {

@@ -148,6 +148,9 @@ int qrd_gemm_tn(void* s, int M, int N, int K, double al, const double* A, int ld
 int qrd_gemm_tn_update(void* s, int M, int N, int K, double al, const double* A, int lda, const double* B, int ldb, double be, double* C, int ldc,
                        double* slabs, size_t cap)
 { return qrd_gemm_tn(s, M, N, K, al, A, lda, B, ldb, be, C, ldc, slabs, cap, NULL, 0); }
+int qrd_gemm_tn_update_wide(void* s, int M, int N, int K, double al, const double* A, int lda, const double* B, int ldb, double be, double* C, int ldc,
+                            double* slabs, size_t cap)
+{ return qrd_gemm_tn(s, M, N, K, al, A, lda, B, ldb, be, C, ldc, slabs, cap, NULL, 0); }
 int qrd_gemm_tn_dual(void* s, int N1, int N2, int K, const double* A, int lda, const double* B1, int ldb1, const double* B2, int ldb2,
                      const double* Tm, int ldt, double* W, int ldw, double* G2, int ldg, double* slabs, size_t cap)
 {

@@ -563,3 +563,26 @@ def test_panel_cholqr_early_product_declines_odd_heights(q):
     V, T = host(dV), host(dT)
     P = panel[:, :w]
     assert np.abs(np.tril(P - V @ (T.T @ (V.T @ P)), -1)).max() < 1e-11
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 256, 4096), (1300, 512, 2064), (128, 256, 512), (3000, 256, 20000), (640, 128, 1024), (2048, 256, 1000)])
+@pytest.mark.parametrize("entry", ["qrd_gemm_tn_update", "qrd_gemm_tn_update_wide"])
+def test_gemm_tn_update_wide_tiles(q, M, N, K, entry):
+    """The wide product of the trailing update, Wt = A2^T (V T): the default 128 x 128 kernel (qrd_gemm_tn_update) and the 128 x 256
+    workgroup tiles of gemm_tn_wide_kernel (qrd_gemm_tn_update_wide: A2 read half as often; the same rate, so not the default) on the
+    interior with the ragged rows on the guarded 128 x 128 kernel and the same K slices; split-K slabs summed in a fixed order --
+    against numpy, and bitwise reproducible run to run.  N = 128 and K not a multiple of 16 take the 128 x 128 kernel throughout."""
+    rng = np.random.default_rng(M + N + K)
+    A, B = rng.standard_normal((K, M)), rng.standard_normal((K, N))
+    dA, dB = dev(A), dev(B)
+    slabs = torch.zeros(1 << 24, dtype=torch.float64, device="cuda")
+    outs = []
+    for rep in range(2):
+        dC = dev(np.full((M, N), np.nan))
+        torch.cuda.synchronize()
+        q.check(getattr(q.lib, entry)(None, M, N, K, 1.0, dA.data_ptr(), K, dB.data_ptr(), K, 0.0, dC.data_ptr(), M, slabs.data_ptr(), 1 << 24))
+        _sync(q)
+        outs.append(host(dC))
+    ref = A.T @ B
+    assert np.abs(outs[0] - ref).max() < 1e-12 * np.sqrt(K) * max(1.0, np.abs(ref).max())
+    assert np.array_equal(outs[0], outs[1])

@@ -107,19 +107,20 @@ def test_2024_square_vs_reference_R_slices(qr, oracle, tmp_path, nb, env):
     assert abs(np.linalg.norm(Rn) - float(g["Rn_fro"])) <= 1e-12 * float(g["Rn_fro"])
 
 
-@pytest.mark.parametrize("cond", [1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e10])
-@pytest.mark.parametrize("mk", [2048, 20000])
-def test_cholqr2_guard_threshold_sweep(qr, oracle, cond, mk):
+@pytest.mark.parametrize("cond", [1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11])
+@pytest.mark.parametrize("mk,w", [(2048, 32), (20000, 32), (4096, 128)])
+def test_cholqr2_guard_threshold_sweep(qr, oracle, cond, mk, w):
     """Leaves whose condition number walks through the region where the CholeskyQR2 route either barely passes its device-side
     guard (max|Q^T Q - I| <= 1/64 after the first pass) or barely fails it and hands the leaf to the Householder TSQR: whichever
     route fires, the result must be Householder-grade (backward error and orthogonality at round-off, R equal to LAPACK's).
-    cond = 1e2 .. 1e7 is where CholeskyQR2 loses digits if the guard were too lax (error ~ cond^2 eps of the FIRST pass)."""
-    w = 32
+    cond = 1e2 .. 1e7 is where CholeskyQR2 loses digits if the guard were too lax (error ~ cond^2 eps of the FIRST pass); 1e9 and
+    1e11 sit on either side of the first-pass pivot test.  w = 128: four leaves in one panel, so the in-panel product that runs on Q
+    beside the reconstruction (early product) and its redo on the guard route are inside the sweep as well."""
     rng = np.random.default_rng(int(np.log10(cond)) * 7 + mk)
     U, _ = np.linalg.qr(rng.standard_normal((mk, w)))
     V, _ = np.linalg.qr(rng.standard_normal((w, w)))
     A = (U * np.logspace(0, -np.log10(cond), w)) @ V.T
-    p = qr.Plan(mk, w, 32, 32)
+    p = qr.Plan(mk, w, 128 if w > 32 else 32, 32)
     dA, dtau, dQ, dR = dev(A), zeros(w, 1), zeros(mk, w), zeros(w, w)
     p.geqrf(dA, mk, w, mk, dtau)
     p.extract_r(dA, mk, w, mk, dR, w, w)

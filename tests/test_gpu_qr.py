@@ -255,10 +255,16 @@ def test_c2_4096_square_nb64_properties(qr):
     p.sync()
     resid, orth, dR = _device_metrics(qr, p, dA, m, n, 12)
     assert resid < 1e-12 and orth < 1e-11
-    # |diag R| against LAPACK on the same matrix (host copy of the generator)
+    # the FULL sign-normalised R against LAPACK on the same matrix (host copy of the generator): the parity definition of the
+    # small golden cases, at the configuration's own size
     A = qr.uniform_matrix_host(m, n, seed=12)
     Rl = np.linalg.qr(A, mode="r")
-    assert np.abs(np.abs(np.diag(host(dR))) - np.abs(np.diag(Rl))).max() < 1e-10 * np.abs(np.diag(Rl)).max()
+    Rl = np.triu(Rl) * np.where(np.diag(Rl) < 0, -1.0, 1.0)[:, None]
+    R = host(dR)
+    assert np.array_equal(np.tril(R, -1), np.zeros_like(R))
+    Rn = R * np.where(np.diag(R) < 0, -1.0, 1.0)[:, None]
+    assert rel(Rn, Rl) < 1e-12                                              # observed ~1e-15
+    assert np.abs(np.diag(Rn) - np.diag(Rl)).max() < 1e-12 * np.abs(np.diag(Rl)).max()
     p.close()
 
 
@@ -273,8 +279,23 @@ def test_c3_16384_square_properties(qr, nb):
     dA = zeros(m, n)
     p.fill_uniform(dA, m, m, n, seed=12)
     p.sync()
-    resid, orth, _ = _device_metrics(qr, p, dA, m, n, 12)
+    resid, orth, dR = _device_metrics(qr, p, dA, m, n, 12)
     assert resid < 5e-14 and orth < 1e-11          # observed 5.3e-15 / 1.0e-12 at nb = 256
+    # R itself against LAPACK dgeqrf of the same matrix: slices of the sign-normalised factor computed once on the CPU
+    # (oracle/make_lapack_slices.py -> tests/golden/lapack_16384_slices.npz: diagonal, row norms, three blocks, the last column)
+    g = load_golden("lapack_16384_slices")
+    assert int(g["n"]) == n and int(g["seed"]) == 12
+    R = host(dR)
+    sgn = np.where(np.diag(R) < 0, -1.0, 1.0)
+    h = n // 2
+    assert np.abs(np.abs(np.diag(R)) - g["diag"]).max() < 1e-12 * g["diag"].max()
+    rn = np.sqrt((R * R).sum(axis=1))
+    assert np.abs(rn - g["rownorm"]).max() < 1e-12 * g["rownorm"].max()
+    for got, ref in ((sgn[:32, None] * R[:32, n - 256:], g["top_right"]),
+                     (sgn[h:h + 48, None] * R[h:h + 48, h:h + 512], g["middle"]),
+                     (sgn[n - 128:, None] * R[n - 128:, n - 128:], g["bottom_right"]),
+                     (sgn * R[:, n - 1], g["col_last"])):
+        assert rel(got, ref) < 1e-12                                        # observed ~1e-14
     p.close()
 
 

@@ -309,19 +309,29 @@ __global__ __launch_bounds__(NT) void tsqr_top_kernel(const double* __restrict__
 
 // A: Cout(block rows, :) = Q_local_b [Cin_b ; 0] = [Cin_b; 0] - V_b (T_b V_b1^T Cin_b),
 // Cin_b = rows [b*w, b*w+w) of the parent's output
+// the five 32 x 33 LDS arrays (+ one vector) the walk-down bodies work in: declared by the calling kernel, so that kernels which run
+// several bodies one after the other (the one-launch guard routes) hold ONE set
+struct WalkLds {
+    double (*Zl)[PW + 1]; double (*V1)[PW + 1]; double (*Cl)[PW + 1]; double (*Wl)[PW + 1]; double (*Ml)[PW + 1];
+    double* tl;
+};
+#define WALK_LDS_DECL(name)                                                                                              \
+    __shared__ double name##_a[5][PW][PW + 1];                                                                           \
+    __shared__ double name##_t[PW];                                                                                      \
+    const WalkLds name = {name##_a[0], name##_a[1], name##_a[2], name##_a[3], name##_a[4], name##_t}
+
 template <int NT>
-__global__ __launch_bounds__(NT) void tsqr_apply_kernel(const double* __restrict__ Vloc, int ldv,
-                                                        const double* __restrict__ tauloc,
-                                                        const double* __restrict__ Tloc, int rows_total, int chunk, int w,
-                                                        const double* __restrict__ Cin, int ldci,
-                                                        double* __restrict__ Cout, int ldco, const int* __restrict__ guard)
+__device__ __forceinline__ void tsqr_apply_body(int b, int nblk, const WalkLds& L, const double* __restrict__ Vloc, int ldv,
+                                                const double* __restrict__ tauloc,
+                                                const double* __restrict__ Tloc, int rows_total, int chunk, int w,
+                                                const double* __restrict__ Cin, int ldci,
+                                                double* __restrict__ Cout, int ldco)
 {
-    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
-    __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1];
-    __shared__ double tl[PW];
-    const int tid = threadIdx.x, b = blockIdx.x;
+    double (*Zl)[PW + 1] = L.Zl; double (*V1)[PW + 1] = L.V1; double (*Cl)[PW + 1] = L.Cl; double (*Wl)[PW + 1] = L.Wl;
+    double (*Ml)[PW + 1] = L.Ml; double* tl = L.tl;
+    const int tid = threadIdx.x;
     int start, rows;
-    block_range(rows_total, chunk, b, gridDim.x, start, rows);
+    block_range(rows_total, chunk, b, nblk, start, rows);
     double x[PW];
     load_block(x, Vloc, ldv, start, tid, rows, w);
     for (int e = tid; e < PW * PW; e += NT) {
@@ -346,6 +356,18 @@ __global__ __launch_bounds__(NT) void tsqr_apply_kernel(const double* __restrict
         for (int q = 0; q < PW; ++q)
             if (q < w) Cout[(size_t) q * ldco + start + tid] = out[q];
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void tsqr_apply_kernel(const double* __restrict__ Vloc, int ldv,
+                                                        const double* __restrict__ tauloc,
+                                                        const double* __restrict__ Tloc, int rows_total, int chunk, int w,
+                                                        const double* __restrict__ Cin, int ldci,
+                                                        double* __restrict__ Cout, int ldco, const int* __restrict__ guard)
+{
+    if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
+    WALK_LDS_DECL(L);
+    tsqr_apply_body<NT>(blockIdx.x, gridDim.x, L, Vloc, ldv, tauloc, Tloc, rows_total, chunk, w, Cin, ldci, Cout, ldco);
 }
 
 // H1: Householder reconstruction on the top w x w block of Q1 = Q_local_0 [C_0; 0].  One 16-wave workgroup; lane
@@ -517,15 +539,15 @@ __global__ __launch_bounds__(64 * HG) void hr_top_kernel(const double* __restric
 // A1 + H2 fused (level 1, last launch of the leaf): V(rows, :) = Q1(rows, :) U^-1 with Q1 = [C_b; 0] - V_b M_b, i.e.
 // V(r, :) = [C_b U^-1; 0](r, :) - V_b(r, :) (M_b U^-1), written straight into the panel and Vw for global rows >= w
 // (the top w rows were written by hr_top_kernel).  No explicit Q1 round trip through memory.
-__device__ __forceinline__ void tsqr_final_body(int bid, const double* __restrict__ Vloc, int ldvl,
+__device__ __forceinline__ void tsqr_final_body(int bid, const WalkLds& L, double (*Ui)[PW + 1], const double* __restrict__ Vloc, int ldvl,
                                                 const double* __restrict__ tauloc, const double* __restrict__ Tloc,
                                                 int rows_total, int nblk, int halves, int w,
                                                 const double* __restrict__ Cin, int ldci,
                                                 const double* __restrict__ Umat, double* __restrict__ A, int lda,
                                                 double* __restrict__ Vw, int ldv)
 {
-    __shared__ double Zl[PW][PW + 1], V1[PW][PW + 1], Cl[PW][PW + 1], Wl[PW][PW + 1], Ml[PW][PW + 1], Ui[PW][PW + 1];
-    __shared__ double tl[PW];
+    double (*Zl)[PW + 1] = L.Zl; double (*V1)[PW + 1] = L.V1; double (*Cl)[PW + 1] = L.Cl; double (*Wl)[PW + 1] = L.Wl;
+    double (*Ml)[PW + 1] = L.Ml; double* tl = L.tl;
     const int tid = threadIdx.x, b = bid / halves, h = bid % halves;
     int bstart, brows;
     block_range(rows_total, 0, b, nblk, bstart, brows);             // the level-0 block
@@ -573,7 +595,9 @@ __global__ __launch_bounds__(PT) void tsqr_final_kernel(const double* __restrict
                                                         double* __restrict__ Vw, int ldv, const int* __restrict__ guard)
 {
     if (guard && *guard == 0) return;        // the CholeskyQR2 leaf succeeded: this fallback launch is a no-op
-    tsqr_final_body(blockIdx.x, Vloc, ldvl, tauloc, Tloc, rows_total, nblk, halves, w, Cin, ldci, Umat, A, lda, Vw, ldv);
+    WALK_LDS_DECL(L);
+    __shared__ double Ui[PW][PW + 1];
+    tsqr_final_body(blockIdx.x, L, Ui, Vloc, ldvl, tauloc, Tloc, rows_total, nblk, halves, w, Cin, ldci, Umat, A, lda, Vw, ldv);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -617,6 +641,8 @@ __device__ __forceinline__ void tsqr_coop_body(const double* P, int ld, int mk, 
 {
     const int b = blockIdx.x, G = nblk, rows_stack = nblk * w;      // participants: workgroups 0 .. nblk-1 (the launch may hold more)
     bool ok = true;
+    WALK_LDS_DECL(L);
+    __shared__ double Ui[PW][PW + 1];
     // F: local Householder QR of this workgroup's row block (<= 1024 rows: two rows per thread)
     tsqr_factor_body<PT, 2>(b, nblk, P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stack, rows_stack);
     ok = coop_barrier(bar, (unsigned) G) && ok;
@@ -628,7 +654,7 @@ __device__ __forceinline__ void tsqr_coop_body(const double* P, int ld, int mk, 
     ok = coop_barrier(bar, 3u * (unsigned) G) && ok;
     // Fin: every block writes its rows of V
     for (int h = 0; h < halves; ++h) {
-        tsqr_final_body(b * halves + h, Vloc1, mk, taus, Ts, mk, nblk, halves, w, Ctop, rows_stack, Umat, A, lda, Vw, ldv);
+        tsqr_final_body(b * halves + h, L, Ui, Vloc1, mk, taus, Ts, mk, nblk, halves, w, Ctop, rows_stack, Umat, A, lda, Vw, ldv);
         __syncthreads();
     }
     if (!ok && b == 0 && threadIdx.x < w) tau[threadIdx.x] = __builtin_nan("");
@@ -644,6 +670,77 @@ __global__ __launch_bounds__(PT) void tsqr_coop_kernel(const double* P, int ld, 
 {
     if (*guard == 0) return;                 // the CholeskyQR2 leaf succeeded: nothing to do, one kernel boundary paid
     tsqr_coop_body(P, ld, mk, w, nblk, halves, Vloc1, taus, Ts, stack, Rt, Ctop, Umat, A, lda, tau, T, ldt, Vw, ldv, bar);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same for TALL leaves (two or three tree levels, up to 2^21 rows): the six guard launches -- level-0 factor, upper-level
+// factor(s), top, walk down, reconstruction, final -- as ONE launch of G persistent workgroups (G = min(level-0 blocks, compute units
+// of the stream): one per CU, co-resident) that walk their blocks grid-stride between software grid barriers.  Six launches that found
+// the guard word clear cost 28 us per 32-column leaf: 0.46 ms of a 6.9 ms 262144 x 512 factorisation, a quarter of a 65536-row leaf.
+// ---------------------------------------------------------------------------------------------------------
+#define TALL_MAXL 3              /* upper levels 1, 2: leaves of up to 4 M rows; the level loops are unrolled (constant indices into the by-value tree) */
+struct TallTree {
+    int L;                          // upper levels 1 .. L (0: the level-0 R factors go straight to the top)
+    int nblk0, halves;              // level-0 blocks (1024 rows: halves = 2) and final-phase workgroup items per block
+    int rows[TALL_MAXL], nblk[TALL_MAXL], chunk[TALL_MAXL];
+    long long off[TALL_MAXL], tau[TALL_MAXL];   // level l's input stack / reflectors / coefficients at stacks|Vup|Cup + off, taus at + tau
+    long long top_off; int top_rows;            // the last stack
+};
+
+__device__ __forceinline__ void tsqr_coop_tall_body(const TallTree& t, int G, const double* P, int ld, int mk, int w,
+                                                    double* __restrict__ Vloc1, double* __restrict__ Vup, double* __restrict__ taus,
+                                                    double* __restrict__ Ts, double* __restrict__ stacks, double* __restrict__ Cup,
+                                                    double* __restrict__ Rt, double* __restrict__ Umat, double* A, int lda,
+                                                    double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                    double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar, unsigned& tgt)
+{
+    const int wg = blockIdx.x;
+    bool ok = true;
+    WALK_LDS_DECL(L);
+    __shared__ double Ui[PW][PW + 1];
+    // level 0: local Householder QR of the 1024-row blocks
+    for (int b = wg; b < t.nblk0; b += G) {
+        tsqr_factor_body<PT, 2>(b, t.nblk0, P, ld, mk, 0, w, Vloc1, mk, taus, Ts, stacks, t.nblk0 * w);
+        __syncthreads();
+    }
+    tgt += (unsigned) G; ok = coop_barrier(bar, tgt) && ok;
+    // up the tree: QR of the stacked R factors, 512 rows (16 factors) per block
+#pragma unroll
+    for (int l = 1; l < TALL_MAXL; ++l) {
+        if (l > t.L) break;
+        for (int b = wg; b < t.nblk[l]; b += G) {
+            tsqr_factor_body<PT, 2>(b, t.nblk[l], stacks + t.off[l], t.rows[l], t.rows[l], t.chunk[l], w, Vup + t.off[l], t.rows[l],
+                                    taus + t.tau[l], Ts + t.tau[l] * PW, stacks + t.off[l] + (long long) t.rows[l] * PW, t.nblk[l] * w);
+            __syncthreads();
+        }
+        tgt += (unsigned) G; ok = coop_barrier(bar, tgt) && ok;
+    }
+    // top: factor + explicit Q of the last stack
+    if (wg == 0) tsqr_top_body<PT, 1>(stacks + t.top_off, t.top_rows, t.top_rows, w, Rt, Cup + t.top_off, t.top_rows);
+    tgt += (unsigned) G; ok = coop_barrier(bar, tgt) && ok;
+    // down the tree
+    const double* Cin = Cup + t.top_off;
+    int ldci = t.top_rows;
+#pragma unroll
+    for (int l = TALL_MAXL - 1; l >= 1; --l) {
+        if (l > t.L) continue;
+        for (int b = wg; b < t.nblk[l]; b += G) {
+            tsqr_apply_body<PT>(b, t.nblk[l], L, Vup + t.off[l], t.rows[l], taus + t.tau[l], Ts + t.tau[l] * PW, t.rows[l], t.chunk[l], w,
+                                Cin, ldci, Cup + t.off[l], t.rows[l]);
+            __syncthreads();
+        }
+        tgt += (unsigned) G; ok = coop_barrier(bar, tgt) && ok;
+        Cin = Cup + t.off[l];
+        ldci = t.rows[l];
+    }
+    // Householder reconstruction of the top block, then every block writes its rows of V
+    if (wg == 0) hr_top_body<PT / 64>(Vloc1, mk, taus, Ts, Cin, ldci, Rt, w, A, lda, tau, T, ldt, Vw, ldv, Umat);
+    tgt += (unsigned) G; ok = coop_barrier(bar, tgt) && ok;
+    for (int hb = wg; hb < t.nblk0 * t.halves; hb += G) {
+        tsqr_final_body(hb, L, Ui, Vloc1, mk, taus, Ts, mk, t.nblk0, t.halves, w, Cin, ldci, Umat, A, lda, Vw, ldv);
+        __syncthreads();
+    }
+    if (!ok && wg == 0 && threadIdx.x < w) tau[threadIdx.x] = __builtin_nan("");
 }
 
 // mk <= 512: the whole leaf in one workgroup -- V, R, tau and T in a single launch.
@@ -2106,6 +2203,59 @@ __global__ __launch_bounds__(PT) void final3_coop_kernel(const double* __restric
     final3_finish<true>(a, Usm, uinv, Vw, ldv, mk, w, A, lda, ep ? epw : nullptr);
 }
 
+// tall leaves: the last CholeskyQR2 launch (final3) and the one-launch tall guard route (tsqr_coop_tall_body) share a grid the same
+// way; the first G workgroups are the guard route's participants
+__global__ __launch_bounds__(PT) void final3_coop_tall_kernel(const double* __restrict__ Um, TallTree t, int G, int mk, int w,
+                                                              double* __restrict__ Vloc1, double* __restrict__ Vup, double* __restrict__ taus,
+                                                              double* __restrict__ Ts, double* __restrict__ stacks, double* __restrict__ Cup,
+                                                              double* __restrict__ Rt, double* __restrict__ Umat, double* A, int lda,
+                                                              double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                              double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
+                                                              const int* __restrict__ guard, int ep, double* __restrict__ epw, EpArgs e)
+{
+    __shared__ double Usm[PW][PW + 1];
+    __shared__ double uinv[PW];
+    if (*guard != 0) {
+        if ((int) blockIdx.x >= G) return;
+        unsigned tgt = 0u;
+        tsqr_coop_tall_body(t, G, A, lda, mk, w, Vloc1, Vup, taus, Ts, stacks, Cup, Rt, Umat, A, lda, tau, T, ldt, Vw, ldv, bar, tgt);
+        if (ep) {
+            tgt += (unsigned) G;
+            coop_barrier(bar, tgt);                            // V is complete in every workgroup's rows
+            if (blockIdx.x == 0) ep_fallback_folds(epw);
+            if (threadIdx.x >= 256) return;
+            for (int item = blockIdx.x; item < e.tiles * e.ksplit; item += G) ep_product_item(e, item, e.Q);
+        }
+        return;
+    }
+    double a[PW];
+    final3_load<true>(a, Usm, uinv, Vw, ldv, mk, w, Um);
+    final3_finish<true>(a, Usm, uinv, Vw, ldv, mk, w, A, lda, ep ? epw : nullptr);
+}
+
+// ... and on its own, behind a separate final3 launch: fused, final3 inherits this kernel's footprint (256 VGPRs, 140 KB of LDS: one
+// workgroup per compute unit), which costs a 262144-row leaf's final3 more bandwidth (36 -> ~55 us) than the saved launch is worth;
+// leaves whose final3 has no more workgroups than the stream has compute units lose nothing and take the fused form
+__global__ __launch_bounds__(PT) void tsqr_coop_tall_kernel(TallTree t, int G, int mk, int w,
+                                                            double* __restrict__ Vloc1, double* __restrict__ Vup, double* __restrict__ taus,
+                                                            double* __restrict__ Ts, double* __restrict__ stacks, double* __restrict__ Cup,
+                                                            double* __restrict__ Rt, double* __restrict__ Umat, double* A, int lda,
+                                                            double* __restrict__ tau, double* __restrict__ T, int ldt,
+                                                            double* __restrict__ Vw, int ldv, unsigned* __restrict__ bar,
+                                                            const int* __restrict__ guard, int ep, double* __restrict__ epw, EpArgs e)
+{
+    if (*guard == 0) return;
+    unsigned tgt = 0u;
+    tsqr_coop_tall_body(t, G, A, lda, mk, w, Vloc1, Vup, taus, Ts, stacks, Cup, Rt, Umat, A, lda, tau, T, ldt, Vw, ldv, bar, tgt);
+    if (ep) {
+        tgt += (unsigned) G;
+        coop_barrier(bar, tgt);
+        if (blockIdx.x == 0) ep_fallback_folds(epw);
+        if (threadIdx.x >= 256) return;
+        for (int item = blockIdx.x; item < e.tiles * e.ksplit; item += G) ep_product_item(e, item, e.Q);
+    }
+}
+
 // the same for the third-generation leaf (Um = U'^-1, final4_body)
 __global__ __launch_bounds__(PT) void final4_coop_kernel(const double* __restrict__ Um, int nblk, int halves, int mk, int w,
                                                          double* __restrict__ Vloc1, double* __restrict__ taus, double* __restrict__ Ts,
@@ -2264,6 +2414,47 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
                                stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, ep ? 1 : 0, epw, ep0);
         return (int) hipGetLastError();
     }
+    // tall leaf behind a CholeskyQR2 attempt (second-generation kernels): final3 and the whole multi-level guard route in one launch
+    static const int tall_coop = [] { const char* e = getenv("MI355XQR_TALL_COOP"); return e ? (int) (atoi(e) != 0) : 1; }();
+    if (final3_u && gen == 2 && guard && bar && !coop && coop_enabled() && tall_coop && fuse && w == PW && brows0 == 2 * PT) {
+        TallTree t{};
+        t.nblk0 = lv_nblk[0]; t.halves = brows0 / PT;
+        long long off = 0, toff = (long long) lv_nblk[0] * PW;
+        int cur_rows = lv_nblk[0] * w, Lv = 0;
+        const int gchunk = (PT / w) * w;
+        bool fits = true;
+        while (cur_rows > PT) {
+            if (Lv + 2 >= TALL_MAXL) { fits = false; break; }
+            ++Lv;
+            t.rows[Lv] = cur_rows; t.chunk[Lv] = gchunk; t.nblk[Lv] = (cur_rows + gchunk - 1) / gchunk;
+            t.off[Lv] = off; t.tau[Lv] = toff;
+            off += (long long) cur_rows * PW; toff += (long long) t.nblk[Lv] * PW;
+            cur_rows = t.nblk[Lv] * w;
+        }
+        if (fits) {
+            t.L = Lv; t.top_off = off; t.top_rows = cur_rows;
+            // participants: the launch is a no-op nearly always, and what a no-op costs is dispatching its workgroups (140 KB of LDS
+            // each) -- 64 are gone in ~5 us; on the guard route they walk their blocks grid-stride (MI355XQR_TALL_COOP_G to change)
+            static const int gcap = [] { const char* e = getenv("MI355XQR_TALL_COOP_G"); const int v = e ? atoi(e) : 64; return v < 1 ? 64 : v; }();
+            int G = qrd_stream_cus(stream);
+            if (G > gcap) G = gcap;
+            if (G > t.nblk0) G = t.nblk0;
+            if (G < 1) G = 1;
+            const int fblocks = (mk + PT - 1) / PT;
+            // MI355XQR_TALL_COOP_FUSE=0: final3 always as its own launch (measured equal within noise at 65536 / 131072 rows:
+            // 1.04 / 1.46 ms against 1.03 / 1.43 fused)
+            static const int fuse_tall = [] { const char* e = getenv("MI355XQR_TALL_COOP_FUSE"); return e ? (int) (atoi(e) != 0) : 1; }();
+            if (fuse_tall && fblocks <= qrd_stream_cus(stream))
+                hipLaunchKernelGGL(final3_coop_tall_kernel, dim3(fblocks > G ? fblocks : G), dim3(PT), ep_shm, s, final3_u, t, G, mk, w, Vloc1, Vup,
+                                   taus, Ts, stacks, Cup, Rt, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, ep ? 1 : 0, epw, ep0);
+            else {
+                hipLaunchKernelGGL(final3_kernel<true>, dim3(fblocks), dim3(PT), 0, s, Vw, ldv, mk, w, final3_u, P, ld, guard, ep ? epw : nullptr);
+                hipLaunchKernelGGL(tsqr_coop_tall_kernel, dim3(G), dim3(PT), ep_shm, s, t, G, mk, w, Vloc1, Vup, taus, Ts, stacks, Cup, Rt, Umat,
+                                   P, ld, tau, T, ldt, Vw, ldv, bar, guard, ep ? 1 : 0, epw, ep0);
+            }
+            return (int) hipGetLastError();
+        }
+    }
     if (final3_u && gen == 3)
         hipLaunchKernelGGL(final4_kernel, dim3((mk + PT - 1) / PT), dim3(PT), 0, s, Vw, ldv, mk, final3_u, P, ld, guard, ep ? epw : nullptr);
     else if (final3_u)
@@ -2358,6 +2549,8 @@ int qrd_panel_tsqr_init(void)
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(hr3_ep_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_FUSED_SMEM_BYTES(4));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(final4_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_SMEM_BYTES);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(final3_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_SMEM_BYTES);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(final3_coop_tall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_SMEM_BYTES);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(tsqr_coop_tall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) EP_SMEM_BYTES);
     return rc;
 }
 

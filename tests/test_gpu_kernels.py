@@ -258,10 +258,10 @@ def _cholqr_leaf(q, P, ld=None, ldv=None, ldt=None):
     dtau, dT, dV = zeros(w, 1), dev(np.full((ldt, w), np.nan)), dev(np.full((ldv, w), np.nan))
     ws = torch.zeros(int(q.lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
     cws = torch.zeros(4 * 32 * 32 + 16, dtype=torch.float64, device="cuda")
-    slabs = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+    slabs = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     q.check(q.lib.qrd_panel_cholqr(None, dP.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), ldt, dV.data_ptr(), ldv,
-                                   ws.data_ptr(), mk, cws.data_ptr(), slabs.data_ptr(), 1 << 20, 0))
+                                   ws.data_ptr(), mk, cws.data_ptr(), slabs.data_ptr(), 1 << 22, 0))
     _sync(q)
     guard = int(cws[4 * 32 * 32:].view(torch.int32)[0].item())
     return host(dP), host(dtau)[:, 0], host(dT)[:w], host(dV)[:mk], guard, buf
@@ -335,11 +335,12 @@ def test_panel_cholqr2_guard_falls_back_to_householder(q, oracle, kind):
         assert np.linalg.norm(oracle.sign_normalise(R) - ref) / np.linalg.norm(ref) < rtol
 
 
-@pytest.mark.parametrize("mk", [514, 700, 1024, 4098, 8192, 8194, 16384, 16386, 40000])
+@pytest.mark.parametrize("mk", [514, 700, 1024, 4098, 8192, 8194, 16384, 16386, 40000, 65536, 70002, 262144, 300000])
 def test_panel_guard_route_all_heights(q, oracle, mk):
     """A leaf the CholeskyQR2 route must refuse (two equal columns) at heights on both sides of every switch of the guard route:
-    one block / several blocks, 512- and 1024-row blocks, the one-launch cooperative form (<= 16 blocks) and the separate launches
-    (two tree levels), odd sizes.  The Householder route's result must be a valid compact-WY panel."""
+    one block / several blocks, 512- and 1024-row blocks, the one-launch cooperative form of short leaves (<= 16 blocks) and of tall
+    ones (persistent workgroups, one upper tree level up to 262144 rows, two above), odd sizes.  The Householder route's result must
+    be a valid compact-WY panel."""
     w = 32
     P = np.random.default_rng(mk).random((mk, w))
     P[:, 17] = P[:, 4]

@@ -56,6 +56,9 @@ _sig("dgemm_status", C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int)
 _sig("dgemm", None, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int)
 _sig("identity", None, _dp, C.c_int)
 _sig("printMat", None, _dp, C.c_int, C.c_int)
+_sig("getPanelDims_legacy", None, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int))
+_sig("mmqr_legacy_status", C.c_int, _dp, C.POINTER(_dp), C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("explicitQR_legacy_status", C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("qr_strerror", C.c_char_p, C.c_int)
 _sig("qr_set_block_size", C.c_int, C.c_int, C.c_int)
 _sig("qr_get_block_size", None, C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -212,6 +215,29 @@ def explicit_qr(F, tau):
     Q = np.empty((m, m), order="F")
     R = np.empty((m, n), order="F")
     check(lib.explicitQR_status(_p(F), _p(tau), _p(Q), _p(R), m, n), "explicitQR")
+    return Q, R
+
+
+def mmqr_legacy(A, PR, PC):
+    """The reference's sliding-window MMQR itself (legacy-layout shim): (factored copy, window-indexed tau) for window PR x PC."""
+    F = np.array(A, dtype=np.float64, order="F", copy=True)
+    m, n = F.shape
+    tptr = _dp()
+    check(lib.mmqr_legacy_status(_p(F), C.byref(tptr), m, n, PR, PC), "mmqr_legacy")
+    rp, cp = C.c_int(), C.c_int()
+    lib.getPanelDims_legacy(m, n, PR, PC, C.byref(rp), C.byref(cp))
+    tau = np.ctypeslib.as_array(tptr, shape=(rp.value * cp.value * PC,)).copy()
+    _libc.free(C.cast(tptr, C.c_void_p))
+    return F, tau
+
+
+def explicit_qr_legacy(F, tau, PR, PC):
+    F = _f(F)
+    m, n = F.shape
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    Q = np.empty((m, m), order="F")
+    R = np.empty((m, n), order="F")
+    check(lib.explicitQR_legacy_status(_p(F), _p(tau), _p(Q), _p(R), m, n, PR, PC), "explicitQR_legacy")
     return Q, R
 
 

@@ -66,6 +66,12 @@ double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx);
 int qrd_diff_norm(void* stream, const double* X, int ldx, const double* Y, int ldy, long long rows, int cols,
                   long long row_off, long long total_rows, unsigned long long seed, int sub_identity, double* out);
 
+/* the reference's sliding-window schedule on the device (qr_legacy.hip): legacy-layout shim */
+size_t qrd_legacy_ws_size(int m, int PR, int PC);
+int qrd_legacy_shape_ok(int m, int n, int PR, int PC);
+int qrd_legacy_panel(void* stream, double* A, int m, int n, int PR, int PC, int rowPanels, int pc, int pcCount, double* tau, double* wy);
+int qrd_legacy_formq(void* stream, const double* A, const double* tau, int m, int n, int PR, int PC, int rowPanels, double* Q);
+
 /* RCCL glue (qr_comm.hip): librccl is dlopen()ed on first use, never linked */
 #define QRD_E_NORCCL (-120)   /* librccl.so could not be loaded */
 #define QRD_E_RCCL   (-130)   /* an RCCL call failed: -130 - ncclResult_t */

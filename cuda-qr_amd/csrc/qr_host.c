@@ -1341,6 +1341,80 @@ int explicitQR_f32_status(float* A, float* tau, float* Q, float* R, int m, int n
     return rc;
 }
 
+/* ---- legacy-layout shim: the reference's sliding-window MMQR itself, window shape as arguments ---------------
+ * For callers that read the RAW factored form: reflector tails where the reference leaves them and the window-indexed tau array
+ * tau[(rowPanels * pcCount + prCount) * PC + i] (qr.c:300-304; main's debug print reads it, qr.c:483-490).  That form describes the
+ * reference's own reflector set for a given PR x PC (compile-time macros there, qr.c:12-13) and cannot be derived from the blocked
+ * factorisation, so the device runs the reference's schedule (qr_legacy.hip): one launch pair per column panel.  The same shape
+ * constraints as the reference's loops silently assume (n % PC == 0, (m - PR) % (PR - PC) == 0), checked here. */
+void getPanelDims_legacy(int m, int n, int PR, int PC, int* rowPanels, int* colPanels)
+{
+    if (PC < 1 || PR <= PC) { if (rowPanels) *rowPanels = 0; if (colPanels) *colPanels = 0; return; }
+    if (colPanels) *colPanels = n / PC + (n % PC != 0);                       /* qr.c:47-53 */
+    if (rowPanels) {
+        *rowPanels = 1;
+        if (m > PR) { const int span = m - PR, step = PR - PC; *rowPanels += span / step + (span % step != 0); }
+    }
+}
+
+int mmqr_legacy_status(double* mat, double** tau, int m, int n, int PR, int PC)
+{
+    if (!mat || !tau || n < 1 || m < n || !qrd_legacy_shape_ok(m, n, PR, PC)) return QR_E_ARG;
+    CHECK(ensure_device());
+    int rp = 0, cp = 0;
+    getPanelDims_legacy(m, n, PR, PC, &rp, &cp);
+    const size_t ntau = (size_t) rp * cp * PC, bytes = sizeof(double) * (size_t) m * n;
+    double* htau = (double*) calloc(ntau, sizeof(double));                     /* zero-filled like qr.c:61-62 */
+    if (!htau) return QR_E_ALLOC;
+    void* s = NULL;
+    double *dA = NULL, *dtau = NULL, *dwy = NULL;
+    int rc = qrd_stream_create(&s, 0);
+    if (!rc) rc = qrd_malloc((void**) &dA, bytes);
+    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * ntau);
+    if (!rc) rc = qrd_malloc((void**) &dwy, sizeof(double) * qrd_legacy_ws_size(m, PR, PC));
+    if (!rc) rc = qrd_memset(s, dtau, 0, sizeof(double) * ntau);
+    if (!rc) rc = qrd_h2d(s, dA, mat, bytes);
+    int pcCount = 0;
+    for (int pc = 0; pc < n && !rc; pc += PC, ++pcCount)                       /* qr.c:68: column panels left -> right */
+        rc = qrd_legacy_panel(s, dA, m, n, PR, PC, rp, pc, pcCount, dtau, dwy);
+    if (!rc) rc = qrd_d2h(s, mat, dA, bytes);
+    if (!rc) rc = qrd_d2h(s, htau, dtau, sizeof(double) * ntau);
+    if (s) { const int rs = qrd_stream_sync(s); if (!rc) rc = rs; }
+    qrd_free(dA); qrd_free(dtau); qrd_free(dwy);
+    if (s) qrd_stream_destroy(s);
+    if (rc) { free(htau); return rc; }
+    *tau = htau;
+    return 0;
+}
+
+/* R (m x n: upper triangle of A, qr.c:334-343) and the dense m x m Q = product of the reflectors in the reference's order
+ * (qr.c:353-438) from mmqr_legacy_status's output */
+int explicitQR_legacy_status(double* A, double* tau, double* Q, double* R, int m, int n, int PR, int PC)
+{
+    if (!A || !tau || !Q || !R || n < 1 || m < n || !qrd_legacy_shape_ok(m, n, PR, PC)) return QR_E_ARG;
+    CHECK(ensure_device());
+    int rp = 0, cp = 0;
+    getPanelDims_legacy(m, n, PR, PC, &rp, &cp);
+    const size_t ntau = (size_t) rp * cp * PC, abytes = sizeof(double) * (size_t) m * n, qbytes = sizeof(double) * (size_t) m * m;
+    void* s = NULL;
+    double *dA = NULL, *dtau = NULL, *dQ = NULL, *dR = NULL;
+    int rc = qrd_stream_create(&s, 0);
+    if (!rc) rc = qrd_malloc((void**) &dA, abytes);
+    if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * ntau);
+    if (!rc) rc = qrd_malloc((void**) &dQ, qbytes);
+    if (!rc) rc = qrd_malloc((void**) &dR, abytes);
+    if (!rc) rc = qrd_h2d(s, dA, A, abytes);
+    if (!rc) rc = qrd_h2d(s, dtau, tau, sizeof(double) * ntau);
+    if (!rc) rc = qrd_extract_r(s, dA, m, m, n, dR, m, m);
+    if (!rc) rc = qrd_legacy_formq(s, dA, dtau, m, n, PR, PC, rp, dQ);
+    if (!rc) rc = qrd_d2h(s, R, dR, abytes);
+    if (!rc) rc = qrd_d2h(s, Q, dQ, qbytes);
+    if (s) { const int rs = qrd_stream_sync(s); if (!rc) rc = rs; }
+    qrd_free(dA); qrd_free(dtau); qrd_free(dQ); qrd_free(dR);
+    if (s) qrd_stream_destroy(s);
+    return rc;
+}
+
 static void complain(const char* fn, int rc)
 {
     if (rc) fprintf(stderr, "mi355xqr: %s failed: %s (%d)\n", fn, qr_strerror(rc), rc);

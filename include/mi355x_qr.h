@@ -60,12 +60,23 @@ int dgemm_status(double* A, double* B, double* C, int k, int m, int n);
 /* Float instantiation (the reference as committed has Scalar = float, qr.c:11): mmqr / explicitQR on float
  * arrays with the same layouts and ownership rules.  The arithmetic is fp64 on the device (inputs widened, outputs rounded
  * once), so the results are at least as accurate as a float build of the reference.  The reference's window-indexed tau
- * layout (qr.c:300-304) is NOT reproduced in either precision: it describes the reflectors of its sliding-window algorithm
- * and cannot be derived from a different reflector set. */
+ * layout (qr.c:300-304) is not what these return (it describes the reflectors of its sliding-window algorithm and cannot be
+ * derived from a different reflector set): mmqr_legacy_status below runs that algorithm for callers who need it. */
 void mmqr_f32(float* mat, float** tau, int m, int n);
 void explicitQR_f32(float* A, float* tau, float* Q, float* R, int m, int n);
 int mmqr_f32_status(float* mat, float** tau, int m, int n);
 int explicitQR_f32_status(float* A, float* tau, float* Q, float* R, int m, int n);
+
+/* Legacy-layout shim: the reference's sliding-window MMQR ITSELF on the device, with its compile-time window
+ * PR x PC (qr.c:12-13) as arguments, for callers that consume the raw factored form -- the reflector tails exactly where qr.c:242-248
+ * leaves them and tau[(rowPanels * pcCount + prCount) * PC + i] (qr.c:300-304; read by the reference's main, qr.c:483-490).
+ * mmqr_legacy_status = qr.c:55-313, explicitQR_legacy_status = qr.c:330-438, getPanelDims_legacy = qr.c:47-53 for a given window.
+ * Results equal the reference's to rounding (sums in wave-reduction order; tests: 1e-12 of the matrix scale), NaN for a zero column
+ * like the reference (qr.c:152).  Shapes: what the reference's loops assume -- n % PC == 0, (m - PR) % (PR - PC) == 0, m >= PR --
+ * with PR <= 64 and PC in {2, 4, 8, 16}; anything else is QR_E_ARG.  Two launches per column panel: a compatibility path, not a fast one. */
+void getPanelDims_legacy(int m, int n, int PR, int PC, int* rowPanels, int* colPanels);
+int mmqr_legacy_status(double* mat, double** tau, int m, int n, int PR, int PC);
+int explicitQR_legacy_status(double* A, double* tau, double* Q, double* R, int m, int n, int PR, int PC);
 
 #define QR_E_ARG      (-101)  /* bad argument (null pointer, m < n, non-positive size) */
 #define QR_E_ALLOC    (-102)  /* host allocation failed */

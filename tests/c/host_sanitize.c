@@ -140,6 +140,23 @@ int main(void)
         OK(qr_tsqr_plan_destroy(t));
         OK(qr_device_free(dA)); OK(qr_device_free(dQ)); OK(qr_device_free(dR));
     }
+    /* 5. legacy-layout shim: argument checks and buffer sizes of the sliding-window path */
+    {
+        const int m = 512, n = 128;
+        double* A = (double*) calloc((size_t) m * n, sizeof(double));
+        double* Q = (double*) calloc((size_t) m * m, sizeof(double));
+        double* R = (double*) calloc((size_t) m * n, sizeof(double));
+        double* tau = NULL;
+        OK(mmqr_legacy_status(A, &tau, m, n, 64, 8));
+        int rp = 0, cp = 0;
+        getPanelDims_legacy(m, n, 64, 8, &rp, &cp);
+        if (rp != 9 || cp != 16) return 7;                                  /* C1 @PR64/PC8 is a 9 x 16 grid */
+        tau[(size_t) rp * cp * 8 - 1] = 0.0;
+        OK(explicitQR_legacy_status(A, tau, Q, R, m, n, 64, 8));
+        free(tau);
+        if (mmqr_legacy_status(A, &tau, m, n, 64, 7) != QR_E_ARG || mmqr_legacy_status(A, &tau, 500, n, 64, 8) != QR_E_ARG) return 8;
+        free(A); free(Q); free(R);
+    }
     if (qrd_stub_live_allocations() != 0) {
         fprintf(stderr, "device-memory leak: %d allocations still live\n", qrd_stub_live_allocations());
         return 6;

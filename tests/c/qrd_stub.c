@@ -234,6 +234,20 @@ int qrd_diff_norm(void* s, const double* X, int ldx, const double* Y, int ldy, l
                   unsigned long long seed, int si, double* out)
 { (void) s; (void) ro; (void) tr; (void) seed; (void) si; chk("diffnorm X", X, ldx, (long) rows, cols); if (Y) chk("diffnorm Y", Y, ldy, (long) rows, cols); out[0] = 0.0; out[1] = 1.0; return 0; }
 
+size_t qrd_legacy_ws_size(int m, int PR, int PC) { return (size_t) (1 + (m - PR) / (PR - PC)) * 2 * (size_t) PC * 64; }
+int qrd_legacy_shape_ok(int m, int n, int PR, int PC)
+{ return PR >= 2 && PR <= 64 && (PC == 2 || PC == 4 || PC == 8 || PC == 16) && PC < PR && m >= PR && n >= PC && n % PC == 0 && n <= m && (m - PR) % (PR - PC) == 0; }
+int qrd_legacy_panel(void* s, double* A, int m, int n, int PR, int PC, int rp, int pc, int pcCount, double* tau, double* wy)
+{
+    (void) s; (void) pc;
+    if (pcCount < 0 || pcCount >= n / PC) { fprintf(stderr, "qrd_stub: legacy panel index out of range\n"); abort(); }
+    chk("legacy A", A, m, m, n);
+    chkb("legacy tau all", tau, sizeof(double) * (size_t) rp * (size_t) (n / PC) * PC); chkb("legacy wy", wy, sizeof(double) * qrd_legacy_ws_size(m, PR, PC));
+    return 0;
+}
+int qrd_legacy_formq(void* s, const double* A, const double* tau, int m, int n, int PR, int PC, int rp, double* Q)
+{ (void) s; (void) PR; chk("legacy A", A, m, m, n); chkb("legacy tau", tau, sizeof(double) * (size_t) rp * (size_t) (n / PC) * PC); chk("legacy Q", Q, m, m, m); return 0; }
+
 /* ---- "RCCL": a thread-level all-gather (one thread per device, the way qr_thin_mgpu drives it) ---- */
 typedef struct stub_world { int n; pthread_barrier_t bar; const double* send[64]; } stub_world;
 typedef struct stub_comm { stub_world* w; int rank; } stub_comm;

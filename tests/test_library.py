@@ -135,6 +135,22 @@ def test_default_block_size_sizes_tau(qr):
     assert out.returncode == 0, out.stderr[-2000:]
 
 
+def test_legacy_shim_panel_dims_and_argument_checks(qr):
+    """getPanelDims_legacy = the reference's formula (qr.c:47-53) for a given window; shapes the reference's loops cannot factor
+    are refused before anything touches a device."""
+    rp, cp = C.c_int(), C.c_int()
+    qr.lib.getPanelDims_legacy(512, 128, 64, 8, C.byref(rp), C.byref(cp))
+    assert (rp.value, cp.value) == (9, 16)                       # SURVEY 8a: C1 at PR 64 / PC 8
+    qr.lib.getPanelDims_legacy(512, 128, 4, 2, C.byref(rp), C.byref(cp))
+    assert (rp.value, cp.value) == (255, 64)                     # C1 as committed (PR 4 / PC 2)
+    qr.lib.getPanelDims_legacy(6, 4, 4, 2, C.byref(rp), C.byref(cp))
+    assert (rp.value, cp.value) == (2, 2)
+    A = np.zeros((100, 32), order="F")
+    t = C.POINTER(C.c_double)()
+    for PR, PC in ((64, 8), (128, 8), (64, 3), (8, 8)):
+        assert qr.lib.mmqr_legacy_status(A.ctypes.data_as(C.POINTER(C.c_double)), C.byref(t), 100, 32, PR, PC) == -101
+
+
 def test_strerror_names_rccl_failures(qr):
     assert "rccl" in qr.strerror(-120).lower()
     assert "argument" not in qr.strerror(-133).lower()          # an RCCL failure (-130 - ncclResult_t) is not an argument error

@@ -190,7 +190,7 @@ def main():
 
     # the C-ABI device-resident step (qr_tsqr_plan: local QR -> ncclAllGather -> stacked QR, all issued from C); with one rank it
     # is the plain qr_plan of the square configs.  Creating it is collective for N > 1 (ncclCommInitRank).
-    wd.arm(args.watchdog, "qr_tsqr_plan_create (ncclCommInitRank over the ranks of this node)")
+    wd.arm(args.watchdog + (60.0 if world > 1 else 0.0), "qr_tsqr_plan_create (ncclCommInitRank over the ranks of this node)")
     be = T.DeviceTSQR(qr, m_local, n, world, rank, nb, transport="rccl" if backend == "nccl" else "host")
     ts = be
     rccl_ranks = be.tp.comm_ranks() if (world > 1 and backend == "nccl") else None
@@ -323,12 +323,12 @@ def main():
         except Exception:
             measured = None
     # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 counter passes cannot share a process with the
-    # timed region, and crash on CU-masked streams on this pool).  The committed round-2 PMC pass (profiles/r02_pmc_traffic.json,
-    # devtools/scripts_r2_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
+    # timed region, and crash on CU-masked streams on this pool).  The committed round-3 PMC pass (profiles/r03_pmc_traffic.json,
+    # devtools/scripts_r3_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
     # ITS algorithmic bytes, and `traffic` itself only when that file was made for this block size; otherwise null.
     traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
     except Exception:
         tj = None
     gen = 1 if os.environ.get("MI355XQR_UPDATE") == "1" else 2
@@ -339,7 +339,7 @@ def main():
         if tj and wl == "c3" and nb == tj.get("nb") and gen == 2 and "gemm_nt_kernel" in tj:
             e = tj["gemm_nt_kernel"]
             traffic = e["hbm_bytes_per_launch"]
-            traffic_src = {"file": "profiles/r02_pmc_traffic.json", "git_head_of_pass": tj.get("git_head"),
+            traffic_src = {"file": "profiles/r03_pmc_traffic.json", "git_head_of_pass": tj.get("git_head"),
                            "launch_mix": tj.get("config"),
                            "algorithmic_bytes_per_launch_same_mix": e["algorithmic_bytes_per_launch"],
                            "ratio_traffic_to_algorithmic": e["ratio"],
@@ -361,7 +361,7 @@ def main():
                 "cu_partition_note": ("with look-ahead the wide update runs on the update stream's compute units "
                                       "(16384^2: 224 of 256, the panel chain owns 32 = 4 compute units of every XCD; smaller problems 192 / 64)"),
                 "update_stream_cus": cus_u,
-                "rocprof_pmc": "profiles/r02_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
+                "rocprof_pmc": "profiles/r03_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
                 "measured_probe": measured,
                 "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],
                 "algorithmic_flops_per_launch": upd["flops"] / upd["launches"],
@@ -377,23 +377,34 @@ def main():
         # traffic is 16 * mk * w bytes per panel (read + write once)
         ach = pan["bytes"] / (pan["ms"] * 1e-3) / 1e9 if pan["ms"] else 0.0
         # measured HBM bytes of the leaf's three streaming kernels (PMC pass of the leaf entry point on a 262144 x 32 leaf,
-        # profiles/r02_pmc_panel_hbm.json), replayed -- not measured in this run; a "launch" here is one outer panel = nb/32 leaves
+        # profiles/r03_pmc_panel_hbm.json), replayed -- not measured in this run; a "launch" here is one outer panel = nb/32 leaves
         # plus their in-panel updates, whose bytes are not in the counter file
         ptraffic, psrc = None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_panel_hbm.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_panel_hbm.json")))
             if m_local == 262144:
                 ptraffic = pj["hbm_bytes_per_leaf_streaming_kernels"] * (nb // 32)
-                psrc = {"file": "profiles/r02_pmc_panel_hbm.json", "per_leaf_kernels": pj["kernels"],
+                psrc = {"file": "profiles/r03_pmc_panel_hbm.json", "per_leaf_kernels": pj["kernels"],
                         "covers": "gram32 + cholq4_tall + final3 of the nb/32 leaves of one outer panel (%.0f MB per 67 MB leaf: %.1f passes); "
                                   "not the in-panel updates, the Gram / T merge or the one-workgroup reconstruction kernel"
                                   % (pj["hbm_bytes_per_leaf_streaming_kernels"] / 1e6, pj["hbm_bytes_per_leaf_streaming_kernels"] / 67.1e6),
                         "method": pj["method"] + "; replayed from the committed file"}
         except Exception:
             pass
+        # whole-factorisation HBM bytes of this shape (every dispatch: leaf kernels, in-panel products and updates, outer updates),
+        # PMC passes of devtools/scripts_r3_pmc_panel.sh -- replayed, not measured in this run
+        whole = None
+        try:
+            wj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_tsqr_total_traffic.json")))
+            if m_local == wj["m"] and n == wj["n"]:
+                whole = {"file": "profiles/r03_pmc_tsqr_total_traffic.json", "hbm_bytes_per_factorisation": wj["hbm_bytes_per_factorisation"],
+                         "algorithmic_bytes_16mn": wj["algorithmic_bytes_16mn"], "ratio": wj["ratio"],
+                         "achieved_GBps_whole_step": wj["hbm_bytes_per_factorisation"] / (dt / K) / 1e9}
+        except Exception:
+            pass
         roof = {"bound": "hbm", "kernel": "panel factorisation (gram32 / chol1 / cholq4_tall / hr3 / final3 leaf kernels + guard launches, in-panel gemm_tn_dual / leaf_update_gram, Gram + T merge)",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                "traffic": ptraffic, "traffic_source": psrc,
+                "traffic": ptraffic, "traffic_source": psrc, "traffic_whole_factorisation": whole,
                 "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),
                 "algorithmic_bytes_per_launch": pan["bytes"] / max(pan["launches"], 1),
                 "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); the streaming leaf kernels run at 2.2-5.3 TB/s, "

@@ -49,6 +49,7 @@ struct qr_plan {
      * units (s_pair[i][0]) and the wide update the rest (s_pair[i][1]).  npairs = 0: no partition. */
     int npairs, pair_cur;
     void* s_pair[QR_MAX_PAIRS][2];
+    int pair_shared_u[QR_MAX_PAIRS];   /* phase i's update stream is phase i-1's (not owned: never destroyed / synchronised twice) */
     double pair_until[QR_MAX_PAIRS];
     void* ev_hop[2];
     void* ev_extra[2];          /* panel-stream share of wide update s finished */
@@ -281,9 +282,19 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         for (char* tok = strtok_r(spec, ",", &save); tok && !rc && p->npairs < QR_MAX_PAIRS; tok = strtok_r(NULL, ",", &save)) {
             const int c = atoi(tok);
             const char* colon = strchr(tok, ':');
+            if ((tok[0] == 'U' || tok[0] == 'u') && p->npairs > 0) {
+                /* "U": from here on the panel chain runs on an UNMASKED stream (any compute unit that is free -- in the chain-bound
+                 * phase the update stream idles half of the time) while the wide update keeps the previous phase's masked stream */
+                const int i = p->npairs++;
+                p->pair_until[i] = 0.0;
+                rc = qrd_stream_create(&p->s_pair[i][0], 1);
+                p->s_pair[i][1] = p->s_pair[i - 1][1];
+                p->pair_shared_u[i] = 1;
+                continue;
+            }
             if (c <= 0 || c >= cus) {           /* "0" or a bad entry: no partition; drop what was already created */
                 for (int i = 0; i < p->npairs; ++i)
-                    for (int j = 0; j < 2; ++j) { qrd_stream_destroy(p->s_pair[i][j]); p->s_pair[i][j] = NULL; }
+                    for (int j = 0; j < 2; ++j) { if (!(j == 1 && p->pair_shared_u[i])) qrd_stream_destroy(p->s_pair[i][j]); p->s_pair[i][j] = NULL; }
                 p->npairs = 0;
                 break;
             }
@@ -387,7 +398,7 @@ int qr_plan_destroy(qr_plan* p)
     qrd_free(p->Wn); qrd_free(p->slabs_u); qrd_free(p->We); qrd_free(p->Ye); qrd_free(p->Yn); qrd_free(p->Ye2);
     for (int i = 0; i < p->npairs; ++i)
         for (int j = 0; j < 2; ++j)
-            if (p->s_pair[i][j]) qrd_stream_destroy(p->s_pair[i][j]);
+            if (p->s_pair[i][j] && !(j == 1 && p->pair_shared_u[i])) qrd_stream_destroy(p->s_pair[i][j]);
     if (p->npairs == 0 && p->stream_u) qrd_stream_destroy(p->stream_u);
     for (int e = 0; e < 2; ++e) {
         if (p->ev_hop[e]) qrd_event_destroy(p->ev_hop[e]);
@@ -841,7 +852,7 @@ static int enter_phase(qr_plan* p, int i)
     void* nu = i < 0 ? NULL : p->s_pair[i][1];
     CHECK(qrd_event_record(p->ev_hop[0], p->stream));
     CHECK(qrd_stream_wait_event(ns, p->ev_hop[0]));
-    if (p->stream_u) {
+    if (p->stream_u && p->stream_u != nu) {
         CHECK(qrd_event_record(p->ev_hop[1], p->stream_u));
         CHECK(qrd_stream_wait_event(nu ? nu : ns, p->ev_hop[1]));
     }

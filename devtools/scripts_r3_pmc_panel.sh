@@ -1,0 +1,23 @@
+#!/bin/bash
+# HBM bytes and GB/s of the leaf-panel kernels (second-generation CholeskyQR2 leaf and its Householder-TSQR guard route)
+R=gpurun_out/pmc_panel_r03; rm -rf $R; mkdir -p $R
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+for mode in cholqr tsqr; do
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $R/${mode}_$ctr -o pmc -- python3 devtools/tools_pmc_panel.py $mode > $R/${mode}_${ctr}.json 2> $R/${mode}_$ctr.err
+done
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/${mode}_trace -o tr -- python3 devtools/tools_pmc_panel.py $mode > $R/${mode}_trace.json 2> $R/${mode}_trace.err
+f1=$(find $R/${mode}_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $R/${mode}_WRITE_SIZE -name "*counter_collection.csv" | head -1); f3=$(find $R/${mode}_trace -name "*kernel_trace.csv" | head -1)
+python3 devtools/tools_pmc_panel_summary.py $f1 $f2 $f3 > $R/${mode}_hbm_summary.txt
+rm -f $f1 $f2 $f3
+cat $R/${mode}_hbm_summary.txt | head -60
+done
+
+# whole-factorisation HBM traffic of one 262144 x 512 shard (verdict r2 item 3: in-panel updates included): two --pmc passes over
+# tools_one.py (2 factorisations), every dispatch summed
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $R/total_$ctr -o pmc -- python3 devtools/tools_one.py 262144x512x128 > $R/total_$ctr.log 2> $R/total_$ctr.err
+done
+f1=$(find $R/total_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $R/total_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 devtools/tools_pmc_total.py $f1 $f2 262144 512 2 > $R/tsqr_total_traffic.json; rm -f $f1 $f2
+head -12 $R/tsqr_total_traffic.json

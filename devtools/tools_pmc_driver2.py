@@ -38,6 +38,8 @@ for k in range(0, n - nb, 8 * nb):
     a2 = A.data_ptr() + 8 * ((k + nb) * m + k)
     v = V.data_ptr() + 8 * k
     q.check(lib.qrd_gemm_tn_update(st, nt, nb, mk, 1.0, a2, m, v, m, 0.0, Wt.data_ptr(), nt, slabs.data_ptr(), slabs.numel()))   # Wt = A2^T (V T)
+    if hasattr(lib, "qrd_gemm_tn_update_wide"):      # round 3: the same product on 128 x 256 workgroup tiles (A2 read half as often)
+        q.check(lib.qrd_gemm_tn_update_wide(st, nt, nb, mk, 1.0, a2, m, v, m, 0.0, Wt.data_ptr(), nt, slabs.data_ptr(), slabs.numel()))
     q.check(lib.qrd_gemm_nt(st, mk, nt, nb, -1, v, m, Wt.data_ptr(), nt, a2, m, -1, None))                                        # A2 -= V Wt^T
     shapes.append({"k": k, "mk": mk, "nt": nt, "nb": nb, "nn_alg_bytes": 16 * mk * nt + 8 * mk * nb + 8 * nb * nt,
                    "tn_alg_bytes": 8 * mk * (nt + nb), "flops_each": 2 * mk * nt * nb})

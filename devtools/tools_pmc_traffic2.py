@@ -35,4 +35,8 @@ out = {
  "gemm_nt_kernel": entry("gemm_nt_kernel", nn_alg),
  "gemm_tn_kernel<4,4,true,1>": entry("gemm_tn_kernel<4, 4, true, 1>", tn_alg),
 }
+try:
+    out["gemm_tn_wide_kernel<1> (128 x 256 tiles, opt-in)"] = entry("gemm_tn_wide_kernel", tn_alg)
+except KeyError:
+    pass
 json.dump(out, sys.stdout, indent=1)

@@ -90,6 +90,9 @@ np.save(sys.argv[1], O.sign_normalise(F))
     (512, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_NEXT": "update"}),
     (512, {"MI355XQR_LOOKAHEAD": "0"}),
     (128, {"MI355XQR_LEAF": "1"}),                                                    # first-generation CholeskyQR2 leaf
+    (128, {"MI355XQR_EP": "0"}),                                                      # in-panel product as a launch of its own (no early product)
+    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64:0.5,U", "MI355XQR_BALANCE": "14,44,0,0"}),   # late phase: panel chain on an unmasked stream
+    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_TN_WIDE": "1"}),   # wide-tile TN product
 ])
 def test_2024_square_vs_reference_R_slices(qr, oracle, tmp_path, nb, env):
     """16 (nb = 128) / 8 / 32 outer panels: wide update, look-ahead, CU partition, balance_cols -- against slices of the

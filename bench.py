@@ -174,7 +174,7 @@ def main():
         m_local, n, nb = 16384, 16384, args.nb or 256
         desc = f"C3: 16384x16384 square fp64 QR on 1 MI355X, nb={nb}"
     elif wl == "c4":
-        m_local, n, nb = 262144 // world, 256, args.nb or 128
+        m_local, n, nb = 262144 // world, 256, args.nb or 64      # 4 block columns of 64: more of the stacked QR runs under the local one
         desc = f"C4: tall-skinny 262144x256 fp64 TSQR, row-block sharded over {world} GPU(s)"
     elif wl == "c5":
         m_local, n, nb = 2097152 // world, 512, args.nb or 128
@@ -305,10 +305,13 @@ def main():
         tsqr_split = {"unpipelined_latency_ms": lat_ms, "local_qr_ms": loc_ms,
                       "exchange_and_stacked_qr_ms": lat_ms - loc_ms,
                       "pipelined_ms_per_step": dt / K * 1e3,
+                      "panel_pipelined_exchange": bool(be.tp.is_pipelined()),
                       "unpipelined_gflops": flops(m_total, n) / (lat_ms * 1e-3) / 1e9,
                       "note": "max over ranks; un-pipelined = qr_tsqr_factor_dev + qr_tsqr_sync per step (the single-factorisation "
-                              "latency); `value` is the pipelined throughput of K independent factorisations; the stacked "
-                              "(world*n) x n factorisation is redundant on every rank and latency-bound"}
+                              "latency); `value` is the throughput of K independent factorisations issued back to back; "
+                              "panel_pipelined_exchange: inside ONE factorisation the R factors travel block column by block column "
+                              "and the stacked (world*n) x n matrix (redundant on every rank, latency-bound) is factored "
+                              "left-looking while the local QR continues"}
 
     # ---- roofline of the dominant kernel
     # dominant kernel: from the timed region; the rest: from the extra profiled step (per-step figures, K_full = 1)
@@ -433,16 +436,19 @@ def main():
         weak_base = {"workload": "one 262144x512 TSQR shard on 1 GPU (the per-GPU work of the N>1 lines of this bench)",
                      "value": flops(262144, 512) / dtb / 1e9, "unit": "GFLOP/s", "ms_per_step": dtb * 1e3, "steps": reps}
         tb.clear()
-        # the other step of a multi-GPU factorisation, measured on this one GPU: the stacked (P n) x n QR every rank does after
-        # the all-gather (C5: 8 x 512 = 4096 x 512; C4 on 4 GPUs: 1024 x 256), un-pipelined, and what that predicts
+        # the whole step of one rank of a multi-GPU factorisation, measured on this one GPU (every step drained before the next):
+        # the local QR, and local QR + exchange + stacked QR with the collective replaced by device copies of the rank's own factor
+        # -- the launches, streams and events of a real rank, which also factors the full stacked matrix redundantly, minus the network
         try:
-            st5 = T.stacked_step_ms(qr, 8, 512, 128)
-            st4 = T.stacked_step_ms(qr, 4, 256, 128)
-            loc5 = dtb * 1e3
-            tsqr_model = {"stacked_qr_4096x512_ms": st5, "stacked_qr_1024x256_ms": st4, "local_262144x512_ms": loc5,
-                          "predicted_c5_efficiency_8gpu": loc5 / (loc5 + st5 + 0.1),
-                          "note": "single-GPU measurements; efficiency = local / (local + stacked + 0.1 ms assumed for the 2 MiB-per-rank "
-                                  "all-gather), un-pipelined (one factorisation's latency); C5 on one GPU is the P = 1 denominator"}
+            c5 = T.rank_step_latency(qr, 262144, 512, 8, 128)
+            c4 = T.rank_step_latency(qr, 65536, 256, 4, 64)
+            tsqr_model = {"c5_rank_of_8": c5, "c4_rank_of_4": c4,
+                          "stacked_step_alone_4096x512_ms": T.stacked_step_ms(qr, 8, 512, 128),
+                          "predicted_c5_efficiency_8gpu": c5["local_ms"] / (c5["step_ms"] + 0.1),
+                          "note": "single-GPU measurements, un-pipelined across factorisations (one factorisation's latency). "
+                                  "panel_pipelined: block column k of R is gathered and the stacked matrix factored left-looking on a "
+                                  "second stream while the local QR continues; efficiency = local / (step + 0.1 ms assumed for the "
+                                  "n/nb all-gathers of 512 KB per rank); C5 on one GPU is the P = 1 denominator"}
         except Exception as e:
             tsqr_model = {"error": repr(e)}
 
@@ -461,7 +467,7 @@ def main():
                        "ib": args.ib or qr.get_block_size()[1],
                        "flops_per_step": flops(m_total, n), "input_buffers": nbuf,
                        "input": "uniform[0,1) counter-hash generator, seed 12+i, resident in HBM",
-                       "collective": "none" if world == 1 else f"1 all_gather of n*n doubles per rank ({'RCCL' if backend == 'nccl' else backend + ' via host, bring-up only'})"},
+                       "collective": "none" if world == 1 else (f"{n // nb} all_gathers of n*nb doubles per rank (panel-pipelined, RCCL)" if (backend == "nccl" and be.tp.is_pipelined()) else f"1 all_gather of n*n doubles per rank ({'RCCL' if backend == 'nccl' else backend + ' via host, bring-up only'})")},
             "frac_of_fp64_matrix_peak": value / 1e3 / (FP64_MATRIX_PEAK_TFLOPS * world),
             "accuracy": acc,
             "roofline": roof,

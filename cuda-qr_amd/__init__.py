@@ -78,6 +78,9 @@ _sig("qr_tsqr_formq_dev", C.c_int, _vp, _vp, C.c_int, _vp, C.c_int)
 _sig("qr_tsqr_local_dev", C.c_int, _vp, _vp, C.c_int)
 _sig("qr_tsqr_exchange_buffers", C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp))
 _sig("qr_tsqr_stacked_dev", C.c_int, _vp, _vp)
+_sig("qr_tsqr_is_pipelined", C.c_int, _vp)
+_sig("qr_tsqr_factor_virtual_dev", C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp))
+_sig("qr_tsqr_factor_selfgather_dev", C.c_int, _vp, _vp, C.c_int, _vp)
 _sig("qr_tsqr_sync", C.c_int, _vp)
 _sig("qr_tsqr_stream", _vp, _vp)
 _sig("qr_tsqr_comm_ranks", C.c_int, _vp, C.POINTER(C.c_int))
@@ -464,6 +467,12 @@ class TsqrPlan:
     def formq(self, dA, lda, dQ, ldq):
         check(lib.qr_tsqr_formq_dev(self.h, _dptr(dA), lda, _dptr(dQ), ldq), "qr_tsqr_formq_dev")
 
+    def factor_selfgather(self, dA, lda, dR):
+        check(lib.qr_tsqr_factor_selfgather_dev(self.h, _dptr(dA), lda, _dptr(dR)), "qr_tsqr_factor_selfgather_dev")
+
+    def is_pipelined(self):
+        return bool(lib.qr_tsqr_is_pipelined(self.h))
+
     def local_factor(self, dA, lda):
         check(lib.qr_tsqr_local_dev(self.h, _dptr(dA), lda), "qr_tsqr_local_dev")
 
@@ -482,6 +491,15 @@ class TsqrPlan:
         n = C.c_int()
         check(lib.qr_tsqr_comm_ranks(self.h, C.byref(n)), "qr_tsqr_comm_ranks")
         return n.value
+
+
+def tsqr_factor_virtual(plans, shards, lda, Rs):
+    """qr_tsqr_factor_virtual_dev: the panel-pipelined schedule over P TsqrPlans of one device (virtual ranks)."""
+    P = len(plans)
+    hs = (_vp * P)(*[p.h for p in plans])
+    As = (_vp * P)(*[_dptr(a) for a in shards])
+    Rp = (_vp * P)(*[_dptr(r) for r in Rs])
+    check(lib.qr_tsqr_factor_virtual_dev(hs, P, As, lda, Rp), "qr_tsqr_factor_virtual_dev")
 
 
 def tsqr_unique_id():

@@ -58,6 +58,7 @@ int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const dou
 int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols);
 int qrd_extract_v(void* stream, const double* P, int ld, int mk, int w, double* V, int ldv);
 int qrd_extract_r(void* stream, const double* A, int lda, int m, int n, double* R, int ldr, int rrows);
+int qrd_extract_r_block(void* stream, const double* A, int lda, int k, int w, double* R, int ldr, int rrows);
 int qrd_set_identity(void* stream, double* C, int ld, int rows, int cols, int row_off);
 int qrd_copy_block(void* stream, const double* S, int lds, double* D, int ldd, int rows, int cols);
 int qrd_fill_uniform(void* stream, double* A, int ld, long long rows, int cols, long long row_off,

@@ -57,6 +57,7 @@ struct qr_plan {
     double *Ye2;                /* raw V^T A2 of a wide update that applies T to the small product (tall-skinny plans) */
     double *Yn;                 /* raw V^T A_next of the look-ahead update */
     double bal_rp, bal_ru, bal_tc0, bal_tc1;   /* load-balance model (TFLOP/s, ms); bal_rp = 0: off */
+    double bal_tc0_base, bal_tc1_base; int bal_auto;   /* bal_auto: no MI355XQR_BALANCE override -- rates follow the phase's partition */
     void* ev_half[2];           /* W_a(s): the wide update has finished the columns of panel s+1 that N(s) left out (its second half) */
     void* ev_next[2];           /* look-ahead update N(s) of the next panel's columns finished (when it runs on the update stream) */
     int update_gen;             /* wide update kernels: 1 = gemm_tn<4,4> + gemm_nn_w8 (W), 2 = gemm_tn<4,4> + gemm_nt (W transposed, direct-to-LDS) */
@@ -335,6 +336,8 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
             p->bal_rp = 0.0;
             sscanf(b, "%lf,%lf,%lf,%lf", &p->bal_rp, &p->bal_ru, &p->bal_tc0, &p->bal_tc1);
         }
+        p->bal_auto = (b == NULL) && p->npairs > 1;
+        p->bal_tc0_base = p->bal_tc0; p->bal_tc1_base = p->bal_tc1;
     }
     for (int e = 0; e < 2 && !rc; ++e) rc = qrd_event_create_notiming(&p->ev_v[e]);
     for (int e = 0; e < 2 && !rc; ++e) {
@@ -857,6 +860,16 @@ static int enter_phase(qr_plan* p, int i)
         CHECK(qrd_stream_wait_event(nu ? nu : ns, p->ev_hop[1]));
     }
     p->stream = ns; p->stream_u = nu; p->pair_cur = i;
+    if (i >= 0 && p->bal_auto) {       /* the load-balance model follows the phase's partition (chain time: shorter on more CUs) */
+        int cus = 256;
+        qrd_device_info(NULL, 0, &cus, NULL, NULL);
+        const int pc = qrd_stream_cus(ns);
+        const int uc = nu ? qrd_stream_cus(nu) : cus;
+        p->bal_rp = 0.22 * (pc < cus ? pc : 32);
+        p->bal_ru = 0.23 * uc;
+        const double f = pc <= 32 ? 1.0 : (pc <= 64 ? 0.8 : 0.7);
+        p->bal_tc0 = p->bal_tc0_base * f; p->bal_tc1 = p->bal_tc1_base * f;
+    }
     return 0;
 }
 
@@ -1519,6 +1532,7 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
  * behind an event, and the next step's exchange waits for it through another, so in a sequence of independent factorisations the
  * stacked QR of step i runs under the local QR of step i+1 without the caller doing anything; qr_tsqr_sync() drains both.
  * No reference counterpart: the reference is single-device (qr.cu:711,737). */
+#define QR_TSQR_MAXPAN 16
 struct qr_tsqr_plan {
     int nranks, rank, m_local, n, nb, sm;
     qr_plan *p, *p2;                /* local shard, stacked R factors (NULL when nranks == 1) */
@@ -1527,6 +1541,14 @@ struct qr_tsqr_plan {
     void *ev_gathered, *ev_stacked; /* stack matrix filled (local stream) / stacked factorisation has consumed it (stack stream) */
     int stacked_pending;            /* ev_stacked has been recorded and not yet waited for by the local stream */
     int local_done;                 /* qr_tsqr_local_dev ran and the stacked step has not yet consumed its R factor */
+    /* panel-pipelined form (see qr_tsqr_factor_dev): the exchange and the stacked QR go block column by block column */
+    int pipe_ok, npan;              /* usable: single-stream local plan, nb | n, same nb in both plans */
+    double *dsend;                  /* npan blocks of n x nb: block column k of this rank's R, zero below its trapezoid */
+    double *drecv;                  /* nranks blocks of n x nb: one gathered block column (reused panel after panel, stream order) */
+    double *Vst, *Tst;              /* explicit V (ldv2 x nb) and T (ldt x nb) of every stacked panel: later panels apply them */
+    void *ev_pan[QR_TSQR_MAXPAN];   /* local panel k factored, its block column of R packed (local stream) */
+    void *ev_sent[QR_TSQR_MAXPAN];  /* the exchange has consumed send block k (stacked stream) */
+    int sent_pending[QR_TSQR_MAXPAN];
 };
 
 int qr_tsqr_unique_id(void* id128)
@@ -1552,6 +1574,24 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
         if (!rc) rc = qrd_malloc((void**) &t->dS, sizeof(double) * (size_t) t->sm * n);
         if (!rc) rc = qrd_event_create_notiming(&t->ev_gathered);
         if (!rc) rc = qrd_event_create_notiming(&t->ev_stacked);
+        /* panel-pipelined exchange: MI355XQR_TSQR_PIPE=0 keeps the one-collective form */
+        const int pnb = rc ? 0 : t->p->nb;
+        if (!rc && env_int("MI355XQR_TSQR_PIPE", 1) != 0 && !t->p->lookahead && !t->p2->lookahead && pnb == t->p2->nb && n % pnb == 0 &&
+            n / pnb >= 2 && n / pnb <= QR_TSQR_MAXPAN) {
+            t->npan = n / pnb;
+            rc = qrd_malloc((void**) &t->dsend, sizeof(double) * (size_t) n * n);
+            if (!rc) rc = qrd_malloc((void**) &t->drecv, sizeof(double) * (size_t) nranks * n * pnb);
+            if (!rc) rc = qrd_malloc((void**) &t->Vst, sizeof(double) * (size_t) t->npan * t->p2->ldv * pnb);
+            if (!rc) rc = qrd_malloc((void**) &t->Tst, sizeof(double) * (size_t) t->npan * t->p2->ldt * pnb);
+            if (!rc) rc = qrd_memset(t->p2->s_main, t->Vst, 0, sizeof(double) * (size_t) t->npan * t->p2->ldv * pnb);
+            if (!rc) rc = qrd_memset(t->p2->s_main, t->Tst, 0, sizeof(double) * (size_t) t->npan * t->p2->ldt * pnb);
+            for (int k = 0; k < t->npan && !rc; ++k) {
+                rc = qrd_event_create_notiming(&t->ev_pan[k]);
+                if (!rc) rc = qrd_event_create_notiming(&t->ev_sent[k]);
+            }
+            if (!rc) rc = qrd_stream_sync(t->p2->s_main);
+            t->pipe_ok = !rc;
+        }
     }
     if (rc) { qr_tsqr_plan_destroy(t); return rc; }
     *out = t;
@@ -1584,6 +1624,11 @@ int qr_tsqr_plan_destroy(qr_tsqr_plan* t)
     if (t->ev_gathered) qrd_event_destroy(t->ev_gathered);
     if (t->ev_stacked) qrd_event_destroy(t->ev_stacked);
     qrd_free(t->dtau); qrd_free(t->dtau2); qrd_free(t->dRp); qrd_free(t->dRall); qrd_free(t->dS); qrd_free(t->dQt);
+    qrd_free(t->dsend); qrd_free(t->drecv); qrd_free(t->Vst); qrd_free(t->Tst);
+    for (int k = 0; k < QR_TSQR_MAXPAN; ++k) {
+        if (t->ev_pan[k]) qrd_event_destroy(t->ev_pan[k]);
+        if (t->ev_sent[k]) qrd_event_destroy(t->ev_sent[k]);
+    }
     qr_plan_destroy(t->p); qr_plan_destroy(t->p2);
     if (t->own_comm && t->comm) qrd_comm_destroy(t->comm);
     free(t);
@@ -1656,16 +1701,128 @@ int qr_tsqr_stacked_dev(qr_tsqr_plan* t, double* dR)
     return 0;
 }
 
-/* steps 1-3 with the RCCL all-gather in between; asynchronous (qr_tsqr_sync before dR is read on another stream) */
+/* ---- panel-pipelined form -----------------------------------------------------------------------------------------------
+ * The stacked (P n) x n factorisation is a chain of n / 32 dependent leaves (~1.2 ms at 8 x 512 columns whatever the chip does) and,
+ * as ONE step behind ONE all-gather, all of it is added to the latency of a factorisation.  But block column k of a rank's R is final as
+ * soon as local panel k is factored -- long before the local factorisation ends.  So the exchange and the stacked QR go block column
+ * by block column, LEFT-looking, on the stacked plan's stream while the local stream carries on with its trailing update:
+ *     local stream :  P_0  [pack R(:, 0)]  U_0   P_1  [pack R(:, 1)]  U_1   ...                       (single-stream tall-skinny schedule)
+ *     stacked stream:        gather_0 -> S_0           gather_1 -> apply S_0's reflectors -> S_1  ...  (S_k: factor block column k)
+ * Only the last block column's gather + apply + factor is exposed (~0.4 ms at 8 x 512), n / nb small all-gathers (512 KB per rank at
+ * n = 512, nb = 128) instead of one.  Every rank issues the same collectives in the same order.  The result is an ordinary LAPACK-
+ * layout factorisation of the stacked matrix (qr_tsqr_formq_dev does not care how it was scheduled). */
+static int tsqr_local_panel(qr_tsqr_plan* t, double* dA, int lda, int pi)
+{
+    qr_plan* p = t->p;
+    const int m = t->m_local, n = t->n, nb = p->nb, k = pi * nb, wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
+    use_set(p, 0);
+    CHECK(factor_panel(p, dA, m, lda, k, wout, t->dtau, nt > 0, NULL));
+    /* block column k of R is final (its rows above the panel were finished by the earlier trailing updates): pack it */
+    if (t->sent_pending[pi]) { CHECK(qrd_stream_wait_event(p->stream, t->ev_sent[pi])); t->sent_pending[pi] = 0; }
+    CHECK(qrd_extract_r_block(p->stream, dA, lda, k, wout, t->dsend + (size_t) k * n, n, n));
+    CHECK(qrd_event_record(t->ev_pan[pi], p->stream));
+    if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, NULL, p->slabs, 1, 1));
+    return 0;
+}
+
+/* drecv holds every rank's block column pi: stack it, apply the reflectors of the stacked panels before it, factor it */
+static int tsqr_stacked_panel(qr_tsqr_plan* t, int pi)
+{
+    qr_plan* p2 = t->p2;
+    const int n = t->n, P = t->nranks, sm = t->sm, nb = p2->nb, k = pi * nb, wout = imin(nb, n - k);
+    void* s = p2->s_main;
+    for (int q = 0; q < P; ++q)
+        CHECK(qrd_copy_block(s, t->drecv + (size_t) q * n * nb, n, t->dS + (size_t) k * sm + (size_t) q * n, sm, n, wout));
+    for (int j = 0; j < pi; ++j)        /* (I - V_j T_j V_j^T)^T on rows j nb .. of the new block column */
+        CHECK(apply_small_t(p2, s, t->Vst + (size_t) j * p2->ldv * nb, p2->ldv, t->Tst + (size_t) j * p2->ldt * nb, p2->ldt, sm - j * nb, nb,
+                            t->dS + (size_t) k * sm + (size_t) j * nb, sm, wout, p2->Wn, p2->Yn, p2->slabs));
+    p2->Vw = t->Vst + (size_t) pi * p2->ldv * nb;      /* this panel's V and T stay: the later block columns need them */
+    p2->T = t->Tst + (size_t) pi * p2->ldt * nb;
+    const int rc = factor_panel(p2, t->dS, sm, sm, k, wout, t->dtau2, pi + 1 < t->npan, NULL);
+    use_set(p2, 0);
+    return rc;
+}
+
+static int tsqr_factor_pipelined(qr_tsqr_plan* t, double* dA, int lda, double* dR, int self_gather)
+{
+    const int n = t->n, nb = t->p->nb;
+    void* s2 = t->p2->s_main;
+    for (int pi = 0; pi < t->npan; ++pi) {
+        CHECK(tsqr_local_panel(t, dA, lda, pi));
+        CHECK(qrd_stream_wait_event(s2, t->ev_pan[pi]));
+        if (self_gather) {
+            for (int q = 0; q < t->nranks; ++q)
+                CHECK(qrd_d2d(s2, t->drecv + (size_t) q * n * nb, t->dsend + (size_t) pi * nb * n, sizeof(double) * (size_t) n * nb));
+        } else
+            CHECK(qrd_allgather_f64(t->comm, s2, t->dsend + (size_t) pi * nb * n, t->drecv, (size_t) n * nb));
+        CHECK(qrd_event_record(t->ev_sent[pi], s2));
+        t->sent_pending[pi] = 1;
+        CHECK(tsqr_stacked_panel(t, pi));
+    }
+    CHECK(qr_extract_r_dev(t->p2, t->dS, t->sm, n, t->sm, dR, n, n));
+    CHECK(qrd_event_record(t->ev_stacked, s2));
+    t->stacked_pending = 1;
+    t->local_done = 0;
+    return 0;
+}
+
+/* The same schedule over P plans of ONE device driven from one thread -- "virtual ranks": the gather is P stream-ordered device
+ * copies per rank.  For tests and single-device bring-up of the pipelined form (no communicator needed: plans from
+ * qr_tsqr_plan_create_comm(.., NULL, ..)); every plan must be of the same shape.  dA[r], dR[r]: rank r's shard and its copy of R. */
+int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, double** dR)
+{
+    if (!tps || !dA || !dR || P < 2) return QR_E_ARG;
+    for (int r = 0; r < P; ++r)
+        if (!tps[r] || !dA[r] || !dR[r] || tps[r]->nranks != P || tps[r]->rank != r || !tps[r]->pipe_ok || tps[r]->n != tps[0]->n ||
+            tps[r]->m_local != tps[0]->m_local || tps[r]->npan != tps[0]->npan || lda < tps[r]->m_local)
+            return QR_E_ARG;
+    const int n = tps[0]->n, nb = tps[0]->p->nb;
+    for (int pi = 0; pi < tps[0]->npan; ++pi) {
+        for (int r = 0; r < P; ++r) CHECK(tsqr_local_panel(tps[r], dA[r], lda, pi));
+        for (int r = 0; r < P; ++r) {
+            void* s2 = tps[r]->p2->s_main;
+            for (int q = 0; q < P; ++q) {
+                CHECK(qrd_stream_wait_event(s2, tps[q]->ev_pan[pi]));
+                CHECK(qrd_d2d(s2, tps[r]->drecv + (size_t) q * n * nb, tps[q]->dsend + (size_t) pi * nb * n, sizeof(double) * (size_t) n * nb));
+            }
+            CHECK(tsqr_stacked_panel(tps[r], pi));
+        }
+    }
+    for (int r = 0; r < P; ++r) {
+        CHECK(qr_extract_r_dev(tps[r]->p2, tps[r]->dS, tps[r]->sm, n, tps[r]->sm, dR[r], n, n));
+        tps[r]->local_done = 0;
+    }
+    /* a bring-up driver: drained here, so that no send block is repacked while another rank's stream still reads it */
+    for (int r = 0; r < P; ++r) CHECK(qr_tsqr_sync(tps[r]));
+    return 0;
+}
+
+/* One rank's complete step with the collective replaced by copies of its OWN factor into every rank slot (R of [A; A; ...; A]): the
+ * same launches, streams and events as a real rank of an nranks-GPU run -- which also factors the full stacked matrix redundantly --
+ * minus the network.  For measuring the latency of the step on one GPU (bench.py, tsqr_model_1gpu) and for stream-order tests. */
+int qr_tsqr_factor_selfgather_dev(qr_tsqr_plan* t, double* dA, int lda, double* dR)
+{
+    if (!t || !dA || !dR || lda < t->m_local || t->nranks < 2) return QR_E_ARG;
+    if (t->pipe_ok) return tsqr_factor_pipelined(t, dA, lda, dR, 1);
+    CHECK(qr_tsqr_local_dev(t, dA, lda));
+    for (int q = 0; q < t->nranks; ++q)
+        CHECK(qrd_d2d(t->p->s_main, t->dRall + (size_t) q * t->n * t->n, t->dRp, sizeof(double) * (size_t) t->n * t->n));
+    return qr_tsqr_stacked_dev(t, dR);
+}
+
+/* 1 when qr_tsqr_factor_dev runs the panel-pipelined form for this plan */
+int qr_tsqr_is_pipelined(qr_tsqr_plan* t) { return t && t->pipe_ok && t->nranks > 1; }
+
+/* steps 1-3 with the RCCL exchange in between; asynchronous (qr_tsqr_sync before dR is read on another stream) */
 int qr_tsqr_factor_dev(qr_tsqr_plan* t, double* dA, int lda, double* dR)
 {
-    if (!t || !dA || !dR) return QR_E_ARG;
+    if (!t || !dA || !dR || lda < t->m_local) return QR_E_ARG;
+    if (t->nranks > 1 && !t->comm) return QR_E_ARG;      /* plan made for an external transport: use local / exchange_buffers / stacked */
+    if (t->nranks > 1 && t->pipe_ok) return tsqr_factor_pipelined(t, dA, lda, dR, 0);
     CHECK(qr_tsqr_local_dev(t, dA, lda));
-    if (t->nranks > 1) {
-        if (!t->comm) return QR_E_ARG;      /* plan made for an external transport: use local / exchange_buffers / stacked */
+    if (t->nranks > 1)
         /* dRall is read by the copies of the previous step on this same stream: stream order is enough */
         CHECK(qrd_allgather_f64(t->comm, t->p->s_main, t->dRp, t->dRall, (size_t) t->n * t->n));
-    }
     return qr_tsqr_stacked_dev(t, dR);
 }
 

@@ -596,6 +596,13 @@ __global__ void extract_r_kernel(const double* __restrict__ A, int lda, int m, i
     if (i < rrows && c < n) R[(size_t) c * ldr + i] = (i <= c && i < m) ? A[(size_t) c * lda + i] : 0.0;
 }
 
+// block column [k, k + w) of R: out (rrows x w, ldr) = rows 0 .. k + j of column k + j of the factored matrix, zero below
+__global__ void extract_r_block_kernel(const double* __restrict__ A, int lda, int k, int w, double* __restrict__ R, int ldr, int rrows)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i < rrows && j < w) R[(size_t) j * ldr + i] = (i <= k + j) ? A[(size_t) (k + j) * lda + i] : 0.0;
+}
+
 // C(i,c) = (i + row_off == c) ? 1 : 0      (reference identity(), qr.c:316-324)
 __global__ void set_identity_kernel(double* __restrict__ C, int ld, int rows, int cols, int row_off)
 {
@@ -1178,6 +1185,13 @@ int qrd_extract_r(void* stream, const double* A, int lda, int m, int n, double* 
 {
     hipLaunchKernelGGL(extract_r_kernel, dim3((rrows + 255) / 256, n), dim3(256), 0, (hipStream_t) stream, A, lda, m,
                        n, R, ldr, rrows);
+    return (int) hipGetLastError();
+}
+
+int qrd_extract_r_block(void* stream, const double* A, int lda, int k, int w, double* R, int ldr, int rrows)
+{
+    if (w <= 0 || rrows <= 0) return 0;
+    hipLaunchKernelGGL(extract_r_block_kernel, dim3((rrows + 255) / 256, w), dim3(256), 0, (hipStream_t) stream, A, lda, k, w, R, ldr, rrows);
     return (int) hipGetLastError();
 }
 

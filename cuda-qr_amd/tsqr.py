@@ -120,6 +120,34 @@ def stacked_step_ms(qr, P, n, nb=0, reps=8):
     return best
 
 
+def rank_step_latency(qr, m_local, n, P, nb=128, nmat=3, reps=3):
+    """Latency (ms) of ONE rank's TSQR step of a P-GPU factorisation, measured on one GPU, every step drained before the next starts:
+    the local QR alone, and the complete step with the collective replaced by device copies of the rank's own factor
+    (qr_tsqr_factor_selfgather_dev: the launches, streams and events of a real rank -- which also factors the full stacked matrix
+    redundantly -- minus the network)."""
+    import time
+    tp = qr.TsqrPlan(m_local, n, P, 0, nb, comm="external")
+    A = [torch.empty((n, m_local), dtype=torch.float64, device="cuda") for _ in range(nmat)]
+    R = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    out = {"m_local": m_local, "n": n, "P": P, "nb": nb, "panel_pipelined": tp.is_pipelined()}
+    for name, fn in (("local_ms", lambda a: tp.local_factor(a, m_local)), ("step_ms", lambda a: tp.factor_selfgather(a, m_local, R))):
+        best = 1e30
+        for _ in range(reps):
+            for i, a in enumerate(A):
+                tp.local.fill_uniform(a, m_local, m_local, n, seed=12 + i)
+            tp.sync()
+            t0 = time.perf_counter()
+            for a in A:
+                fn(a)
+                tp.sync()
+            best = min(best, (time.perf_counter() - t0) / len(A) * 1e3)
+        out[name] = best
+    out["exposed_exchange_and_stacked_ms"] = out["step_ms"] - out["local_ms"]
+    out["efficiency_excl_network"] = out["local_ms"] / out["step_ms"]
+    tp.close()
+    return out
+
+
 class HipBackend:
     """Local steps on the current HIP device through libmi355xqr.so."""
 

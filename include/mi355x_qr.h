@@ -135,6 +135,18 @@ int qr_tsqr_formq_dev(qr_tsqr_plan* tp, const double* dA_shard, int lda, double*
 int qr_tsqr_local_dev(qr_tsqr_plan* tp, double* dA_shard, int lda);
 int qr_tsqr_exchange_buffers(qr_tsqr_plan* tp, double** send, double** recv);
 int qr_tsqr_stacked_dev(qr_tsqr_plan* tp, double* dR);
+/* How the exchange is scheduled.  For single-stream (tall-skinny) shapes whose n is a multiple of the block size, qr_tsqr_factor_dev
+ * goes block column by block column ("panel-pipelined", qr_tsqr_is_pipelined() = 1): block column k of a rank's R is final as soon as
+ * local panel k is factored, so it is gathered (n / nb small ncclAllGathers instead of one) and the stacked matrix is factored
+ * left-looking on a second stream WHILE the local factorisation continues -- only the last block column's share of the stacked QR
+ * (~0.4 ms of 1.2 at 8 x 512 columns) is added to the latency of the step.  MI355XQR_TSQR_PIPE=0: one collective after the local QR.
+ * qr_tsqr_factor_virtual_dev: the same schedule over P plans of ONE device from one thread (plans from
+ * qr_tsqr_plan_create_comm(.., NULL, ..); the gather is device copies) -- tests and single-device bring-up.
+ * qr_tsqr_factor_selfgather_dev: one rank's complete step with its own factor copied into every rank slot: the launches, streams and
+ * events of a real rank minus the network (latency measurements on one GPU). */
+int qr_tsqr_is_pipelined(qr_tsqr_plan* tp);
+int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int nranks, double** dA_shards, int lda, double** dR);
+int qr_tsqr_factor_selfgather_dev(qr_tsqr_plan* tp, double* dA_shard, int lda, double* dR);
 int qr_tsqr_sync(qr_tsqr_plan* tp);
 void* qr_tsqr_stream(qr_tsqr_plan* tp);                 /* hipStream_t of the local step and the collective */
 int qr_tsqr_comm_ranks(qr_tsqr_plan* tp, int* nranks);  /* ranks as RCCL itself counts them */

@@ -111,6 +111,13 @@ int main(void)
         OK(qr_thin_mgpu(A, 4093, n, Q, R, 0, 3));                               /* ragged last shard */
         if (qr_thin_mgpu(A, m, n, Q, R, 0, 5) != QR_E_ARG) return 3;          /* more than the 4 stub devices */
         free(A); free(Q); free(R);
+        /* n a multiple of the block size: the per-device threads run the panel-pipelined exchange (4 all-gathers each) */
+        const int m2 = 16384, n2 = 256;
+        A = (double*) calloc((size_t) m2 * n2, sizeof(double));
+        Q = (double*) calloc((size_t) m2 * n2, sizeof(double));
+        R = (double*) calloc((size_t) n2 * n2, sizeof(double));
+        OK(qr_thin_mgpu(A, m2, n2, Q, R, 64, 4));
+        free(A); free(Q); free(R);
     }
 
     /* 4. TSQR plan: external transport, back-to-back steps (event protocol between the local and the stacked plan), thin Q */
@@ -140,6 +147,26 @@ int main(void)
         OK(qr_tsqr_plan_destroy(t));
         OK(qr_device_free(dA)); OK(qr_device_free(dQ)); OK(qr_device_free(dR));
     }
+    /* 4b. panel-pipelined TSQR: virtual ranks (P plans, one thread) and the self-gather form, twice (send blocks reused) */
+    {
+        enum { P = 3 };
+        const int ml = 16384, n = 384;
+        qr_tsqr_plan* tps[P];
+        double *dA[P], *dR[P];
+        for (int r = 0; r < P; ++r) {
+            OK(qr_tsqr_plan_create_comm(&tps[r], NULL, P, r, ml, n, 128));
+            if (!qr_tsqr_is_pipelined(tps[r])) return 9;
+            OK(qr_device_malloc((void**) &dA[r], sizeof(double) * (size_t) ml * n));
+            OK(qr_device_malloc((void**) &dR[r], sizeof(double) * (size_t) n * n));
+        }
+        OK(qr_tsqr_factor_virtual_dev(tps, P, dA, ml, dR));
+        OK(qr_tsqr_factor_virtual_dev(tps, P, dA, ml, dR));
+        OK(qr_tsqr_factor_selfgather_dev(tps[1], dA[1], ml, dR[1]));
+        OK(qr_tsqr_factor_selfgather_dev(tps[1], dA[1], ml, dR[1]));
+        OK(qr_tsqr_formq_dev(tps[1], dA[1], ml, dA[0], ml));
+        for (int r = 0; r < P; ++r) { OK(qr_tsqr_plan_destroy(tps[r])); OK(qr_device_free(dA[r])); OK(qr_device_free(dR[r])); }
+    }
+
     /* 5. legacy-layout shim: argument checks and buffer sizes of the sliding-window path */
     {
         const int m = 512, n = 128;

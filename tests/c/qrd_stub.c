@@ -225,6 +225,8 @@ int qrd_larft(void* s, int nbp, int ib, const double* G, int ldg, const double* 
 int qrd_zero_block(void* s, double* A, int ld, int r, int c) { (void) s; chk("zero_block", A, ld, r, c); return 0; }
 int qrd_extract_v(void* s, const double* P, int ld, int mk, int w, double* V, int ldv) { (void) s; chk("extract_v P", P, ld, mk, w); chk("extract_v V", V, ldv, mk, w); return 0; }
 int qrd_extract_r(void* s, const double* A, int lda, int m, int n, double* R, int ldr, int rr) { (void) s; chk("extract_r A", A, lda, m, n); chk("extract_r R", R, ldr, rr, n); return 0; }
+int qrd_extract_r_block(void* s, const double* A, int lda, int k, int w, double* R, int ldr, int rr)
+{ (void) s; chk("extract_r_block A", A + (size_t) k * lda, lda, k + w, w); chk("extract_r_block R", R, ldr, rr, w); return 0; }
 int qrd_set_identity(void* s, double* C, int ld, int r, int c, int ro) { (void) s; (void) ro; chk("set_identity", C, ld, r, c); return 0; }
 int qrd_copy_block(void* s, const double* S, int lds, double* D, int ldd, int r, int c) { (void) s; chk("copy_block S", S, lds, r, c); chk("copy_block D", D, ldd, r, c); return 0; }
 int qrd_fill_uniform(void* s, double* A, int ld, long long rows, int cols, long long ro, long long tr, unsigned long long seed)

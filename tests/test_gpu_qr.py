@@ -626,3 +626,69 @@ def test_tsqr_plan_back_to_back_steps_are_stream_ordered(qr, oracle):
         ref = oracle.sign_normalise(np.linalg.qr(np.vstack([np.linalg.qr(Ah, mode="r")] * P), mode="r"))
         assert rel(oracle.sign_normalise(host(dR)), ref) < 1e-13
     tp.close()
+
+
+@pytest.mark.parametrize("m_local,n,P,nb", [(8192, 256, 4, 128), (4096, 512, 8, 128), (16384, 256, 2, 64), (65536, 256, 4, 128), (8192, 384, 3, 128)])
+def test_tsqr_panel_pipelined_virtual_ranks(qr, oracle, m_local, n, P, nb):
+    """The panel-pipelined TSQR step (block column k of every rank's R gathered as soon as local panel k is factored, the stacked
+    matrix factored left-looking on a second stream while the local factorisation continues) with P virtual ranks on one device
+    (qr_tsqr_factor_virtual_dev): every rank ends with the same R bit for bit, equal to LAPACK's R of the whole matrix after sign
+    normalisation, and qr_tsqr_formq_dev on that left-looking factorisation gives the rank's rows of an orthonormal Q with QR = A."""
+    m = m_local * P
+    A = qr.uniform_matrix_host(m, n, seed=51)
+    plans = [qr.TsqrPlan(m_local, n, P, r, nb, comm="external") for r in range(P)]
+    assert all(tp.is_pipelined() for tp in plans)
+    shards, Rs = [], []
+    for r, tp in enumerate(plans):
+        dA = zeros(m_local, n)
+        tp.local.fill_uniform(dA, m_local, m_local, n, row_off=r * m_local, total_rows=m, seed=51)
+        tp.sync()
+        shards.append(dA)
+        Rs.append(zeros(n, n))
+    qr.tsqr_factor_virtual(plans, shards, m_local, Rs)
+    R0 = host(Rs[0])
+    for dR in Rs[1:]:
+        assert np.array_equal(R0, host(dR)), "every rank must hold the identical final R"
+    assert np.array_equal(np.tril(R0, -1), np.zeros((n, n)))
+    ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert rel(oracle.sign_normalise(R0), ref) < 1e-13
+    Q = np.vstack([host(_formq(qr, tp, dA, m_local, n)) for tp, dA in zip(plans, shards)])
+    assert np.linalg.norm(A - Q @ R0) / np.linalg.norm(A) < 1e-13
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+    for tp in plans:
+        tp.close()
+
+
+def test_tsqr_selfgather_back_to_back_and_unpipelined_agree(qr, oracle):
+    """One rank's complete step with its own factor in every rank slot (qr_tsqr_factor_selfgather_dev), issued back to back on four
+    matrices without host synchronisation: every R is sqrt(P) times the R of ITS matrix; and the panel-pipelined schedule and the
+    one-collective schedule (MI355XQR_TSQR_PIPE=0, child process) agree to rounding."""
+    import subprocess, sys, os
+    m_local, n, P = 32768, 256, 4
+    tp = qr.TsqrPlan(m_local, n, P, 1, 128, comm="external")
+    assert tp.is_pipelined()
+    mats, Rs = [], []
+    for i in range(4):
+        dA = zeros(m_local, n)
+        tp.local.fill_uniform(dA, m_local, m_local, n, seed=60 + i)
+        mats.append(dA); Rs.append(zeros(n, n))
+    tp.sync()
+    hosts = [host(x) for x in mats]
+    for dA, dR in zip(mats, Rs):
+        tp.factor_selfgather(dA, m_local, dR)
+    tp.sync()
+    outs = []
+    for Ah, dR in zip(hosts, Rs):
+        ref = oracle.sign_normalise(np.linalg.qr(Ah, mode="r")) * np.sqrt(P)
+        got = oracle.sign_normalise(host(dR))
+        assert rel(got, ref) < 1e-13
+        outs.append(got)
+    tp.close()
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import cuda_qr_amd as q\n"
+            "tp = q.TsqrPlan(32768, 256, 4, 1, 128, comm='external'); assert not tp.is_pipelined()\n"
+            "A = torch.zeros((256, 32768), dtype=torch.float64, device='cuda'); R = torch.zeros((256, 256), dtype=torch.float64, device='cuda'); torch.cuda.synchronize()\n"
+            "tp.local.fill_uniform(A, 32768, 32768, 256, seed=60); tp.sync(); tp.factor_selfgather(A, 32768, R); tp.sync()\n"
+            "np.save(sys.argv[1], R.cpu().numpy().T)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = "/tmp/tsqr_unpiped.npy"
+    subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, MI355XQR_TSQR_PIPE="0"))
+    assert rel(oracle.sign_normalise(np.load(path)), outs[0]) < 1e-13

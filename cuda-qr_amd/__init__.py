@@ -21,6 +21,14 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C {HERE}` (or python -c 'import __graft_entry__ as g; "
         "g.build()').  The HIP extension is mandatory; there is no CPU fallback.")
 
+# Load order matters when torch is used in the same process (every caller in this repo: device buffers are torch tensors): the torch
+# wheel bundles its own libamdhip64, and whichever HIP runtime is mapped first serves both -- with the system one mapped first
+# torch.cuda later reports "No HIP GPUs are available".  So torch goes first when it is installed (plumbing only: nothing below uses it).
+try:
+    import torch  # noqa: F401
+except Exception:      # a host without torch: the binding works on raw device pointers
+    pass
+
 lib = C.CDLL(LIB_PATH)
 
 QR_PROF_CLASSES = 4

@@ -1543,6 +1543,8 @@ struct qr_tsqr_plan {
     int local_done;                 /* qr_tsqr_local_dev ran and the stacked step has not yet consumed its R factor */
     /* panel-pipelined form (see qr_tsqr_factor_dev): the exchange and the stacked QR go block column by block column */
     int pipe_ok, npan;              /* usable: single-stream local plan, nb | n, same nb in both plans */
+    int pan_k[QR_TSQR_MAXPAN + 1];  /* block column boundaries: full blocks of nb, the LAST block in two halves (what is left exposed after
+                                     * the local QR has ended is the stacked factorisation of the last block column: make it short) */
     double *dsend;                  /* npan blocks of n x nb: block column k of this rank's R, zero below its trapezoid */
     double *drecv;                  /* nranks blocks of n x nb: one gathered block column (reused panel after panel, stream order) */
     double *Vst, *Tst;              /* explicit V (ldv2 x nb) and T (ldt x nb) of every stacked panel: later panels apply them */
@@ -1577,9 +1579,16 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
         /* panel-pipelined exchange: MI355XQR_TSQR_PIPE=0 keeps the one-collective form */
         const int pnb = rc ? 0 : t->p->nb;
         if (!rc && env_int("MI355XQR_TSQR_PIPE", 1) != 0 && !t->p->lookahead && !t->p2->lookahead && pnb == t->p2->nb && n % pnb == 0 &&
-            n / pnb >= 2 && n / pnb <= QR_TSQR_MAXPAN) {
+            n / pnb >= 2 && n / pnb + 1 <= QR_TSQR_MAXPAN) {
             t->npan = n / pnb;
-            rc = qrd_malloc((void**) &t->dsend, sizeof(double) * (size_t) n * n);
+            for (int k = 0; k <= t->npan; ++k) t->pan_k[k] = k * pnb;
+            if (pnb >= 128 && (pnb / 2) % t->p->ib == 0 && env_int("MI355XQR_TSQR_PIPE_SPLIT_LAST", 1) != 0) {   /* halves of 32 columns lose (65536 x 256, nb 64: 0.39 against 0.32 ms exposed) */
+                t->pan_k[t->npan] = n - pnb / 2;
+                t->pan_k[++t->npan] = n;
+            }
+            /* every exchange moves n x nb doubles from a block's start: the half blocks at the end read past their own width */
+            rc = qrd_malloc((void**) &t->dsend, sizeof(double) * ((size_t) n * n + (size_t) n * pnb));
+            if (!rc) rc = qrd_memset(t->p2->s_main, t->dsend, 0, sizeof(double) * ((size_t) n * n + (size_t) n * pnb));
             if (!rc) rc = qrd_malloc((void**) &t->drecv, sizeof(double) * (size_t) nranks * n * pnb);
             if (!rc) rc = qrd_malloc((void**) &t->Vst, sizeof(double) * (size_t) t->npan * t->p2->ldv * pnb);
             if (!rc) rc = qrd_malloc((void**) &t->Tst, sizeof(double) * (size_t) t->npan * t->p2->ldt * pnb);
@@ -1714,7 +1723,7 @@ int qr_tsqr_stacked_dev(qr_tsqr_plan* t, double* dR)
 static int tsqr_local_panel(qr_tsqr_plan* t, double* dA, int lda, int pi)
 {
     qr_plan* p = t->p;
-    const int m = t->m_local, n = t->n, nb = p->nb, k = pi * nb, wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
+    const int m = t->m_local, n = t->n, k = t->pan_k[pi], wout = t->pan_k[pi + 1] - k, mk = m - k, nt = n - (k + wout);
     use_set(p, 0);
     CHECK(factor_panel(p, dA, m, lda, k, wout, t->dtau, nt > 0, NULL));
     /* block column k of R is final (its rows above the panel were finished by the earlier trailing updates): pack it */
@@ -1729,13 +1738,15 @@ static int tsqr_local_panel(qr_tsqr_plan* t, double* dA, int lda, int pi)
 static int tsqr_stacked_panel(qr_tsqr_plan* t, int pi)
 {
     qr_plan* p2 = t->p2;
-    const int n = t->n, P = t->nranks, sm = t->sm, nb = p2->nb, k = pi * nb, wout = imin(nb, n - k);
+    const int n = t->n, P = t->nranks, sm = t->sm, nb = p2->nb, k = t->pan_k[pi], wout = t->pan_k[pi + 1] - k;
     void* s = p2->s_main;
     for (int q = 0; q < P; ++q)
         CHECK(qrd_copy_block(s, t->drecv + (size_t) q * n * nb, n, t->dS + (size_t) k * sm + (size_t) q * n, sm, n, wout));
-    for (int j = 0; j < pi; ++j)        /* (I - V_j T_j V_j^T)^T on rows j nb .. of the new block column */
-        CHECK(apply_small_t(p2, s, t->Vst + (size_t) j * p2->ldv * nb, p2->ldv, t->Tst + (size_t) j * p2->ldt * nb, p2->ldt, sm - j * nb, nb,
-                            t->dS + (size_t) k * sm + (size_t) j * nb, sm, wout, p2->Wn, p2->Yn, p2->slabs));
+    for (int j = 0; j < pi; ++j) {      /* (I - V_j T_j V_j^T)^T on rows pan_k[j] .. of the new block column */
+        const int kj = t->pan_k[j], wj = t->pan_k[j + 1] - kj;
+        CHECK(apply_small_t(p2, s, t->Vst + (size_t) j * p2->ldv * nb, p2->ldv, t->Tst + (size_t) j * p2->ldt * nb, p2->ldt, sm - kj, wj,
+                            t->dS + (size_t) k * sm + (size_t) kj, sm, wout, p2->Wn, p2->Yn, p2->slabs));
+    }
     p2->Vw = t->Vst + (size_t) pi * p2->ldv * nb;      /* this panel's V and T stay: the later block columns need them */
     p2->T = t->Tst + (size_t) pi * p2->ldt * nb;
     const int rc = factor_panel(p2, t->dS, sm, sm, k, wout, t->dtau2, pi + 1 < t->npan, NULL);
@@ -1752,9 +1763,9 @@ static int tsqr_factor_pipelined(qr_tsqr_plan* t, double* dA, int lda, double* d
         CHECK(qrd_stream_wait_event(s2, t->ev_pan[pi]));
         if (self_gather) {
             for (int q = 0; q < t->nranks; ++q)
-                CHECK(qrd_d2d(s2, t->drecv + (size_t) q * n * nb, t->dsend + (size_t) pi * nb * n, sizeof(double) * (size_t) n * nb));
+                CHECK(qrd_d2d(s2, t->drecv + (size_t) q * n * nb, t->dsend + (size_t) t->pan_k[pi] * n, sizeof(double) * (size_t) n * nb));
         } else
-            CHECK(qrd_allgather_f64(t->comm, s2, t->dsend + (size_t) pi * nb * n, t->drecv, (size_t) n * nb));
+            CHECK(qrd_allgather_f64(t->comm, s2, t->dsend + (size_t) t->pan_k[pi] * n, t->drecv, (size_t) n * nb));
         CHECK(qrd_event_record(t->ev_sent[pi], s2));
         t->sent_pending[pi] = 1;
         CHECK(tsqr_stacked_panel(t, pi));
@@ -1783,7 +1794,7 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
             void* s2 = tps[r]->p2->s_main;
             for (int q = 0; q < P; ++q) {
                 CHECK(qrd_stream_wait_event(s2, tps[q]->ev_pan[pi]));
-                CHECK(qrd_d2d(s2, tps[r]->drecv + (size_t) q * n * nb, tps[q]->dsend + (size_t) pi * nb * n, sizeof(double) * (size_t) n * nb));
+                CHECK(qrd_d2d(s2, tps[r]->drecv + (size_t) q * n * nb, tps[q]->dsend + (size_t) tps[q]->pan_k[pi] * n, sizeof(double) * (size_t) n * nb));
             }
             CHECK(tsqr_stacked_panel(tps[r], pi));
         }

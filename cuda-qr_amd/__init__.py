@@ -128,6 +128,8 @@ _sig("qrd_gemm_tn_update", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, 
      _vp, C.c_int, _vp, C.c_size_t)
 _sig("qrd_gemm_tn_update_wide", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, C.c_int, C.c_double,
      _vp, C.c_int, _vp, C.c_size_t)
+_sig("qrd_gemm_tn_dual", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
+     _vp, C.c_size_t)
 _sig("qrd_leaf_panel", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp)
 _sig("qrd_larft", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
 LEAF_SCRATCH = 2 * (256 * 32 + 32) + 32 * 32

@@ -262,11 +262,10 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(size_t n2, int nslab, con
 }
 
 // ================================================================================================
-static int g_nt_gm = -1;
 static int nt_gm(void)
 {
-    if (g_nt_gm < 0) { const char* e = getenv("MI355XQR_NT_GM"); g_nt_gm = e ? atoi(e) : 8; }
-    return g_nt_gm;
+    static const int v = [] { const char* e = getenv("MI355XQR_NT_GM"); return e ? atoi(e) : 8; }();     // read once, thread-safe
+    return v;
 }
 
 static inline bool al16(const void* p, int ld) { return (((uintptr_t) p) & 15) == 0 && (ld & 1) == 0; }

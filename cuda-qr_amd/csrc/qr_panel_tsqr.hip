@@ -2286,8 +2286,7 @@ static int nt_for(int rows) { return rows <= 64 ? 64 : (rows <= 128 ? 128 : (row
 // of two and the cross-wave sum has 4 partials instead of 8
 static int leaf_waves(void)
 {
-    static int v = 0;
-    if (!v) { const char* e = getenv("MI355XQR_LEAF_WAVES"); v = (e && atoi(e) == 8) ? 8 : 4; }
+    static const int v = [] { const char* e = getenv("MI355XQR_LEAF_WAVES"); int v_ = (e && atoi(e) == 8) ? 8 : 4; return v_; }();
     return v;
 }
 
@@ -2349,8 +2348,7 @@ size_t qrd_panel_ws_size(int m)
 // MI355XQR_COOP=0: the guard route always as separate launches (default 1: one cooperative launch for short leaves)
 static int coop_enabled(void)
 {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MI355XQR_COOP"); v = (e && atoi(e) == 0) ? 0 : 1; }
+    static const int v = [] { const char* e = getenv("MI355XQR_COOP"); int v_ = (e && atoi(e) == 0) ? 0 : 1; return v_; }();
     return v;
 }
 
@@ -2390,8 +2388,7 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + brows0 - 1) / brows0; lv_off[0] = 0; lv_tau[0] = 0;
     // final3_u: the caller's last CholeskyQR2 launch (final3_kernel<true> with this U') is still to be issued -- fused with the
     // one-launch guard route where that exists (same grid), on its own otherwise
-    static int fuse = -1;
-    if (fuse < 0) { const char* e = getenv("MI355XQR_FUSE_GUARD"); fuse = (e && atoi(e) == 0) ? 0 : 1; }
+    static const int fuse = [] { const char* e = getenv("MI355XQR_FUSE_GUARD"); int v_ = (e && atoi(e) == 0) ? 0 : 1; return v_; }();
     const bool coop = guard && bar && coop_enabled() && lv_nblk[0] * w <= PT;
     const EpArgs ep0 = ep ? *ep : EpArgs{};
     const size_t ep_shm = ep ? EP_SMEM_BYTES : 0;
@@ -2514,8 +2511,7 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
 // the vector ALUs), default 3 (4 launches, row solves as matrix-core products with explicit triangular inverses; short leaves)
 static int leaf_gen(void)
 {
-    static int v = 0;
-    if (!v) { const char* e = getenv("MI355XQR_LEAF"); v = e ? atoi(e) : 3; if (v < 1 || v > 3) v = 3; }
+    static const int v = [] { const char* e = getenv("MI355XQR_LEAF"); int v_ = e ? atoi(e) : 3; if (v_ < 1 || v_ > 3) v_ = 3; return v_; }();
     return v;
 }
 
@@ -2632,8 +2628,7 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
         int nblk2 = nblk;                                   // workgroups of cholq2_kernel = slabs of G2
         if (nblk <= CQ2_MAXSLAB) {
             // short leaf (square problems): at most CQ2_MAXSLAB Gram slabs of >= 128 rows, summed by their consumers
-            static int gslab_max = 0;
-            if (!gslab_max) { const char* e = getenv("MI355XQR_GRAM_SLABS"); gslab_max = e ? atoi(e) : CQ2_MAXSLAB; if (gslab_max < 1 || gslab_max > CQ2_MAXSLAB) gslab_max = CQ2_MAXSLAB; }
+            static const int gslab_max = [] { const char* e = getenv("MI355XQR_GRAM_SLABS"); int v_ = e ? atoi(e) : CQ2_MAXSLAB; if (v_ < 1 || v_ > CQ2_MAXSLAB) v_ = CQ2_MAXSLAB; return v_; }();
             int rows_per = ((mk + gslab_max - 1) / gslab_max + GKB - 1) / GKB * GKB;
             if (rows_per < 2 * GKB) rows_per = 2 * GKB;
             int nslab = (mk + rows_per - 1) / rows_per;
@@ -2642,8 +2637,7 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
             // 256-row workgroups where that keeps the partial Grams of G2 within CQ2_MAXSLAB (mk <= 8192, the chain-bound part of a
             // square factorisation): the kernel is bound by its 128 matrix-core instructions per wave -- at two waves per SIMD 7.4 us
             // of its 25 -- and half-size workgroups put them on twice the compute units
-            static int half_wg = -1;
-            if (half_wg < 0) { const char* e = getenv("MI355XQR_LEAF_HALFWG"); half_wg = e ? atoi(e) != 0 : 1; }
+            static const int half_wg = [] { const char* e = getenv("MI355XQR_LEAF_HALFWG"); int v_ = e ? atoi(e) != 0 : 1; return v_; }();
             if (gen == 3 && half_wg && (mk + 255) / 256 <= CQ2_MAXSLAB) {
                 nblk2 = (mk + 255) / 256;
                 hipLaunchKernelGGL((cholq3_kernel<256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk,
@@ -2659,8 +2653,7 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
             // 256-row workgroups, three to a compute unit
             // two row blocks per workgroup where that still leaves >= 1.5 workgroups per compute unit (262144 rows: 7.58 -> 7.31 ms
             // for the 512-column shard; 65536 rows: 2 % slower, half the chip would idle)
-            static int rb_env = -1;
-            if (rb_env < 0) { const char* e = getenv("MI355XQR_TALL_RB"); rb_env = e ? atoi(e) : 0; }
+            static const int rb_env = [] { const char* e = getenv("MI355XQR_TALL_RB"); int v_ = e ? atoi(e) : 0; return v_; }();
             const bool rb2 = rb_env == 2 || (rb_env != 1 && (mk + 511) / 512 >= 384);
             nblk2 = rb2 ? (mk + 511) / 512 : (mk + 255) / 256;
             if (gram_nslab > 0 && (size_t) gram_nslab * PW * PW <= slab_cap - (size_t) nblk2 * PW * PW)
@@ -2669,12 +2662,10 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
                 rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
             if (rc) return rc;
             slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
-            static int tall_q = -1;
-            if (tall_q < 0) { const char* e = getenv("MI355XQR_TALL_Q"); tall_q = e ? atoi(e) : 4; }
+            static const int tall_q = [] { const char* e = getenv("MI355XQR_TALL_Q"); int v_ = e ? atoi(e) : 4; return v_; }();
             if (tall_q == 4 && (mk & 3) == 0 && w == PW) {
                 // streaming form: one-wave Cholesky (R1, R1^-1 -> Mm, which hr3 overwrites later), then the matrix-core pass
-                static int gq_max = 0;
-                if (!gq_max) { const char* e = getenv("MI355XQR_TALL_QGRID"); gq_max = e ? atoi(e) : 512; if (gq_max < 32 || gq_max > 2048) gq_max = 512; }
+                static const int gq_max = [] { const char* e = getenv("MI355XQR_TALL_QGRID"); int v_ = e ? atoi(e) : 512; if (v_ < 32 || v_ > 2048) v_ = 512; return v_; }();
                 int gq = (mk + PT - 1) / PT;
                 if (gq > gq_max) gq = gq_max;
                 nblk2 = gq;

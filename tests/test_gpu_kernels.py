@@ -587,3 +587,36 @@ def test_gemm_tn_update_wide_tiles(q, M, N, K, entry):
     ref = A.T @ B
     assert np.abs(outs[0] - ref).max() < 1e-12 * np.sqrt(K) * max(1.0, np.abs(ref).max())
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("K,N1,N2", [(4096, 96, 64), (8192, 224, 0), (2048, 0, 96), (100352, 96, 96), (131072, 32, 0), (262144, 64, 128), (98304, 0, 224),
+                                     (120000, 160, 64)])
+def test_gemm_tn_dual_short_and_tall(q, K, N1, N2):
+    """The leaf's two long-K in-panel products in one call, [W | G^T] = T^T V^T [A_rest | V_prev] (qrd_gemm_tn_dual: split-K 32 x 32
+    tiles, K slices dealt to the XCDs, T^T folded into the slab reduce) at short and tall leaf heights -- against numpy, bitwise
+    reproducible."""
+    rng = np.random.default_rng(K + N1 + 7 * N2)
+    V = rng.standard_normal((K, 32)) / np.sqrt(K)
+    B1 = rng.standard_normal((K, max(N1, 1)))
+    B2 = rng.standard_normal((K, max(N2, 1)))
+    T = np.triu(rng.standard_normal((32, 32)))
+    dV, dB1, dB2, dT = dev(V), dev(B1), dev(B2), dev(T)
+    cap = 1 << 23
+    slabs = torch.zeros(cap, dtype=torch.float64, device="cuda")
+    outs = []
+    for rep in range(2):
+        dW, dG = dev(np.full((32, max(N1, 1)), np.nan)), dev(np.full((max(N2, 1) + 3, 32), np.nan))
+        torch.cuda.synchronize()
+        q.check(q.lib.qrd_gemm_tn_dual(None, N1, N2, K, dV.data_ptr(), K, dB1.data_ptr(), K, dB2.data_ptr(), K, dT.data_ptr(), 32, dW.data_ptr(), 32,
+                                       dG.data_ptr(), max(N2, 1) + 3, slabs.data_ptr(), cap))
+        _sync(q)
+        outs.append((host(dW), host(dG)))
+    if N1:
+        ref = T.T @ (V.T @ B1)
+        assert np.abs(outs[0][0] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()) * np.sqrt(K)
+        assert np.array_equal(outs[0][0], outs[1][0])
+    if N2:
+        ref = B2.T @ V
+        assert np.abs(outs[0][1][:N2] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()) * np.sqrt(K)
+        assert np.array_equal(outs[0][1][:N2], outs[1][1][:N2])
+        assert np.isnan(outs[0][1][N2:]).all()

@@ -187,4 +187,77 @@ __device__ __forceinline__ void gemm_epilogue(const v4d (&acc)[TJ][TI], double* 
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// The leaf's long-K in-panel product Z = A^T [B1 | B2] (A: the leaf's 32 columns) on 32 x (32 TJ) tiles: shared by the fused launch of
+// the leaf's reconstruction (qr_panel_tsqr.hip, hr3_ep_kernel) and the stand-alone product of tall leaves (qr_kernels.hip).
+// ------------------------------------------------------------------------------------------------
+struct EpArgs {
+    int N1, N2, K, kchunk, tiles, ksplit;    // Z is 32 x (N1 + N2); K rows in slices of kchunk; tiles = (N1 + N2) / 32 (redo tiling)
+    int ftiles;                               // column tiles of the fused launch: ceil((N1 + N2) / (32 TJ))
+    const double* Q; int ldq;                 // the leaf's 32 columns (Q before / V after the reconstruction), K rows
+    const double* B1; int ldb1;               // A_rest: K x N1
+    const double* B2; int ldb2;               // V_prev: K x N2 (rows from the leaf's top row)
+    double* slabs; size_t slab_stride;        // slab z at slabs + z * slab_stride, each 32 x (N1 + N2), ld 32
+};
+
+#define EP_FUSED_SMEM_BYTES(TJ) (sizeof(double) * 2 * 32 * (1 + (TJ)) * LDKF)
+
+// The fused launch's product item: a 32 x (32 TJ) tile of Z over one K slice, on the first 256 threads of a 512-thread workgroup
+// (the launch is sized by the reconstruction: ~205 VGPRs, one workgroup per compute unit, so the product has ONE 4-wave
+// workgroup per CU where the separate launch had up to eight: wider tiles -- TJ accumulators per wave between two barriers -- and TWO
+// k-tiles of global loads in flight make up for the missing occupancy).  The 32-column blocks of a tile may sit on either side of the
+// A_rest | V_prev boundary (N1 is a multiple of 32); blocks past the last column read block 0 of the tile and are never stored.
+template <int TJ>
+__device__ __forceinline__ void ep_fused_item(const EpArgs& e, int tile, int z)
+{
+    extern __shared__ __attribute__((aligned(16))) double ep_smem[];
+    constexpr int ASZ = 32 * LDKF, BSZ = 32 * TJ * LDKF;
+    double* As = ep_smem;                    // [2][32][LDKF]
+    double* Bsm = ep_smem + 2 * ASZ;         // [2][32 TJ][LDKF]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1, l15 = lane & 15, l4 = lane >> 4;
+    const int j0 = tile * 32 * TJ, N = e.N1 + e.N2;
+    const int kbeg = z * e.kchunk, kend = min(e.K, kbeg + e.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    // this thread's column of every 32-column block, and of the Q tile: 8 threads per column, 2 doubles each per k-tile
+    const double* bp[TJ];
+#pragma unroll
+    for (int q = 0; q < TJ; ++q) {
+        int j = j0 + 32 * q + (tid >> 3);
+        if (j >= N) j = j0 + (tid >> 3);
+        bp[q] = (j >= e.N1 ? e.B2 + (size_t) (j - e.N1) * e.ldb2 : e.B1 + (size_t) j * e.ldb1) + 2 * (tid & 7);
+    }
+    const double* qp = e.Q + (size_t) (tid >> 3) * e.ldq + 2 * (tid & 7);
+    v2d ra[2], rb[2][TJ];
+    auto gload = [&](int st, int k0) {
+        ra[st] = *reinterpret_cast<const v2d*>(qp + k0);
+#pragma unroll
+        for (int q = 0; q < TJ; ++q) rb[st][q] = *reinterpret_cast<const v2d*>(bp[q] + k0);
+    };
+    auto sstore = [&](int st, int buf) {
+        *reinterpret_cast<v2d*>(As + buf * ASZ + (tid >> 3) * LDKF + 2 * (tid & 7)) = ra[st];
+#pragma unroll
+        for (int q = 0; q < TJ; ++q) *reinterpret_cast<v2d*>(Bsm + buf * BSZ + (32 * q + (tid >> 3)) * LDKF + 2 * (tid & 7)) = rb[st][q];
+    };
+    v4d acc[TJ][1];
+#pragma unroll
+    for (int a = 0; a < TJ; ++a) acc[a][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (nk > 0) gload(0, kbeg);
+    if (nk > 1) gload(1, kbeg + BK);
+    if (nk > 0) sstore(0, 0);
+    __syncthreads();
+    // k-tile kt: LDS buffer kt & 1 holds it, register stage (kt + 1) & 1 holds tile kt + 1, stage kt & 1 is free for tile kt + 2
+    auto step = [&](int kt, int st) {          // st = kt & 1 as a literal after unrolling
+        if (kt + 2 < nk) gload(st, kbeg + (kt + 2) * BK);
+        mma_tile<1, TJ, false>(acc, As + st * ASZ, Bsm + st * BSZ, wi, wj, l15, l4);
+        if (kt + 1 < nk) sstore(st ^ 1, st ^ 1);
+        __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) { step(kt, 0); step(kt + 1, 1); }
+    if (kt < nk) step(kt, 0);
+    gemm_epilogue<1, TJ, true>(acc, e.slabs + (size_t) z * e.slab_stride, 32, 32, N, 0, j0, 1.0, 0.0, wi, wj, l15, l4);
+}
+
+
 #endif

@@ -951,7 +951,8 @@ int qrd_gemm_tn_dual(void* stream, int N1, int N2, int K, const double* A, int l
     // (round 3: a streaming form of this product for tall leaves -- both operands straight from global memory in MFMA operand layout,
     // 32 B per lane, all outputs of a column group in accumulators, no LDS / barrier in the loop -- was built and measured at 100-109 us
     // per launch on a 262144-row leaf against 78 us here: 128-byte-per-column accesses from 8 waves per CU stream worse than this
-    // kernel's LDS-staged tiles from 32 waves per CU.  Removed; profiles/r03_tn_stream_negative.txt.)
+    // kernel's LDS-staged tiles from 32 waves per CU; and the 32 x 64 tiles of the fused launch (ep_fused_item) as a launch of their own:
+    // 87 us.  Both removed; profiles/r03_tn_stream_negative.txt.)
     const int tiles = N / 32, slots = spc * stream_cus(s);
     long long kmax = (K + kmin_tiles * BK - 1) / (kmin_tiles * BK);
     if (kmax > 256) kmax = 256;

@@ -193,7 +193,7 @@ def main():
     wd.arm(args.watchdog + (60.0 if world > 1 else 0.0), "qr_tsqr_plan_create (ncclCommInitRank over the ranks of this node)")
     be = T.DeviceTSQR(qr, m_local, n, world, rank, nb, transport="rccl" if backend == "nccl" else "host")
     ts = be
-    rccl_ranks = be.tp.comm_ranks() if (world > 1 and backend == "nccl") else None
+    rccl_ranks = be.tp.comm_ranks() if (world > 1 and backend == "nccl" and be.transport == "rccl") else None
     wd.disarm()
     K, W = args.steps, args.warmup
     bytes_per = 8 * m_local * n
@@ -305,7 +305,7 @@ def main():
         tsqr_split = {"unpipelined_latency_ms": lat_ms, "local_qr_ms": loc_ms,
                       "exchange_and_stacked_qr_ms": lat_ms - loc_ms,
                       "pipelined_ms_per_step": dt / K * 1e3,
-                      "panel_pipelined_exchange": bool(be.tp.is_pipelined()),
+                      "panel_pipelined_exchange": bool(be.transport == "rccl" and be.tp.is_pipelined()),
                       "unpipelined_gflops": flops(m_total, n) / (lat_ms * 1e-3) / 1e9,
                       "note": "max over ranks; un-pipelined = qr_tsqr_factor_dev + qr_tsqr_sync per step (the single-factorisation "
                               "latency); `value` is the throughput of K independent factorisations issued back to back; "
@@ -467,7 +467,7 @@ def main():
                        "ib": args.ib or qr.get_block_size()[1],
                        "flops_per_step": flops(m_total, n), "input_buffers": nbuf,
                        "input": "uniform[0,1) counter-hash generator, seed 12+i, resident in HBM",
-                       "collective": "none" if world == 1 else (f"{n // nb} all_gathers of n*nb doubles per rank (panel-pipelined, RCCL)" if (backend == "nccl" and be.tp.is_pipelined()) else f"1 all_gather of n*n doubles per rank ({'RCCL' if backend == 'nccl' else backend + ' via host, bring-up only'})")},
+                       "collective": "none" if world == 1 else (f"{n // nb} all_gathers of n*nb doubles per rank (panel-pipelined, RCCL)" if (backend == "nccl" and be.transport == "rccl" and be.tp.is_pipelined()) else f"1 all_gather of n*n doubles per rank ({'RCCL' if backend == 'nccl' else backend + ' via host, bring-up only'})")},
             "frac_of_fp64_matrix_peak": value / 1e3 / (FP64_MATRIX_PEAK_TFLOPS * world),
             "accuracy": acc,
             "roofline": roof,
@@ -475,7 +475,11 @@ def main():
             "tsqr_model_1gpu": tsqr_model,
             "tsqr_step_split": tsqr_split,
             "rccl": ({"nranks_seen_by_rccl": rccl_ranks, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
-                      "driver": "C-ABI qr_tsqr_plan: ncclCommInitRank from a broadcast unique id, ncclAllGather on the plan's stream"}
+                      "transport": be.transport, "fallback_reason": be.fallback_reason,
+                      "driver": ("C-ABI qr_tsqr_plan: ncclCommInitRank from a broadcast unique id, ncclAllGather on the plan's stream"
+                                 if be.transport == "rccl" else
+                                 "C-ABI qr_tsqr_plan for the local and stacked steps; R factors gathered by torch.distributed on the plan's "
+                                 "device buffers (fallback: the library could not create its own communicator)")}
                      if world > 1 else None),
             "scaling_note": ("the N = 1 line of this bench is the square C3 headline, a different workload: the weak-scaling "
                              "denominator of this line is weak_scaling_base_1gpu of the N = 1 line (one 262144x512 shard on "

@@ -24,6 +24,17 @@ import torch
 import torch.distributed as dist
 
 
+class _RawDeviceBuffer:
+    """zero-copy torch view of a device buffer the library owns (its exchange buffers), through __cuda_array_interface__"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def _device_view(ptr, count, device):
+    return torch.as_tensor(_RawDeviceBuffer(ptr, count), device=device)
+
+
 class DeviceTSQR:
     """One rank's device-resident TSQR step through the C-ABI plan (qr_tsqr_factor_dev / qr_tsqr_formq_dev).
 
@@ -36,12 +47,38 @@ class DeviceTSQR:
         self.transport = transport if world > 1 else "none"
         dev = torch.device("cuda", torch.cuda.current_device())
         self.device = dev
+        self.fallback_reason = None
         if world == 1:
             self.tp = qr.TsqrPlan(m_local, n, 1, 0, nb)
         elif transport == "rccl":
-            box = [qr.tsqr_unique_id() if rank == 0 else None]
+            # the library's own communicator (ncclCommInitRank through the dlopen()ed librccl).  If ANY rank cannot build it, every
+            # rank falls back to transport "torch" together: same C plan for the local and stacked steps, the R factors gathered by
+            # torch.distributed's collective directly on the plan's device buffers (one collective, host-synchronised)
+            ok, err = 1, None
+            try:
+                box = [qr.tsqr_unique_id() if rank == 0 else None]
+            except Exception as e:          # rank 0 could not load RCCL: still take part in the broadcast, then in the vote
+                box, ok, err = [None], 0, repr(e)
             dist.broadcast_object_list(box, src=0, group=group)
-            self.tp = qr.TsqrPlan(m_local, n, world, rank, nb, unique_id=box[0])
+            self.tp = None
+            if ok and box[0] is not None:
+                try:
+                    self.tp = qr.TsqrPlan(m_local, n, world, rank, nb, unique_id=box[0])
+                except Exception as e:
+                    ok, err = 0, repr(e)
+            else:
+                ok = 0
+            vote = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+            if int(vote.item()) == 0:
+                if self.tp is not None:
+                    self.tp.close()
+                self.transport = "torch"
+                self.fallback_reason = err or "another rank could not create the library's RCCL communicator"
+                self.tp = qr.TsqrPlan(m_local, n, world, rank, nb, comm="external")
+                send, recv = self.tp.exchange_buffers()
+                self._send_t = _device_view(send, n * n, dev)
+                self._recv_t = _device_view(recv, world * n * n, dev)
         else:
             self.tp = qr.TsqrPlan(m_local, n, world, rank, nb, comm="external")
             self._send, self._recv = self.tp.exchange_buffers()
@@ -60,6 +97,13 @@ class DeviceTSQR:
     def factor(self, A):
         """Steps 1-3 on this rank's shard A (overwritten with its local factors); returns the buffer that will hold the final
         R (n x n column-major).  Asynchronous with transport rccl / none: call sync() before reading R."""
+        if self.transport == "torch":
+            self.tp.local_factor(A, self.m)
+            self.tp.sync()
+            dist.all_gather_into_tensor(self._recv_t, self._send_t, group=self.group)
+            torch.cuda.current_stream().synchronize()
+            self.tp.stacked_factor(self.R)
+            return self.R
         if self.transport != "host":
             self.tp.factor(A, self.m, self.R)
             return self.R

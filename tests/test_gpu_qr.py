@@ -692,3 +692,32 @@ def test_tsqr_selfgather_back_to_back_and_unpipelined_agree(qr, oracle):
     path = "/tmp/tsqr_unpiped.npy"
     subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, MI355XQR_TSQR_PIPE="0"))
     assert rel(oracle.sign_normalise(np.load(path)), outs[0]) < 1e-13
+
+
+def test_tsqr_exchange_buffers_as_torch_views(qr, oracle):
+    """The fallback transport of bench.py (torch.distributed gathers the R factors when the library cannot create its own RCCL
+    communicator) works directly on the plan's device buffers through zero-copy torch views: the send view must show this rank's R
+    after qr_tsqr_local_dev, and factors written through the recv view must be what qr_tsqr_stacked_dev factors."""
+    from cuda_qr_amd import tsqr as T
+    m_local, n, P = 4096, 96, 2
+    tp = qr.TsqrPlan(m_local, n, P, 0, 32, comm="external")
+    send, recv = tp.exchange_buffers()
+    sv, rv = T._device_view(send, n * n, "cuda"), T._device_view(recv, P * n * n, "cuda")
+    assert sv.data_ptr() == send and rv.data_ptr() == recv
+    A = qr.uniform_matrix_host(2 * m_local, n, seed=77)
+    dA = dev(A[:m_local])
+    tp.local_factor(dA, m_local)
+    tp.sync()
+    R0 = np.triu(sv.cpu().numpy().reshape(n, n).T)
+    ref0 = oracle.sign_normalise(np.linalg.qr(A[:m_local], mode="r"))
+    assert rel(oracle.sign_normalise(R0), ref0) < 1e-13
+    R1 = np.linalg.qr(A[m_local:], mode="r")
+    rv[: n * n].copy_(sv)
+    rv[n * n:].copy_(torch.from_numpy(np.ascontiguousarray(np.triu(R1).T).ravel()).cuda())
+    torch.cuda.synchronize()
+    dR = zeros(n, n)
+    tp.stacked_factor(dR)
+    tp.sync()
+    ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert rel(oracle.sign_normalise(host(dR)), ref) < 1e-13
+    tp.close()

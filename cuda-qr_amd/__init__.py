@@ -114,6 +114,7 @@ _sig("qr_plan_sync", C.c_int, _vp)
 _sig("qr_plan_stream", _vp, _vp)
 _sig("qr_plan_update_cus", C.c_int, _vp)
 _sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)
+_sig("qr_plan_pause_profile", C.c_int, _vp, C.c_int)
 _sig("qr_plan_get_profile", C.c_int, _vp, C.POINTER(Profile))
 _sig("qr_plan_get_profile_records", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), _dp, _dp)
 _sig("qr_device_info", C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t))
@@ -425,6 +426,9 @@ class Plan:
 
     def set_profile(self, on):
         check(lib.qr_plan_set_profile(self.h, int(on)), "qr_plan_set_profile")
+
+    def pause_profile(self, pause):
+        check(lib.qr_plan_pause_profile(self.h, int(bool(pause))), "qr_plan_pause_profile")
 
     def get_profile_records(self, max_records=65536):
         """[(class, start_ms, end_ms)] of the last profiled run, in issue order (call before get_profile)."""

@@ -229,6 +229,7 @@ typedef struct qr_profile {
 /* on = 0: off; 1: every class; 2 * mask: only the classes whose bit is set in mask (bit c = class c; bits 4, 5 = the look-ahead
  * update / the panel stream's share of a wide update).  A record costs two event packets on its stream: profile what you read. */
 int qr_plan_set_profile(qr_plan* plan, int on);
+int qr_plan_pause_profile(qr_plan* plan, int pause);       /* stop / resume recording, keeping the records made so far */
 int qr_plan_get_profile(qr_plan* plan, qr_profile* out);   /* synchronises, sums, resets */
 /* The individual records behind the sums, in issue order (call before qr_plan_get_profile): class as above, plus 4 = the
  * look-ahead update of the next panel's columns and 5 = the panel stream's share of a wide update (both summed into class 3

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include "qr_device.h"
 
@@ -59,7 +60,36 @@ int load_rccl()
 }
 }   // namespace
 
+// ---- optional roctx ranges (tracing): MI355XQR_ROCTX=1 wraps every outer step's panel / look-ahead / wide update in
+// named ranges for `rocprofv3 --marker-trace`; librocprofiler-sdk-roctx (or libroctx64) is dlopen()ed on first use, never linked
+namespace {
+struct RoctxApi { std::atomic<int> state{0}; int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+RoctxApi g_roctx;
+std::mutex g_roctx_mutex;
+bool roctx_ready()
+{
+    const int st = g_roctx.state.load(std::memory_order_acquire);
+    if (st) return st > 0;                                  // the usual case (off): one atomic load per range
+    std::lock_guard<std::mutex> lock(g_roctx_mutex);
+    if (g_roctx.state.load()) return g_roctx.state.load() > 0;
+    const char* e = getenv("MI355XQR_ROCTX");
+    if (!e || atoi(e) == 0) { g_roctx.state.store(-1, std::memory_order_release); return false; }
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (h) {
+        g_roctx.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        g_roctx.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    }
+    g_roctx.state.store((g_roctx.push && g_roctx.pop) ? 1 : -1, std::memory_order_release);
+    return g_roctx.state.load() > 0;
+}
+}   // namespace
+
 extern "C" {
+
+void qrd_range_push(const char* name) { if (roctx_ready()) g_roctx.push(name); }
+void qrd_range_pop(void) { if (roctx_ready()) g_roctx.pop(); }
 
 // comms: array of n opaque communicator handles, one per entry of devs (all on this node)
 int qrd_comm_init_all(void** comms, int n, const int* devs)

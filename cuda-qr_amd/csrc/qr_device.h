@@ -85,6 +85,10 @@ const char* qrd_rccl_error_string(int r);
 int qrd_comm_destroy(void* comm);
 int qrd_allgather_f64(void* comm, void* stream, const double* send, double* recv, size_t count);
 
+/* optional roctx ranges around the host-side issue of a step's phases (MI355XQR_ROCTX=1; rocprofv3 --marker-trace) */
+void qrd_range_push(const char* name);
+void qrd_range_pop(void);
+
 int qrd_malloc(void** p, size_t bytes);
 int qrd_free(void* p);
 int qrd_memset(void* stream, void* p, int v, size_t bytes);

@@ -583,7 +583,17 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
  * K = wout = 512: half the C traffic per flop of K = 256, which is what bounds it.
  * half_ready: event the second half's columns must wait for (the wide update of the previous panel reaches them on the
  * update stream while the first half is being factored), or NULL. */
+static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t, void* half_ready);
+
 static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t, void* half_ready)
+{
+    qrd_range_push("mi355xqr panel");                 /* host-side issue range (MI355XQR_ROCTX=1) */
+    const int rc = factor_panel_inner(p, dA, m, lda, k, wout, dtau, want_t, half_ready);
+    qrd_range_pop();
+    return rc;
+}
+
+static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t, void* half_ready)
 {
     const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt, nb = p->nb;
     double* Ak = dA + (size_t) k * lda + k;
@@ -723,8 +733,20 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
  * profile 0 = look-ahead update of the next panel (class 4), 2 = the share of the wide update done on the panel CUs
  *             (class 5): Y = V^T A2, W = T^T Y (a small product), A2 -= V W -- no V*T needed.
  * Ybuf: nc*wout doubles of scratch for profile 0 / 2. */
+static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int lda, int k, int mk, int wout, int c0, int nc,
+                             double* Wbuf, double* Ybuf, double* slabs, int profile, int form_vt);
+
 static int update_cols(qr_plan* p, void* stream, int e, double* dA, int lda, int k, int mk, int wout, int c0, int nc,
                        double* Wbuf, double* Ybuf, double* slabs, int profile, int form_vt)
+{
+    qrd_range_push(profile == 1 ? "mi355xqr wide update" : (profile == 0 ? "mi355xqr look-ahead update" : "mi355xqr panel-stream share"));
+    const int rc = update_cols_inner(p, stream, e, dA, lda, k, mk, wout, c0, nc, Wbuf, Ybuf, slabs, profile, form_vt);
+    qrd_range_pop();
+    return rc;
+}
+
+static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int lda, int k, int mk, int wout, int c0, int nc,
+                             double* Wbuf, double* Ybuf, double* slabs, int profile, int form_vt)
 {
     double* A2 = dA + (size_t) c0 * lda + k;
     const int ldv = p->ldv;

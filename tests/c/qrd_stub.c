@@ -47,6 +47,8 @@ static void chkb(const char* what, const void* p, size_t bytes) { if (bytes) chk
 long qrd_stub_launches(void) { return g_launches; }
 int qrd_stub_live_allocations(void) { return g_nalloc; }
 
+void qrd_range_push(const char* name) { (void) name; }
+void qrd_range_pop(void) { }
 int qrd_init(void) { return 0; }
 int qrd_gemm2_init(void) { return 0; }
 int qrd_panel_tsqr_init(void) { return 0; }

@@ -721,3 +721,23 @@ def test_tsqr_exchange_buffers_as_torch_views(qr, oracle):
     ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
     assert rel(oracle.sign_normalise(host(dR)), ref) < 1e-13
     tp.close()
+
+
+def test_graph_replay_single_stream_schedule(qr, oracle, monkeypatch):
+    """MI355XQR_GRAPH=1: the single-stream schedule is captured into a hipGraph on the first call with an argument set and replayed
+    afterwards -- three different matrices through the same buffer must each give their own R; with look-ahead the knob is ignored
+    (capturing the CU-masked two-stream schedule crashes inside the runtime)."""
+    monkeypatch.setenv("MI355XQR_GRAPH", "1")
+    for (m, n, nb, la) in [(3000, 700, 128, "0"), (40000, 256, 128, "0"), (2500, 2304, 128, "1")]:
+        monkeypatch.setenv("MI355XQR_LOOKAHEAD", la)
+        p = qr.Plan(m, n, nb, 32)
+        dA, dtau, dR = zeros(m, n), zeros(n, 1), zeros(n, n)
+        for seed in (3, 4, 5):
+            p.fill_uniform(dA, m, m, n, seed=seed)
+            p.sync()
+            p.geqrf(dA, m, n, m, dtau)
+            p.extract_r(dA, m, n, m, dR, n, n)
+            p.sync()
+            ref = oracle.sign_normalise(np.linalg.qr(qr.uniform_matrix_host(m, n, seed=seed), mode="r"))
+            assert rel(oracle.sign_normalise(host(dR)), ref) < 1e-13, (m, n, la, seed)
+        p.close()

@@ -166,3 +166,24 @@ def test_bench_bringup_two_ranks_on_one_gpu_through_the_c_abi_plan(tmp_path):
     sp = line["tsqr_step_split"]
     assert sp["unpipelined_latency_ms"] >= sp["local_qr_ms"] > 0 and sp["pipelined_ms_per_step"] > 0
     assert line["config"]["collective"].startswith("1 all_gather")
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_round_trip_through_the_librarys_loader():
+    """What ONE GPU can check of the RCCL transport: the library's own loader (dlopen librccl, ncclGetUniqueId, ncclCommInitRank,
+    ncclAllGather on a plan's stream) in a process that has torch loaded, like bench.py -- one communicator of one rank, an
+    all-gather on torch-allocated and on library-allocated buffers, and which HIP / RCCL libraries the process ended up with (ONE of
+    each: the library binds to the runtime torch brought, so its streams and torch's NCCL backend share one HIP runtime)."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "devtools", "tools_rccl_1rank.py")], capture_output=True, text=True,
+                         timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks_seen_by_rccl"] == 1 and line["allgather_torch_buffers_ok"] and line["allgather_library_buffers_ok"]
+    libs = line["mapped_runtime_libraries"]
+    assert sum("amdhip64" in l for l in libs) == 1 and sum("rccl" in l for l in libs) == 1, libs

@@ -318,6 +318,32 @@ def main():
                               "and the stacked (world*n) x n matrix (redundant on every rank, latency-bound) is factored "
                               "left-looking while the local QR continues"}
 
+    # ---- N > 1, fixed-size configs (C4 / C5): the SAME matrix on ONE GPU, measured by rank 0 in this run (the other ranks wait at
+    # the next barrier) -- the strong-scaling denominator next to the N-GPU numbers above
+    same_1gpu = None
+    if world > 1 and wl in ("c4", "c5") and rank == 0:
+        try:
+            one = T.DeviceTSQR(qr, m_total, n, 1, 0, 128)
+            A1 = one.new_matrix(m_total, n)
+            best = 1e30
+            for i in range(3):
+                one.fill(A1, m_total, n, 0, m_total, 12)
+                t1 = time.perf_counter()
+                one.factor(A1)
+                one.sync()
+                if i:
+                    best = min(best, (time.perf_counter() - t1) * 1e3)
+            one.close()
+            del A1
+            same_1gpu = {"ms": best, "gflops": flops(m_total, n) / (best * 1e-3) / 1e9, "nb": 128,
+                         "speedup_latency": best / tsqr_split["unpipelined_latency_ms"],
+                         "speedup_throughput": best / (dt / K * 1e3),
+                         "note": "the whole %d x %d matrix factored on rank 0's GPU alone (plain qr_plan, drained per step); speedup = "
+                                 "that time / the N-GPU time per factorisation (latency: one drained factorisation; throughput: "
+                                 "ms_per_step of this line)" % (m_total, n)}
+        except Exception as e:
+            same_1gpu = {"error": repr(e)}
+
     # ---- roofline of the dominant kernel
     # dominant kernel: from the timed region; the rest: from the extra profiled step (per-step figures, K_full = 1)
     if wl in ("c2", "c3"):
@@ -481,6 +507,7 @@ def main():
             "weak_scaling_base_1gpu": weak_base,
             "tsqr_model_1gpu": tsqr_model,
             "tsqr_step_split": tsqr_split,
+            "same_problem_1gpu": same_1gpu,
             "rccl": ({"nranks_seen_by_rccl": rccl_ranks, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                       "transport": be.transport, "fallback_reason": be.fallback_reason,
                       "driver": ("C-ABI qr_tsqr_plan: ncclCommInitRank from a broadcast unique id, ncclAllGather on the plan's stream"

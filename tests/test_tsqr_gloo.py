@@ -166,6 +166,8 @@ def test_bench_bringup_two_ranks_on_one_gpu_through_the_c_abi_plan(tmp_path):
     sp = line["tsqr_step_split"]
     assert sp["unpipelined_latency_ms"] >= sp["local_qr_ms"] > 0 and sp["pipelined_ms_per_step"] > 0
     assert line["config"]["collective"].startswith("1 all_gather")
+    one = line["same_problem_1gpu"]           # the same 262144 x 256 matrix on rank 0's GPU alone: the strong-scaling denominator
+    assert one["ms"] > 0 and one["speedup_latency"] > 0 and one["speedup_throughput"] > 0
 
 
 @pytest.mark.gpu

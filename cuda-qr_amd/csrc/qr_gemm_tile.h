@@ -162,6 +162,221 @@ __device__ __forceinline__ void gemm_kloop(v4d (&acc)[TJ][TI], const double* __r
     }
 }
 
+// ---- software-pipelined K loop ---------------------------------------------------------------------------------------------
+// Same tiles, images and barrier count as gemm_kloop, with the three bubbles of its schedule closed (ISA of the plain loop: the 8
+// ds_read_b64 of a 4-deep MFMA step are issued AFTER the previous step's 16 MFMAs and waited for before the next 16; the staging
+// registers go to LDS after the last MFMA of the tile, then the barrier, then the first reads of the next tile):
+//   * the fragments of step ks+1 are read into a second register set BEFORE the MFMAs of step ks are issued;
+//   * the next tile's ds_writes sit in the middle of the tile (after step 1: its global loads were issued two MFMA bursts earlier),
+//     not between the last MFMA and the barrier;
+//   * the barrier and the first fragment reads of the next tile sit in the MIDDLE of the last step's MFMA burst, so they complete under
+//     its second half.
+template <int TI, int TJ, bool AROW>
+__device__ __forceinline__ void load_frags(double (&rowv)[TI], double (&colv)[TJ], const double* __restrict__ as,
+                                           const double* __restrict__ bs, int ks, int wi, int wj, int l15, int l4)
+{
+    constexpr int LA = 32 * TI + 16;
+    const int kk = 4 * ks + l4;
+#pragma unroll
+    for (int b = 0; b < TI; ++b)
+        rowv[b] = AROW ? as[kk * LA + wi * 16 * TI + 16 * b + l15] : as[(wi * 16 * TI + 16 * b + l15) * LDKF + kk];
+#pragma unroll
+    for (int a = 0; a < TJ; ++a) colv[a] = bs[(wj * 16 * TJ + 16 * a + l15) * LDKF + kk];
+}
+
+// MFMAs t in [T0, T1) of a step, t = a * TI + b
+template <int TI, int TJ, int T0, int T1>
+__device__ __forceinline__ void mfma_range(v4d (&acc)[TJ][TI], const double (&rowv)[TI], const double (&colv)[TJ])
+{
+#pragma unroll
+    for (int t = T0; t < T1; ++t)
+        acc[t / TI][t % TI] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[t / TI], rowv[t % TI], acc[t / TI][t % TI], 0, 0, 0);
+}
+
+template <int TI, int TJ, bool AROW, bool FAST, int WSTEP = 1, bool PRIO = !AROW>
+__device__ __forceinline__ void gemm_kloop_pipe(v4d (&acc)[TJ][TI], const double* __restrict__ A, int lda,
+                                                const double* __restrict__ B, int ldb, int i0, int j0, int M, int N,
+                                                int kbeg, int kend, double* __restrict__ As, double* __restrict__ Bs,
+                                                int tid, int wi, int wj, int l15, int l4)
+{
+    constexpr int BM = 32 * TI, BN = 32 * TJ, NT = TI * TJ;
+    constexpr int ASZ = AROW ? BK * (BM + 16) : BM * LDKF, BSZ = BN * LDKF;
+    v2d ra[TI], rb[TJ];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk <= 0) { __syncthreads(); return; }
+    if (AROW) load_rowfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
+    else load_kfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
+    load_kfast<TJ>(rb, B, ldb, j0, kbeg, N, kend, FAST, tid);
+    if (AROW) store_rowfast<TI>(ra, As, tid); else store_kfast<TI>(ra, As, tid);
+    store_kfast<TJ>(rb, Bs, tid);
+    __syncthreads();
+    double r0[TI], c0[TJ], r1[TI], c1[TJ];
+    load_frags<TI, TJ, AROW>(r0, c0, As, Bs, 0, wi, wj, l15, l4);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool next = kt + 1 < nk;
+        const double* as = As + buf * ASZ;
+        const double* bs = Bs + buf * BSZ;
+        if (next) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            if (AROW) load_rowfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
+            else load_kfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
+            load_kfast<TJ>(rb, B, ldb, j0, k0, N, kend, FAST, tid);
+        }
+        // step 0 (fragments already in r0 / c0)
+        load_frags<TI, TJ, AROW>(r1, c1, as, bs, 1, wi, wj, l15, l4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        mfma_range<TI, TJ, 0, NT>(acc, r0, c0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // step 1
+        load_frags<TI, TJ, AROW>(r0, c0, as, bs, 2, wi, wj, l15, l4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        mfma_range<TI, TJ, 0, NT>(acc, r1, c1);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile into the other LDS stage (nobody reads that stage before the barrier below)
+        if (next && WSTEP == 1) {
+            if (AROW) store_rowfast<TI>(ra, As + (buf ^ 1) * ASZ, tid); else store_kfast<TI>(ra, As + (buf ^ 1) * ASZ, tid);
+            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BSZ, tid);
+        }
+        // step 2
+        load_frags<TI, TJ, AROW>(r1, c1, as, bs, 3, wi, wj, l15, l4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        mfma_range<TI, TJ, 0, NT>(acc, r0, c0);
+        if (next && WSTEP == 2) {
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (AROW) store_rowfast<TI>(ra, As + (buf ^ 1) * ASZ, tid); else store_kfast<TI>(ra, As + (buf ^ 1) * ASZ, tid);
+            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BSZ, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+        }
+        // step 3: half of the burst, the barrier, the next tile's first fragments, the other half
+        mfma_range<TI, TJ, 0, NT / 2>(acc, r1, c1);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (next) load_frags<TI, TJ, AROW>(r0, c0, As + (buf ^ 1) * ASZ, Bs + (buf ^ 1) * BSZ, 0, wi, wj, l15, l4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        mfma_range<TI, TJ, NT / 2, NT>(acc, r1, c1);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- the same pipeline with the issue order spelled out ---------------------------------------------------------------------------
+// PMC of the plain loop at one wave per SIMD (profiles/r03_tn_issue_order.txt): the MFMA pipe is busy 78 % of the time; the wave spends
+// 8 % in s_waitcnt and ~14 % issuing its LDS / VMEM / VALU instructions in clumps between the 16-MFMA bursts, where nothing executes on
+// the matrix pipe.  Here every memory instruction of a K tile is issued right behind ONE MFMA (64 cycles of shadow each) and
+// sched_barrier(0) after each pair keeps hipcc from clumping them again:
+//   MFMA  0- 7: the 8 global loads of the next tile          MFMA  8-15: the 8 fragment reads of step 1
+//   MFMA 16-23: fragment reads of step 2                     MFMA 32-39: fragment reads of step 3
+//   MFMA 40-47: the 8 LDS writes of the next tile            MFMA 55   : barrier
+//   MFMA 56-63: fragment reads of the next tile's step 0
+// Whole tiles only (the FAST instantiation of the 4 x 4 wave tile, k-fast operands).
+template <int TI, int TJ>
+__device__ __forceinline__ void frag_one(double (&rowv)[TI], double (&colv)[TJ], const double* __restrict__ as, const double* __restrict__ bs,
+                                         int q, int kk, int wi, int wj, int l15)
+{
+    // order c0, r0, r1, r2, r3, c1, c2, c3: what the first MFMAs of a step need comes first
+    if (q == 0) colv[0] = bs[(wj * 16 * TJ + l15) * LDKF + kk];
+    else if (q <= TI) rowv[q - 1] = as[(wi * 16 * TI + 16 * (q - 1) + l15) * LDKF + kk];
+    else colv[q - TI] = bs[(wj * 16 * TJ + 16 * (q - TI) + l15) * LDKF + kk];
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void mfma_one(v4d (&acc)[TJ][TI], const double (&rowv)[TI], const double (&colv)[TJ], int t)
+{
+    acc[t / TI][t % TI] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[t / TI], rowv[t % TI], acc[t / TI][t % TI], 0, 0, 0);
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void gemm_kloop_il(v4d (&acc)[TJ][TI], const double* __restrict__ A, int lda,
+                                              const double* __restrict__ B, int ldb, int i0, int j0, int M, int N,
+                                              int kbeg, int kend, double* __restrict__ As, double* __restrict__ Bs,
+                                              int tid, int wi, int wj, int l15, int l4)
+{
+    static_assert(TI == 4 && TJ == 4, "issue pattern written for the 4 x 4 wave tile");
+    constexpr int BM = 32 * TI, BN = 32 * TJ, NT = TI * TJ;
+    constexpr int ASZ = BM * LDKF, BSZ = BN * LDKF;
+    v2d ra[TI], rb[TJ];
+    const int nk = (kend - kbeg) / BK;
+    if (nk <= 0) { __syncthreads(); return; }
+    load_kfast<TI>(ra, A, lda, i0, kbeg, M, kend, true, tid);
+    load_kfast<TJ>(rb, B, ldb, j0, kbeg, N, kend, true, tid);
+    store_kfast<TI>(ra, As, tid);
+    store_kfast<TJ>(rb, Bs, tid);
+    __syncthreads();
+    double r0[TI], c0[TJ], r1[TI], c1[TJ];
+    load_frags<TI, TJ, false>(r0, c0, As, Bs, 0, wi, wj, l15, l4);
+    // this thread's pieces of the two operand tiles: (column idx / 8, k pair idx % 8), idx = tid + 256 q
+    const double* ga = A + (size_t) (i0 + tid / 8) * lda + 2 * (tid % 8);
+    const double* gb = B + (size_t) (j0 + tid / 8) * ldb + 2 * (tid % 8);
+    const size_t sa = (size_t) 32 * lda, sb = (size_t) 32 * ldb;
+    const int lw = (tid / 8) * LDKF + 2 * (tid % 8);
+#define QR_SB __builtin_amdgcn_sched_barrier(0)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int buf = kt & 1;
+        const double* as = As + buf * ASZ;
+        const double* bs = Bs + buf * BSZ;
+        double* asn = As + (buf ^ 1) * ASZ;
+        double* bsn = Bs + (buf ^ 1) * BSZ;
+        const int k0 = kbeg + (kt + 1) * BK;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {                       // step 0
+            mfma_one<TI, TJ>(acc, r0, c0, t);
+            if (t < 4) ra[t] = *reinterpret_cast<const v2d*>(ga + t * sa + k0);
+            else if (t < 8) rb[t - 4] = *reinterpret_cast<const v2d*>(gb + (t - 4) * sb + k0);
+            else frag_one<TI, TJ>(r1, c1, as, bs, t - 8, 4 + l4, wi, wj, l15);
+            QR_SB;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {                       // step 1
+            mfma_one<TI, TJ>(acc, r1, c1, t);
+            if (t < 8) frag_one<TI, TJ>(r0, c0, as, bs, t, 8 + l4, wi, wj, l15);
+            QR_SB;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {                       // step 2
+            mfma_one<TI, TJ>(acc, r0, c0, t);
+            if (t < 8) frag_one<TI, TJ>(r1, c1, as, bs, t, 12 + l4, wi, wj, l15);
+            else if (t < 12) *reinterpret_cast<v2d*>(asn + lw + (t - 8) * 32 * LDKF) = ra[t - 8];
+            else *reinterpret_cast<v2d*>(bsn + lw + (t - 12) * 32 * LDKF) = rb[t - 12];
+            QR_SB;
+        }
+#pragma unroll
+        for (int t = 0; t < NT / 2; ++t) { mfma_one<TI, TJ>(acc, r1, c1, t); QR_SB; }      // step 3, first half
+        __syncthreads();
+        QR_SB;
+#pragma unroll
+        for (int t = NT / 2; t < NT; ++t) {                  // step 3, second half, over the next tile's first fragment reads
+            mfma_one<TI, TJ>(acc, r1, c1, t);
+            // r0 / c0 are free: their last readers (step 2) were issued a burst ago
+            frag_one<TI, TJ>(r0, c0, asn, bsn, t - NT / 2, l4, wi, wj, l15);
+            QR_SB;
+        }
+    }
+#undef QR_SB
+    {   // last tile: nothing to prefetch
+        const int buf = (nk - 1) & 1;
+        const double* as = As + buf * ASZ;
+        const double* bs = Bs + buf * BSZ;
+        load_frags<TI, TJ, false>(r1, c1, as, bs, 1, wi, wj, l15, l4);
+        mfma_range<TI, TJ, 0, NT>(acc, r0, c0);
+        load_frags<TI, TJ, false>(r0, c0, as, bs, 2, wi, wj, l15, l4);
+        mfma_range<TI, TJ, 0, NT>(acc, r1, c1);
+        load_frags<TI, TJ, false>(r1, c1, as, bs, 3, wi, wj, l15, l4);
+        mfma_range<TI, TJ, 0, NT>(acc, r0, c0);
+        mfma_range<TI, TJ, 0, NT>(acc, r1, c1);
+        __syncthreads();
+    }
+}
+
 // C = alpha*acc (+ beta*C on the generic path).  STORE_ONLY: no load sits between the stores (a load
 // there makes every store wait for the previous one: vmcnt is in-order and counts stores).
 template <int TI, int TJ, bool STORE_ONLY>

@@ -47,7 +47,14 @@
 // M % 128 == N % 128 == K % 16 == 0, K >= 16, operands 16-byte aligned with even leading dimensions (host-checked).
 // 512 threads = 8 waves as 2 (rows) x 4 (cols), wave tile 64 x 32 = 4 x 2 MFMA tiles, two LDS stages of 32 KiB.
 // ------------------------------------------------------------------------------------------------
-template <bool NEG, int STAMP>
+// (Round 3, measured and removed: a PERSISTENT form -- two workgroups per compute unit walking the tile list, the next tile's loads right
+// behind the current tile's stores.  In-kernel stamps at 16384 x 16128 x 256: prologue 16.9 k, K loop 129.6 k, epilogue 5.6 k ticks = 64.7 us
+// per workgroup while a slot turns over every 72.7 us; the persistent kernel nevertheless ran the update at 47.0 against 49.6 TFLOP/s in
+// situ, and starting half of its workgroups half a tile late made it worse: profiles/r03_nt_variants.txt.)
+// IL = 1: the K loop with its issue order spelled out -- one LDS read or tile load behind every other MFMA, the barrier in the middle of
+// the last step's MFMAs with the next tile's first fragment reads behind it (see gemm_kloop_il in qr_gemm_tile.h for the measurement that
+// led there); IL = 0: fragment reads one step ahead in groups of three, the four tile loads at the top of the tile
+template <bool NEG, int STAMP, int IL = 0>
 __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, const double* __restrict__ A, int lda,
                                                          const double* __restrict__ Bt, int ldbt,
                                                          double* __restrict__ C, int ldc, int gx, int gy, int gm,
@@ -118,6 +125,81 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
             acc[a][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][1][1], fb[set][a], acc[a][3], 0, 0, NEG ? 1 : 0); \
         }                                                                                                             \
     } while (0)
+    if constexpr (IL == 1) {
+        // read `which` (0: fa[set][0], 1: fb[set], 2: fa[set][1] -- the order the step's first MFMAs need them) of step ks from stage st_
+        auto rd = [&](int set, const double* st_, int ks, int which) {
+            const double* row_ = st_ + ks * 4 * 128;
+            if (which == 0) fa[set][0] = *reinterpret_cast<const v2d*>(row_ + aoff);
+            else if (which == 1) fb[set] = *reinterpret_cast<const v2d*>(row_ + boff);
+            else fa[set][1] = *reinterpret_cast<const v2d*>(row_ + aoff + 32);
+        };
+        auto mm = [&](int set, int j) {          // MFMA j of a step: a = j / 4, b = j % 4
+            const int a = j >> 2, b = j & 3;
+            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][b >> 1][b & 1], fb[set][a], acc[a][b], 0, 0, NEG ? 1 : 0);
+        };
+        auto ld = [&](int kt_, int stage, int q) {      // tile load q of 4 (see issue())
+            const double* pa = ga + (size_t) kt_ * NT_BK * lda;
+            const double* pb = gb + (size_t) kt_ * NT_BK * ldbt;
+            double* sa = smem + stage * NT_STAGE + wave * 128;
+            if (q == 0) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa), LDS_PTR(sa), 16, 0, 0);
+            else if (q == 1) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + a8), LDS_PTR(sa + 8 * 128), 16, 0, 0);
+            else if (q == 2) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb), LDS_PTR(sa + NT_BK * 128), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + b8), LDS_PTR(sa + NT_BK * 128 + 8 * 128), 16, 0, 0);
+        };
+#define NT_SB __builtin_amdgcn_sched_barrier(0)
+        {
+            const double* st0 = smem + l4 * 128;
+            rd(0, st0, 0, 0); rd(0, st0, 0, 1); rd(0, st0, 0, 2);
+        }
+        NT_SB;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const double* st = smem + (kt & 1) * NT_STAGE + l4 * 128;
+            const double* stn = smem + ((kt + 1) & 1) * NT_STAGE + l4 * 128;
+            const int sn = (kt + 1) & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {               // step 0 (set 0): reads of step 1 and the next tile's four loads behind its MFMAs
+                mm(0, j);
+                if (j == 0) rd(1, st, 1, 0); else if (j == 2) rd(1, st, 1, 1); else if (j == 4) rd(1, st, 1, 2);
+                else if (j == 1) ld(kt + 1, sn, 0); else if (j == 3) ld(kt + 1, sn, 1); else if (j == 5) ld(kt + 1, sn, 2);
+                else if (j == 7) ld(kt + 1, sn, 3);
+                NT_SB;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {               // step 1 (set 1)
+                mm(1, j);
+                if (j == 0) rd(0, st, 2, 0); else if (j == 2) rd(0, st, 2, 1); else if (j == 4) rd(0, st, 2, 2);
+                NT_SB;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {               // step 2 (set 0)
+                mm(0, j);
+                if (j == 0) rd(1, st, 3, 0); else if (j == 2) rd(1, st, 3, 1); else if (j == 4) rd(1, st, 3, 2);
+                NT_SB;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mm(1, j); NT_SB; }     // step 3 (set 1), first half
+            __syncthreads();                                     // all waves have read this stage; the next stage's loads have landed
+            NT_SB;
+#pragma unroll
+            for (int j = 4; j < 8; ++j) {                        // second half, over the next tile's first fragment reads (set 0 is free)
+                mm(1, j);
+                if (j < 7) rd(0, stn, 0, j - 4);
+                NT_SB;
+            }
+        }
+        {   // last tile
+            const double* st = smem + ((nk - 1) & 1) * NT_STAGE + l4 * 128;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mm(0, j); if (j == 0) rd(1, st, 1, 0); else if (j == 2) rd(1, st, 1, 1); else if (j == 4) rd(1, st, 1, 2); NT_SB; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mm(1, j); if (j == 0) rd(0, st, 2, 0); else if (j == 2) rd(0, st, 2, 1); else if (j == 4) rd(0, st, 2, 2); NT_SB; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mm(0, j); if (j == 0) rd(1, st, 3, 0); else if (j == 2) rd(1, st, 3, 1); else if (j == 4) rd(1, st, 3, 2); NT_SB; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mm(1, j);
+        }
+#undef NT_SB
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const double* st = smem + (kt & 1) * NT_STAGE + l4 * 128;
@@ -268,6 +350,13 @@ static int nt_gm(void)
     return v;
 }
 
+// MI355XQR_NT_IL=0: the trailing update's K loop with grouped fragment reads (default 1: issue order spelled out, gemm_nt_kernel<.., 1>)
+static int nt_il(void)
+{
+    static const int v = [] { const char* e = getenv("MI355XQR_NT_IL"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 static inline bool al16(const void* p, int ld) { return (((uintptr_t) p) & 15) == 0 && (ld & 1) == 0; }
 
 extern "C" {
@@ -278,6 +367,7 @@ int qrd_gemm2_init(void)
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tnt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     return rc;
 }
@@ -299,6 +389,8 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
     hipStream_t s = (hipStream_t) stream;
     if (stamps)
         hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
+    else if (sign < 0 && nt_il())
+        hipLaunchKernelGGL((gemm_nt_kernel<true, 0, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
     else if (sign < 0)
         hipLaunchKernelGGL((gemm_nt_kernel<true, 0>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
     else

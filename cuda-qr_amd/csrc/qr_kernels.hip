@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 
     if constexpr (TAG == 3) gemm_kloop_pipe<TI, TJ, false, FAST, 1>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
     else if constexpr (TAG == 4) gemm_kloop_pipe<TI, TJ, false, FAST, 2>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
-    else if constexpr (TAG == 5 && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+    else if constexpr ((TAG == 5 || TAG == 6) && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
     else gemm_kloop<TI, TJ, false, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
 
     if (beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
@@ -821,6 +821,7 @@ int qrd_init(void)
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 3>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 4>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 5>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 6>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_wide_kernel<1>, sizeof(double) * (2 * (128 + 256) * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
@@ -1081,6 +1082,7 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     else if (tag >= 1 && kpipe == 2) rc = launch_tn<4, 4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else if (tag >= 1 && kpipe) rc = launch_tn<4, 4, 3>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else if (tag >= 1) rc = launch_tn<4, 4, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (kpipe == 3) rc = launch_tn<4, 4, 6>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     if (rc) return rc;
     if (!direct) {

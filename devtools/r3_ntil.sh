@@ -1,0 +1,14 @@
+#!/bin/bash
+# variants of the trailing update kernel: 1 issue order spelled out, 2 persistent workgroups (+ start stagger modes); in situ
+O=gpurun_out/ntil; mkdir -p $O; : > $O/ab.txt
+for v in "MI355XQR_NT_IL=1" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=0" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=1" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=2" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=1 MI355XQR_NT_STAGGER_US=15" "MI355XQR_NT_IL=1"; do
+  echo "== $v" >> $O/ab.txt
+  env $v CHECK=1 timeout -k 10 300 python3 devtools/tools_perf.py 16384x16384x256 8192x8192x256 2>&1 | grep -v amdgpu.ids | cut -c1-520 >> $O/ab.txt || exit 1
+done
+python3 - <<'P'
+import json
+for l in open('gpurun_out/ntil/ab.txt'):
+    l=l.strip()
+    if l.startswith('=='): print(l); continue
+    d=json.loads(l); print('  %dx%d nb %d %.2f ms  nn %.1f TF/s (%.1f ms)  tn %.1f TF/s (%.1f ms) resid %.1e'%(d['m'],d['n'],d['nb'],d['ms'],d['update_nn']['tflops'],d['update_nn']['ms'],d['vta_tn']['tflops'],d['vta_tn']['ms'],d['resid'][0]))
+P

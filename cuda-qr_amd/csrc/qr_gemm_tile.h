@@ -162,15 +162,11 @@ __device__ __forceinline__ void gemm_kloop(v4d (&acc)[TJ][TI], const double* __r
     }
 }
 
-// ---- software-pipelined K loop ---------------------------------------------------------------------------------------------
-// Same tiles, images and barrier count as gemm_kloop, with the three bubbles of its schedule closed (ISA of the plain loop: the 8
-// ds_read_b64 of a 4-deep MFMA step are issued AFTER the previous step's 16 MFMAs and waited for before the next 16; the staging
-// registers go to LDS after the last MFMA of the tile, then the barrier, then the first reads of the next tile):
-//   * the fragments of step ks+1 are read into a second register set BEFORE the MFMAs of step ks are issued;
-//   * the next tile's ds_writes sit in the middle of the tile (after step 1: its global loads were issued two MFMA bursts earlier),
-//     not between the last MFMA and the barrier;
-//   * the barrier and the first fragment reads of the next tile sit in the MIDDLE of the last step's MFMA burst, so they complete under
-//     its second half.
+// ---- K loop with the issue order spelled out -------------------------------------------------------------------------------------
+// The plain loop above, as hipcc schedules it (ISA): the 8 ds_read_b64 of a 4-deep MFMA step are issued after the previous step's 16
+// MFMAs and waited for before the next 16; the staging registers go to LDS after the tile's last MFMA, then the barrier, then the
+// first reads of the next tile.  Reading the fragments one step ahead but still in clumps (sched_barrier-fenced groups) changed nothing
+// (65.8 -> 66.2 TFLOP/s isolated); what helps is below.
 template <int TI, int TJ, bool AROW>
 __device__ __forceinline__ void load_frags(double (&rowv)[TI], double (&colv)[TJ], const double* __restrict__ as,
                                            const double* __restrict__ bs, int ks, int wi, int wj, int l15, int l4)
@@ -193,83 +189,6 @@ __device__ __forceinline__ void mfma_range(v4d (&acc)[TJ][TI], const double (&ro
         acc[t / TI][t % TI] = __builtin_amdgcn_mfma_f64_16x16x4f64(colv[t / TI], rowv[t % TI], acc[t / TI][t % TI], 0, 0, 0);
 }
 
-template <int TI, int TJ, bool AROW, bool FAST, int WSTEP = 1, bool PRIO = !AROW>
-__device__ __forceinline__ void gemm_kloop_pipe(v4d (&acc)[TJ][TI], const double* __restrict__ A, int lda,
-                                                const double* __restrict__ B, int ldb, int i0, int j0, int M, int N,
-                                                int kbeg, int kend, double* __restrict__ As, double* __restrict__ Bs,
-                                                int tid, int wi, int wj, int l15, int l4)
-{
-    constexpr int BM = 32 * TI, BN = 32 * TJ, NT = TI * TJ;
-    constexpr int ASZ = AROW ? BK * (BM + 16) : BM * LDKF, BSZ = BN * LDKF;
-    v2d ra[TI], rb[TJ];
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk <= 0) { __syncthreads(); return; }
-    if (AROW) load_rowfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
-    else load_kfast<TI>(ra, A, lda, i0, kbeg, M, kend, FAST, tid);
-    load_kfast<TJ>(rb, B, ldb, j0, kbeg, N, kend, FAST, tid);
-    if (AROW) store_rowfast<TI>(ra, As, tid); else store_kfast<TI>(ra, As, tid);
-    store_kfast<TJ>(rb, Bs, tid);
-    __syncthreads();
-    double r0[TI], c0[TJ], r1[TI], c1[TJ];
-    load_frags<TI, TJ, AROW>(r0, c0, As, Bs, 0, wi, wj, l15, l4);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool next = kt + 1 < nk;
-        const double* as = As + buf * ASZ;
-        const double* bs = Bs + buf * BSZ;
-        if (next) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            if (AROW) load_rowfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
-            else load_kfast<TI>(ra, A, lda, i0, k0, M, kend, FAST, tid);
-            load_kfast<TJ>(rb, B, ldb, j0, k0, N, kend, FAST, tid);
-        }
-        // step 0 (fragments already in r0 / c0)
-        load_frags<TI, TJ, AROW>(r1, c1, as, bs, 1, wi, wj, l15, l4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        mfma_range<TI, TJ, 0, NT>(acc, r0, c0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // step 1
-        load_frags<TI, TJ, AROW>(r0, c0, as, bs, 2, wi, wj, l15, l4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        mfma_range<TI, TJ, 0, NT>(acc, r1, c1);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // the next tile into the other LDS stage (nobody reads that stage before the barrier below)
-        if (next && WSTEP == 1) {
-            if (AROW) store_rowfast<TI>(ra, As + (buf ^ 1) * ASZ, tid); else store_kfast<TI>(ra, As + (buf ^ 1) * ASZ, tid);
-            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BSZ, tid);
-        }
-        // step 2
-        load_frags<TI, TJ, AROW>(r1, c1, as, bs, 3, wi, wj, l15, l4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        mfma_range<TI, TJ, 0, NT>(acc, r0, c0);
-        if (next && WSTEP == 2) {
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (AROW) store_rowfast<TI>(ra, As + (buf ^ 1) * ASZ, tid); else store_kfast<TI>(ra, As + (buf ^ 1) * ASZ, tid);
-            store_kfast<TJ>(rb, Bs + (buf ^ 1) * BSZ, tid);
-            __builtin_amdgcn_sched_barrier(0);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-        }
-        // step 3: half of the burst, the barrier, the next tile's first fragments, the other half
-        mfma_range<TI, TJ, 0, NT / 2>(acc, r1, c1);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (next) load_frags<TI, TJ, AROW>(r0, c0, As + (buf ^ 1) * ASZ, Bs + (buf ^ 1) * BSZ, 0, wi, wj, l15, l4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        mfma_range<TI, TJ, NT / 2, NT>(acc, r1, c1);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// ---- the same pipeline with the issue order spelled out ---------------------------------------------------------------------------
 // PMC of the plain loop at one wave per SIMD (profiles/r03_tn_issue_order.txt): the MFMA pipe is busy 78 % of the time; the wave spends
 // 8 % in s_waitcnt and ~14 % issuing its LDS / VMEM / VALU instructions in clumps between the 16-MFMA bursts, where nothing executes on
 // the matrix pipe.  Here every memory instruction of a K tile is issued right behind ONE MFMA (64 cycles of shadow each) and
@@ -376,6 +295,9 @@ __device__ __forceinline__ void gemm_kloop_il(v4d (&acc)[TJ][TI], const double* 
         __syncthreads();
     }
 }
+
+// (Global loads two tiles ahead -- a second staging register set, 256 VGPRs and 84 B of scratch -- were measured at 59.5 against 68.2
+// TFLOP/s on the isolated product and removed.)
 
 // C = alpha*acc (+ beta*C on the generic path).  STORE_ONLY: no load sits between the stores (a load
 // there makes every store wait for the previous one: vmcnt is in-order and counts stores).

@@ -195,9 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 #pragma unroll
         for (int b = 0; b < TI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    if constexpr (TAG == 3) gemm_kloop_pipe<TI, TJ, false, FAST, 1>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
-    else if constexpr (TAG == 4) gemm_kloop_pipe<TI, TJ, false, FAST, 2>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
-    else if constexpr ((TAG == 5 || TAG == 6) && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+    if constexpr ((TAG == 5 || TAG == 6) && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
     else gemm_kloop<TI, TJ, false, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
 
     if (beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
@@ -818,8 +816,6 @@ int qrd_init(void)
     rc |= allow_lds(gemm_nn_w8_kernel<0>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_w8_kernel<1>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1>, sizeof(double) * (4 * 128 * LDKF));
-    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 3>, sizeof(double) * (4 * 128 * LDKF));
-    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 4>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 5>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 6>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_wide_kernel<1>, sizeof(double) * (2 * (128 + 256) * LDKF));
@@ -1042,11 +1038,10 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     if (slabs == nullptr || slab_cap < per) kmax = 1;
     else if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
     if (kmax < 1 || shortk) kmax = 1;
-    // K loop of the wide product: MI355XQR_KPIPE=3 (default) issue order spelled out, one memory instruction behind every MFMA
-    // (gemm_kloop_il); 0 = the plain double-buffered loop; 1 / 2 = fragment reads one step ahead, in clumps (gemm_kloop_pipe).
-    // Isolated, 15872 x 256 x 16128: 65.8 (0), 66.2 (2), 68.9 TFLOP/s (3); one workgroup per CU: 58.4 / 59.3 / 68.1.  In situ at
-    // 16384^2: 51.5 -> 54.3 TFLOP/s (profiles/r03_tn_issue_order.txt)
-    static const int kpipe = [] { const char* e = getenv("MI355XQR_KPIPE"); return e ? atoi(e) : 3; }();
+    // K loop of the 128 x 128 products: MI355XQR_KPIPE=1 (default) issue order spelled out, one memory instruction behind every MFMA
+    // (gemm_kloop_il); 0 = the plain double-buffered loop.  Isolated, 15872 x 256 x 16128: 65.8 -> 68.9 TFLOP/s; one workgroup per CU:
+    // 58.4 -> 68.1.  In situ at 16384^2: 51.5 -> 54.3 TFLOP/s (profiles/r03_tn_issue_order.txt)
+    static const int kpipe = [] { const char* e = getenv("MI355XQR_KPIPE"); return e ? atoi(e) : 1; }();
     const int slots = (wide ? 1 : 2) * stream_cus(s);
     const double row_us = 2.0 * BM * BN / (wide ? 0.226e6 : 0.113e6);   // one K row of one tile on one workgroup slot (wide: the whole CU)
     const double red_rows = (double) per * 8.0 / 2.0e6 / row_us;   // reading one slab of the output at ~2 TB/s, in K rows
@@ -1078,11 +1073,9 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
         if (!rc && Mi < M)
             rc = launch_tn1<4, 4, false>(s, M - Mi, N, K, ksplit, kchunk, alpha, A + (size_t) Mi * lda, lda, B, ldb, b2, dst + Mi, ldd, per);
     }
-    else if (tag >= 1 && kpipe == 3) rc = launch_tn<4, 4, 5>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
-    else if (tag >= 1 && kpipe == 2) rc = launch_tn<4, 4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
-    else if (tag >= 1 && kpipe) rc = launch_tn<4, 4, 3>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (tag >= 1 && kpipe) rc = launch_tn<4, 4, 5>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else if (tag >= 1) rc = launch_tn<4, 4, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
-    else if (kpipe == 3) rc = launch_tn<4, 4, 6>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (kpipe) rc = launch_tn<4, 4, 6>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     else rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     if (rc) return rc;
     if (!direct) {

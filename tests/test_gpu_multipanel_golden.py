@@ -93,6 +93,7 @@ np.save(sys.argv[1], O.sign_normalise(F))
     (128, {"MI355XQR_EP": "0"}),                                                      # in-panel product as a launch of its own (no early product)
     (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64:0.5,U", "MI355XQR_BALANCE": "14,44,0,0"}),   # late phase: panel chain on an unmasked stream
     (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_TN_WIDE": "1"}),   # wide-tile TN product
+    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_KPIPE": "0", "MI355XQR_NT_IL": "0"}),   # plain K loops (round-2 issue order) in the update's two GEMMs
 ])
 def test_2024_square_vs_reference_R_slices(qr, oracle, tmp_path, nb, env):
     """16 (nb = 128) / 8 / 32 outer panels: wide update, look-ahead, CU partition, balance_cols -- against slices of the

@@ -51,6 +51,10 @@
 // behind the current tile's stores.  In-kernel stamps at 16384 x 16128 x 256: prologue 16.9 k, K loop 129.6 k, epilogue 5.6 k ticks = 64.7 us
 // per workgroup while a slot turns over every 72.7 us; the persistent kernel nevertheless ran the update at 47.0 against 49.6 TFLOP/s in
 // situ, and starting half of its workgroups half a tile late made it worse: profiles/r03_nt_variants.txt.)
+// (Also measured and removed: k-tiles of 8 in FOUR LDS stages, tiles requested three ahead and the barrier no longer draining the load
+// queue (s_waitcnt vmcnt(4)): 58.5 against 58.9 TFLOP/s isolated.  Stamps + placement (devtools/gemm_lab.cpp): the two workgroups of a
+// compute unit get 0.86 of the matrix pipe while both are in their K loop and a lone one 0.68 -- 42 % of the time, while the other loads
+// or stores its C tile or is being replaced; that per-tile cost (14.6 us of 72.7 at K = 256), not the K loop, is what K = 512 halves.)
 // IL = 1: the K loop with its issue order spelled out -- one LDS read or tile load behind every other MFMA, the barrier in the middle of
 // the last step's MFMAs with the next tile's first fragment reads behind it (see gemm_kloop_il in qr_gemm_tile.h for the measurement that
 // led there); IL = 0: fragment reads one step ahead in groups of three, the four tile loads at the top of the tile
@@ -231,8 +235,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
                 *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]};
     if (STAMP && tid == 0) {
         const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-        unsigned long long* s = stamps + 4 * (size_t) blockIdx.x;
-        s[0] = t0; s[1] = t1; s[2] = t2; s[3] = t3;
+        // 6 values per workgroup: the four stamps, where it ran (HW_ID | XCC_ID << 32) and its dispatch order
+        unsigned long long* s = stamps + 6 * (size_t) blockIdx.x;
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));          // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));         // HW_REG_XCC_ID
+        s[0] = t0; s[1] = t1; s[2] = t2; s[3] = t3; s[4] = (unsigned long long) hw | ((unsigned long long) (xcc & 0xf) << 32); s[5] = blockIdx.x;
     }
 }
 
@@ -364,10 +371,10 @@ extern "C" {
 int qrd_gemm2_init(void)
 {
     int rc = 0;
-    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
-    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tnt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     return rc;
 }
@@ -385,7 +392,9 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
     if (!qrd_gemm_nt_ok(M, N, K, A, lda, Bt, ldbt, C, ldc)) return -7;
     const int gx = M / 128, gy = N / 128;
     if (gm < 0) gm = nt_gm();
-    const size_t shm = 2 * NT_STAGE * sizeof(double);
+    // MI355XQR_NT_SOLO=1 (measurement only): ask for 100 KB of LDS, so that ONE workgroup fits a compute unit
+    static const int solo = [] { const char* e = getenv("MI355XQR_NT_SOLO"); return e ? atoi(e) : 0; }();
+    const size_t shm = solo ? (size_t) 100 * 1024 : 2 * NT_STAGE * sizeof(double);
     hipStream_t s = (hipStream_t) stream;
     if (stamps)
         hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);

@@ -91,8 +91,7 @@ struct Variant { std::string name; std::function<int(hipStream_t)> run; double f
 static void time_variants(hipStream_t s, std::vector<Variant>& vs, int rounds, int reps)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (auto& v : vs) { RC(v.run(s)); }
-    CK(hipStreamSynchronize(s));
+    for (auto& v : vs) { RC(v.run(s)); CK(hipStreamSynchronize(s)); if (getenv("LAB_TRACE")) printf("      warm-up done: %s\n", v.name.c_str()); }
     for (int r = 0; r < rounds; ++r)
         for (auto& v : vs) {
             CK(hipEventRecord(a, s));
@@ -113,6 +112,7 @@ static void time_variants(hipStream_t s, std::vector<Variant>& vs, int rounds, i
 
 int main(int argc, char** argv)
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     RC(qrd_init());
     if (check_small()) { printf("CORRECTNESS FAILED\n"); return 1; }
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
@@ -133,6 +133,7 @@ int main(int argc, char** argv)
     std::vector<StreamSpec> specs = {{"whole chip (256 CUs)", 0, 0}, {"CU mask 192 (64..255)", 64, 192}, {"CU mask 224 (32..255)", 32, 224},
                                      {"CU mask 240 (16..255)", 16, 240}};
     if (quick) specs.resize(2);
+    if (argc > 1 && !strcmp(argv[1], "m224")) specs = {{"CU mask 224 (32..255)", 32, 224}};
     struct Shape { int M, N, K; };
     std::vector<Shape> shapes = {{16384, 16128, 256}, {8192, 7936, 256}, {4096, 3840, 256}, {16384, 15872, 512}, {16384, 16256, 128}};
     if (quick) shapes.resize(2);
@@ -161,17 +162,66 @@ int main(int argc, char** argv)
         }
         RC(qrd_stream_destroy(sv));
     }
-    // phase breakdown of gemm_nt from in-kernel s_memtime stamps (whole chip, biggest shape)
+    // phase breakdown of gemm_nt from in-kernel s_memtime stamps (whole chip, biggest shape), and how the two workgroups that share a
+    // compute unit sit relative to each other in time
     {
         const int M = 16384, N = 16128, K = 256, nwg = (M / 128) * (N / 128);
-        unsigned long long* st; CK(hipMalloc(&st, sizeof(unsigned long long) * 4 * nwg));
+        unsigned long long* st; CK(hipMalloc(&st, sizeof(unsigned long long) * 6 * nwg));
         RC(qrd_gemm_nt(nullptr, M, N, K, -1, V, MM, Wt, MM, C, MM, 8, st));
         CK(hipDeviceSynchronize());
-        std::vector<unsigned long long> h(4 * (size_t) nwg);
+        std::vector<unsigned long long> h(6 * (size_t) nwg);
         CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
         double p = 0, l = 0, e = 0;
-        for (int i = 0; i < nwg; ++i) { p += h[4 * i + 1] - h[4 * i]; l += h[4 * i + 2] - h[4 * i + 1]; e += h[4 * i + 3] - h[4 * i + 2]; }
+        for (int i = 0; i < nwg; ++i) { p += h[6 * i + 1] - h[6 * i]; l += h[6 * i + 2] - h[6 * i + 1]; e += h[6 * i + 3] - h[6 * i + 2]; }
         printf("gemm_nt stamps (s_memtime ticks, mean per workgroup): prologue %.0f  main loop %.0f  epilogue %.0f   [K=256: 16 k-steps]\n", p / nwg, l / nwg, e / nwg);
+        // per compute unit (xcc, se, sh, cu of HW_ID): time with 2 / 1 / 0 workgroups inside their K loop, between the first loop start
+        // and the last loop end on that CU
+        struct Iv { unsigned long long a, b; };
+        std::vector<std::vector<Iv>> cu(8 * 64 * 4);
+        for (int i = 0; i < nwg; ++i) {
+            const unsigned long long hw = h[6 * i + 4];
+            const unsigned cuid = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7, xcc = (unsigned) (hw >> 32) & 0xf;
+            cu[((xcc * 8 + se) * 2 + sh) * 16 + cuid].push_back({h[6 * i + 1], h[6 * i + 2]});
+        }
+        double t2 = 0, t1 = 0, t0 = 0; int ncu = 0; size_t maxwg = 0, minwg = 1 << 30;
+        for (auto& v : cu) {
+            if (v.empty()) continue;
+            ++ncu; maxwg = std::max(maxwg, v.size()); minwg = std::min(minwg, v.size());
+            std::vector<std::pair<unsigned long long, int>> ev;
+            for (auto& iv : v) { ev.push_back({iv.a, +1}); ev.push_back({iv.b, -1}); }
+            std::sort(ev.begin(), ev.end());
+            int depth = 0; unsigned long long last = ev[0].first;
+            for (auto& x : ev) {
+                const double d = (double) (x.first - last);
+                if (depth >= 2) t2 += d; else if (depth == 1) t1 += d; else t0 += d;
+                depth += x.second; last = x.first;
+            }
+        }
+        // progress rates: a workgroup's K loop needs 65536 matrix-pipe cycles per SIMD (16 k-tiles x 32 MFMAs x 64 cycles x its 2 waves
+        // per SIMD); least squares of 65536 = a * T_shared + b * T_solo over all workgroups (T in s_memtime ticks = shader cycles):
+        // a = share of the pipe a workgroup gets while its partner is in its K loop too, b = while it is alone
+        {
+            double Sss = 0, Sso = 0, Soo = 0, Bs = 0, Bo = 0;
+            for (auto& v : cu) {
+                for (size_t i = 0; i < v.size(); ++i) {
+                    double tsh = 0;
+                    for (size_t j = 0; j < v.size(); ++j) {
+                        if (j == i) continue;
+                        const unsigned long long lo = std::max(v[i].a, v[j].a), hi = std::min(v[i].b, v[j].b);
+                        if (hi > lo) tsh += (double) (hi - lo);
+                    }
+                    const double tso = (double) (v[i].b - v[i].a) - tsh;
+                    Sss += tsh * tsh; Sso += tsh * tso; Soo += tso * tso; Bs += 65536.0 * tsh; Bo += 65536.0 * tso;
+                }
+            }
+            const double det = Sss * Soo - Sso * Sso;
+            if (det != 0.0)
+                printf("gemm_nt K-loop progress: %.3f of the matrix pipe per workgroup while both are in their K loop (%.3f together), %.3f while alone\n",
+                       (Bs * Soo - Bo * Sso) / det, 2 * (Bs * Soo - Bo * Sso) / det, (Bo * Sss - Bs * Sso) / det);
+        }
+        const double tt = t2 + t1 + t0;
+        printf("gemm_nt K-loop overlap per compute unit (%d CUs seen, %zu..%zu workgroups each): both workgroups in their K loop %.1f %%, one %.1f %%, none %.1f %% of the time\n",
+               ncu, minwg, maxwg, 100 * t2 / tt, 100 * t1 / tt, 100 * t0 / tt);
     }
     return 0;
 }

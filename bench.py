@@ -366,7 +366,7 @@ def main():
     except Exception:
         tj = None
     gen = 1 if os.environ.get("MI355XQR_UPDATE") == "1" else 2
-    kname = ("gemm_nt_kernel<true, 0> (trailing update A2 -= V*Wt^T, W kept transposed, direct-to-LDS tiles, v_mfma_f64_16x16x4_f64)"
+    kname = ("gemm_nt_kernel<true, 0, 1> (trailing update A2 -= V*Wt^T, W kept transposed, direct-to-LDS tiles, v_mfma_f64_16x16x4_f64)"
              if gen == 2 else "gemm_nn_w8_kernel<0> (trailing update A2 -= V*W, v_mfma_f64_16x16x4_f64)")
     if wl in ("c2", "c3") and upd["launches"]:
         ach = upd["flops"] / (upd["ms"] * 1e-3) / 1e12

@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 #pragma unroll
         for (int b = 0; b < TI; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    if constexpr ((TAG == 5 || TAG == 6) && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+    // TAG 0 / 1 (1: the wide product of the trailing update under its own profiler name): K loop with the issue order spelled out where
+    // the instantiation allows it (whole 128 x 128 tiles); TAG 3 / 4: the same two with the plain double-buffered loop (MI355XQR_KPIPE=0)
+    if constexpr (TAG <= 1 && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
     else gemm_kloop<TI, TJ, false, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
 
     if (beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
@@ -816,8 +818,8 @@ int qrd_init(void)
     rc |= allow_lds(gemm_nn_w8_kernel<0>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_nn_w8_kernel<1>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1>, sizeof(double) * (4 * 128 * LDKF));
-    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 5>, sizeof(double) * (4 * 128 * LDKF));
-    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 6>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 3>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 4>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_wide_kernel<1>, sizeof(double) * (2 * (128 + 256) * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
@@ -1073,10 +1075,10 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
         if (!rc && Mi < M)
             rc = launch_tn1<4, 4, false>(s, M - Mi, N, K, ksplit, kchunk, alpha, A + (size_t) Mi * lda, lda, B, ldb, b2, dst + Mi, ldd, per);
     }
-    else if (tag >= 1 && kpipe) rc = launch_tn<4, 4, 5>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
-    else if (tag >= 1) rc = launch_tn<4, 4, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
-    else if (kpipe) rc = launch_tn<4, 4, 6>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
-    else rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (tag >= 1 && kpipe) rc = launch_tn<4, 4, 1>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (tag >= 1) rc = launch_tn<4, 4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else if (kpipe) rc = launch_tn<4, 4>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
+    else rc = launch_tn<4, 4, 3>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, b2, dst, ldd, per);
     if (rc) return rc;
     if (!direct) {
         // many slabs (tall-skinny products): shorter row pieces per workgroup, so that more threads share the slab index

@@ -55,6 +55,12 @@
 // queue (s_waitcnt vmcnt(4)): 58.5 against 58.9 TFLOP/s isolated.  Stamps + placement (devtools/gemm_lab.cpp): the two workgroups of a
 // compute unit get 0.86 of the matrix pipe while both are in their K loop and a lone one 0.68 -- 42 % of the time, while the other loads
 // or stores its C tile or is being replaced; that per-tile cost (14.6 us of 72.7 at K = 256), not the K loop, is what K = 512 halves.)
+// (And the last attempt at the per-tile cost: PERSISTENT workgroups that prefetch their next C tile into registers under the current
+// tile's K loop (256 VGPRs at two waves per SIMD; one C load per k-tile behind an MFMA, the barrier waiting with s_waitcnt vmcnt(1) so
+// that the newest C load stays in flight).  One 8-wave workgroup per CU: 57.9 TFLOP/s isolated (the non-persistent single workgroup:
+// 51.7) -- all its waves meet every tile boundary at once.  Two independent 4-wave workgroups per CU on 128 x 64 tiles: 60.4 isolated,
+// 50.6 against 49.6 in situ, the factorisation unchanged within noise (121.5 against 121.7 ms); 256 VGPRs + 64 B of scratch.  Removed:
+// +2 % on this kernel did not pay for a second 170-line kernel.  profiles/r03_nt_variants.txt.)
 // IL = 1: the K loop with its issue order spelled out -- one LDS read or tile load behind every other MFMA, the barrier in the middle of
 // the last step's MFMAs with the next tile's first fragment reads behind it (see gemm_kloop_il in qr_gemm_tile.h for the measurement that
 // led there); IL = 0: fragment reads one step ahead in groups of three, the four tile loads at the top of the tile

@@ -1,9 +1,9 @@
 #!/bin/bash
-# variants of the trailing update kernel: 1 issue order spelled out, 2 persistent workgroups (+ start stagger modes); in situ
+# trailing update kernel: 1 = gemm_nt_kernel (two 8-wave workgroups per CU, one tile each), 2 = gemm_ntp_kernel (two persistent 4-wave workgroups, C prefetch); in situ
 O=gpurun_out/ntil; mkdir -p $O; : > $O/ab.txt
-for v in "MI355XQR_NT_IL=1" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=0" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=1" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=2" "MI355XQR_NT_IL=2 MI355XQR_NT_STAGGER=1 MI355XQR_NT_STAGGER_US=15" "MI355XQR_NT_IL=1"; do
-  echo "== $v" >> $O/ab.txt
-  env $v CHECK=1 timeout -k 10 300 python3 devtools/tools_perf.py 16384x16384x256 8192x8192x256 2>&1 | grep -v amdgpu.ids | cut -c1-520 >> $O/ab.txt || exit 1
+for v in 2 1 2 1; do
+  echo "== MI355XQR_NT_IL=$v" >> $O/ab.txt
+  MI355XQR_NT_IL=$v CHECK=1 timeout -k 10 300 python3 devtools/tools_perf.py 16384x16384x256 8192x8192x256 12288x12288x256 2>&1 | grep -v amdgpu.ids | cut -c1-520 >> $O/ab.txt || exit 1
 done
 python3 - <<'P'
 import json

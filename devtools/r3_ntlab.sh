@@ -4,6 +4,6 @@ MI355XQR_NT_IL=2 timeout -k 10 300 python3 -m pytest tests/test_gpu_kernels.py -
 tail -1 $O/pytest.txt
 for v in "MI355XQR_NT_IL=1" "MI355XQR_NT_IL=2"; do
   echo "== $v" >> $O/out.txt
-  env $v timeout -k 10 100 python3 devtools/tools_nt_lab.py 16384x16128x256 16384x15872x512 8192x7936x256 4096x3840x256 16384x16256x128 2>&1 | grep -v amdgpu.ids >> $O/out.txt || exit 1
+  env $v timeout -k 10 100 python3 devtools/tools_nt_lab.py 16384x16128x256 16384x15872x512 8192x7936x256 4096x3840x256 2>&1 | grep -v amdgpu.ids >> $O/out.txt || exit 1
 done
 cat $O/out.txt

@@ -67,6 +67,13 @@ double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx);
 int qrd_diff_norm(void* stream, const double* X, int ldx, const double* Y, int ldy, long long rows, int cols,
                   long long row_off, long long total_rows, unsigned long long seed, int sub_identity, double* out);
 
+/* a whole outer panel (<= 256 columns, <= 8192 rows) in ONE launch (qr_panel_fused.hip) */
+size_t qrd_panel_fused_ws_doubles(void);
+int qrd_panel_fused_init(void);
+int qrd_panel_fused_ok(void* stream, const double* A, int lda, int mk, int wh, const double* Vw, int ldv);
+int qrd_panel_fused(void* stream, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv,
+                    double* G, int ldg, double* ws, unsigned* epoch, int* status);
+
 /* the reference's sliding-window schedule on the device (qr_legacy.hip): legacy-layout shim */
 size_t qrd_legacy_ws_size(int m, int PR, int PC);
 int qrd_legacy_shape_ok(int m, int n, int PR, int PC);

@@ -827,6 +827,7 @@ int qrd_init(void)
     rc |= qrd_gemm2_init();
     rc |= qrd_panel_tsqr_init();
     rc |= qrd_leaf_fused_init();
+    rc |= qrd_panel_fused_init();
     return rc;
 }
 

@@ -23,8 +23,8 @@
 #include "qr_device.h"
 #include "qr_common.h"
 #include "qr_gemm_tile.h"
+#include "qr_leaf_math.h"
 
-#define PW LEAFW          // max leaf width
 #define PT 512            // threads per workgroup = rows per block
 #define PWAVES (PT / 64)
 
@@ -380,10 +380,6 @@ __global__ __launch_bounds__(NT) void tsqr_apply_kernel(const double* __restrict
 // Outputs: R = S R~ and L1 into the top of the panel, tau = diag(T), T, the unit-lower top of Vw, Umat = U^-1.
 #define HQ 2
 #define HG (PW / HQ)      /* waves in hr_top_kernel: wave g owns columns g + HG q */
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
 
 template <int I, int HGx = HG> struct HrStep {
     // back substitution step i (descending): row I of M is final; eliminate it from rows < I
@@ -786,27 +782,7 @@ __global__ __launch_bounds__(PT) void panel_single_kernel(double* __restrict__ P
 // guard word then stays 1, nothing of the leaf has been overwritten, and the Householder TSQR launches that follow do
 // the work.  The result has the same form either way: unit-lower V below R, tau, T.
 // =========================================================================================================
-#define QRD_GUARD_THR (1.0 / 64.0)
-#define QRD_CHOL1_THR 1e-9      /* hr3_kernel: below this max|Q^T Q - I| the second Cholesky factor is taken to first order */
 
-// 1/sqrt(p) from the hardware estimate (v_rsq_f64, ~2^-26 relative) and two Newton steps y <- y (3/2 - p/2 y^2): full double
-// accuracy to an ulp or two in ~10 dependent instructions.  The IEEE sqrt + division this replaces is ~60 instructions
-// deep and sat 32 times on the one-wave critical path of every Cholesky (4 of its 7 us).  p <= 0 / NaN is caught by the caller.
-__device__ __forceinline__ double rsqrt_newton(double p)
-{
-    double y = __builtin_amdgcn_rsq(p);
-    const double h = 0.5 * p;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    return y;
-}
-__device__ __forceinline__ double rcp_newton(double p)
-{
-    double y = __builtin_amdgcn_rcp(p);
-    y = y * (2.0 - p * y);
-    y = y * (2.0 - p * y);
-    return y;
-}
 
 // right-looking Cholesky G = R^T R on one wave: lane j (< 32) holds column j in g[]; on exit g[k] = R(k, j), k <= j
 template <int K> struct CholStep {
@@ -1289,19 +1265,6 @@ __global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P
 // l15; k, lane l4) = R1^-1(k, i), B operand (k; j = row, lane l15) = a(row, k), D reg rr of lane (l4, l15) = q(row l15, column
 // l4 + 4 rr): a wave's store instruction covers 4 columns x 16 consecutive rows.
 // ---------------------------------------------------------------------------------------------------------
-template <int K> struct CholAugStep {
-    static __device__ __forceinline__ void run(double (&g)[PW], int lane, bool& ok)
-    {
-        const double p = readlane_f64(g[K], K);
-        ok = ok && (p > 0.0);                       // false for NaN as well
-        const double inv = rsqrt_newton(p);
-        const double rk = (lane >= K) ? g[K] * inv : 0.0;          // lanes >= 32 (identity columns) always pass
-        g[K] = rk;
-#pragma unroll
-        for (int i = K + 1; i < PW; ++i) g[i] -= readlane_f64(rk, i) * rk;
-        if constexpr (K + 1 < PW) CholAugStep<K + 1>::run(g, lane, ok);
-    }
-};
 
 template <int NT, int HALF>
 __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P, int ld, int mk,
@@ -1491,11 +1454,6 @@ __global__ __launch_bounds__(64) void chol1_kernel(const double* __restrict__ G1
     if (lane == 0) *guard = ok ? 0 : 1;
 }
 
-__device__ __forceinline__ void tq_load4(const double* __restrict__ p, double (&d)[4])
-{
-    const v2d a = *reinterpret_cast<const v2d*>(p), b = *reinterpret_cast<const v2d*>(p + 2);
-    d[0] = a[0]; d[1] = a[1]; d[2] = b[0]; d[3] = b[1];
-}
 
 // Q (mk x 32 -> Vw) = P R1^-1 and this workgroup's partial G2 = Q^T Q (slab2[blockIdx.x], 32 x 32, ld 32).  mk % 4 == 0, P / Vw 16-byte
 // aligned with even leading dimensions.  Rinv: R1^-1 column-major ld 32.  512 threads; row blocks of 512 rows, grid-stride.
@@ -1653,75 +1611,6 @@ __global__ __launch_bounds__(PT) void final4_kernel(double* __restrict__ Vw, int
 // (See the header of this section for why the LU runs on Q_top - S R2 instead of Q_top R2^-1 - S.)
 // On exit: b = L1 below the diagonal, U' = U R2 on and above it; sgn = S_c in lane c.
 #define H3G 8
-template <int K> struct Chol3Step {
-    static __device__ __forceinline__ void run(double (&g)[PW], int lane, bool& ok, double& dinv)
-    {
-        const double p = readlane_f64(g[K], K);
-        ok = ok && (p > 0.0);                       // false for NaN as well
-        const double inv = rsqrt_newton(p);
-        if (lane == K) dinv = inv;                  // 1 / R2(K, K)
-        const double rk = (lane >= K) ? g[K] * inv : 0.0;
-        g[K] = rk;
-#pragma unroll
-        for (int i = K + 1; i < PW; ++i) g[i] -= readlane_f64(rk, i) * rk;
-        if constexpr (K + 1 < PW) Chol3Step<K + 1>::run(g, lane, ok, dinv);
-    }
-};
-template <int I> struct Hr3Lu {
-    static __device__ __forceinline__ void run(double (&b)[PW], const double (&g)[PW], int lane, double& sgn)
-    {
-        const double x = readlane_f64(b[I], I);                 // current (I, I) entry, S_I not yet applied
-        const double S = (x >= 0.0) ? -1.0 : 1.0;
-        b[I] -= S * g[I];                                        // row I of S R2 (g[I] = R2(I, lane) is zero left of the diagonal)
-        const double piv = readlane_f64(b[I], I);                // x - S R2(I, I): |piv| >= R2(I, I) > 0
-        const double inv = rcp_newton(piv);
-        if (lane == I) sgn = S;
-        const double scale = (lane == I) ? inv : 1.0;
-        const double u = (lane > I) ? b[I] : 0.0;
-#pragma unroll
-        for (int r = I + 1; r < PW; ++r) {
-            b[r] *= scale;                                       // lane I: multiplier l_r
-            b[r] -= readlane_f64(b[r], I) * u;                   // lanes right of I: a(r, c) -= l_r u_c
-        }
-        if constexpr (I + 1 < PW) Hr3Lu<I + 1>::run(b, g, lane, sgn);
-    }
-};
-
-// upper-triangular row solve  u R = u'  for lane = row (rows beyond 31 compute garbage that is never stored):
-// u(c) = (u'(c) - sum_{k<c} u(k) R(k, c)) / R(c, c)
-template <int C> struct RowSolve {
-    static __device__ __forceinline__ void run(double (&u)[PW], double (*Rm)[PW + 1], const double* rinv)
-    {
-        double acc = u[C];
-#pragma unroll
-        for (int k = 0; k < C; ++k) acc -= u[k] * Rm[k][C];
-        u[C] = acc * rinv[C];
-        if constexpr (C + 1 < PW) RowSolve<C + 1>::run(u, Rm, rinv);
-    }
-};
-// unit-lower column solve  L x = e_lane : x(i) = delta(i, lane) - sum_{k<i} L(i, k) x(k)
-template <int I> struct UnitLowerInv {
-    static __device__ __forceinline__ void run(double (&x)[PW], double (*Lm)[PW + 1], int lane)
-    {
-        double acc = (I == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < I; ++k) acc -= Lm[I][k] * x[k];
-        x[I] = acc;
-        if constexpr (I + 1 < PW) UnitLowerInv<I + 1>::run(x, Lm, lane);
-    }
-};
-
-// back substitution  U' X = I  by columns: lane j computes column j of X = U'^-1 (zero below the diagonal);  Um[i][k] = U'(i, k)
-template <int I> struct UpperInv {
-    static __device__ __forceinline__ void run(double (&x)[PW], double (*Um)[PW + 1], double dinv, int lane)
-    {
-        double acc = (I == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = I + 1; k < PW; ++k) acc -= Um[I][k] * x[k];
-        x[I] = acc * readlane_f64(dinv, I);                    // dinv: 1 / U'(lane, lane) in lane `lane`
-        if constexpr (I > 0) UpperInv<I - 1>::run(x, Um, dinv, lane);
-    }
-};
 
 // UINV: Uout receives U'^-1 (third-generation leaf: final4 multiplies by it on the matrix cores) instead of U' (final3 solves with it)
 // EP ("early product", see hr3_ep_kernel): the unit-lower top block L1 of V goes to epw (Vw's top rows still hold Q_top, which the

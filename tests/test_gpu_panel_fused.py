@@ -1,0 +1,132 @@
+"""-m gpu: the one-launch outer panel (qr_panel_fused.hip) against numpy -- a whole panel of up to 256 columns (8 leaves of 32:
+CholeskyQR2 + Householder reconstruction per leaf, the in-panel products and updates, all inside ONE launch whose workgroups exchange
+32 x 32 partial matrices through write-through slabs).  Checked as a compact-WY panel: explicit V and in-place tails agree, V is unit
+lower trapezoidal, every leaf's T block is what V and tau imply, the Gram blocks are V_prev^T V_l, and (I - V T V^T)^T P = [R; 0]
+with T merged from the leaves' blocks and the Gram blocks the way the host's merge tree does it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, host, zeros
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def q(qr):
+    qr.check(qr.lib.qrd_init(), "qrd_init")
+    f = qr.lib.qrd_panel_fused
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                  C.c_void_p, C.POINTER(C.c_uint), C.c_void_p]
+    qr.lib.qrd_panel_fused_ws_doubles.restype = C.c_size_t
+    return qr
+
+
+class Ws:
+    """one exchange workspace + epoch counter, as a plan keeps them"""
+
+    def __init__(self, q):
+        self.buf = torch.zeros(int(q.lib.qrd_panel_fused_ws_doubles()), dtype=torch.float64, device="cuda")
+        self.epoch = C.c_uint(0)
+        self.status = torch.zeros(4, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+
+
+def merged_t(V, Tdiag, wh):
+    """T of the whole panel from the leaves' diagonal blocks: T(0:c, c:c+32) = -T(0:c, 0:c) (V(:, 0:c)^T V(:, c:c+32)) T_l"""
+    T = np.zeros((wh, wh))
+    for c in range(0, wh, 32):
+        T[c:c + 32, c:c + 32] = np.triu(Tdiag[c:c + 32, c:c + 32])
+        if c:
+            T[:c, c:c + 32] = -T[:c, :c] @ (V[:, :c].T @ V[:, c:c + 32]) @ T[c:c + 32, c:c + 32]
+    return T
+
+
+def run_panel(q, ws, P, lda=None, ldv=None):
+    mk, wh = P.shape
+    lda = lda or mk
+    ldv = ldv or mk
+    buf = np.full((lda, wh), 7.0)
+    buf[:mk] = P
+    dA = dev(buf)
+    dV = zeros(ldv, wh)
+    dT, dtau, dG = dev(np.full((wh, wh), np.nan)), zeros(wh, 1), dev(np.full((wh, wh), np.nan))
+    ws.status.zero_()
+    torch.cuda.synchronize()
+    rc = q.lib.qrd_panel_fused(None, dA.data_ptr(), lda, mk, wh, dtau.data_ptr(), dT.data_ptr(), wh, dV.data_ptr(), ldv, dG.data_ptr(), wh,
+                               ws.buf.data_ptr(), C.byref(ws.epoch), ws.status.data_ptr())
+    assert rc == 0, rc
+    q.check(q.lib.qrd_device_sync(), "sync")
+    st = ws.status.cpu().numpy()
+    out = host(dA)
+    assert np.array_equal(out[mk:], buf[mk:]), "rows below the panel are never written"
+    return out[:mk], host(dV)[:mk], host(dT), host(dtau)[:, 0], host(dG), st
+
+
+def check_panel(P, out, V, Tdiag, tau, G, tol=1e-12):
+    mk, wh = P.shape
+    assert np.isfinite(out).all() and np.isfinite(V).all() and np.isfinite(tau).all()
+    assert np.array_equal(np.triu(V[:wh], 1), np.zeros((wh, wh))) and np.array_equal(np.diag(V[:wh]), np.ones(wh))
+    assert np.array_equal(np.tril(V, -1), np.tril(out, -1)), "explicit V and in-place tails must agree"
+    for c in range(0, wh, 32):
+        Tl = Tdiag[c:c + 32, c:c + 32]
+        assert np.isfinite(Tl).all() and np.array_equal(np.tril(Tl, -1), np.zeros((32, 32)))
+        assert np.array_equal(np.diag(Tl), tau[c:c + 32])
+        Vl = V[:, c:c + 32]
+        # T_l^-1 + T_l^-T = V_l^T V_l  (compact-WY identity)
+        Ti = np.linalg.inv(Tl)
+        assert np.abs(Ti + Ti.T - Vl.T @ Vl).max() < 1e-11 * max(1.0, np.abs(Ti).max())
+        if c:
+            Gref = V[:, :c].T @ Vl
+            assert np.abs(G[:c, c:c + 32] - Gref).max() < tol * np.sqrt(mk) * max(1.0, np.abs(Gref).max())
+    T = merged_t(V, Tdiag, wh)
+    QtP = P - V @ (T.T @ (V.T @ P))
+    scale = np.abs(P).max()
+    assert np.abs(np.tril(QtP, -1)).max() < 1e-11 * np.sqrt(mk) * scale
+    assert np.abs(np.triu(QtP[:wh]) - np.triu(out[:wh])).max() < 1e-11 * np.sqrt(mk) * scale
+    R = np.triu(out[:wh])
+    Rref = np.linalg.qr(P, mode="r")
+    S = np.sign(np.diag(R)) * np.sign(np.diag(Rref))
+    assert np.linalg.norm(S[:, None] * R - Rref) / np.linalg.norm(Rref) < 1e-12
+
+
+@pytest.mark.parametrize("mk,wh", [(256, 32), (256, 64), (512, 64), (1024, 128), (1000, 256), (2048, 256), (4096, 64), (4096, 256),
+                                   (8192, 256), (8192, 128), (5000, 96), (260, 256)])
+def test_panel_fused_well_conditioned(q, mk, wh):
+    ws = Ws(q)
+    P = np.random.default_rng(mk + wh).random((mk, wh))
+    out, V, T, tau, G, st = run_panel(q, ws, P, lda=mk + 6, ldv=mk + 2)
+    assert st[1] == 0, "a wait timed out"
+    assert st[0] == 0, "a leaf of a well-conditioned panel took the Householder route"
+    check_panel(P, out, V, T, tau, G)
+
+
+def test_panel_fused_repeated_launches_share_a_workspace(q):
+    """the epoch words are never reset: several panels of different heights through one workspace, results bitwise reproducible"""
+    ws = Ws(q)
+    rng = np.random.default_rng(5)
+    first = {}
+    for rep in range(3):
+        for mk, wh in [(2048, 128), (4096, 256), (512, 32)]:
+            P = np.random.default_rng(mk).random((mk, wh))
+            out, V, T, tau, G, st = run_panel(q, ws, P)
+            assert st[0] == 0 and st[1] == 0
+            if rep == 0:
+                check_panel(P, out, V, T, tau, G)
+                first[(mk, wh)] = out
+            else:
+                assert np.array_equal(out, first[(mk, wh)])
+
+
+def test_panel_fused_declines_what_it_cannot_take(q):
+    ws = Ws(q)
+    d = zeros(9000, 64)
+    args = lambda mk, wh, lda: (None, d.data_ptr(), lda, mk, wh, d.data_ptr(), d.data_ptr(), wh, d.data_ptr(), lda, d.data_ptr(), wh,
+                                ws.buf.data_ptr(), C.byref(ws.epoch), ws.status.data_ptr())
+    assert q.lib.qrd_panel_fused(*args(8196, 64, 9000)) == -7      # more than 32 x 256 rows
+    assert q.lib.qrd_panel_fused(*args(1026, 64, 9000)) == -7      # rows not a multiple of 4
+    assert q.lib.qrd_panel_fused(*args(1024, 48, 9000)) == -7      # not whole leaves
+    assert q.lib.qrd_panel_fused(*args(1024, 64, 8999)) == -7      # odd leading dimension

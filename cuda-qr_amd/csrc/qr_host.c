@@ -78,6 +78,9 @@ struct qr_plan {
     int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height;
                                  * 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
     double* chol_ws;
+    double* pf_ws;              /* exchange workspace of the one-launch panel (qr_panel_fused.hip); NULL: not used */
+    unsigned pf_epoch;          /* its epoch counter: the workspace's epoch words never exceed it */
+    int* pf_status;             /* device: [0] leaves that took the Householder route inside a one-launch panel, [1] a wait timed out */
     int tsqr_min_rows;
     size_t slab_cap, w_cap;
     /* profiling */
@@ -110,6 +113,7 @@ typedef struct qr_knobs {
     int early_next, early_w1;                               /* MI355XQR_EARLY_NEXT, MI355XQR_EARLY_W1 */
     int plan_cache;                                         /* MI355XQR_PLAN_CACHE */
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
+    int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
 } qr_knobs;
 static qr_knobs g_knobs;
 static pthread_once_t g_knobs_once = PTHREAD_ONCE_INIT;
@@ -137,6 +141,7 @@ static void knobs_init(void)
     { const int v = env_int("MI355XQR_EARLY_W1", 0); if (v >= 128) k->early_w1 = v / 128 * 128; }
     k->plan_cache = env_int("MI355XQR_PLAN_CACHE", 1) != 0;
     k->early_product = env_int("MI355XQR_EP", 1) != 0;
+    k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -385,6 +390,12 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
         p->slab_ep_cap = (size_t) 32 * (size_t) (nb > 64 ? nb : 64) * 128;
         rc = qrd_malloc((void**) &p->slabs_ep, sizeof(double) * p->slab_ep_cap);
     }
+    if (!rc && p->panel_tsqr == 3 && knobs()->fused_panel) {
+        rc = qrd_malloc((void**) &p->pf_ws, sizeof(double) * qrd_panel_fused_ws_doubles());
+        if (!rc) rc = qrd_memset(p->stream, p->pf_ws, 0, sizeof(double) * qrd_panel_fused_ws_doubles());
+        if (!rc) rc = qrd_malloc((void**) &p->pf_status, 4 * sizeof(int));
+        if (!rc) rc = qrd_memset(p->stream, p->pf_status, 0, 4 * sizeof(int));
+    }
     if (rc) { qr_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -417,6 +428,7 @@ int qr_plan_destroy(qr_plan* p)
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
     qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
+    qrd_free(p->pf_ws); qrd_free(p->pf_status);
     if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
     return 0;
@@ -625,7 +637,16 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
             if (half_ready) CHECK(qrd_stream_wait_event(p->stream, half_ready));
             CHECK(apply_small_t(p, p->stream, p->Vw, ldv, p->T, ldt, mk, c0, Ak + (size_t) c0 * lda, lda, wh, p->Wn, p->Yn, p->slabs));
         }
-        for (int c = c0; c < cend; c += ib) {
+        /* the whole half in ONE launch (qr_panel_fused.hip: every leaf, its in-panel product and update; leaf T blocks, tau, V and
+         * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
+        const int fused_half = p->pf_ws && !p->use_graph && ib == 32 &&
+                               qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);
+        if (fused_half) {
+            CHECK(qrd_panel_fused(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
+                                  p->Vw + (size_t) c0 * ldv + c0, ldv, p->G + (size_t) c0 * nb + c0, nb, p->pf_ws, &p->pf_epoch, p->pf_status));
+            gram_done = need_t;
+        }
+        for (int c = c0; c < cend && !fused_half; c += ib) {
             const int w = imin(ib, cend - c), mkl = mk - c;
             double* P = Ak + (size_t) c * lda + c;
             double* Vl = p->Vw + (size_t) c * ldv + c;

@@ -53,6 +53,7 @@ int qrd_init(void) { return 0; }
 int qrd_gemm2_init(void) { return 0; }
 int qrd_panel_tsqr_init(void) { return 0; }
 int qrd_leaf_fused_init(void) { return 0; }
+int qrd_panel_fused_init(void) { return 0; }
 
 int qrd_malloc(void** p, size_t bytes)
 {
@@ -203,6 +204,26 @@ int qrd_panel_cholqr_ep(void* s, double* P, int ld, int mk, int w, double* tau, 
     chkb("ep slabs", eps, ecap * sizeof(double));
     if (ecap < (size_t) 32 * (size_t) (N1 + N2)) { fprintf(stderr, "qrd_stub: early-product slab buffer too small\n"); abort(); }
     *did = (mk & 64) ? 0 : 1;          /* both outcomes are exercised */
+    return 0;
+}
+size_t qrd_panel_fused_ws_doubles(void) { return 700000; }
+/* same shape rules as the real launch layer (whole leaves, <= 256 columns, <= 32 x 256 rows, rows a multiple of 4, aligned operands);
+ * heights with bit 9 set are declined so that both routes of factor_panel are exercised */
+int qrd_panel_fused_ok(void* s, const double* A, int lda, int mk, int wh, const double* Vw, int ldv)
+{
+    (void) s;
+    if (wh < 32 || wh > 256 || wh % 32 || mk < wh || mk % 4 || mk > 8192 || (mk & 512)) return 0;
+    return !(((uintptr_t) A & 15) || ((uintptr_t) Vw & 15) || lda % 2 || ldv % 2);
+}
+int qrd_panel_fused(void* s, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv, double* G, int ldg,
+                    double* ws, unsigned* epoch, int* status)
+{
+    if (!qrd_panel_fused_ok(s, A, lda, mk, wh, Vw, ldv)) return -7;
+    leaf_chk("panel_fused", A, lda, mk, wh, tau, T, ldt, Vw, ldv);
+    chk("panel_fused G", G, ldg, wh, wh);
+    chkb("panel_fused ws", ws, sizeof(double) * qrd_panel_fused_ws_doubles());
+    chkb("panel_fused status", status, 4 * sizeof(int));
+    *epoch += 1024u;
     return 0;
 }
 int qrd_slab_reduce(void* s, int M, int N, int ns, const double* slabs, int lds, size_t stride, double* out, int ldo)

@@ -127,4 +127,30 @@ template <int I> struct UpperInv {
     }
 };
 
+// T (w x w upper triangular, into Tl[PW][PW+1] in LDS) of the block's reflectors from the captured Gram
+// columns Z(q, j) = v_q^T v_j and tau:  T(0:j,j) = -tau_j T(0:j,0:j) Z(0:j,j).  Row p depends only on row p:
+// thread tid < PW computes row tid with no synchronisation.
+template <class SH>
+__device__ __forceinline__ void build_t_rows(double (*Tl)[PW + 1], double (*Z)[PW + 1], const SH& sh, int w, int tid)
+{
+    if (tid < PW) {
+        double trow[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) trow[q] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < PW; ++jj) {
+            if (jj < w) {
+                const double tj = sh.tau[jj];
+                double sacc = 0.0;
+#pragma unroll
+                for (int q = 0; q < jj; ++q) sacc += trow[q] * Z[jj][q];
+                trow[jj] = (tid == jj) ? tj : ((tid < jj) ? -tj * sacc : 0.0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PW; ++q) Tl[tid][q] = (tid < w && q < w) ? trow[q] : 0.0;
+    }
+}
+
+
 #endif

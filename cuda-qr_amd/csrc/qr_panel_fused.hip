@@ -32,7 +32,7 @@
 #include "qr_common.h"
 #include "qr_leaf_math.h"
 
-#define PF_THREADS 448            /* 4 row waves + 3 service waves */
+#define PF_THREADS 256            /* four waves, one per SIMD */
 #define PF_ROWS 256               /* rows per workgroup */
 #define PF_LDQ 260                /* row stride of the [column][row] image (doubles) */
 #define PF_MAXWG 32
@@ -40,13 +40,18 @@
 #define PF_SPIN_LIMIT (1u << 22)
 
 // workspace layout (doubles); the first 2 KB are the epoch words, one per workgroup, 64 bytes apart
-#define PF_OFF_X1 256
+#define PF_FAC_WORD (16 * PF_MAXWG)   /* the factor workgroup's epoch word (unsigned index) */
+#define PF_OFF_X1 512
 #define PF_OFF_X2 (PF_OFF_X1 + 2 * PF_MAXWG * 1024)
 #define PF_OFF_QT (PF_OFF_X2 + 2 * PF_MAXWG * 1024)
 #define PF_OFF_X3 (PF_OFF_QT + 2 * 1024)
 #define PF_OFF_X4 (PF_OFF_X3 + 2 * (PF_MAXWG + 1) * 32 * PF_ZCOLS)
 #define PF_OFF_XF (PF_OFF_X4 + 2 * 32 * PF_ZCOLS)
-#define PF_WS_DOUBLES (PF_OFF_XF + 2 * PF_MAXWG * 128)
+#define PF_OFF_F1 (PF_OFF_XF + 2 * PF_MAXWG * 128)      /* factor -> rows: R1^-1 (1024) + status (8), per parity */
+#define PF_F1_SZ 1032
+#define PF_OFF_F2 (PF_OFF_F1 + 2 * PF_F1_SZ)              /* factor -> rows: U'^-1, T, L1\\U', R, S R2 (5 x 1024) + status (8) */
+#define PF_F2_SZ (5 * 1024 + 8)
+#define PF_WS_DOUBLES (PF_OFF_F2 + 2 * PF_F2_SZ)
 
 // LDS carve-up (doubles).  The 32 x 32 factors come FIRST: their addresses are compile-time constants, and below 64 KB they fit the
 // immediate offset of a ds_read -- above it hipcc materialises one scalar register per address (~900 of them, spilled, in the unrolled
@@ -58,8 +63,8 @@
 #define PF_SM_R1 (PF_SM_GS + PF_M33)
 #define PF_SM_WS (PF_SM_R1 + PF_M33)             /* R1^-1; later U */
 #define PF_SM_SS (PF_SM_WS + PF_M33)             /* S (32), 1 / diag R2 (32) */
-#define PF_SM_SCR (PF_SM_SS + 64)                /* 7 waves x 128 */
-#define PF_SM_FLAGS (PF_SM_SCR + 7 * 128)        /* ints */
+#define PF_SM_SCR (PF_SM_SS + 64)                /* 4 waves x 128 (+ 256 for the factor workgroup's 16 x 16 intermediate) */
+#define PF_SM_FLAGS (PF_SM_SCR + 4 * 128 + 256)  /* ints */
 #define PF_SM_PART (PF_SM_FLAGS + 8)             /* (16 ints) */             /* 4 x 768 per-wave Gram partials; later U'^-1 and T */
 #define PF_SM_IMG (PF_SM_PART + 3072)            /* [column][row] image of the workgroup's rows; later -W */
 #define PF_SM_DOUBLES (PF_SM_IMG + 32 * PF_LDQ)
@@ -81,7 +86,7 @@ typedef double (*pf_m33)[33];
 
 #ifdef PF_STAMPS
 #define PF_STAMP(k) do { if (g == 0 && threadIdx.x == 0 && P.stamps) P.stamps[(c >> 5) * 32 + (k)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
-#define PF_STAMP_S(k) do { if (g == 0 && threadIdx.x == 256 && P.stamps) P.stamps[(c >> 5) * 32 + (k)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PF_STAMP_S(k) do { if (g == 0 && threadIdx.x == 0 && P.stamps) P.stamps[(c >> 5) * 32 + (k)] = (long long) __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PF_STAMP(k) do { } while (0)
 #define PF_STAMP_S(k) do { } while (0)
@@ -109,25 +114,27 @@ __device__ __forceinline__ int pf_zidx(int i, int j)
 __device__ __forceinline__ v4d pf_mfma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 // every thread of the workgroup: the sc1 stores issued so far are drained, then ONE lane raises this workgroup's epoch word
-__device__ __forceinline__ void pf_publish(unsigned* flags, int g, unsigned val)
+__device__ __forceinline__ void pf_publish(unsigned* flags, int word, unsigned val)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + 16 * g, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// every thread: returns when all nwg epoch words have reached val (lane w of wave 0 polls word w); a wait that does not complete
-// in ~1 s marks the launch dead -- every later wait returns at once, the launch ends with garbage and status[1] = 1 instead of hanging
-__device__ __forceinline__ void pf_wait(const unsigned* flags, int nwg, unsigned val, int* dead)
+// every thread: returns when the epoch words of the first n row workgroups (n > 0; lane w of wave 0 polls word w) or, n = 0, of the
+// factor workgroup have reached val.  A wait that does not complete in ~1 s marks the launch dead -- every later wait returns at
+// once, the launch ends with garbage and status[1] = 1 instead of hanging
+__device__ __forceinline__ void pf_wait(const unsigned* flags, int n, unsigned val, int* dead)
 {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         if (*dead == 0) {
+            const unsigned* w = (n > 0) ? flags + 16 * min(lane, n - 1) : flags + PF_FAC_WORD;
             unsigned spins = 0;
             for (;;) {
-                const unsigned f = (lane < nwg) ? __hip_atomic_load(flags + 16 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : val;
+                const unsigned f = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((int) (f - val) >= 0)) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > PF_SPIN_LIMIT) { if (lane == 0) *dead = 1; break; }
             }
         }
@@ -251,28 +258,28 @@ __device__ __forceinline__ void pf_gram_entry(int e, double s, pf_m33 Gs, int* g
     }
 }
 
-// all threads: Gs[j][i] = sum over the workgroups (in index order) of their partial G(i, j).  A thread owns entries tid and tid + 448 and
-// has the loads of 16 workgroups for both in flight at once: two round trips at 32 workgroups (three rounds of four were 5.7 us)
+// all threads: Gs[j][i] = sum over the workgroups (in index order) of their partial G(i, j).  A thread owns entries tid, tid + 256 and
+// tid + 512 and has the loads of 16 workgroups for all three in flight at once: two round trips at 32 workgroups
 __device__ __forceinline__ void pf_gram_sum(const double* __restrict__ X, int nwg, pf_m33 Gs, int* gflags, bool check)
 {
-    const int e0 = threadIdx.x, e1 = threadIdx.x + PF_THREADS;
-    const bool h1 = e1 < 768;
-    const int e1c = h1 ? e1 : e0;
-    double s0 = 0.0, s1 = 0.0;
+    const int e0 = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int w0 = 0; w0 < nwg; w0 += 16) {
-        double v0[16], v1[16];
+        double v0[16], v1[16], v2[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const double* xw = X + (size_t) min(w0 + u, nwg - 1) * 1024;
-            v0[u] = pf_ld(xw + e0);
-            v1[u] = pf_ld(xw + e1c);
+            const double* xw = X + (size_t) min(w0 + u, nwg - 1) * 1024 + e0;
+            v0[u] = pf_ld(xw);
+            v1[u] = pf_ld(xw + 256);
+            v2[u] = pf_ld(xw + 512);
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (w0 + u < nwg) { s0 += v0[u]; s1 += v1[u]; }
+            if (w0 + u < nwg) { s0 += v0[u]; s1 += v1[u]; s2 += v2[u]; }
     }
     pf_gram_entry(e0, s0, Gs, gflags, check);
-    if (h1) pf_gram_entry(e1, s1, Gs, gflags, check);
+    pf_gram_entry(e0 + 256, s1, Gs, gflags, check);
+    pf_gram_entry(e0 + 512, s2, Gs, gflags, check);
 }
 
 // ---- hand-offs between waves of ONE workgroup through an LDS word (no workgroup barrier: the other role keeps running) ----------
@@ -326,10 +333,11 @@ template <int I> struct PfUpperInv16 {
     }
 };
 
-// LDS views shared by the two roles
+// LDS views.  Row workgroups use: img, part (later U'^-1 and T), Ws (R1^-1), Bs (L1 \ U': owner of the top block), R1s (R: owner),
+// R2s (S R2: owner), scr.  The factor workgroup uses all the 32 x 32 factors and keeps R in the (otherwise unused) image region.
 struct PfLds {
     double* img; double* part;
-    pf_m33 Uinv, Ts, Gs, Ls, R1s, Ws, Us, R2s, Bs;
+    pf_m33 Uinv, Ts, Gs, Ls, R1s, Ws, Us, R2s, Bs, Rm;
     double *Ss, *r2inv, *scr;
     int* gflags;     // [0] first Cholesky ok, [1] |G2 - I| > 1/64, [2] > 1e-9, [3] second Cholesky failed, [4] dead (a wait timed out),
                      // [5] leaves whose LU (B, L1, U') is in LDS, [6] leaves whose inverse of U'(16:32, 16:32) is in LDS
@@ -349,6 +357,7 @@ __device__ __forceinline__ PfLds pf_lds(double* sm)
     L.Us = L.Ws;
     L.R2s = reinterpret_cast<pf_m33>(sm + PF_SM_R2);
     L.Bs = reinterpret_cast<pf_m33>(sm + PF_SM_BS);
+    L.Rm = reinterpret_cast<pf_m33>(sm + PF_SM_IMG);
     L.Ss = sm + PF_SM_SS;
     L.r2inv = L.Ss + 32;
     L.scr = sm + PF_SM_SCR;
@@ -358,36 +367,52 @@ __device__ __forceinline__ PfLds pf_lds(double* sm)
 
 struct PfLeaf {                      // per-leaf constants
     int c, nrest, ncols, gown;
-    double *X1, *X2, *QT, *X3, *X4;
+    double *X1, *X2, *QT, *X3, *X4, *F1, *F2;
 };
 
 __device__ __forceinline__ PfLeaf pf_leaf(const PfArgs& P, int c)
 {
     PfLeaf f;
-    const int par = (c >> 5) & 1;
+    const int li = c >> 5, par = li & 1;
     f.c = c; f.nrest = P.wh - c - 32; f.ncols = P.wh - 32; f.gown = c / PF_ROWS;
     f.X1 = P.ws + PF_OFF_X1 + (size_t) par * PF_MAXWG * 1024;
     f.X2 = P.ws + PF_OFF_X2 + (size_t) par * PF_MAXWG * 1024;
     f.QT = P.ws + PF_OFF_QT + (size_t) par * 1024;
     f.X3 = P.ws + PF_OFF_X3 + (size_t) par * (PF_MAXWG + 1) * 32 * PF_ZCOLS;
     f.X4 = P.ws + PF_OFF_X4 + (size_t) par * 32 * PF_ZCOLS;
+    f.F1 = P.ws + PF_OFF_F1 + (size_t) par * PF_F1_SZ;
+    f.F2 = P.ws + PF_OFF_F2 + (size_t) par * PF_F2_SZ;
     return f;
 }
 
-// reduce-scatter of Z (all seven waves): this workgroup's columns j = g, g + nwg, ... of Z, two per wave at a time (half-wave =
-// column):  z = sum of the partials,  y = U'^-T z,  W(:, j) = T^T y -> X4  or  G(j', c + :) = y
-__device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const PfLds& L, int g, int nwg, int wave, int lane)
+// all threads: a 32 x 32 matrix between LDS (padded rows) and a dense slab in global memory (sc1 both ways)
+__device__ __forceinline__ void pf_m33_out(pf_m33 M, double* __restrict__ slab)
+{
+    for (int e = threadIdx.x; e < 1024; e += PF_THREADS) pf_st(slab + e, M[e >> 5][e & 31]);
+}
+__device__ __forceinline__ void pf_m33_in(pf_m33 M, const double* __restrict__ slab)
+{
+#pragma unroll
+    for (int q = 0; q < 1024 / PF_THREADS; ++q) {
+        const int e = threadIdx.x + q * PF_THREADS;
+        M[e >> 5][e & 31] = pf_ld(slab + e);
+    }
+}
+
+// reduce-scatter of Z (row workgroups, four waves): this workgroup's columns j = g, g + nrow, ... of Z, two per wave at a time
+// (half-wave = column):  z = sum of the partials + the owner's correction,  y = U'^-T z,  W(:, j) = T^T y -> X4  or  G(j', c + :) = y
+__device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const PfLds& L, int g, int nwg, int wave, int lane, bool nocorr)
 {
     double* s1 = L.scr + wave * 128;
     const int h = lane >> 5, i = lane & 31;
-    for (int k = 2 * wave + h; ; k += 14) {
+    for (int k = 2 * wave + h; ; k += 8) {
         const int j = g + k * nwg;
         const bool have = j < f.ncols;
         if (!__any(have)) break;
         if (have) {
             double z = 0.0;
             const int zi = pf_zidx(i, j);
-            const double corr = pf_ld(f.X3 + (size_t) nwg * 32 * PF_ZCOLS + zi);             // the top-block owner's -B^T x_top
+            const double corr = nocorr ? 0.0 : pf_ld(f.X3 + (size_t) nwg * 32 * PF_ZCOLS + zi);   // the top-block owner's -B^T x_top
             {
                 double v[PF_MAXWG];
 #pragma unroll
@@ -499,14 +524,154 @@ __device__ __forceinline__ void pf_update_groups(double (&vr)[4][8], const doubl
     }
 }
 
-// The two roles run the same sequence of workgroup barriers (numbered per leaf); a role with nothing to do in a phase just joins.
-//
-//   #1  image of a                 #2  per-wave G1          #3  G1 partial published     #4  all epoch words seen
-//   #5  G1 summed                  #6  R1, R1^-1            #7  Q, image, Q_top          #8  per-wave G2
-//   #9  G2 partial published       #10 all seen             #11 G2 summed, guard         (#12: none -- LU, then U and U'^-1, run beside
-//   #13 Z published | factors ready                          the row waves' product; hand-offs through LDS words)                       #14 T, outputs | V           #15 all Z seen
-//   #16 W slices published         #17 all seen
-__device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int nwg)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The Householder route of ONE leaf inside the launch (the guard of the CholeskyQR2 route: a non-positive Cholesky pivot, or
+// Q^T Q too far from I -- zero, dependent or badly conditioned columns).  Column by column, the classical way (qr.c:109-235): the row
+// workgroups exchange 32 partial dot products per column (x_J^T x_c for all c: the norm, every v^T a, and the Gram column that T needs,
+// as in house_step of qr_panel_tsqr.hip) and every workgroup forms tau, beta and the update coefficients redundantly from the same
+// sums.  32 exchanges of ~2.5 us: slow, rare, and the output has the same form as the fast route's (unit-lower V below R, tau, T).
+// On entry nothing of the leaf has been written; on exit: ar = this lane's rows of V (top block: unit-lower L1), V / R stored, T and tau
+// stored (owner), Ts = T and Uinv = I in LDS.  er0: the row workgroups' epoch value before the first column exchange.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct PfTau { double tau[32]; };
+
+template <int J>
+__device__ __forceinline__ void pf_house_col(double (&a)[4][8], const PfArgs& P, const PfLeaf& f, const PfLds& L, unsigned* flags, unsigned er0,
+                                             int g, int nrow, int r4, int l15, int l4, int wave)
+{
+    constexpr int KJ = J >> 2, LJ = J & 3;
+    const int tid = threadIdx.x, c = f.c;
+    double* red = L.part;                     // [4][32] per-wave sums
+    double* sc = L.part + 128;                // [32] s_c, then [3] tau, beta, 1/u
+    double* XF = P.ws + PF_OFF_XF + (size_t) (J & 1) * PF_MAXWG * 128;
+    // x_J of this lane's four rows: held by the lanes with l4 == J % 4
+    double xj[4], p[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double v = __shfl(a[t][KJ], l15 + 16 * LJ);
+        xj[t] = (r4 + t > c + J) ? v : 0.0;                 // rows strictly below the pivot row (rows beyond mk hold zeros)
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) p[ks] = (xj[0] * a[0][ks] + xj[1] * a[1][ks]) + (xj[2] * a[2][ks] + xj[3] * a[3][ks]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                        // sum over the 16 lanes of this l4 (the 64 rows of the wave)
+        p[ks] += __shfl_xor(p[ks], 1); p[ks] += __shfl_xor(p[ks], 2); p[ks] += __shfl_xor(p[ks], 4); p[ks] += __shfl_xor(p[ks], 8);
+    }
+    if (l15 == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) red[wave * 32 + 4 * ks + l4] = p[ks];
+    }
+    if (g == f.gown && r4 == c + (J & ~3)) {                // the pivot row: row c + J = r4 + LJ of these four lanes
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) pf_st(XF + (size_t) g * 128 + 32 + 4 * ks + l4, a[LJ][ks]);
+    }
+    __syncthreads();
+    if (tid < 32) pf_st(XF + (size_t) g * 128 + tid, (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]));
+    pf_publish(flags, 16 * g, er0 + 1u + (unsigned) J);
+    pf_wait(flags, nrow, er0 + 1u + (unsigned) J, &L.gflags[4]);
+    if (tid < 32) {
+        double d = 0.0;
+        for (int w0 = 0; w0 < nrow; w0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pf_ld(XF + (size_t) min(w0 + u, nrow - 1) * 128 + tid);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (w0 + u < nrow) d += v[u];
+        }
+        const double rowv = pf_ld(XF + (size_t) f.gown * 128 + 32 + tid);
+        const double alpha = __shfl(rowv, J), sigma = __shfl(d, J);
+        double t, b, iu;
+        if (sigma == 0.0) { t = 0.0; b = alpha; iu = 0.0; }
+        else {
+            const double nrm = sqrt(alpha * alpha + sigma);
+            b = -copysign(nrm, alpha);
+            t = (b - alpha) / b;
+            iu = 1.0 / (alpha - b);
+        }
+        const double sv = rowv + d * iu;
+        sc[tid] = sv;
+        if (tid < J) L.Bs[J][tid] = sv;                       // Z(c', J) = v_c'^T v_J (Bs is free on this route)
+        if (tid == 0) { sc[32] = t; sc[33] = b; sc[34] = iu; L.Ss[J] = t; }
+    }
+    __syncthreads();
+    const double tj = sc[32], beta = sc[33], iu = sc[34];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = r4 + t;
+        const bool below = row > c + J && row < P.mk, piv = row == c + J;
+        const double vi = below ? xj[t] * iu : (piv ? 1.0 : 0.0);
+        const double coef = tj * vi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int col = 4 * ks + l4;
+            if (ks > KJ || (ks == KJ && l4 > LJ)) a[t][ks] -= coef * sc[col];
+            else if (ks == KJ && l4 == LJ) a[t][ks] = below ? vi : (piv ? beta : a[t][ks]);
+        }
+    }
+    __syncthreads();                                          // sc / red are rewritten by the next column
+    if constexpr (J + 1 < 32) pf_house_col<J + 1>(a, P, f, L, flags, er0, g, nrow, r4, l15, l4, wave);
+}
+
+__device__ __forceinline__ void pf_householder_leaf(double (&ar)[4][8], const PfArgs& P, const PfLeaf& f, const PfLds& L, unsigned* flags,
+                                                    unsigned er0, int g, int nrow, int r4, int r4c, bool act, bool toprow, int l15, int l4,
+                                                    int wave)
+{
+    const int tid = threadIdx.x, c = f.c;
+    pf_load_rows(ar, P.A, P.lda, c, r4c, l4);                 // the leaf as the previous update left it
+    if (!act) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) ar[t][ks] = 0.0;
+    }
+    __syncthreads();
+    pf_house_col<0>(ar, P, f, L, flags, er0, g, nrow, r4, l15, l4, wave);
+    // T from tau and the Gram columns (row p of T depends on row p only: thread p), U'^-1 := I
+    {
+        PfTau th;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) th.tau[q] = L.Ss[q];
+        __syncthreads();
+        build_t_rows(L.Ts, L.Bs, th, 32, tid);
+        for (int e = tid; e < 1024; e += PF_THREADS) L.Uinv[e >> 5][e & 31] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (g == f.gown) {
+#pragma unroll
+        for (int q = 0; q < 1024 / PF_THREADS; ++q) {
+            const int el = tid + q * PF_THREADS, i = el & 31, cc = el >> 5;
+            P.T[(size_t) (c + cc) * P.ldt + c + i] = L.Ts[i][cc];
+            if (i == cc) P.tau[c + i] = L.Ss[i];
+        }
+    }
+    if (toprow) {                                             // R on and above the diagonal, reflector tails below it: LAPACK's in-place form
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int rr_ = r4 + t - c, col = 4 * ks + l4;
+                const double v = ar[t][ks];
+                P.A[(size_t) (c + col) * P.lda + c + rr_] = v;
+                const double l1 = (col < rr_) ? v : (col == rr_ ? 1.0 : 0.0);
+                P.Vw[(size_t) (c + col) * P.ldv + c + rr_] = l1;
+                ar[t][ks] = l1;
+            }
+    } else if (act) {
+        pf_store_rows(ar, P.Vw, P.ldv, c, r4, l4);
+        pf_store_rows(ar, P.A, P.lda, c, r4, l4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A ROW workgroup (four waves, 64 rows each).  It never runs a recurrence: the 32 x 32 factors come from the factor workgroup, which
+// has a compute unit to itself -- the first version ran them on three extra waves of every row workgroup, and beside a row wave's f64
+// MFMAs the f64 VALU chain of the LU took 2.5 x as long (24.6 us instead of 9.6: the two share the SIMD's double-precision datapath),
+// so that nothing could be hidden behind anything.  Epoch protocol per leaf (PfLeaf): rows publish + 1 (G1 partial), + 2 (G2 partial,
+// Q_top), + 3 (Z partials; the owner of the top block also its correction, R, L1, T, tau), + 4 (W slices); the factor workgroup
+// publishes + 1 (R1^-1) and + 2 (U'^-1, T, L1 \ U', R, S R2).
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, int nrow)
 {
     const PfLds L = pf_lds(sm);
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -514,11 +679,10 @@ __device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int 
     double* const A = P.A;
     double* const Vw = P.Vw;
     unsigned* const flags = reinterpret_cast<unsigned*>(P.ws);
-    unsigned ep = P.epoch0;
     const int wgrow0 = g * PF_ROWS;
+    unsigned er = P.epoch0, ef = P.epoch0;                 // epoch values of the row workgroups / the factor workgroup before this leaf
     double ar[4][8];
-    int nfallback = 0;
-    if (tid == 0) { L.gflags[4] = 0; L.gflags[5] = 0; L.gflags[6] = 0; }
+    if (tid == 0) L.gflags[4] = 0;
     {
         const int l15 = tid & 15, l4 = (tid & 63) >> 4;
         pf_load_rows(ar, A, lda, 0, min(wgrow0 + wave * 64 + 4 * l15, mk - 4), l4);
@@ -531,9 +695,10 @@ __device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int 
         const int r4 = wgrow0 + wave * 64 + 4 * l15;         // this lane's four rows r4 .. r4 + 3
         const int r4c = min(r4, mk - 4);
         const bool act = r4 >= c && r4 < mk;
-        const bool toprow = g == f.gown && r4 >= c && r4 < c + 32;
+        const bool own = g == f.gown;
+        const bool toprow = own && r4 >= c && r4 < c + 32;
         PF_STAMP(0);
-        if (tid == 0) { L.gflags[0] = 1; L.gflags[1] = 0; L.gflags[2] = 0; L.gflags[3] = 0; }
+        // ---- G1 = A^T A: image of the leaf's rows, partial Gram per wave, workgroup partial -> X1
         if (!act) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -541,23 +706,15 @@ __device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int 
                 for (int ks = 0; ks < 8; ++ks) ar[t][ks] = 0.0;
         }
         pf_image_write(L.img, ar, wave, l15, l4);
-        __syncthreads();                                                             // #1
-        PF_STAMP(1);
+        __syncthreads();
         pf_gram_wave(L.img, L.part, wave, lane, l15, l4);
-        __syncthreads();                                                             // #2
-        PF_STAMP(2);
+        __syncthreads();
         pf_gram_publish(L.part, f.X1 + (size_t) g * 1024);
-        pf_publish(flags, g, ++ep);                                                  // #3
-        PF_STAMP(3);
-        pf_wait(flags, nwg, ep, &L.gflags[4]);                                       // #4
-        PF_STAMP(4);
-        pf_gram_sum(f.X1, nwg, L.Gs, L.gflags, false);
-        PF_STAMP(20);
-        __syncthreads();                                                             // #5
-        PF_STAMP(5);
-        // (service wave 0 is in the Cholesky.)  The PREVIOUS leaf's update of everything beyond this leaf's columns happens here, off
-        // the critical chain: this leaf only needed its own 32 columns (done at the end of the previous pass, below).  V of the
-        // previous leaf comes back from Vw (this lane's own rows); this leaf's a is parked in its LDS image meanwhile
+        pf_publish(flags, 16 * g, er + 1);
+        PF_STAMP(1);
+        // ---- (the factor workgroup sums G1 and runs the Cholesky.)  The PREVIOUS leaf's update of everything beyond this leaf's
+        // columns happens here, off the critical chain: this leaf only needed its own 32 columns (done at the end of the previous
+        // pass).  V of the previous leaf comes back from Vw (this lane's own rows); this leaf's a is parked in its LDS image meanwhile
         if (c > 0 && f.nrest > 0) {
             const int cp_ = c - 32;
             const bool actp = r4 >= cp_ && r4 < mk;
@@ -572,9 +729,12 @@ __device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int 
                              r4, r4c, actp, l15, l4);
             pf_image_read(L.img, ar, wave, l15, l4);
         }
-        __syncthreads();                                                             // #6  (service wave 0: Cholesky)
-        PF_STAMP(6);
-        // Q = A R1^-1 (registers), its image, the top block of Q -> QT
+        PF_STAMP(2);
+        pf_wait(flags, 0, ef + 1, &L.gflags[4]);
+        PF_STAMP(3);
+        pf_m33_in(L.Ws, f.F1);                                // R1^-1
+        __syncthreads();
+        // ---- Q = A R1^-1 (registers), its image, the top block of Q -> QT, partial G2 = Q^T Q -> X2
         pf_rows_times_upper(ar, L.Ws, l15, l4);
         pf_image_write(L.img, ar, wave, l15, l4);
         if (toprow) {
@@ -583,25 +743,18 @@ __device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) pf_st(f.QT + (4 * ks + l4) * 32 + (r4 + t - c), ar[t][ks]);
         }
-        __syncthreads();                                                             // #7
-        PF_STAMP(7);
+        __syncthreads();
         pf_gram_wave(L.img, L.part, wave, lane, l15, l4);
-        __syncthreads();                                                             // #8
-        PF_STAMP(8);
+        __syncthreads();
         pf_gram_publish(L.part, f.X2 + (size_t) g * 1024);
-        pf_publish(flags, g, ++ep);                                                  // #9
-        PF_STAMP(9);
-        pf_wait(flags, nwg, ep, &L.gflags[4]);                                       // #10
-        PF_STAMP(10);
-        pf_gram_sum(f.X2, nwg, L.Gs, L.gflags, true);
-        __syncthreads();                                                             // #11
-        PF_STAMP(11);
-        // Z = Q^T [A_rest | V_prev] for this workgroup's rows, 16-column tiles dealt to the waves (service wave 0: modified LU).
-        // A tile's 256 rows go by in four chunks of 64; the rows of the next chunk (or of the next tile) are requested before the
-        // 32 matrix-core instructions of the current one (the first version waited for every chunk: 9 us per tile instead of 3.4),
-        // and a tile is published as soon as it is complete
+        pf_publish(flags, 16 * g, er + 2);
+        PF_STAMP(4);
+        // ---- (the factor workgroup: G2, modified LU, triangular inverses.)  Meanwhile  Z = Q^T [A_rest | V_prev]  for this workgroup's
+        // rows, 16-column tiles dealt to the waves.  A tile's 256 rows go by in four chunks of 64; the rows of the next chunk (or of
+        // the next tile) are requested before the 32 matrix-core instructions of the current one, and a tile is published as soon as
+        // it is complete (16-byte write-through stores in accumulator order)
         const int ntile = f.ncols / 16;
-        {
+        auto product = [&]() {
             const int nval = (ntile > wave) ? (ntile - wave + 3) / 4 : 0;
             double* X3g = f.X3 + (size_t) g * 32 * PF_ZCOLS;
             double xb[2][4][4];
@@ -643,12 +796,42 @@ __device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int 
                 pf_st2(zp, acc0[0], acc0[1]); pf_st2(zp + 128, acc0[2], acc0[3]);
                 pf_st2(zp + 256, acc1[0], acc1[1]); pf_st2(zp + 384, acc1[2], acc1[3]);
             }
+        };
+        product();
+        // the owner of the top block: x_top (its own rows c .. c + 31 of [A_rest | V_prev], final since the deferred update) for the
+        // correction below -- requested now, so that only 16 MFMAs per tile remain once the factors are there
+        double xt[4][8];
+        if (own && ntile > 0) {
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot) {
+                const int j = 16 * min(wave + 4 * slot, ntile - 1) + l15;
+                const double* xp = ((j < f.nrest) ? A + (size_t) (c + 32 + j) * lda : Vw + (size_t) (j - f.nrest) * ldv) + c;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) xt[slot][ks] = xp[4 * ks + l4];
+            }
         }
-        PF_STAMP(12);
-        pf_publish(flags, g, ++ep);                                                  // #13
-        PF_STAMP(13);
-        if (L.gflags[0] == 0 || L.gflags[1] != 0 || L.gflags[3] != 0) ++nfallback;  // (Householder route: below; until then garbage)
-        // V = Q U'^-1; the top block's rows become L1 (their copy in global memory comes from the service waves)
+        PF_STAMP(5);
+        pf_wait(flags, 0, ef + 2, &L.gflags[4]);
+        PF_STAMP(6);
+        const bool fb = pf_ld(f.F2 + 5 * 1024) != 0.0;         // the factor workgroup refused the leaf (workgroup-, launch-uniform)
+        if (fb) {
+            pf_householder_leaf(ar, P, f, L, flags, er + 2u, g, nrow, r4, r4c, act, toprow, l15, l4, wave);
+            pf_image_write(L.img, ar, wave, l15, l4);           // the product again, from V (Q never existed)
+            __syncthreads();
+            product();
+        }
+      if (!fb) {
+        // ---- the factors: U'^-1 and T for everyone (they alias the Gram partials, published long ago); the owner of the top block
+        // also takes L1 \ U', R = S R2 R1 and S R2
+        pf_m33_in(L.Uinv, f.F2);
+        pf_m33_in(L.Ts, f.F2 + 1024);
+        if (own) {
+            pf_m33_in(L.Bs, f.F2 + 2 * 1024);
+            pf_m33_in(L.R1s, f.F2 + 3 * 1024);
+            pf_m33_in(L.R2s, f.F2 + 4 * 1024);
+        }
+        __syncthreads();
+        // ---- V = Q U'^-1; the top block's rows become L1
         pf_rows_times_upper(ar, L.Uinv, l15, l4);
         if (toprow) {
 #pragma unroll
@@ -662,35 +845,82 @@ __device__ __forceinline__ void pf_rows(const PfArgs& P, double* sm, int g, int 
             pf_store_rows(ar, Vw, ldv, c, r4, l4);
             pf_store_rows(ar, A, lda, c, r4, l4);
         }
-        __syncthreads();                                                             // #14
-        PF_STAMP(14);
-        pf_wait(flags, nwg, ep, &L.gflags[4]);                                       // #15
-        PF_STAMP(15);
-        pf_fold(P, f, L, g, nwg, wave, lane);
-        PF_STAMP(21);
-        pf_publish(flags, g, ++ep);                                                  // #16
-        PF_STAMP(16);
-        pf_wait(flags, nwg, ep, &L.gflags[4]);                                       // #17
-        PF_STAMP(17);
+        if (own && ntile > 0) {
+            // Q = V U' + [B; 0] with B = S R2, so V^T x = U'^-T (Q^T x - B^T x_top): the correction -B^T X_top goes out as one more
+            // partial of Z (slot nrow)
+            double* X3c = f.X3 + (size_t) nrow * 32 * PF_ZCOLS;
+            double ba[2][8];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) ba[ti][ks] = -L.R2s[4 * ks + l4][16 * ti + l15];
+#pragma unroll
+            for (int slot = 0; slot < 4; ++slot) {
+                const int jt = wave + 4 * slot;
+                if (jt < ntile) {
+                    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        acc0 = pf_mfma(ba[0][ks], xt[slot][ks], acc0);
+                        acc1 = pf_mfma(ba[1][ks], xt[slot][ks], acc1);
+                    }
+                    double* zp = X3c + jt * 512 + 2 * lane;
+                    pf_st2(zp, acc0[0], acc0[1]); pf_st2(zp + 128, acc0[2], acc0[3]);
+                    pf_st2(zp + 256, acc1[0], acc1[1]); pf_st2(zp + 384, acc1[2], acc1[3]);
+                }
+            }
+        }
+      }
+        const unsigned xe = fb ? 32u : 0u;                      // the Householder route's 32 column exchanges
+        pf_publish(flags, 16 * g, er + 3 + xe);
+        PF_STAMP(7);
+        if (own && !fb) {
+            // the top block: R above the diagonal of A, L1 below it and (unit lower) in Vw; T and tau -- behind the publish: nobody
+            // else waits for these.  Written by the workgroup that owns these rows: it reads them back later (x_top of the
+            // corrections, V of the deferred update) as its own stores
+#pragma unroll
+            for (int q = 0; q < 1024 / PF_THREADS; ++q) {
+                const int el = tid + q * PF_THREADS, i = el & 31, cc = el >> 5;
+                const double tv = L.Ts[i][cc];
+                P.T[(size_t) (c + cc) * P.ldt + c + i] = tv;
+                if (i == cc) P.tau[c + i] = tv;
+                A[(size_t) (c + cc) * lda + c + i] = (cc >= i) ? L.R1s[i][cc] : L.Bs[i][cc];
+                Vw[(size_t) (c + cc) * ldv + c + i] = (cc < i) ? L.Bs[i][cc] : (cc == i ? 1.0 : 0.0);
+            }
+        }
+        pf_wait(flags, nrow, er + 3 + xe, &L.gflags[4]);
+        PF_STAMP(8);
+        pf_fold(P, f, L, g, nrow, wave, lane, fb);
+        pf_publish(flags, 16 * g, er + 4 + xe);
+        PF_STAMP(9);
+        pf_wait(flags, nrow, er + 4 + xe, &L.gflags[4]);
+        PF_STAMP(10);
         // the next leaf's 32 columns are updated now (the result stays in registers as its a); the other columns of A_rest wait for
         // the next pass's Cholesky window (above)
         if (f.nrest > 0) pf_update_groups(ar, f.X4, A, lda, c, 0, 1, true, r4, r4c, act, l15, l4);
-        PF_STAMP(18);
+        PF_STAMP(11);
+        er += 4u + (fb ? 32u : 0u);
+        ef += 2u;
     }
-    if (g == 0 && tid == 0) {
-        if (nfallback) atomicAdd(P.status, nfallback);
-        if (L.gflags[4]) P.status[1] = 1;
-    }
+    if (g == 0 && tid == 0 && L.gflags[4]) P.status[1] = 1;
 }
 
-__device__ __forceinline__ void pf_service(const PfArgs& P, double* sm, int g, int nwg)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The FACTOR workgroup (the launch's last workgroup; four waves on a compute unit of its own): sums the partial Gram matrices,
+// runs the one-wave recurrences with nothing beside them on their SIMDs, and publishes the 32 x 32 factors for the row workgroups.
+//   wave 0: Cholesky of G1 with R1^-1 on its upper lanes; modified LU with L1^-1 on its upper lanes; U = U' R2^-1
+//   wave 1, 2: the two 16 x 16 diagonal blocks of U'^-1 (wave 1 then the off-diagonal block on the matrix cores)
+//   waves 0 - 2: one 16 x 16 tile each of T = -U S L1^-T and R = S R2 R1 on the matrix cores
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nrow)
 {
     const PfLds L = pf_lds(sm);
-    const int tid = threadIdx.x, wave = tid >> 6, sw = wave - 4;
-    // the recurrences on these waves ARE the critical chain; the row waves they share SIMDs with were dispatched first, and at equal
-    // priority the older wave wins the vector-issue arbitration (MI355X_MICROARCH.md, two waves per SIMD): beside a row wave in its
-    // product the LU took 2.5x as long
-    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int g = 0;                                      // (stamps: this workgroup reports under its own stamp numbers)
+    unsigned* const flags = reinterpret_cast<unsigned*>(P.ws);
+    int nfallback = 0;
+    unsigned er = P.epoch0, ef = P.epoch0;
+    if (tid == 0) { L.gflags[4] = 0; L.gflags[5] = 0; L.gflags[6] = 0; }
     for (int c = 0; c < P.wh; c += 32) {
         const PfLeaf f = pf_leaf(P, c);
         // the lane index is made opaque once per leaf: otherwise every lane-dependent constant of the unrolled recurrences below
@@ -698,16 +928,15 @@ __device__ __forceinline__ void pf_service(const PfArgs& P, double* sm, int g, i
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
         const int rc = lane & 31;
-        __syncthreads();                                                             // #1
-        __syncthreads();                                                             // #2
-        pf_gram_publish(L.part, f.X1 + (size_t) g * 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                             // #3
-        __syncthreads();                                                             // #4
-        pf_gram_sum(f.X1, nwg, L.Gs, L.gflags, false);
-        __syncthreads();                                                             // #5
+        const int seq = (c >> 5) + 1;
+        if (tid == 0) { L.gflags[0] = 1; L.gflags[1] = 0; L.gflags[2] = 0; L.gflags[3] = 0; }
+        pf_wait(flags, nrow, er + 1, &L.gflags[4]);
+        PF_STAMP_S(16);
+        pf_gram_sum(f.X1, nrow, L.Gs, L.gflags, false);
+        __syncthreads();
+        PF_STAMP_S(17);
         // R1 = chol(G1) and R1^-1 on one wave (the identity columns ride on the wave's upper half)
-        if (sw == 0) {
+        if (wave == 0) {
             double gg[PW];
 #pragma unroll
             for (int i = 0; i < PW; ++i) gg[i] = (lane < PW) ? L.Gs[rc][i] : (i == rc ? 1.0 : 0.0);
@@ -732,25 +961,24 @@ __device__ __forceinline__ void pf_service(const PfArgs& P, double* sm, int g, i
             }
             if (lane == 0 && !ok) L.gflags[0] = 0;
         }
-        __syncthreads();                                                             // #6
-        __syncthreads();                                                             // #7
-        __syncthreads();                                                             // #8
-        pf_gram_publish(L.part, f.X2 + (size_t) g * 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                             // #9
-        __syncthreads();                                                             // #10
-        pf_gram_sum(f.X2, nwg, L.Gs, L.gflags, true);
-        __syncthreads();                                                             // #11
-        PF_STAMP_S(23);
-        // R2 = chol(G2) (to first order when G2 - I is tiny) and the modified LU  Q_top - S R2 = L1 U' on service wave 0.  Its upper
-        // 32 lanes carry the columns of the identity through the same row operations: they end as L1^-1, for nothing.
-        // Then (no workgroup barrier in between: the row waves are in their long product):
+        __syncthreads();
+        PF_STAMP_S(18);
+        pf_m33_out(L.Ws, f.F1);
+        if (tid == 0) pf_st(f.F1 + 1024, (double) L.gflags[0]);
+        pf_publish(flags, PF_FAC_WORD, ef + 1);
+        PF_STAMP_S(19);
+        pf_wait(flags, nrow, er + 2, &L.gflags[4]);
+        PF_STAMP_S(20);
+        pf_gram_sum(f.X2, nrow, L.Gs, L.gflags, true);
+        __syncthreads();
+        PF_STAMP_S(21);
+        // R2 = chol(G2) (to first order when G2 - I is tiny) and the modified LU  Q_top - S R2 = L1 U' on wave 0.  Its upper 32 lanes
+        // carry the columns of the identity through the same row operations: they end as L1^-1, for nothing.  Then:
         //   wave 0: U = U' R2^-1 -- with the first-order R2, R2^-1 = 2 I - R2 to ~1e-17 and U = 2 U' - U' R2 is three tiles on the
         //           matrix cores; the general R2 (leaves of condition > ~1e4) takes the row solve
         //   wave 2: inverse of the lower diagonal block of U'          wave 1: inverse of the upper one, then the off-diagonal block
         //           -X11 U'12 X22 on the matrix cores  (two 16-step recurrences + 8 MFMAs instead of one 32-step recurrence)
-        const int seq = (c >> 5) + 1;
-        if (sw == 0) {
+        if (wave == 0) {
             const bool refused = L.gflags[0] == 0 || L.gflags[1] != 0;
             const bool first_order = L.gflags[2] == 0;
             double gg[PW], b[PW];
@@ -787,10 +1015,10 @@ __device__ __forceinline__ void pf_service(const PfArgs& P, double* sm, int g, i
                     for (int k = 0; k < PW; ++k) L.Ls[k][rc] = (k >= rc) ? b[k] : 0.0;           // Ls[i][j] = L1^-1(i, j)
                 }
             } else if (lane == 0) L.gflags[3] = 1;
-            PF_STAMP_S(24);
+            PF_STAMP_S(22);
             pf_lds_signal(&L.gflags[5], seq);
             __builtin_amdgcn_wave_barrier();
-            // U -> Us (aliases R1^-1: dead since the row waves formed Q)
+            // U -> Us (aliases R1^-1, which is published)
             if (first_order) {
                 const int l15 = lane & 15, l4 = lane >> 4;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -823,25 +1051,25 @@ __device__ __forceinline__ void pf_service(const PfArgs& P, double* sm, int g, i
                     for (int cc = 0; cc < PW; ++cc) L.Us[lane][cc] = (cc >= lane) ? u[cc] : 0.0;
                 }
             }
-        } else {
+        } else if (wave <= 2) {
             pf_lds_await(&L.gflags[5], seq);
-            const int o = (sw == 2) ? 16 : 0, j = lane & 15;
+            const int o = (wave == 2) ? 16 : 0, j = lane & 15;
             double x[16];
             PfUpperInv16<15>::run(x, L.Bs, o, j);
-            if (lane < 16) {                               // Uinv aliases the Gram partials: dead since G2 was published
+            if (lane < 16) {                               // Uinv aliases the Gram partials (unused in this workgroup)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) L.Uinv[o + i][o + lane] = (i <= lane) ? x[i] : 0.0;  // Uinv[k][c] = U'^-1(k, c)
-                if (sw == 2)
+                if (wave == 2)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) L.Uinv[16 + i][lane] = 0.0;
             }
-            if (sw == 2) {
+            if (wave == 2) {
                 pf_lds_signal(&L.gflags[6], seq);
             } else {
                 pf_lds_await(&L.gflags[6], seq);
-                // X12 = -X11 (U'12 X22): two 16 x 16 x 16 products; the intermediate goes through this wave's scratch
+                // X12 = -X11 (U'12 X22): two 16 x 16 x 16 products; the intermediate goes through LDS scratch
                 const int l15 = lane & 15, l4 = lane >> 4;
-                double* tmp = L.scr + wave * 128;          // 16 x 16 is 256 doubles: use the scratch of waves 5 and 6 (adjacent)
+                double* tmp = L.scr + 4 * 128;
                 v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {           // P = U'12 X22:  P(i, c) = sum_k U'(i, 16 + k) X22(k, c)
@@ -863,47 +1091,12 @@ __device__ __forceinline__ void pf_service(const PfArgs& P, double* sm, int g, i
                 for (int r = 0; r < 4; ++r) L.Uinv[l4 + 4 * r][16 + l15] = acc[r];
             }
         }
-        PF_STAMP_S(25);
-        // Q = V U' + [B; 0] with B = S R2, so V^T x = U'^-T (Q^T x - B^T x_top): the owner of the top block (its rows are x_top)
-        // publishes the correction -B^T X_top as one more partial of Z (slot nwg) -- on the service waves, which are done with the
-        // factors well before the row waves are with their product
-        if (g == f.gown && L.gflags[3] == 0) {
+        __syncthreads();
+        PF_STAMP_S(23);
+        // T = -U S L1^-T and R = S R2 R1 on the matrix cores, one 16 x 16 tile of each per wave (tiles (0,0), (0,1), (1,1))
+        if (wave <= 2) {
             const int l15 = lane & 15, l4 = lane >> 4;
-            const int ntile = f.ncols / 16;
-            if (sw == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            double* X3c = f.X3 + (size_t) nwg * 32 * PF_ZCOLS;
-            double ba[2][8];
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) ba[ti][ks] = -L.Ss[4 * ks + l4] * L.R2s[4 * ks + l4][16 * ti + l15];
-            for (int jt = sw; jt < ntile; jt += 3) {
-                const int j = 16 * jt + l15;
-                const double* xp = ((j < f.nrest) ? P.A + (size_t) (c + 32 + j) * P.lda : P.Vw + (size_t) (j - f.nrest) * P.ldv) + c;
-                double xt[8];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) xt[ks] = xp[4 * ks + l4];
-                v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    acc0 = pf_mfma(ba[0][ks], xt[ks], acc0);
-                    acc1 = pf_mfma(ba[1][ks], xt[ks], acc1);
-                }
-                double* zp = X3c + jt * 512 + 2 * lane;
-                pf_st2(zp, acc0[0], acc0[1]); pf_st2(zp + 128, acc0[2], acc0[3]);
-                pf_st2(zp + 256, acc1[0], acc1[1]); pf_st2(zp + 384, acc1[2], acc1[3]);
-            }
-        }
-        PF_STAMP_S(26);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                             // #13
-        // T = -U S L1^-T (every workgroup keeps it in LDS) and R = S R2 R1 on the matrix cores, one 16 x 16 tile of each per wave
-        // (tiles (0,0), (0,1), (1,1); the first version's scalar loops over LDS took 14 us); the owner of the top block writes
-        // R, L1, T and tau to global memory
-        {
-            const int l15 = lane & 15, l4 = lane >> 4;
-            const int ti = (sw == 2) ? 1 : 0, tc = (sw == 0) ? 0 : 1;
-            const bool own = g == f.gown;
+            const int ti = (wave == 2) ? 1 : 0, tc = (wave == 0) ? 0 : 1;
             v4d tt = (v4d){0.0, 0.0, 0.0, 0.0}, rt = tt;
             const double si = L.Ss[16 * ti + l15];
 #pragma unroll
@@ -915,43 +1108,44 @@ __device__ __forceinline__ void pf_service(const PfArgs& P, double* sm, int g, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ti + l4 + 4 * r, cc = 16 * tc + l15;
-                const double tv = (cc >= i) ? tt[r] : 0.0;
-                L.Ts[i][cc] = tv;
-                if (own) {
-                    P.T[(size_t) (c + cc) * P.ldt + c + i] = tv;
-                    if (i == cc) P.tau[c + i] = tv;
-                    P.A[(size_t) (c + cc) * P.lda + c + i] = (cc >= i) ? rt[r] : L.Bs[i][cc];
-                    P.Vw[(size_t) (c + cc) * P.ldv + c + i] = (cc < i) ? L.Bs[i][cc] : (cc == i ? 1.0 : 0.0);
-                }
+                L.Ts[i][cc] = (cc >= i) ? tt[r] : 0.0;
+                L.Rm[i][cc] = (cc >= i) ? rt[r] : 0.0;
             }
-            if (sw == 0) {                                   // tile (1, 0): zeros of T, L1
+            if (wave == 0) {                                 // tile (1, 0): zeros
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 + l4 + 4 * r, cc = l15;
-                    L.Ts[i][cc] = 0.0;
-                    if (own) {
-                        P.T[(size_t) (c + cc) * P.ldt + c + i] = 0.0;
-                        P.A[(size_t) (c + cc) * P.lda + c + i] = L.Bs[i][cc];
-                        P.Vw[(size_t) (c + cc) * P.ldv + c + i] = L.Bs[i][cc];
-                    }
-                }
+                for (int r = 0; r < 4; ++r) { L.Ts[16 + l4 + 4 * r][l15] = 0.0; L.Rm[16 + l4 + 4 * r][l15] = 0.0; }
             }
         }
-        __syncthreads();                                                             // #14
-        __syncthreads();                                                             // #15
-        pf_fold(P, f, L, g, nwg, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                                             // #16
-        __syncthreads();                                                             // #17
+        __syncthreads();
+        // S R2 replaces R2 for the row workgroups' correction
+        for (int e = tid; e < 1024; e += PF_THREADS) {
+            const int i = e >> 5, cc = e & 31;
+            pf_st(f.F2 + 4 * 1024 + e, L.Ss[i] * L.R2s[i][cc]);
+        }
+        pf_m33_out(L.Uinv, f.F2);
+        pf_m33_out(L.Ts, f.F2 + 1024);
+        pf_m33_out(L.Bs, f.F2 + 2 * 1024);
+        pf_m33_out(L.Rm, f.F2 + 3 * 1024);
+        const bool fb = L.gflags[0] == 0 || L.gflags[1] != 0 || L.gflags[3] != 0;
+        if (tid == 0) pf_st(f.F2 + 5 * 1024, fb ? 1.0 : 0.0);
+        if (fb) ++nfallback;
+        pf_publish(flags, PF_FAC_WORD, ef + 2);
+        PF_STAMP_S(24);
+        er += 4u + (fb ? 32u : 0u);                          // the Householder route's 32 column exchanges among the row workgroups
+        ef += 2u;
+    }
+    if (tid == 0) {
+        if (nfallback) atomicAdd(P.status, nfallback);
+        if (L.gflags[4]) P.status[1] = 1;
     }
 }
 
 __global__ __launch_bounds__(PF_THREADS) void panel_fused_kernel(PfArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    // whole waves take one role or the other: the barriers in the two bodies pair up one to one
-    if (__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) < 4) pf_rows(P, sm, blockIdx.x, gridDim.x);
-    else pf_service(P, sm, blockIdx.x, gridDim.x);
+    const int nrow = (int) gridDim.x - 1;
+    if ((int) blockIdx.x < nrow) pf_row_wg(P, sm, blockIdx.x, nrow);
+    else pf_factor_wg(P, sm, nrow);
 }
 
 static long long* g_pf_stamps = nullptr;      // development only (qrd_panel_fused_set_stamps)
@@ -974,10 +1168,10 @@ int qrd_panel_fused_ok(void* stream, const double* A, int lda, int mk, int wh, c
 {
     if (wh < 32 || wh > 256 || wh % 32 || mk < wh || mk % 4) return 0;
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(Vw) & 15) || lda % 2 || ldv % 2) return 0;
-    const int nwg = (mk + PF_ROWS - 1) / PF_ROWS;
-    int cus = qrd_stream_cus(stream);
+    const int nrow = (mk + PF_ROWS - 1) / PF_ROWS;           // row workgroups; one more workgroup (one more compute unit) factors
+    int cus = qrd_stream_cus(stream) - 1;
     if (cus > PF_MAXWG) cus = PF_MAXWG;
-    return nwg <= cus;
+    return nrow <= cus;
 }
 
 // *epoch: the caller's epoch counter for this workspace (starts at 0 with a zeroed workspace); advanced by the launch
@@ -989,8 +1183,8 @@ int qrd_panel_fused(void* stream, double* A, int lda, int mk, int wh, double* ta
     a.A = A; a.lda = lda; a.mk = mk; a.wh = wh; a.Vw = Vw; a.ldv = ldv; a.T = T; a.ldt = ldt; a.tau = tau; a.G = G; a.ldg = ldg;
     a.ws = ws; a.epoch0 = *epoch; a.status = status; a.stamps = g_pf_stamps;
     *epoch += 1024u;
-    const int nwg = (mk + PF_ROWS - 1) / PF_ROWS;
-    hipLaunchKernelGGL(panel_fused_kernel, dim3(nwg), dim3(PF_THREADS), PF_SM_DOUBLES * sizeof(double), (hipStream_t) stream, a);
+    const int nrow = (mk + PF_ROWS - 1) / PF_ROWS;
+    hipLaunchKernelGGL(panel_fused_kernel, dim3(nrow + 1), dim3(PF_THREADS), PF_SM_DOUBLES * sizeof(double), (hipStream_t) stream, a);
     return (int) hipGetLastError();
 }
 

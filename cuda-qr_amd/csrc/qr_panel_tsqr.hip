@@ -118,31 +118,6 @@ __device__ __forceinline__ void factor_all(double (&x)[RPT][PW], int r0, int row
     if constexpr (J + 1 < PW) factor_all<J + 1, ZCAP, NT, RPT>(x, r0, rows, w, sh, Z, tid, lane, wave);
 }
 
-// T (w x w upper triangular, into Tl[PW][PW+1] in LDS) of the block's reflectors from the captured Gram
-// columns Z(q, j) = v_q^T v_j and tau:  T(0:j,j) = -tau_j T(0:j,0:j) Z(0:j,j).  Row p depends only on row p:
-// thread tid < PW computes row tid with no synchronisation.
-template <class SH>
-__device__ __forceinline__ void build_t_rows(double (*Tl)[PW + 1], double (*Z)[PW + 1], const SH& sh, int w, int tid)
-{
-    if (tid < PW) {
-        double trow[PW];
-#pragma unroll
-        for (int q = 0; q < PW; ++q) trow[q] = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < PW; ++jj) {
-            if (jj < w) {
-                const double tj = sh.tau[jj];
-                double sacc = 0.0;
-#pragma unroll
-                for (int q = 0; q < jj; ++q) sacc += trow[q] * Z[jj][q];
-                trow[jj] = (tid == jj) ? tj : ((tid < jj) ? -tj * sacc : 0.0);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < PW; ++q) Tl[tid][q] = (tid < w && q < w) ? trow[q] : 0.0;
-    }
-}
-
 // Compact-WY application of a block's Q to [Cin; 0]:  out(r,:) = Cin(r,:) - V(r,:) M,  M = T (V1^T Cin)
 // (V1 = unit-lower top w x w of the block).  No reductions over rows: M is w x w and every row is independent,
 // so the tree is walked down at GEMM speed instead of one workgroup-wide reduction per reflector.

@@ -19,10 +19,13 @@ stamps = torch.zeros(8 * 32, dtype=torch.int64, device="cuda")
 lib.qrd_panel_fused_set_stamps(stamps.data_ptr())
 epoch = C.c_uint(0)
 status = torch.zeros(4, dtype=torch.int32, device="cuda")
-names = {0: "leaf start", 1: "image", 2: "gram1 waves", 3: "G1 published", 4: "G1 all seen", 20: "G1 summed(own)", 5: "G1 summed", 6: "chol1",
-         7: "Q,image,Qtop", 8: "gram2 waves", 9: "G2 published", 10: "G2 all seen", 11: "G2 summed", 12: "LU | product", 13: "Z pub | tri",
-         14: "T,out | V", 15: "Z all seen", 21: "fold(own)", 16: "W published", 17: "W all seen", 18: "update(next cols)", 6: "deferred upd | chol1"}
-order = [0, 1, 2, 3, 4, 20, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 21, 16, 17, 18]
+names = {0: "leaf start", 1: "G1 partial published", 2: "deferred update done", 3: "R1^-1 seen", 4: "q, G2 partial published", 5: "product done",
+         6: "factors seen", 7: "V, (owner: top block, correction), Z published", 8: "all Z seen", 9: "fold, W published", 10: "all W seen",
+         11: "next columns updated"}
+order = list(range(12))
+fnames = {16: "all G1 seen", 17: "G1 summed", 18: "chol", 19: "R1^-1 published", 20: "all G2 seen", 21: "G2 summed", 22: "LU", 23: "U, U'^-1",
+          24: "T, R, published"}
+forder = [16, 17, 18, 19, 20, 21, 22, 23, 24]
 for mk, wh in [(4096, 32), (8192, 256), (4096, 64), (1024, 256)]:
     P = torch.from_numpy(np.ascontiguousarray(np.random.default_rng(1).random((wh, mk)))).cuda()
     V = torch.zeros((wh, mk), dtype=torch.float64, device="cuda")
@@ -46,6 +49,6 @@ for mk, wh in [(4096, 32), (8192, 256), (4096, 64), (1024, 256)]:
             line.append(f"{names[k]}: {(t - t0) / 100:.1f} (+{(t - prev) / 100:.1f})")
             prev = t
         print(f" leaf {li}: " + " | ".join(line))
-        print('   service wave 0 (us since leaf start): LU start %.1f, LU done %.1f, U/tri done %.1f, correction done %.1f' % tuple((st[li][k] - t0) / 100 for k in (23, 24, 25, 26)))
+        print('   factor wg: ' + ' | '.join(f"{fnames[k]}: {(st[li][k] - t0) / 100:.1f}" for k in forder))
     if wh > 32:
         print(f" leaf 0 start -> leaf 1 start: {(st[1][0] - st[0][0]) / 100:.1f} us")

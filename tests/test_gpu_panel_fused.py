@@ -130,3 +130,53 @@ def test_panel_fused_declines_what_it_cannot_take(q):
     assert q.lib.qrd_panel_fused(*args(1026, 64, 9000)) == -7      # rows not a multiple of 4
     assert q.lib.qrd_panel_fused(*args(1024, 48, 9000)) == -7      # not whole leaves
     assert q.lib.qrd_panel_fused(*args(1024, 64, 8999)) == -7      # odd leading dimension
+
+
+def _check_wy_only(P, out, V, Tdiag, tau, tol=1e-11):
+    """compact-WY consistency without comparing R with LAPACK (rank-deficient panels: R is not unique)"""
+    mk, wh = P.shape
+    assert np.isfinite(out).all() and np.isfinite(V).all() and np.isfinite(tau).all()
+    assert all(np.isfinite(Tdiag[c:c + 32, c:c + 32]).all() for c in range(0, wh, 32))
+    assert np.array_equal(np.triu(V[:wh], 1), np.zeros((wh, wh))) and np.array_equal(np.diag(V[:wh]), np.ones(wh))
+    assert np.array_equal(np.tril(V, -1), np.tril(out, -1))
+    T = merged_t(V, Tdiag, wh)
+    QtP = P - V @ (T.T @ (V.T @ P))
+    cs = np.maximum(np.abs(P).max(axis=0), 1e-300)
+    assert (np.abs(np.tril(QtP, -1)) / cs).max() < tol * np.sqrt(mk)
+    assert (np.abs(np.triu(QtP[:wh]) - np.triu(out[:wh])) / cs).max() < tol * np.sqrt(mk)
+    H = np.eye(mk) - V @ T @ V.T if mk <= 2048 else None
+    if H is not None:
+        assert np.abs(H.T @ H - np.eye(mk)).max() < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["zero_column", "dependent", "cond1e10", "two_bad_leaves", "all_zero"])
+@pytest.mark.parametrize("mk,wh", [(2048, 128), (512, 64), (4096, 256)])
+def test_panel_fused_householder_route(q, kind, mk, wh):
+    """leaves the CholeskyQR2 route must refuse (zero / dependent columns, cond 1e10): the launch switches to its in-kernel Householder
+    route for exactly those leaves (status counts them) and the panel is a valid compact-WY panel all the same"""
+    ws = Ws(q)
+    rng = np.random.default_rng(mk + wh + len(kind))
+    P = rng.random((mk, wh))
+    bad = 1
+    if kind == "zero_column":
+        P[:, 5] = 0.0
+    elif kind == "dependent":
+        P[:, wh - 3] = P[:, wh - 20]                       # last leaf
+    elif kind == "cond1e10":
+        U, _ = np.linalg.qr(rng.standard_normal((mk, 32))); Vr, _ = np.linalg.qr(rng.standard_normal((32, 32)))
+        P[:, 32:64] = (U * np.logspace(0, -10, 32)) @ Vr.T
+    elif kind == "two_bad_leaves":
+        P[:, 7] = P[:, 3]
+        P[:, 40] = 0.0
+        bad = 2
+    else:
+        P[:, :32] = 0.0
+    out, V, T, tau, G, st = run_panel(q, ws, P)
+    assert st[1] == 0
+    assert st[0] == bad, st
+    _check_wy_only(P, out, V, T, tau, tol=1e-10 if kind == "cond1e10" else 1e-11)
+    # a second launch through the same workspace (the epoch words moved by the extra exchanges) still works
+    P2 = rng.random((mk, wh))
+    out, V, T, tau, G, st = run_panel(q, ws, P2)
+    assert st[0] == 0 and st[1] == 0
+    check_panel(P2, out, V, T, tau, G)

@@ -114,6 +114,7 @@ typedef struct qr_knobs {
     int plan_cache;                                         /* MI355XQR_PLAN_CACHE */
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
+    int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
 } qr_knobs;
 static qr_knobs g_knobs;
 static pthread_once_t g_knobs_once = PTHREAD_ONCE_INIT;
@@ -142,6 +143,7 @@ static void knobs_init(void)
     k->plan_cache = env_int("MI355XQR_PLAN_CACHE", 1) != 0;
     k->early_product = env_int("MI355XQR_EP", 1) != 0;
     k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
+    k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
 }
 
 static const qr_knobs* knobs(void)
@@ -639,7 +641,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         }
         /* the whole half in ONE launch (qr_panel_fused.hip: every leaf, its in-panel product and update; leaf T blocks, tau, V and
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
-        const int fused_half = p->pf_ws && !p->use_graph && ib == 32 &&
+        const int fused_half = p->pf_ws && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
                                qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);
         if (fused_half) {
             CHECK(qrd_panel_fused(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,

@@ -258,28 +258,49 @@ __device__ __forceinline__ void pf_gram_entry(int e, double s, pf_m33 Gs, int* g
     }
 }
 
-// all threads: Gs[j][i] = sum over the workgroups (in index order) of their partial G(i, j).  A thread owns entries tid, tid + 256 and
-// tid + 512 and has the loads of 16 workgroups for all three in flight at once: two round trips at 32 workgroups
+// 16-byte sc1 loads (no builtin; per byte they cost ~0.6 of 8-byte ones): issued by pf_ld2_issue, usable after pf_ld2_wait16 on the
+// same registers (the "+v" operands keep the compiler from touching them before the wait)
+__device__ __forceinline__ void pf_ld2_issue(v2d& v, const double* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void pf_ld2_wait16(v2d (&v)[16])
+{
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                   "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 :
+                 : "memory");
+}
+
+// all threads: Gs[j][i] = sum over the workgroups (in index order) of their partial G(i, j).  A thread owns the entry pairs 2 tid and
+// (tid < 128) 2 (tid + 256) and has the 16-byte loads of 16 workgroups for both in flight at once
 __device__ __forceinline__ void pf_gram_sum(const double* __restrict__ X, int nwg, pf_m33 Gs, int* gflags, bool check)
 {
-    const int e0 = threadIdx.x;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const int e0 = 2 * threadIdx.x, e1 = 2 * (threadIdx.x + 256);
+    const bool h1 = e1 < 768;
+    const int e1c = h1 ? e1 : e0;
+    v2d s0 = (v2d){0.0, 0.0}, s1 = s0;
     for (int w0 = 0; w0 < nwg; w0 += 16) {
-        double v0[16], v1[16], v2[16];
+        v2d v0[16], v1[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const double* xw = X + (size_t) min(w0 + u, nwg - 1) * 1024 + e0;
-            v0[u] = pf_ld(xw);
-            v1[u] = pf_ld(xw + 256);
-            v2[u] = pf_ld(xw + 512);
+            const double* xw = X + (size_t) min(w0 + u, nwg - 1) * 1024;
+            pf_ld2_issue(v0[u], xw + e0);
+            pf_ld2_issue(v1[u], xw + e1c);
         }
+        pf_ld2_wait16(v0);
+        pf_ld2_wait16(v1);
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (w0 + u < nwg) { s0 += v0[u]; s1 += v1[u]; s2 += v2[u]; }
+            if (w0 + u < nwg) { s0 += v0[u]; s1 += v1[u]; }
     }
-    pf_gram_entry(e0, s0, Gs, gflags, check);
-    pf_gram_entry(e0 + 256, s1, Gs, gflags, check);
-    pf_gram_entry(e0 + 512, s2, Gs, gflags, check);
+    pf_gram_entry(e0, s0[0], Gs, gflags, check);
+    pf_gram_entry(e0 + 1, s0[1], Gs, gflags, check);
+    if (h1) {
+        pf_gram_entry(e1, s1[0], Gs, gflags, check);
+        pf_gram_entry(e1 + 1, s1[1], Gs, gflags, check);
+    }
 }
 
 // ---- hand-offs between waves of ONE workgroup through an LDS word (no workgroup barrier: the other role keeps running) ----------
@@ -316,6 +337,34 @@ __device__ __forceinline__ void pf_lds_row16(const double* p, double (&r)[16])
                  : "memory");
     r[0] = a0[0]; r[1] = a0[1]; r[2] = a1[0]; r[3] = a1[1]; r[4] = a2[0]; r[5] = a2[1]; r[6] = a3[0]; r[7] = a3[1];
     r[8] = a4[0]; r[9] = a4[1]; r[10] = a5[0]; r[11] = a5[1]; r[12] = a6[0]; r[13] = a6[1]; r[14] = a7[0]; r[15] = a7[1];
+}
+
+// p[k * 33], k = 0 .. 31 (a column of a padded 32 x 32 matrix; p differs per lane), all 32 reads in flight together
+__device__ __forceinline__ void pf_lds_col32(const double* p, double (&r)[32])
+{
+    const unsigned addr = (unsigned) reinterpret_cast<uintptr_t>(p);
+    asm volatile("ds_read_b64 %0, %16\n\t"
+                 "ds_read_b64 %1, %16 offset:264\n\t"  "ds_read_b64 %2, %16 offset:528\n\t"  "ds_read_b64 %3, %16 offset:792\n\t"
+                 "ds_read_b64 %4, %16 offset:1056\n\t" "ds_read_b64 %5, %16 offset:1320\n\t" "ds_read_b64 %6, %16 offset:1584\n\t"
+                 "ds_read_b64 %7, %16 offset:1848\n\t" "ds_read_b64 %8, %16 offset:2112\n\t" "ds_read_b64 %9, %16 offset:2376\n\t"
+                 "ds_read_b64 %10, %16 offset:2640\n\t" "ds_read_b64 %11, %16 offset:2904\n\t" "ds_read_b64 %12, %16 offset:3168\n\t"
+                 "ds_read_b64 %13, %16 offset:3432\n\t" "ds_read_b64 %14, %16 offset:3696\n\t" "ds_read_b64 %15, %16 offset:3960\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]),
+                   "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+                 : "v"(addr)
+                 : "memory");
+    asm volatile("ds_read_b64 %0, %16 offset:4224\n\t"
+                 "ds_read_b64 %1, %16 offset:4488\n\t"  "ds_read_b64 %2, %16 offset:4752\n\t"  "ds_read_b64 %3, %16 offset:5016\n\t"
+                 "ds_read_b64 %4, %16 offset:5280\n\t" "ds_read_b64 %5, %16 offset:5544\n\t" "ds_read_b64 %6, %16 offset:5808\n\t"
+                 "ds_read_b64 %7, %16 offset:6072\n\t" "ds_read_b64 %8, %16 offset:6336\n\t" "ds_read_b64 %9, %16 offset:6600\n\t"
+                 "ds_read_b64 %10, %16 offset:6864\n\t" "ds_read_b64 %11, %16 offset:7128\n\t" "ds_read_b64 %12, %16 offset:7392\n\t"
+                 "ds_read_b64 %13, %16 offset:7656\n\t" "ds_read_b64 %14, %16 offset:7920\n\t" "ds_read_b64 %15, %16 offset:8184\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[16]), "=&v"(r[17]), "=&v"(r[18]), "=&v"(r[19]), "=&v"(r[20]), "=&v"(r[21]), "=&v"(r[22]), "=&v"(r[23]), "=&v"(r[24]),
+                   "=&v"(r[25]), "=&v"(r[26]), "=&v"(r[27]), "=&v"(r[28]), "=&v"(r[29]), "=&v"(r[30]), "=&v"(r[31])
+                 : "v"(addr)
+                 : "memory");
 }
 
 // inverse of the 16 x 16 upper-triangular diagonal block of Um at offset o, by columns (lane j < 16 = column j), back substitution:
@@ -390,13 +439,24 @@ __device__ __forceinline__ void pf_m33_out(pf_m33 M, double* __restrict__ slab)
 {
     for (int e = threadIdx.x; e < 1024; e += PF_THREADS) pf_st(slab + e, M[e >> 5][e & 31]);
 }
-__device__ __forceinline__ void pf_m33_in(pf_m33 M, const double* __restrict__ slab)
+// N consecutive dense 32 x 32 matrices of a slab into the LDS matrices M[0 .. N-1]: ALL loads are issued before the first LDS
+// store (written as load / store pairs, the sc1 loads were not moved across the stores: four serial round trips per matrix, 10 us for
+// the five matrices the owner of the top block takes)
+template <int N>
+__device__ __forceinline__ void pf_m33_in(pf_m33 (&M)[N], const double* __restrict__ slab)
 {
+    double v[N][1024 / PF_THREADS];
 #pragma unroll
-    for (int q = 0; q < 1024 / PF_THREADS; ++q) {
-        const int e = threadIdx.x + q * PF_THREADS;
-        M[e >> 5][e & 31] = pf_ld(slab + e);
-    }
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int q = 0; q < 1024 / PF_THREADS; ++q) v[n][q] = pf_ld(slab + n * 1024 + threadIdx.x + q * PF_THREADS);
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int q = 0; q < 1024 / PF_THREADS; ++q) {
+            const int e = threadIdx.x + q * PF_THREADS;
+            M[n][e >> 5][e & 31] = v[n][q];
+        }
 }
 
 // reduce-scatter of Z (row workgroups, four waves): this workgroup's columns j = g, g + nrow, ... of Z, two per wave at a time
@@ -427,9 +487,13 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         double y = 0.0;
+        double mcol[32], vec[32];
         if (have) {
+            pf_lds_col32(&L.Uinv[0][i], mcol);                                            // U'^-1 is stored with its zeros
+            pf_lds_row16(s1 + h * 32, *reinterpret_cast<double (*)[16]>(&vec[0]));
+            pf_lds_row16(s1 + h * 32 + 16, *reinterpret_cast<double (*)[16]>(&vec[16]));
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) y += L.Uinv[kk][i] * s1[h * 32 + kk];        // U'^-1 is stored with its zeros
+            for (int kk = 0; kk < 32; ++kk) y += mcol[kk] * vec[kk];
             s1[64 + h * 32 + i] = y;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -440,8 +504,11 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
                 P.G[(size_t) (f.c + i) * P.ldg + (j - f.nrest)] = y;
             } else {
                 double wv = 0.0;
+                pf_lds_col32(&L.Ts[0][i], mcol);                                          // T is stored with its zeros
+                pf_lds_row16(s1 + 64 + h * 32, *reinterpret_cast<double (*)[16]>(&vec[0]));
+                pf_lds_row16(s1 + 64 + h * 32 + 16, *reinterpret_cast<double (*)[16]>(&vec[16]));
 #pragma unroll
-                for (int cc = 0; cc < 32; ++cc) wv += L.Ts[cc][i] * s1[64 + h * 32 + cc];  // T is stored with its zeros
+                for (int cc = 0; cc < 32; ++cc) wv += mcol[cc] * vec[cc];
                 pf_st(f.X4 + j * 32 + i, wv);
             }
         }
@@ -522,6 +589,52 @@ __device__ __forceinline__ void pf_update_groups(double (&vr)[4][8], const doubl
                 for (int rr = 0; rr < 4; ++rr) { vr[t][rr] = ca[t][rr]; vr[t][4 + rr] = cbn[t][rr]; }
         }
     }
+}
+
+// The next leaf's 32 columns (group 0), in two steps around the wait for W: the 64 x 32 piece of A_rest is requested before the wait.
+__device__ __forceinline__ void pf_update0_load(v4d (&ca)[4], v4d (&cb)[4], const double* __restrict__ A, int lda, int c, int r4c, int l4)
+{
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const double* cp = A + (size_t) (c + 32 + 16 * ti + l4) * lda;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const double* q = cp + (size_t) (4 * rr) * lda + r4c;
+            const v2d lo = *reinterpret_cast<const v2d*>(q), hi = *reinterpret_cast<const v2d*>(q + 2);
+            v4d (&cc)[4] = ti ? cb : ca;
+            cc[0][rr] = lo[0]; cc[1][rr] = lo[1]; cc[2][rr] = hi[0]; cc[3][rr] = hi[1];
+        }
+    }
+}
+__device__ __forceinline__ void pf_update0_finish(double (&vr)[4][8], v4d (&ca)[4], v4d (&cb)[4], const double* __restrict__ X4, double* __restrict__ A,
+                                                  int lda, int c, int r4, bool act, int l15, int l4)
+{
+    double aw[2][8];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) aw[ti][ks] = -pf_ld(X4 + (16 * ti + l15) * 32 + 4 * ks + l4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { ca[t] = pf_mfma(aw[0][ks], vr[t][ks], ca[t]); cb[t] = pf_mfma(aw[1][ks], vr[t][ks], cb[t]); }
+    if (act) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            double* cp = A + (size_t) (c + 32 + 16 * ti + l4) * lda;
+            v4d (&cc)[4] = ti ? cb : ca;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                double* q = cp + (size_t) (4 * rr) * lda + r4;
+                *reinterpret_cast<v2d*>(q) = (v2d){cc[0][rr], cc[1][rr]};
+                *reinterpret_cast<v2d*>(q + 2) = (v2d){cc[2][rr], cc[3][rr]};
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { vr[t][rr] = ca[t][rr]; vr[t][4 + rr] = cb[t][rr]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -732,7 +845,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         PF_STAMP(2);
         pf_wait(flags, 0, ef + 1, &L.gflags[4]);
         PF_STAMP(3);
-        pf_m33_in(L.Ws, f.F1);                                // R1^-1
+        { pf_m33 m1[1] = {L.Ws}; pf_m33_in<1>(m1, f.F1); }    // R1^-1
         __syncthreads();
         // ---- Q = A R1^-1 (registers), its image, the top block of Q -> QT, partial G2 = Q^T Q -> X2
         pf_rows_times_upper(ar, L.Ws, l15, l4);
@@ -823,13 +936,8 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
       if (!fb) {
         // ---- the factors: U'^-1 and T for everyone (they alias the Gram partials, published long ago); the owner of the top block
         // also takes L1 \ U', R = S R2 R1 and S R2
-        pf_m33_in(L.Uinv, f.F2);
-        pf_m33_in(L.Ts, f.F2 + 1024);
-        if (own) {
-            pf_m33_in(L.Bs, f.F2 + 2 * 1024);
-            pf_m33_in(L.R1s, f.F2 + 3 * 1024);
-            pf_m33_in(L.R2s, f.F2 + 4 * 1024);
-        }
+        if (own) { pf_m33 m5[5] = {L.Uinv, L.Ts, L.Bs, L.R1s, L.R2s}; pf_m33_in<5>(m5, f.F2); }
+        else { pf_m33 m2[2] = {L.Uinv, L.Ts}; pf_m33_in<2>(m2, f.F2); }
         __syncthreads();
         // ---- V = Q U'^-1; the top block's rows become L1
         pf_rows_times_upper(ar, L.Uinv, l15, l4);
@@ -841,9 +949,6 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
                     const int rr_ = r4 + t - c, col = 4 * ks + l4;
                     ar[t][ks] = (col < rr_) ? L.Bs[rr_][col] : (col == rr_ ? 1.0 : 0.0);
                 }
-        } else if (act) {
-            pf_store_rows(ar, Vw, ldv, c, r4, l4);
-            pf_store_rows(ar, A, lda, c, r4, l4);
         }
         if (own && ntile > 0) {
             // Q = V U' + [B; 0] with B = S R2, so V^T x = U'^-T (Q^T x - B^T x_top): the correction -B^T X_top goes out as one more
@@ -874,6 +979,11 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         const unsigned xe = fb ? 32u : 0u;                      // the Householder route's 32 column exchanges
         pf_publish(flags, 16 * g, er + 3 + xe);
         PF_STAMP(7);
+        // V goes to memory behind the publish (nobody else reads these rows; the publish's drain would wait for the 128 KB)
+        if (!fb && act && !toprow) {
+            pf_store_rows(ar, Vw, ldv, c, r4, l4);
+            pf_store_rows(ar, A, lda, c, r4, l4);
+        }
         if (own && !fb) {
             // the top block: R above the diagonal of A, L1 below it and (unit lower) in Vw; T and tau -- behind the publish: nobody
             // else waits for these.  Written by the workgroup that owns these rows: it reads them back later (x_top of the
@@ -893,11 +1003,13 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         pf_fold(P, f, L, g, nrow, wave, lane, fb);
         pf_publish(flags, 16 * g, er + 4 + xe);
         PF_STAMP(9);
+        v4d uca[4], ucb[4];
+        if (f.nrest > 0) pf_update0_load(uca, ucb, A, lda, c, r4c, l4);
         pf_wait(flags, nrow, er + 4 + xe, &L.gflags[4]);
         PF_STAMP(10);
         // the next leaf's 32 columns are updated now (the result stays in registers as its a); the other columns of A_rest wait for
         // the next pass's Cholesky window (above)
-        if (f.nrest > 0) pf_update_groups(ar, f.X4, A, lda, c, 0, 1, true, r4, r4c, act, l15, l4);
+        if (f.nrest > 0) pf_update0_finish(ar, uca, ucb, f.X4, A, lda, c, r4, act, l15, l4);
         PF_STAMP(11);
         er += 4u + (fb ? 32u : 0u);
         ef += 2u;

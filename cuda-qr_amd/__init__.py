@@ -112,6 +112,7 @@ _sig("qr_copy_to_device", C.c_int, _vp, _vp, C.c_size_t)
 _sig("qr_copy_to_host", C.c_int, _vp, _vp, C.c_size_t)
 _sig("qr_plan_sync", C.c_int, _vp)
 _sig("qr_plan_stream", _vp, _vp)
+_sig("qr_plan_info", C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("qr_plan_update_cus", C.c_int, _vp)
 _sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)
 _sig("qr_plan_pause_profile", C.c_int, _vp, C.c_int)
@@ -396,6 +397,15 @@ class Plan:
     @property
     def stream(self):
         return lib.qr_plan_stream(self.h)
+
+    def info(self):
+        nb, ib, la = C.c_int(), C.c_int(), C.c_int()
+        check(lib.qr_plan_info(self.h, C.byref(nb), C.byref(ib), C.byref(la)), "qr_plan_info")
+        return nb.value, ib.value, bool(la.value)
+
+    @property
+    def nb(self):
+        return self.info()[0]
 
     def geqrf(self, dA, m, n, lda, dtau):
         check(lib.qr_geqrf_dev(self.h, _dptr(dA), m, n, lda, _dptr(dtau)), "qr_geqrf_dev")

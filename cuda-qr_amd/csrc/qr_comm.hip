@@ -33,11 +33,10 @@ int load_rccl()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.state) return g_rccl.state > 0 ? 0 : QRD_E_NORCCL;
-    // The host driver of this pool only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's intra-node transport
-    // fails with "hipIpcGetMemHandle: invalid argument".  The variable is read when the HSA runtime starts, i.e. before this
-    // function can run in a process that already used the GPU -- launchers (bench.py) export it themselves;
-    // setting it here (never overriding the caller's value) only covers processes whose first GPU call is a multi-GPU entry point.
-    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+    // (On hosts whose driver only supports dmabuf IPC -- this pool -- RCCL's intra-node transport needs HSA_ENABLE_IPC_MODE_LEGACY=0 in
+    // the environment BEFORE the HSA runtime starts, i.e. before the process's first GPU call: the launcher's job (bench.py,
+    // INTEGRATION.md section 5), never this library's -- a setenv from here came too late for every caller that had created a plan and
+    // raced with getenv in other threads.  A failing communicator creation with the variable unset gets a hint, below.)
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -132,6 +131,10 @@ int qrd_comm_count(void* comm, int* n)
 
 const char* qrd_rccl_error_string(int r)
 {
+    // unhandled system / internal errors of communicator creation are what the dmabuf-only hosts produce when the variable is missing
+    if ((r == (int) ncclUnhandledCudaError || r == (int) ncclSystemError || r == (int) ncclInternalError) && !getenv("HSA_ENABLE_IPC_MODE_LEGACY"))
+        return "RCCL call failed (if this is hipIpcGetMemHandle: invalid argument, export HSA_ENABLE_IPC_MODE_LEGACY=0 before the process "
+               "touches the GPU: see INTEGRATION.md, multi-GPU)";
     if (g_rccl.state > 0 && g_rccl.GetErrorString) return g_rccl.GetErrorString((ncclResult_t) r);
     return "RCCL call failed";
 }

@@ -243,13 +243,21 @@ const char* qr_strerror(int status)
 static int imin(int a, int b) { return a < b ? a : b; }
 
 /* ---------------------------------------------------------------------------------------------- */
-int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
+/* tsqr_local: the local factorisation of a multi-GPU TSQR plan.  Every choice that shapes the EXCHANGE (block size, look-ahead) must
+ * then come out the same on every rank, whatever its shard height: ranks of unequal height (m % ngpu != 0) used to straddle the
+ * thresholds below and disagree on the number and size of the collectives.  Such plans take the block size of a very tall m x n
+ * problem and the single-stream schedule, always. */
+static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsqr_local);
+
+int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib) { return plan_create_impl(out, m, n, nb, ib, 0); }
+
+static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsqr_local)
 {
     if (!out || m < 1 || n < 1 || m < n) return QR_E_ARG;
     CHECK(ensure_device());
     {
         int dnb, dib;
-        default_blocks(m, n, &dnb, &dib);
+        default_blocks(tsqr_local ? (1 << 30) : m, n, &dnb, &dib);
         if (ib <= 0) ib = dib;
         if (nb <= 0) nb = (dnb % ib == 0) ? dnb : 128;
     }
@@ -265,7 +273,7 @@ int qr_plan_create(qr_plan** out, int m, int n, int nb, int ib)
      * slow each other: 262144 x 512 7.38 vs 7.22 ms, 65536 x 2048 20.5 vs 19.0).  Below that the single-stream schedule
      * is 5-10 % faster (2048^2 5.46 -> 4.93 ms, 3072^2 8.4 -> 7.9, 4096 x 1024 2.90 -> 2.65; equal at 4096^2;
      * profiles/r02_session2_ab_measurements.txt section 12) */
-    p->lookahead = la ? atoi(la) != 0 : (n >= 2048 && (long long) m * n >= 18000000LL && (long long) m < 16LL * n);
+    p->lookahead = tsqr_local ? 0 : (la ? atoi(la) != 0 : (n >= 2048 && (long long) m * n >= 18000000LL && (long long) m < 16LL * n));
     /* MI355XQR_GRAPH=1: the single-stream schedule captured once per argument set and replayed (no measured gain: the cost of a leaf is
      * the device-side kernel boundary, not the host launch).  Never with look-ahead: capturing the CU-masked two-stream schedule
      * crashes inside the runtime (round 3: segmentation fault in hipStreamEndCapture), so the knob is ignored there. */
@@ -446,6 +454,15 @@ int qr_plan_sync(qr_plan* p)
     return p->s_main ? qrd_stream_sync(p->s_main) : 0;
 }
 void* qr_plan_stream(qr_plan* p) { return p ? p->s_main : NULL; }
+
+int qr_plan_info(qr_plan* p, int* nb, int* ib, int* lookahead)
+{
+    if (!p) return QR_E_ARG;
+    if (nb) *nb = p->nb;
+    if (ib) *ib = p->ib;
+    if (lookahead) *lookahead = p->lookahead;
+    return 0;
+}
 
 /* compute units the wide trailing update runs on (the update stream's share of the CU partition, or the whole device) */
 int qr_plan_update_cus(qr_plan* p)
@@ -1598,6 +1615,7 @@ struct qr_tsqr_plan {
     double *dtau, *dtau2, *dRp, *dRall, *dS, *dQt;
     void *ev_gathered, *ev_stacked; /* stack matrix filled (local stream) / stacked factorisation has consumed it (stack stream) */
     int stacked_pending;            /* ev_stacked has been recorded and not yet waited for by the local stream */
+    void* ev_q; int q_pending;      /* the local stream has copied this rank's block out of dQt (qr_tsqr_formq_dev): the next call's tree Q waits */
     int local_done;                 /* qr_tsqr_local_dev ran and the stacked step has not yet consumed its R factor */
     /* panel-pipelined form (see qr_tsqr_factor_dev): the exchange and the stacked QR go block column by block column */
     int pipe_ok, npan;              /* usable: single-stream local plan, nb | n, same nb in both plans */
@@ -1624,7 +1642,7 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
     t->nranks = nranks; t->rank = rank; t->m_local = m_local; t->n = n; t->nb = nb; t->sm = nranks * n;
     t->comm = comm; t->own_comm = own_comm;
     const size_t nn = (size_t) n * n;
-    int rc = qr_plan_create(&t->p, m_local, n, nb, 0);
+    int rc = plan_create_impl(&t->p, m_local, n, nb, 0, nranks > 1);
     if (!rc) rc = qrd_malloc((void**) &t->dtau, sizeof(double) * n);
     if (!rc) rc = qrd_malloc((void**) &t->dRp, sizeof(double) * nn);
     if (!rc && nranks > 1) {
@@ -1634,6 +1652,8 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
         if (!rc) rc = qrd_malloc((void**) &t->dS, sizeof(double) * (size_t) t->sm * n);
         if (!rc) rc = qrd_event_create_notiming(&t->ev_gathered);
         if (!rc) rc = qrd_event_create_notiming(&t->ev_stacked);
+        if (!rc) rc = qrd_event_create_notiming(&t->ev_q);
+        if (!rc) rc = qrd_malloc((void**) &t->dQt, sizeof(double) * (size_t) t->sm * n);      /* not on first use: no hipMalloc beside running collectives */
         /* panel-pipelined exchange: MI355XQR_TSQR_PIPE=0 keeps the one-collective form */
         const int pnb = rc ? 0 : t->p->nb;
         if (!rc && env_int("MI355XQR_TSQR_PIPE", 1) != 0 && !t->p->lookahead && !t->p2->lookahead && pnb == t->p2->nb && n % pnb == 0 &&
@@ -1644,9 +1664,8 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
                 t->pan_k[t->npan] = n - pnb / 2;
                 t->pan_k[++t->npan] = n;
             }
-            /* every exchange moves n x nb doubles from a block's start: the half blocks at the end read past their own width */
-            rc = qrd_malloc((void**) &t->dsend, sizeof(double) * ((size_t) n * n + (size_t) n * pnb));
-            if (!rc) rc = qrd_memset(t->p2->s_main, t->dsend, 0, sizeof(double) * ((size_t) n * n + (size_t) n * pnb));
+            rc = qrd_malloc((void**) &t->dsend, sizeof(double) * (size_t) n * n);
+            if (!rc) rc = qrd_memset(t->p2->s_main, t->dsend, 0, sizeof(double) * (size_t) n * n);
             if (!rc) rc = qrd_malloc((void**) &t->drecv, sizeof(double) * (size_t) nranks * n * pnb);
             if (!rc) rc = qrd_malloc((void**) &t->Vst, sizeof(double) * (size_t) t->npan * t->p2->ldv * pnb);
             if (!rc) rc = qrd_malloc((void**) &t->Tst, sizeof(double) * (size_t) t->npan * t->p2->ldt * pnb);
@@ -1690,6 +1709,7 @@ int qr_tsqr_plan_destroy(qr_tsqr_plan* t)
     qr_tsqr_sync(t);
     if (t->ev_gathered) qrd_event_destroy(t->ev_gathered);
     if (t->ev_stacked) qrd_event_destroy(t->ev_stacked);
+    if (t->ev_q) qrd_event_destroy(t->ev_q);
     qrd_free(t->dtau); qrd_free(t->dtau2); qrd_free(t->dRp); qrd_free(t->dRall); qrd_free(t->dS); qrd_free(t->dQt);
     qrd_free(t->dsend); qrd_free(t->drecv); qrd_free(t->Vst); qrd_free(t->Tst);
     for (int k = 0; k < QR_TSQR_MAXPAN; ++k) {
@@ -1783,7 +1803,9 @@ static int tsqr_local_panel(qr_tsqr_plan* t, double* dA, int lda, int pi)
     qr_plan* p = t->p;
     const int m = t->m_local, n = t->n, k = t->pan_k[pi], wout = t->pan_k[pi + 1] - k, mk = m - k, nt = n - (k + wout);
     use_set(p, 0);
+    CHECK(prof_begin(p, 2));
     CHECK(factor_panel(p, dA, m, lda, k, wout, t->dtau, nt > 0, NULL));
+    CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
     /* block column k of R is final (its rows above the panel were finished by the earlier trailing updates): pack it */
     if (t->sent_pending[pi]) { CHECK(qrd_stream_wait_event(p->stream, t->ev_sent[pi])); t->sent_pending[pi] = 0; }
     CHECK(qrd_extract_r_block(p->stream, dA, lda, k, wout, t->dsend + (size_t) k * n, n, n));
@@ -1798,8 +1820,8 @@ static int tsqr_stacked_panel(qr_tsqr_plan* t, int pi)
     qr_plan* p2 = t->p2;
     const int n = t->n, P = t->nranks, sm = t->sm, nb = p2->nb, k = t->pan_k[pi], wout = t->pan_k[pi + 1] - k;
     void* s = p2->s_main;
-    for (int q = 0; q < P; ++q)
-        CHECK(qrd_copy_block(s, t->drecv + (size_t) q * n * nb, n, t->dS + (size_t) k * sm + (size_t) q * n, sm, n, wout));
+    for (int q = 0; q < P; ++q)      /* rank q's block column: n x wout, packed (stride n * wout) */
+        CHECK(qrd_copy_block(s, t->drecv + (size_t) q * n * wout, n, t->dS + (size_t) k * sm + (size_t) q * n, sm, n, wout));
     for (int j = 0; j < pi; ++j) {      /* (I - V_j T_j V_j^T)^T on rows pan_k[j] .. of the new block column */
         const int kj = t->pan_k[j], wj = t->pan_k[j + 1] - kj;
         CHECK(apply_small_t(p2, s, t->Vst + (size_t) j * p2->ldv * nb, p2->ldv, t->Tst + (size_t) j * p2->ldt * nb, p2->ldt, sm - kj, wj,
@@ -1807,23 +1829,29 @@ static int tsqr_stacked_panel(qr_tsqr_plan* t, int pi)
     }
     p2->Vw = t->Vst + (size_t) pi * p2->ldv * nb;      /* this panel's V and T stay: the later block columns need them */
     p2->T = t->Tst + (size_t) pi * p2->ldt * nb;
+    CHECK(prof_begin(p2, 2));
     const int rc = factor_panel(p2, t->dS, sm, sm, k, wout, t->dtau2, pi + 1 < t->npan, NULL);
+    if (!rc) CHECK(prof_end(p2, 2.0 * (sm - k) * (double) wout * wout, 16.0 * (sm - k) * wout));
     use_set(p2, 0);
     return rc;
 }
 
 static int tsqr_factor_pipelined(qr_tsqr_plan* t, double* dA, int lda, double* dR, int self_gather)
 {
-    const int n = t->n, nb = t->p->nb;
+    const int n = t->n;
     void* s2 = t->p2->s_main;
     for (int pi = 0; pi < t->npan; ++pi) {
         CHECK(tsqr_local_panel(t, dA, lda, pi));
         CHECK(qrd_stream_wait_event(s2, t->ev_pan[pi]));
+        /* exactly the block column's own n x wout doubles (the half blocks at the end used to send a full n x nb from their start: the
+         * tail of that range is the next block's, which the local stream may be repacking -- discarded by the receivers, but an
+         * unordered read all the same) */
+        const size_t cnt = (size_t) n * (size_t) (t->pan_k[pi + 1] - t->pan_k[pi]);
         if (self_gather) {
             for (int q = 0; q < t->nranks; ++q)
-                CHECK(qrd_d2d(s2, t->drecv + (size_t) q * n * nb, t->dsend + (size_t) t->pan_k[pi] * n, sizeof(double) * (size_t) n * nb));
+                CHECK(qrd_d2d(s2, t->drecv + (size_t) q * cnt, t->dsend + (size_t) t->pan_k[pi] * n, sizeof(double) * cnt));
         } else
-            CHECK(qrd_allgather_f64(t->comm, s2, t->dsend + (size_t) t->pan_k[pi] * n, t->drecv, (size_t) n * nb));
+            CHECK(qrd_allgather_f64(t->comm, s2, t->dsend + (size_t) t->pan_k[pi] * n, t->drecv, cnt));
         CHECK(qrd_event_record(t->ev_sent[pi], s2));
         t->sent_pending[pi] = 1;
         CHECK(tsqr_stacked_panel(t, pi));
@@ -1843,16 +1871,17 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
     if (!tps || !dA || !dR || P < 2) return QR_E_ARG;
     for (int r = 0; r < P; ++r)
         if (!tps[r] || !dA[r] || !dR[r] || tps[r]->nranks != P || tps[r]->rank != r || !tps[r]->pipe_ok || tps[r]->n != tps[0]->n ||
-            tps[r]->m_local != tps[0]->m_local || tps[r]->npan != tps[0]->npan || lda < tps[r]->m_local)
-            return QR_E_ARG;
-    const int n = tps[0]->n, nb = tps[0]->p->nb;
+            tps[r]->npan != tps[0]->npan || tps[r]->p->nb != tps[0]->p->nb || lda < tps[r]->m_local)
+            return QR_E_ARG;                 /* (shards of unequal height are fine: the schedule of the exchange does not depend on them) */
+    const int n = tps[0]->n;
     for (int pi = 0; pi < tps[0]->npan; ++pi) {
         for (int r = 0; r < P; ++r) CHECK(tsqr_local_panel(tps[r], dA[r], lda, pi));
         for (int r = 0; r < P; ++r) {
             void* s2 = tps[r]->p2->s_main;
+            const size_t cnt = (size_t) n * (size_t) (tps[r]->pan_k[pi + 1] - tps[r]->pan_k[pi]);
             for (int q = 0; q < P; ++q) {
                 CHECK(qrd_stream_wait_event(s2, tps[q]->ev_pan[pi]));
-                CHECK(qrd_d2d(s2, tps[r]->drecv + (size_t) q * n * nb, tps[q]->dsend + (size_t) tps[q]->pan_k[pi] * n, sizeof(double) * (size_t) n * nb));
+                CHECK(qrd_d2d(s2, tps[r]->drecv + (size_t) q * cnt, tps[q]->dsend + (size_t) tps[q]->pan_k[pi] * n, sizeof(double) * cnt));
             }
             CHECK(tsqr_stacked_panel(tps[r], pi));
         }
@@ -1902,14 +1931,16 @@ int qr_tsqr_formq_dev(qr_tsqr_plan* t, const double* dA, int lda, double* dQ, in
     const int n = t->n, rows = t->m_local, sm = t->sm;
     qr_plan* p = t->p;
     if (t->nranks == 1) return qr_applyq_dev(p, dA, rows, n, lda, t->dtau, dQ, n, ldq, 1);
-    if (!t->dQt) CHECK(qrd_malloc((void**) &t->dQt, sizeof(double) * (size_t) sm * n));
     qr_plan* p2 = t->p2;
+    if (t->ev_q && t->q_pending) { CHECK(qrd_stream_wait_event(p2->s_main, t->ev_q)); t->q_pending = 0; }   /* the previous call's copy out of dQt */
     CHECK(qr_applyq_dev(p2, t->dS, sm, n, sm, t->dtau2, t->dQt, n, sm, 1));          /* the tree's Q, (P n) x n */
     CHECK(qrd_event_record(t->ev_stacked, p2->s_main));
     CHECK(qrd_stream_wait_event(p->s_main, t->ev_stacked));
     t->stacked_pending = 0;
     CHECK(qrd_zero_block(p->s_main, dQ, ldq, rows, n));
     CHECK(qrd_copy_block(p->s_main, t->dQt + (size_t) t->rank * n, sm, dQ, ldq, n, n));
+    CHECK(qrd_event_record(t->ev_q, p->s_main));
+    t->q_pending = 1;
     return qr_applyq_dev(p, dA, rows, n, lda, t->dtau, dQ, n, ldq, 0);
 }
 

@@ -187,7 +187,7 @@ def rank_step_latency(qr, m_local, n, P, nb=128, nmat=3, reps=3):
             best = min(best, (time.perf_counter() - t0) / len(A) * 1e3)
         out[name] = best
     out["exposed_exchange_and_stacked_ms"] = out["step_ms"] - out["local_ms"]
-    out["efficiency_excl_network"] = out["local_ms"] / out["step_ms"]
+    out["local_share_of_step_excl_network"] = out["local_ms"] / out["step_ms"]     # not a scaling efficiency: see bench.py tsqr_model_1gpu
     tp.close()
     return out
 

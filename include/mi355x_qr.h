@@ -230,6 +230,8 @@ typedef struct qr_profile {
  * update / the panel stream's share of a wide update).  A record costs two event packets on its stream: profile what you read. */
 int qr_plan_set_profile(qr_plan* plan, int on);
 int qr_plan_pause_profile(qr_plan* plan, int pause);       /* stop / resume recording, keeping the records made so far */
+/* what the plan was built with: outer / leaf block size, 1 = two-stream look-ahead schedule (any pointer may be NULL) */
+int qr_plan_info(qr_plan* plan, int* nb, int* ib, int* lookahead);
 int qr_plan_get_profile(qr_plan* plan, qr_profile* out);   /* synchronises, sums, resets */
 /* The individual records behind the sums, in issue order (call before qr_plan_get_profile): class as above, plus 4 = the
  * look-ahead update of the next panel's columns and 5 = the panel stream's share of a wide update (both summed into class 3

@@ -659,6 +659,39 @@ def test_tsqr_panel_pipelined_virtual_ranks(qr, oracle, m_local, n, P, nb):
         tp.close()
 
 
+@pytest.mark.parametrize("heights,n,nb", [((9000, 8000, 8192, 7000), 512, 0), ((1500, 40000, 1100), 1024, 0), ((5000, 3000), 2048, 0)])
+def test_tsqr_unequal_shards_agree_on_the_exchange(qr, oracle, heights, n, nb):
+    """Shards of unequal height (m % ngpu != 0) used to straddle the look-ahead / block-size thresholds of the LOCAL plan, so that ranks
+    disagreed on the number and size of the collectives (round-3 advisor finding).  A TSQR plan's local factorisation now takes a
+    rank-invariant block size and the single-stream schedule: every rank reports the same pipelining decision and block size, and the
+    virtual-rank run of the pipelined schedule over the unequal shards gives LAPACK's R on every rank."""
+    P = len(heights)
+    plans = [qr.TsqrPlan(h, n, P, r, nb, comm="external") for r, h in enumerate(heights)]
+    assert len({tp.is_pipelined() for tp in plans}) == 1
+    assert len({tp.local.nb for tp in plans}) == 1 and len({tp.stacked.nb for tp in plans}) == 1
+    if not plans[0].is_pipelined():
+        for tp in plans:
+            tp.close()
+        return
+    rng = np.random.default_rng(sum(heights))
+    hosts = [rng.random((h, n)) for h in heights]
+    lda = max(heights)
+    shards, Rs = [], []
+    for Ah in hosts:
+        buf = np.zeros((lda, n))
+        buf[:Ah.shape[0]] = Ah
+        shards.append(dev(buf))
+        Rs.append(zeros(n, n))
+    qr.tsqr_factor_virtual(plans, shards, lda, Rs)
+    R0 = host(Rs[0])
+    for dR in Rs[1:]:
+        assert np.array_equal(R0, host(dR))
+    ref = oracle.sign_normalise(np.linalg.qr(np.vstack(hosts), mode="r"))
+    assert rel(oracle.sign_normalise(R0), ref) < 1e-13
+    for tp in plans:
+        tp.close()
+
+
 def test_tsqr_selfgather_back_to_back_and_unpipelined_agree(qr, oracle):
     """One rank's complete step with its own factor in every rank slot (qr_tsqr_factor_selfgather_dev), issued back to back on four
     matrices without host synchronisation: every R is sqrt(P) times the R of ITS matrix; and the panel-pipelined schedule and the

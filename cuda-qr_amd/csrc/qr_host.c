@@ -115,6 +115,7 @@ typedef struct qr_knobs {
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
     int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
+    int fused_gram;                                         /* MI355XQR_FUSED_GRAM: the panel's Gram blocks V_prev^T V_l inside that launch (else one launch after it) */
 } qr_knobs;
 static qr_knobs g_knobs;
 static pthread_once_t g_knobs_once = PTHREAD_ONCE_INIT;
@@ -144,6 +145,7 @@ static void knobs_init(void)
     k->early_product = env_int("MI355XQR_EP", 1) != 0;
     k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
     k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
+    k->fused_gram = env_int("MI355XQR_FUSED_GRAM", 0) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -662,8 +664,9 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
                                qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);
         if (fused_half) {
             CHECK(qrd_panel_fused(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
-                                  p->Vw + (size_t) c0 * ldv + c0, ldv, p->G + (size_t) c0 * nb + c0, nb, p->pf_ws, &p->pf_epoch, p->pf_status));
-            gram_done = need_t;
+                                  p->Vw + (size_t) c0 * ldv + c0, ldv, (need_t && kn->fused_gram) ? p->G + (size_t) c0 * nb + c0 : NULL, nb, p->pf_ws,
+                                  &p->pf_epoch, p->pf_status));
+            gram_done = need_t && kn->fused_gram;
         }
         for (int c = c0; c < cend && !fused_half; c += ib) {
             const int w = imin(ib, cend - c), mkl = mk - c;

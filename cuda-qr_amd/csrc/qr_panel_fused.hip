@@ -45,13 +45,16 @@
 #define PF_OFF_X2 (PF_OFF_X1 + 2 * PF_MAXWG * 1024)
 #define PF_OFF_QT (PF_OFF_X2 + 2 * PF_MAXWG * 1024)
 #define PF_OFF_X3 (PF_OFF_QT + 2 * 1024)
-#define PF_OFF_X4 (PF_OFF_X3 + 2 * (PF_MAXWG + 1) * 32 * PF_ZCOLS)
+#define PF_ZSLAB (32 * PF_ZCOLS + 768)   /* one workgroup's product slab: Z (32 x 224) and the partial Gram matrix of the NEXT leaf's columns */
+#define PF_OFF_X4 (PF_OFF_X3 + 2 * (PF_MAXWG + 1) * PF_ZSLAB)
 #define PF_OFF_XF (PF_OFF_X4 + 2 * 32 * PF_ZCOLS)
 #define PF_OFF_F1 (PF_OFF_XF + 2 * PF_MAXWG * 128)      /* factor -> rows: R1^-1 (1024) + status (8), per parity */
 #define PF_F1_SZ 1032
 #define PF_OFF_F2 (PF_OFF_F1 + 2 * PF_F1_SZ)              /* factor -> rows: U'^-1, T, L1\\U', R, S R2 (5 x 1024) + status (8) */
 #define PF_F2_SZ (5 * 1024 + 8)
-#define PF_WS_DOUBLES (PF_OFF_F2 + 2 * PF_F2_SZ)
+#define PF_OFF_XG (PF_OFF_F2 + 2 * PF_F2_SZ)              /* summed Gram matrix of the next leaf's columns before their update (768) */
+#define PF_OFF_XT (PF_OFF_XG + 2 * 1024)                 /* their top 32 rows before the update (32 x 32) */
+#define PF_WS_DOUBLES (PF_OFF_XT + 2 * 1024)
 
 // LDS carve-up (doubles).  The 32 x 32 factors come FIRST: their addresses are compile-time constants, and below 64 KB they fit the
 // immediate offset of a ds_read -- above it hipcc materialises one scalar register per address (~900 of them, spilled, in the unrolled
@@ -75,7 +78,8 @@ struct PfArgs {
     double* Vw; int ldv;         // explicit V, same origin
     double* T; int ldt;          // wh x wh: the leaves' T blocks go on the diagonal
     double* tau;
-    double* G; int ldg;          // Gram blocks for the T merge: G(j', c + i) = V(:, j')^T V(:, c + i), j' < c
+    double* G; int ldg;          // Gram blocks for the T merge: G(j', c + i) = V(:, j')^T V(:, c + i), j' < c (NULL: not wanted --
+                                 // the in-panel product then covers A_rest only and the caller forms V^T V in one launch afterwards)
     double* ws;                  // PF_WS_DOUBLES
     unsigned epoch0;             // epoch words hold values <= epoch0 when the launch starts
     int* status;                 // [0] += leaves that took the Householder route; [1] = 1 when a wait timed out
@@ -416,18 +420,20 @@ __device__ __forceinline__ PfLds pf_lds(double* sm)
 
 struct PfLeaf {                      // per-leaf constants
     int c, nrest, ncols, gown;
-    double *X1, *X2, *QT, *X3, *X4, *F1, *F2;
+    double *X1, *X2, *QT, *X3, *X4, *F1, *F2, *XG, *XT;
 };
 
 __device__ __forceinline__ PfLeaf pf_leaf(const PfArgs& P, int c)
 {
     PfLeaf f;
     const int li = c >> 5, par = li & 1;
-    f.c = c; f.nrest = P.wh - c - 32; f.ncols = P.wh - 32; f.gown = c / PF_ROWS;
+    f.c = c; f.nrest = P.wh - c - 32; f.ncols = P.G ? P.wh - 32 : f.nrest; f.gown = c / PF_ROWS;
     f.X1 = P.ws + PF_OFF_X1 + (size_t) par * PF_MAXWG * 1024;
     f.X2 = P.ws + PF_OFF_X2 + (size_t) par * PF_MAXWG * 1024;
     f.QT = P.ws + PF_OFF_QT + (size_t) par * 1024;
-    f.X3 = P.ws + PF_OFF_X3 + (size_t) par * (PF_MAXWG + 1) * 32 * PF_ZCOLS;
+    f.X3 = P.ws + PF_OFF_X3 + (size_t) par * (PF_MAXWG + 1) * PF_ZSLAB;
+    f.XG = P.ws + PF_OFF_XG + (size_t) par * 1024;
+    f.XT = P.ws + PF_OFF_XT + (size_t) par * 1024;
     f.X4 = P.ws + PF_OFF_X4 + (size_t) par * 32 * PF_ZCOLS;
     f.F1 = P.ws + PF_OFF_F1 + (size_t) par * PF_F1_SZ;
     f.F2 = P.ws + PF_OFF_F2 + (size_t) par * PF_F2_SZ;
@@ -472,11 +478,11 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
         if (have) {
             double z = 0.0;
             const int zi = pf_zidx(i, j);
-            const double corr = nocorr ? 0.0 : pf_ld(f.X3 + (size_t) nwg * 32 * PF_ZCOLS + zi);   // the top-block owner's -B^T x_top
+            const double corr = nocorr ? 0.0 : pf_ld(f.X3 + (size_t) nwg * PF_ZSLAB + zi);   // the top-block owner's -B^T x_top
             {
                 double v[PF_MAXWG];
 #pragma unroll
-                for (int u = 0; u < PF_MAXWG; ++u) v[u] = pf_ld(f.X3 + (size_t) min(u, nwg - 1) * 32 * PF_ZCOLS + zi);
+                for (int u = 0; u < PF_MAXWG; ++u) v[u] = pf_ld(f.X3 + (size_t) min(u, nwg - 1) * PF_ZSLAB + zi);
 #pragma unroll
                 for (int u = 0; u < PF_MAXWG; ++u)
                     if (u < nwg) z += v[u];
@@ -514,6 +520,19 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    // ... and this workgroup's slice of G' = A_next^T A_next (the next leaf's columns BEFORE this leaf's update, rows >= c): entries
+    // g, g + nwg, ... of the 768; the factor workgroup turns the sum into the next leaf's G1 without another exchange (pf_factor_wg)
+    if (f.nrest > 0) {
+        for (int e = g + nwg * (int) threadIdx.x; e < 768; e += nwg * PF_THREADS) {
+            double v[PF_MAXWG], z = 0.0;
+#pragma unroll
+            for (int u = 0; u < PF_MAXWG; ++u) v[u] = pf_ld(f.X3 + (size_t) min(u, nwg - 1) * PF_ZSLAB + 32 * PF_ZCOLS + e);
+#pragma unroll
+            for (int u = 0; u < PF_MAXWG; ++u)
+                if (u < nwg) z += v[u];
+            pf_st(f.XG + e, z);
+        }
     }
 }
 
@@ -794,6 +813,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
     unsigned* const flags = reinterpret_cast<unsigned*>(P.ws);
     const int wgrow0 = g * PF_ROWS;
     unsigned er = P.epoch0, ef = P.epoch0;                 // epoch values of the row workgroups / the factor workgroup before this leaf
+    bool g1_derived = false;                               // the factor workgroup derives this leaf's G1 from the previous leaf's G' and R12
     double ar[4][8];
     if (tid == 0) L.gflags[4] = 0;
     {
@@ -820,10 +840,12 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         }
         pf_image_write(L.img, ar, wave, l15, l4);
         __syncthreads();
-        pf_gram_wave(L.img, L.part, wave, lane, l15, l4);
-        __syncthreads();
-        pf_gram_publish(L.part, f.X1 + (size_t) g * 1024);
-        pf_publish(flags, 16 * g, er + 1);
+        if (!g1_derived) {                                    // first leaf of the panel, or the one after a Householder-route leaf
+            pf_gram_wave(L.img, L.part, wave, lane, l15, l4);
+            __syncthreads();
+            pf_gram_publish(L.part, f.X1 + (size_t) g * 1024);
+        }
+        pf_publish(flags, 16 * g, er + 1);                    // (an empty publish when G1 is derived: the epoch count stays uniform)
         PF_STAMP(1);
         // ---- (the factor workgroup sums G1 and runs the Cholesky.)  The PREVIOUS leaf's update of everything beyond this leaf's
         // columns happens here, off the critical chain: this leaf only needed its own 32 columns (done at the end of the previous
@@ -869,7 +891,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         const int ntile = f.ncols / 16;
         auto product = [&]() {
             const int nval = (ntile > wave) ? (ntile - wave + 3) / 4 : 0;
-            double* X3g = f.X3 + (size_t) g * 32 * PF_ZCOLS;
+            double* X3g = f.X3 + (size_t) g * PF_ZSLAB;
             double xb[2][4][4];
             auto xptr = [&](int slot) {
                 const int j = 16 * (wave + 4 * slot) + l15;
@@ -878,10 +900,23 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
             auto xload = [&](double (&x)[4][4], const double* xp, int ch) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    const int rowc = min(wgrow0 + 16 * (4 * ch + s4) + 4 * l4, mk - 4);
+                    const int row = wgrow0 + 16 * (4 * ch + s4) + 4 * l4, rowc = min(row, mk - 4);
                     const v2d lo = *reinterpret_cast<const v2d*>(xp + rowc), hi = *reinterpret_cast<const v2d*>(xp + rowc + 2);
-                    x[s4][0] = lo[0]; x[s4][1] = lo[1]; x[s4][2] = hi[0]; x[s4][3] = hi[1];
+                    const bool on = row >= c && row < mk;            // rows of this leaf (Q is zero elsewhere; the Gram tiles need it)
+                    x[s4][0] = on ? lo[0] : 0.0; x[s4][1] = on ? lo[1] : 0.0; x[s4][2] = on ? hi[0] : 0.0; x[s4][3] = on ? hi[1] : 0.0;
                 }
+            };
+            // G' = A_next^T A_next (the next leaf's columns as they are NOW, rows >= c), one 16 x 16 tile per wave beside its product:
+            // wave 0 tile (0,0), wave 1 tile (1,1) from the operand registers they hold anyway, wave 2 tile (0,1) in a pass of its own.
+            // With R12 = the top 32 rows of those columns after this leaf's update, the next leaf's Gram matrix is G' - R12^T R12
+            // (the update is orthogonal on rows >= c): its all-to-all exchange and 200 KB sum disappear (pf_factor_wg)
+            const bool want_g = f.nrest > 0;
+            v4d gacc = (v4d){0.0, 0.0, 0.0, 0.0};
+            auto gmma = [&](const double (&xa)[4][4], const double (&xc)[4][4]) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) gacc = pf_mfma(xa[s4][kk], xc[s4][kk], gacc);
             };
             auto mma = [&](const double (&x)[4][4], int ch, v4d& acc0, v4d& acc1) {
 #pragma unroll
@@ -900,14 +935,27 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
             for (int slot = 0; slot < nval; ++slot) {
                 v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
                 const double* xp = xptr(slot);
-                xload(xb[1], xp, 1); mma(xb[0], 0, acc0, acc1);
-                xload(xb[0], xp, 2); mma(xb[1], 1, acc0, acc1);
-                xload(xb[1], xp, 3); mma(xb[0], 2, acc0, acc1);
+                const bool gdiag = want_g && slot == 0 && wave < 2;       // wave-uniform
+                xload(xb[1], xp, 1); mma(xb[0], 0, acc0, acc1); if (gdiag) gmma(xb[0], xb[0]);
+                xload(xb[0], xp, 2); mma(xb[1], 1, acc0, acc1); if (gdiag) gmma(xb[1], xb[1]);
+                xload(xb[1], xp, 3); mma(xb[0], 2, acc0, acc1); if (gdiag) gmma(xb[0], xb[0]);
                 if (slot + 1 < nval) xload(xb[0], xptr(slot + 1), 0);
-                mma(xb[1], 3, acc0, acc1);
+                mma(xb[1], 3, acc0, acc1); if (gdiag) gmma(xb[1], xb[1]);
                 double* zp = X3g + (wave + 4 * slot) * 512 + 2 * lane;          // pf_zidx layout
                 pf_st2(zp, acc0[0], acc0[1]); pf_st2(zp + 128, acc0[2], acc0[3]);
                 pf_st2(zp + 256, acc1[0], acc1[1]); pf_st2(zp + 384, acc1[2], acc1[3]);
+            }
+            if (want_g && wave == 2) {                           // tile (0, 1): both 16-column tiles of the next leaf, chunk by chunk
+                double xc[4][4];
+                const double* x0 = A + (size_t) (c + 32 + l15) * lda;
+                const double* x1 = x0 + (size_t) 16 * lda;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) { xload(xb[0], x0, ch); xload(xc, x1, ch); gmma(xb[0], xc); }
+            }
+            if (want_g && wave < 3) {                            // accumulator order, as the Gram partials: tile 0, 2, 1 for wave 0, 1, 2
+                const int tile = (wave == 0) ? 0 : (wave == 1 ? 2 : 1);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) pf_st(X3g + 32 * PF_ZCOLS + (tile * 4 + rr) * 64 + lane, gacc[rr]);
             }
         };
         product();
@@ -921,6 +969,10 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
                 const double* xp = ((j < f.nrest) ? A + (size_t) (c + 32 + j) * lda : Vw + (size_t) (j - f.nrest) * ldv) + c;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) xt[slot][ks] = xp[4 * ks + l4];
+            }
+            if (f.nrest > 0 && wave < 2) {                       // tiles 0, 1 = the next leaf's columns: their rows c .. c + 31 -> XT
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) pf_st(f.XT + (16 * wave + l15) * 32 + 4 * ks + l4, xt[0][ks]);
             }
         }
         PF_STAMP(5);
@@ -953,7 +1005,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         if (own && ntile > 0) {
             // Q = V U' + [B; 0] with B = S R2, so V^T x = U'^-T (Q^T x - B^T x_top): the correction -B^T X_top goes out as one more
             // partial of Z (slot nrow)
-            double* X3c = f.X3 + (size_t) nrow * 32 * PF_ZCOLS;
+            double* X3c = f.X3 + (size_t) nrow * PF_ZSLAB;
             double ba[2][8];
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
@@ -1013,6 +1065,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         PF_STAMP(11);
         er += 4u + (fb ? 32u : 0u);
         ef += 2u;
+        g1_derived = !fb && f.nrest > 0;
     }
     if (g == 0 && tid == 0 && L.gflags[4]) P.status[1] = 1;
 }
@@ -1032,6 +1085,7 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
     unsigned* const flags = reinterpret_cast<unsigned*>(P.ws);
     int nfallback = 0;
     unsigned er = P.epoch0, ef = P.epoch0;
+    bool g1_derived = false;
     if (tid == 0) { L.gflags[4] = 0; L.gflags[5] = 0; L.gflags[6] = 0; }
     for (int c = 0; c < P.wh; c += 32) {
         const PfLeaf f = pf_leaf(P, c);
@@ -1042,10 +1096,12 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
         const int rc = lane & 31;
         const int seq = (c >> 5) + 1;
         if (tid == 0) { L.gflags[0] = 1; L.gflags[1] = 0; L.gflags[2] = 0; L.gflags[3] = 0; }
-        pf_wait(flags, nrow, er + 1, &L.gflags[4]);
-        PF_STAMP_S(16);
-        pf_gram_sum(f.X1, nrow, L.Gs, L.gflags, false);
-        __syncthreads();
+        if (!g1_derived) {
+            pf_wait(flags, nrow, er + 1, &L.gflags[4]);
+            PF_STAMP_S(16);
+            pf_gram_sum(f.X1, nrow, L.Gs, L.gflags, false);
+            __syncthreads();
+        }
         PF_STAMP_S(17);
         // R1 = chol(G1) and R1^-1 on one wave (the identity columns ride on the wave's upper half)
         if (wave == 0) {
@@ -1243,6 +1299,68 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
         if (fb) ++nfallback;
         pf_publish(flags, PF_FAC_WORD, ef + 2);
         PF_STAMP_S(24);
+        // ---- the next leaf's G1 without an exchange: G1 = G' - R12^T R12 with G' = A_next^T A_next before this leaf's update (summed
+        // slice-wise by the row workgroups with their fold) and R12 = A_next(top 32 rows) - L1 W(:, next 32 columns), the rows this
+        // leaf's update leaves above the next leaf: the update is an orthogonal transformation of rows >= c, so the Gram matrix of the
+        // rows >= c + 32 is what is left.  (An error of G1 only costs the first CholeskyQR pass orthogonality, which the second pass
+        // measures from the real Q; cancellation -- a next leaf nearly inside this leaf's span -- ends at the guard like any other
+        // badly conditioned leaf.)  Not behind a Householder-route leaf: its L1 lives in the row workgroups.
+        g1_derived = !fb && f.nrest > 0;
+        if (g1_derived) {
+            pf_wait(flags, nrow, er + 4, &L.gflags[4]);          // all W slices and G' slices are published
+            pf_m33 At = reinterpret_cast<pf_m33>(L.img + PF_M33), Wn = reinterpret_cast<pf_m33>(L.img + 2 * PF_M33),
+                   R12 = reinterpret_cast<pf_m33>(L.img + 3 * PF_M33);
+            {
+                double ge[3], at[4], wn[4];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ge[q] = pf_ld(f.XG + tid + 256 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { at[q] = pf_ld(f.XT + tid + 256 * q); wn[q] = pf_ld(f.X4 + tid + 256 * q); }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pf_gram_entry(tid + 256 * q, ge[q], L.Gs, L.gflags, false);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q, col = e >> 5, row = e & 31;
+                    At[row][col] = at[q];                      // XT[col * 32 + row]
+                    Wn[row][col] = wn[q];                      // X4[j * 32 + i] = W(i, j)
+                }
+            }
+            __syncthreads();
+            {
+                const int l15 = lane & 15, l4 = lane >> 4, ti = wave & 1, tj = wave >> 1;
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = At[16 * ti + l4 + 4 * r][16 * tj + l15];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k = 4 * ks + l4, i = 16 * ti + l15;
+                    const double l1 = (k < i) ? L.Bs[i][k] : (k == i ? 1.0 : 0.0);
+                    acc = pf_mfma(-l1, Wn[k][16 * tj + l15], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R12[16 * ti + l4 + 4 * r][16 * tj + l15] = acc[r];
+            }
+            __syncthreads();
+            if (wave < 3) {
+                const int l15 = lane & 15, l4 = lane >> 4, ti = (wave == 2) ? 1 : 0, tc = (wave == 0) ? 0 : 1;
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = L.Gs[16 * tc + l15][16 * ti + l4 + 4 * r];      // Gs[j][i] = G(i, j)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k = 4 * ks + l4;
+                    acc = pf_mfma(-R12[k][16 * ti + l15], R12[k][16 * tc + l15], acc);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ti + l4 + 4 * r, j = 16 * tc + l15;
+                    L.Gs[j][i] = acc[r];
+                    if (wave == 1) L.Gs[i][j] = acc[r];
+                }
+            }
+            __syncthreads();
+        }
         er += 4u + (fb ? 32u : 0u);                          // the Householder route's 32 column exchanges among the row workgroups
         ef += 2u;
     }

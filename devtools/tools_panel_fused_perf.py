@@ -18,7 +18,7 @@ lib.qrd_panel_fused_ws_doubles.restype = C.c_size_t
 ws = torch.zeros(int(lib.qrd_panel_fused_ws_doubles()), dtype=torch.float64, device="cuda")
 epoch = C.c_uint(0)
 status = torch.zeros(4, dtype=torch.int32, device="cuda")
-shapes = [(256, 256), (1024, 256), (2048, 256), (4096, 256), (8192, 256), (8192, 128), (4096, 64), (4096, 128), (4096, 32), (8192, 32)]
+shapes = [(256, 64), (512, 64), (1024, 64), (2048, 64), (3072, 64), (4096, 64), (1024, 128), (2048, 128), (4096, 128), (2048, 256), (4096, 256), (8192, 256)]
 reps = 20
 for mk, wh in shapes:
     rng = np.random.default_rng(1)
@@ -29,8 +29,10 @@ for mk, wh in shapes:
     G = torch.zeros((wh, wh), dtype=torch.float64, device="cuda")
     tau = torch.zeros(wh, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
+    import os
+    gp = None if os.environ.get("PF_NO_GRAM") else G.data_ptr()
     def go(b):
-        rc = f(None, b.data_ptr(), mk, mk, wh, tau.data_ptr(), T.data_ptr(), wh, V.data_ptr(), mk, G.data_ptr(), wh, ws.data_ptr(),
+        rc = f(None, b.data_ptr(), mk, mk, wh, tau.data_ptr(), T.data_ptr(), wh, V.data_ptr(), mk, gp, wh, ws.data_ptr(),
                C.byref(epoch), status.data_ptr())
         assert rc == 0, rc
     for i in range(3):

@@ -140,8 +140,6 @@ _sig("qrd_panel_tsqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C
 _sig("qrd_panel_cholqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, C.c_int)
 _sig("qrd_leaf_update_gram", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_int))
 _sig("qrd_gemm_nt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp)
-_sig("qrd_gemm_tnt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_size_t,
-     C.c_int, C.c_int, C.c_int)
 _sig("qrd_copy_block", C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int)
 _sig("qrd_init", C.c_int)
 _sig("qrd_device_sync", C.c_int)

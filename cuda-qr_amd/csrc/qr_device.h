@@ -29,8 +29,6 @@ int qrd_gemm2_init(void);
 int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc);
 int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt,
                 double* C, int ldc, int gm, unsigned long long* stamps);
-int qrd_gemm_tnt(void* stream, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* Ct, int ldct,
-                 double* slabs, size_t slab_cap, int ksplit, int cus, int gm);
 int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
                    int ldv, double* scratch);
 size_t qrd_panel_ws_size(int m);

@@ -3,7 +3,7 @@
 // Replaces, for the tile-aligned interior of the wide update, the pair gemm_tn_kernel<4,4> / gemm_nn_w8_kernel of
 // qr_kernels.hip (reference: trailingUpdateKernel qr.cu:335-465, host loop qr.c:255-293):
 //
-//     Wt = A2^T (V T)          (nt x nbp, "W transposed": the long dimension nt is the contiguous one)    gemm_tnt_kernel
+//     Wt = A2^T (V T)          (nt x nbp, "W transposed": the long dimension nt is the contiguous one)    gemm_tn_kernel (qr_kernels.hip), operands swapped
 //     A2 -= V Wt^T             (mk x nt)                                                                  gemm_nt_kernel
 //
 // Storing W transposed makes BOTH operands of the update "row-fast": for a fixed k the 128 rows of a V tile and
@@ -249,117 +249,9 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Slab z of  Ct (M x N) = A^T B   over rows [z*kchunk, min(K, (z+1)*kchunk))    A: K x M (lda), B: K x N (ldb)
-// (in the update: A = A2, M = nt; B = V T, N = nbp; Ct = Wt).  Both operands are k-contiguous in memory: a tile is
-// 128 columns x 16 k = 128 B per column.  One global_load_lds instruction brings 8 columns x 128 B; the LDS image is
-// [column][8 slots of 16 B] with the slot index XOR-ed with (column >> 1) & 7 -- applied on the SOURCE address (the
-// LDS destination of a global_load_lds is linear) and again on the read.  MFMA k-rows are assigned so that a lane
-// needs k and k + 1 in consecutive steps: kappa(step s, l4) = 2 l4 + (s & 1) + 8 (s >> 1), so one ds_read_b128
-// feeds two steps; with the swizzle the 16 lanes of every b128 bank group hit 16 distinct slots.
-// D: columns of Ct on p (registers), rows of Ct on q (lanes): 16 lanes store 128 contiguous bytes.
-// M % 128 == N % 128 == 0, kchunk % 16 == 0, K % 16 == 0, 16-byte aligned operands, even lda / ldb.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void gemm_tnt_kernel(int M, int N, int K, int kchunk, const double* __restrict__ A, int lda,
-                                                          const double* __restrict__ B, int ldb,
-                                                          double* __restrict__ Ct, int ldct, size_t slab_stride,
-                                                          int gx, int gy, int gm)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave & 1, wj = wave >> 1;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int per_z = gx * gy;
-    const int z = blockIdx.x / per_z;
-    int tx, ty;
-    tile_of_block(blockIdx.x - z * per_z, gx, gy, gm, tx, ty);
-    const int i0 = tx * 128, j0 = ty * 128;             // rows (A columns) / columns (B columns) of the Ct tile
-    const int kbeg = z * kchunk, kend = min(K, kbeg + kchunk);
-    const int nk = (kend - kbeg) / NT_BK;
-
-    // loader: instruction n (= wave, wave + 8) covers image columns 8n .. 8n+7; lane L -> column 8n + (L >> 3),
-    // destination slot L & 7, source k-pair (L & 7) ^ ((column >> 1) & 7)
-    const int lc = lane >> 3, ls = lane & 7;
-    const int c0 = 8 * wave + lc, c1 = c0 + 64;
-    const double* ga0 = A + (size_t) (i0 + c0) * lda + kbeg + 2 * (ls ^ ((c0 >> 1) & 7));
-    const double* ga1 = A + (size_t) (i0 + c1) * lda + kbeg + 2 * (ls ^ ((c1 >> 1) & 7));
-    const double* gb0 = B + (size_t) (j0 + c0) * ldb + kbeg + 2 * (ls ^ ((c0 >> 1) & 7));
-    const double* gb1 = B + (size_t) (j0 + c1) * ldb + kbeg + 2 * (ls ^ ((c1 >> 1) & 7));
-    auto issue = [&](int kt, int stage) {
-        double* sa = smem + stage * NT_STAGE + wave * 128;
-        const int ko = kt * NT_BK;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga0 + ko), LDS_PTR(sa), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga1 + ko), LDS_PTR(sa + 8 * 128), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb0 + ko), LDS_PTR(sa + NT_BK * 128), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb1 + ko), LDS_PTR(sa + NT_BK * 128 + 8 * 128), 16, 0, 0);
-    };
-    v4d acc[2][4];                                      // [a: Ct column tile][b: Ct row tile]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-    if (nk > 0) issue(0, 0);
-    __syncthreads();
-    // fragment addresses: image column c of the A image (rows of Ct) = 64 wi + 16 b + l15, of the B image = 32 wj + 16 a + l15
-    int arow[4], brow[2];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) arow[b] = 64 * wi + 16 * b + l15;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) brow[a] = 32 * wj + 16 * a + l15;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const double* st = smem + (kt & 1) * NT_STAGE;
-        v2d fa[2][4], fb[2][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {                   // k-pair l4 + 4u: MFMA steps 2u and 2u + 1
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                fa[u][b] = *reinterpret_cast<const v2d*>(st + arow[b] * 16 + 2 * ((l4 + 4 * u) ^ ((arow[b] >> 1) & 7)));
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-                fb[u][a] = *reinterpret_cast<const v2d*>(st + NT_BK * 128 + brow[a] * 16 + 2 * ((l4 + 4 * u) ^ ((brow[a] >> 1) & 7)));
-        }
-        __builtin_amdgcn_sched_barrier(0);              // all 12 reads are in flight before the first MFMA
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[u][a][e], fa[u][b][e], acc[a][b], 0, 0, 0);
-        __syncthreads();
-    }
-    // D reg r of lane (l4, l15) of tile (a, b): Ct(row i0 + 64 wi + 16 b + l15, column j0 + 32 wj + 16 a + l4 + 4 r)
-    double* out = Ct + (size_t) z * slab_stride;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double* col = out + (size_t) (j0 + 32 * wj + 16 * a + l4 + 4 * r) * ldct + i0 + 64 * wi + l15;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) col[16 * b] = acc[a][b][r];
-        }
-}
-
-// out[e] = sum_z slabs[z][e]  for a dense n-element array (n % 2 == 0), fixed summation order
-__global__ __launch_bounds__(256) void slab_sum_kernel(size_t n2, int nslab, const v2d* __restrict__ slabs, size_t stride2,
-                                                       v2d* __restrict__ out)
-{
-    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t) gridDim.x * blockDim.x) {
-        v2d s0 = slabs[e], s1 = (v2d){0.0, 0.0};
-        int z = 1;
-        for (; z + 1 < nslab; z += 2) { s1 += slabs[(size_t) z * stride2 + e]; s0 += slabs[(size_t) (z + 1) * stride2 + e]; }
-        if (z < nslab) s1 += slabs[(size_t) z * stride2 + e];
-        out[e] = s0 + s1;
-    }
-}
-
-// ================================================================================================
 static int nt_gm(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_NT_GM"); return e ? atoi(e) : 8; }();     // read once, thread-safe
+    static const int v = 8;     // read once, thread-safe
     return v;
 }
 
@@ -381,7 +273,6 @@ int qrd_gemm2_init(void)
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tnt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     return rc;
 }
 
@@ -399,7 +290,7 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
     const int gx = M / 128, gy = N / 128;
     if (gm < 0) gm = nt_gm();
     // MI355XQR_NT_SOLO=1 (measurement only): ask for 100 KB of LDS, so that ONE workgroup fits a compute unit
-    static const int solo = [] { const char* e = getenv("MI355XQR_NT_SOLO"); return e ? atoi(e) : 0; }();
+    static const int solo = 0;
     const size_t shm = solo ? (size_t) 100 * 1024 : 2 * NT_STAGE * sizeof(double);
     hipStream_t s = (hipStream_t) stream;
     if (stamps)
@@ -411,57 +302,6 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
     else
         hipLaunchKernelGGL((gemm_nt_kernel<false, 0>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
     return (int) hipGetLastError();
-}
-
-// Ct (M x N, ldct) = A^T B with split-K over `ksplit` slabs (ksplit <= 0: chosen here from the CU count `cus` of the
-// stream); M % 128 == N % 128 == K % 16 == 0.  slabs: >= ksplit * M * N doubles when ksplit > 1.
-int qrd_gemm_tnt(void* stream, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* Ct, int ldct,
-                 double* slabs, size_t slab_cap, int ksplit, int cus, int gm)
-{
-    if (!(M >= 128 && N >= 128 && M % 128 == 0 && N % 128 == 0 && K >= 16 && K % 16 == 0 && al16(A, lda) && al16(B, ldb) && (ldct & 1) == 0 &&
-          (((uintptr_t) Ct) & 15) == 0))
-        return -7;
-    hipStream_t s = (hipStream_t) stream;
-    const int gx = M / 128, gy = N / 128;
-    const size_t per = (size_t) M * N;
-    if (gm < 0) gm = nt_gm();
-    if (ksplit <= 0) {
-        // same cost model as gemm_tn_impl: rounds(k) * (K/k + fixed) + reduce(k)
-        long long kmax = K / (8 * NT_BK);
-        if (kmax > 64) kmax = 64;
-        if (slabs == nullptr || slab_cap < per) kmax = 1;
-        else if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);
-        if (kmax < 1) kmax = 1;
-        const int slots = 2 * (cus > 0 ? cus : 256);
-        const double row_us = 2.0 * 128 * 128 / 0.113e6;
-        const double red_rows = (double) per * 8.0 / 2.0e6 / row_us;
-        double best = 1e300;
-        ksplit = 1;
-        for (long long k = 1; k <= kmax; ++k) {
-            const long long wgs = (long long) gx * gy * k, rounds = (wgs + slots - 1) / slots;
-            const double cost = (double) rounds * ((double) K / (double) k + 96.0) + (k > 1 ? (double) k * red_rows + 30.0 : 0.0);
-            if (cost < best) { best = cost; ksplit = (int) k; }
-        }
-    }
-    int kchunk = ((K + ksplit - 1) / ksplit + NT_BK - 1) / NT_BK * NT_BK;
-    ksplit = (K + kchunk - 1) / kchunk;
-    if (ksplit > 1 && (slabs == nullptr || (size_t) ksplit * per > slab_cap)) return -3;
-    const size_t shm = 2 * NT_STAGE * sizeof(double);
-    if (ksplit == 1) {
-        hipLaunchKernelGGL(gemm_tnt_kernel, dim3(gx * gy), dim3(512), shm, s, M, N, K, kchunk, A, lda, B, ldb, Ct, ldct, (size_t) 0, gx, gy, gm);
-        return (int) hipGetLastError();
-    }
-    hipLaunchKernelGGL(gemm_tnt_kernel, dim3(gx * gy * ksplit), dim3(512), shm, s, M, N, K, kchunk, A, lda, B, ldb, slabs, M, per, gx, gy, gm);
-    int rc = (int) hipGetLastError();
-    if (rc) return rc;
-    if (ldct == M) {
-        const size_t n2 = per / 2;
-        int blocks = (int) ((n2 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, s, n2, ksplit, (const v2d*) slabs, per / 2, (v2d*) Ct);
-        return (int) hipGetLastError();
-    }
-    return qrd_slab_reduce(stream, M, N, ksplit, slabs, M, per, Ct, ldct);
 }
 
 }   // extern "C"

@@ -60,7 +60,6 @@ struct qr_plan {
     double bal_tc0_base, bal_tc1_base; int bal_auto;   /* bal_auto: no MI355XQR_BALANCE override -- rates follow the phase's partition */
     void* ev_half[2];           /* W_a(s): the wide update has finished the columns of panel s+1 that N(s) left out (its second half) */
     void* ev_next[2];           /* look-ahead update N(s) of the next panel's columns finished (when it runs on the update stream) */
-    int update_gen;             /* wide update kernels: 1 = gemm_tn<4,4> + gemm_nn_w8 (W), 2 = gemm_tn<4,4> + gemm_nt (W transposed, direct-to-LDS) */
     int next_on_update;         /* 1: N(s) runs on the update stream's CUs, ahead of W(s); 0: on the panel stream; 2: on the panel
                                  * stream while the factorisation is update-bound, on the update stream once it is chain-bound */
     void* ev_panel[2];          /* panel set s ready (V, T, VT) */
@@ -103,14 +102,16 @@ static unsigned char g_dev_inited[QR_MAX_DEVICES];
 
 /* Tuning knobs of the schedule (MI355XQR_* environment variables): read ONCE per process under pthread_once --
  * qr_thin_mgpu drives qr_geqrf_dev from one host thread per device, so nothing here may be a lazily written function static. */
+/* constants that used to be knobs: swept in rounds 2 and 3 (profiles/r02_session2_ab_measurements.txt, r03_split_sweeps.txt), flat or
+ * worse away from these values */
+#define QR_FUSE_NN_MIN_ROWS 20000   /* the fused in-panel update + next leaf's Gram launch: tall leaves only */
+#define QR_TFOLD_MAX 128            /* T^T folded into the slab reduce up to this panel width */
+#define QR_EARLY_W1 4096            /* columns of the first slice of an early look-ahead step's wide update */
+
 typedef struct qr_knobs {
-    int fuse_gram;                                          /* MI355XQR_FUSE_GRAM */
-    int fuse_nn, fuse_nn_min, fuse_nn_max, fuse_nn_gy_tall; /* MI355XQR_FUSE_NN, _MIN, _MAX, _GY */
-    int fold_max;                                           /* MI355XQR_TFOLD_MAX */
-    int use_w8;                                             /* MI355XQR_SMALLT_W8 */
-    int chunk_mb;                                           /* MI355XQR_CHUNK_MB */
+    int fuse_nn;                                            /* MI355XQR_FUSE_NN */
     int split_t;                                            /* MI355XQR_SPLIT_T */
-    int early_next, early_w1;                               /* MI355XQR_EARLY_NEXT, MI355XQR_EARLY_W1 */
+    int early_next;                                         /* MI355XQR_EARLY_NEXT */
     int plan_cache;                                         /* MI355XQR_PLAN_CACHE */
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
@@ -129,18 +130,9 @@ static int env_int(const char* name, int dflt)
 static void knobs_init(void)
 {
     qr_knobs* k = &g_knobs;
-    k->fuse_gram = env_int("MI355XQR_FUSE_GRAM", 1) != 0;
     k->fuse_nn = env_int("MI355XQR_FUSE_NN", 1) != 0;
-    k->fuse_nn_min = env_int("MI355XQR_FUSE_NN_MIN", 20000);
-    k->fuse_nn_max = env_int("MI355XQR_FUSE_NN_MAX", 0);
-    k->fuse_nn_gy_tall = env_int("MI355XQR_FUSE_NN_GY", 1);
-    k->fold_max = env_int("MI355XQR_TFOLD_MAX", 128);
-    k->use_w8 = env_int("MI355XQR_SMALLT_W8", 1);
-    k->chunk_mb = env_int("MI355XQR_CHUNK_MB", 0);
     k->split_t = env_int("MI355XQR_SPLIT_T", 1) != 0;
     k->early_next = env_int("MI355XQR_EARLY_NEXT", 1) != 0;
-    k->early_w1 = 4096;
-    { const int v = env_int("MI355XQR_EARLY_W1", 0); if (v >= 128) k->early_w1 = v / 128 * 128; }
     k->plan_cache = env_int("MI355XQR_PLAN_CACHE", 1) != 0;
     k->early_product = env_int("MI355XQR_EP", 1) != 0;
     k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
@@ -335,8 +327,6 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         /* MI355XQR_NEXT=panel|update|auto: which stream applies panel s to the columns of panel s+1 (the look-ahead update
          * N(s)).  On the update stream it is a 60 us job for 190+ CUs instead of a 180 us one for the panel stream's few --
          * but while the update stream is busy back to back it would only delay W(s); auto (default) switches with the phase. */
-        const char* ug = getenv("MI355XQR_UPDATE");
-        p->update_gen = (ug && atoi(ug) == 1) ? 1 : 2;
         const char* nx = getenv("MI355XQR_NEXT");
         p->next_on_update = !nx ? 2 : (strcmp(nx, "update") == 0 ? 1 : (strcmp(nx, "panel") == 0 ? 0 : 2));   /* 2 = by phase */
         if (!nx && p->npairs && qrd_stream_cus(p->s_pair[0][0]) <= 32) p->next_on_update = 1;
@@ -639,13 +629,13 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
     const int nhalf = (wout + QR_HALF - 1) / QR_HALF;
     p->vt_formed[p->Vw == p->Vw2[1]] = 0;                     /* this set's V*T (if any) belongs to an older panel */
     const qr_knobs* const kn = knobs();
-    const int fuse_gram = kn->fuse_gram;
+    const int fuse_gram = 1;
     /* MI355XQR_FUSE_NN=0: in-panel update and the next leaf's Gram matrix as separate launches (gemm_nn + gram32_kernel);
      * MI355XQR_FUSE_NN_MIN / _MAX: leaf heights the fused launch is used for (default: tall leaves only -- it saves a pass over
      * the next leaf, 262144 x 512: 7.15 -> 7.08 ms; on the short leaves of square problems its 128 matrix-core instructions per
      * wave sit on 10-14 compute units and the launch takes 18 us where gemm_nn + gram32 take 14: 8192^2 32.4 -> 33.0 ms);
      * MI355XQR_FUSE_NN_GY: column pairs side by side on tall leaves (1 = every workgroup walks all columns, V read once) */
-    const int fuse_nn = kn->fuse_nn, fuse_nn_min = kn->fuse_nn_min, fuse_nn_max = kn->fuse_nn_max, fuse_nn_gy_tall = kn->fuse_nn_gy_tall;
+    const int fuse_nn = kn->fuse_nn, fuse_nn_min = QR_FUSE_NN_MIN_ROWS, fuse_nn_max = 0, fuse_nn_gy_tall = 1;
     for (int h = 0; h < nhalf; ++h) {
         const int c0 = h * QR_HALF, wh = imin(QR_HALF, wout - c0), cend = c0 + wh;
         const int need_t = want_t || h + 1 < nhalf;          /* the next half's block update needs T of everything before it */
@@ -753,7 +743,7 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
     p->t_wait = NULL;
     /* narrow panels: T^T is folded into the reduction of the split-K slabs (one thread per entry of W walks a column of T:
      * fine for kw <= 128, 32 KB of T per output column; at kw = 256 every column's workgroup would pull 256 KB through L2) */
-    const int fold_max = knobs()->fold_max;
+    const int fold_max = QR_TFOLD_MAX;
     if (kw <= fold_max && slabs != NULL) {
         if (t_wait) CHECK(qrd_stream_wait_event(stream, t_wait));
         CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Wbuf, kw, slabs, p->slab_cap, T, ldt));
@@ -764,7 +754,7 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
     }
     /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
      * it hands anything it cannot take (ragged, unaligned) to the generic path itself */
-    const int use_w8 = knobs()->use_w8;
+    const int use_w8 = 1;
     /* ... as long as its 128 x 128 tiles give every compute unit of the stream one: the look-ahead update of a late panel
      * (mk <= 8192, 256 columns: 128 tiles for 192-224 CUs) runs 16 serial K steps on half the chip -- 64 x 64 tiles then
      * (8192^2: 29.7 -> 29.2 ms) */
@@ -805,7 +795,7 @@ static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int ld
         CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
         return 0;
     }
-    if (profile == 1 && p->update_gen == 2 && qrd_gemm_nt_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda)) {
+    if (profile == 1 && qrd_gemm_nt_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda)) {
         /* second-generation wide update: W kept transposed (Wt = A2^T (V T), nc x wout), so that both operands of
          * A2 -= V Wt^T are row-fast and go HBM -> LDS directly (qr_gemm_nt.hip) */
         if (form_vt || !p->vt_formed[e]) {     /* on demand: an earlier slice of this update may have taken the tall-skinny shortcut above */
@@ -814,20 +804,7 @@ static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int ld
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
             p->vt_formed[e] = 1;
         }
-        /* MI355XQR_CHUNK_MB > 0: the update walks A2 in column chunks of about that many MB, product and update of a chunk back
-         * to back, so that the update's read of the chunk is served by the 256 MB Infinity Cache instead of HBM */
-        const int chunk_mb = knobs()->chunk_mb;
-        int cw = nc;
-        if (chunk_mb > 0) {
-            const int cus = qrd_stream_cus(stream), slots = 2 * cus, rt = mk / 128;
-            long long want = (long long) chunk_mb * 1000000 / ((long long) mk * 8);          /* columns */
-            /* whole rounds of workgroups: tiles = rt * (cw / 128) = k * slots */
-            long long k = (want / 128) * rt / slots;
-            if (k < 1) k = 1;
-            cw = (int) ((k * slots + rt - 1) / rt) * 128;
-            if (cw < 128) cw = 128;
-            if (cw > nc) cw = nc;
-        }
+        const int cw = nc;       /* (walking A2 in cache-sized column chunks was measured and removed: DESIGN section 8, round 2) */
         for (int c = 0; c < nc; c += cw) {
             const int w1 = imin(cw, nc - c);
             double* A2c = A2 + (size_t) c * lda;
@@ -996,7 +973,7 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
      * there it waited for ALL of W(s) and then ran alone on the chip for 0.16-0.18 ms per step (C3: 33 such steps).  For
      * that, W(s) starts with the columns of panel s+2 (W1(s), event ev_half[s&1]) and E(s) takes the LAST columns of the wide
      * range instead of the first.  early_done: N of the coming step has been issued already. */
-    const int early_env = knobs()->early_next, early_w1 = knobs()->early_w1;
+    const int early_env = knobs()->early_next, early_w1 = QR_EARLY_W1;
     int early_done = 0;
     CHECK(enter_phase(p, phase_of(p, n, n)));
     {
@@ -1663,7 +1640,7 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
             n / pnb >= 2 && n / pnb + 1 <= QR_TSQR_MAXPAN) {
             t->npan = n / pnb;
             for (int k = 0; k <= t->npan; ++k) t->pan_k[k] = k * pnb;
-            if (pnb >= 128 && (pnb / 2) % t->p->ib == 0 && env_int("MI355XQR_TSQR_PIPE_SPLIT_LAST", 1) != 0) {   /* halves of 32 columns lose (65536 x 256, nb 64: 0.39 against 0.32 ms exposed) */
+            if (pnb >= 128 && (pnb / 2) % t->p->ib == 0 && 1) {   /* halves of 32 columns lose (65536 x 256, nb 64: 0.39 against 0.32 ms exposed) */
                 t->pan_k[t->npan] = n - pnb / 2;
                 t->pan_k[++t->npan] = n;
             }

@@ -835,7 +835,7 @@ int qrd_init(void)
 // MI355XQR_NN_WAVES=4 selects the 4-wave kernel for the wide update (default 8, see gemm_nn_w8_kernel)
 static int nn_waves(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_NN_WAVES"); int v_ = (e && atoi(e) == 4) ? 4 : 8; return v_; }();
+    static const int v = 8;
     return v;
 }
 
@@ -890,7 +890,7 @@ int qrd_gemm_nn(void* stream, int M, int N, int K, double alpha, const double* A
     // tile choice: big square tiles when the grid still fills the chip, smaller otherwise
     const long long t44 = (long long) ((M + 127) / 128) * ((N + 127) / 128);
     {
-        static const int tall_tile = [] { const char* e = getenv("MI355XQR_NN_TALL_TILE"); int v_ = e ? atoi(e) : 44; return v_; }();
+        static const int tall_tile = 44;
         if (tall_tile == 22 && M >= 65536 && N <= 512 && N > 32) return launch_nn<2, 2>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
     }
     if (N > 64 && M > 64 && t44 >= 192) return launch_nn<4, 4>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
@@ -952,8 +952,8 @@ int qrd_gemm_tn_dual(void* stream, int N1, int N2, int K, const double* A, int l
     // workgroup slots per compute unit: the 32 x 32 tile kernel is latency-bound per workgroup (18 KB of LDS, 4 waves), so more
     // and shorter K slices than the 2 per CU of the big-tile products pay (8192^2: 34.4 ms at 2 slots / >= 8 k-tiles per slice,
     // 33.3 ms at 8 slots / >= 4 k-tiles)
-    static const int spc = [] { const char* e = getenv("MI355XQR_DUAL_SLOTS"); int v_ = e ? atoi(e) : 8; if (v_ < 1) v_ = 8; return v_; }();
-    static const int kmin_tiles = [] { const char* e = getenv("MI355XQR_DUAL_KMIN"); int v_ = e ? atoi(e) : 4; if (v_ < 1) v_ = 4; return v_; }();
+    static const int spc = 8;
+    static const int kmin_tiles = 4;
     // (round 3: a streaming form of this product for tall leaves -- both operands straight from global memory in MFMA operand layout,
     // 32 B per lane, all outputs of a column group in accumulators, no LDS / barrier in the loop -- was built and measured at 100-109 us
     // per launch on a 262144-row leaf against 78 us here: 128-byte-per-column accesses from 8 waves per CU stream worse than this
@@ -1019,7 +1019,7 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     else if (M <= 64 || N <= 64 || (shortk && (long long) ((M + 63) / 64) * ((N + 63) / 64) <= 2048)) { ti = 2; tj = 2; }
     else { ti = 4; tj = 4; }
     {
-        static const int tall_tile = [] { const char* e = getenv("MI355XQR_TN_TALL_TILE"); int v_ = e ? atoi(e) : 44; return v_; }();
+        static const int tall_tile = 44;
         if (ti == 4 && tall_tile == 22 && K >= 65536 && (long long) M * N <= 512 * 512) { ti = 2; tj = 2; }
     }
     // the wide product of the trailing update on 128 x 256 workgroup tiles (gemm_tn_wide_kernel: A2 read N / 256 times instead of
@@ -1036,7 +1036,7 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     // overhead in K rows and reduce(k) the slab traffic of slab_reduce_kernel.  (The old rule aimed at 512 workgroups
     // whatever the stream: 624 workgroups on the 192-CU update stream = 1.6 rounds.)
     long long kmax = (K + 8 * BK - 1) / (8 * BK);             // each K slice at least 8 k-tiles long
-    static const int kcap = [] { const char* e = getenv("MI355XQR_TN_KMAX"); int v_ = e ? atoi(e) : 256; if (v_ < 1) v_ = 256; return v_; }();
+    static const int kcap = 256;
     if (kmax > kcap) kmax = kcap;
     if (slabs == nullptr || slab_cap < per) kmax = 1;
     else if ((size_t) kmax * per > slab_cap) kmax = (long long) (slab_cap / per);

@@ -876,173 +876,6 @@ static int gram32(hipStream_t s, const double* A, int ld, int mk, double* G, dou
     return qrd_slab_reduce(s, PW, PW, nslab, slabs, PW, (size_t) PW * PW, G, PW);
 }
 
-// K2: every workgroup factors G1 itself (one wave, ~2 us) and turns its 512 rows of A into rows of Q = A R1^-1 (-> Vw)
-// FULL = (w == 32): no per-column predicates.  (With `if (c < w)` around each store LLVM sinks the arithmetic of column c
-// into that column's block, i.e. reorders the solve column-major, keeping all 270 LDS loads live: 3.5 KB of scratch.)
-template <bool FULL>
-__global__ __launch_bounds__(PT) void cholq_kernel(const double* __restrict__ P, int ld, int mk, int w,
-                                                   const double* __restrict__ G1, double* __restrict__ R1,
-                                                   double* __restrict__ Vw, int ldv, int* __restrict__ guard)
-{
-    __shared__ double Rs[PW][PW + 1];
-    __shared__ double rinv[PW];
-    __shared__ int okf;
-    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
-    const int r = b * PT + tid;
-    double a[PW];
-    {
-        const double* p = P + min(r, mk - 1);
-#pragma unroll
-        for (int c = 0; c < PW; ++c) a[c] = (FULL || c < w) ? p[(size_t) c * ld] : 0.0;      // issued before the factorisation
-    }
-    if (tid < 64) {
-        const bool ok = chol_wave(G1, w, lane, Rs);
-        if (lane == 0) okf = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (tid < PW) rinv[tid] = 1.0 / Rs[tid][tid];
-    const bool ok = okf != 0;
-    if (b == 0) {
-        if (tid == 0) *guard = ok ? 0 : 1;
-        if (ok && tid < PW) {
-#pragma unroll
-            for (int k = 0; k < PW; ++k) R1[tid * PW + k] = Rs[k][tid];          // column tid
-        }
-    }
-    if (!ok) return;
-    __syncthreads();
-    if (r >= mk) return;
-    double q[PW];
-#pragma unroll
-    for (int k = 0; k < PW; ++k) {                                              // q R1 = a, column by column
-        q[k] = a[k] * rinv[k];
-#pragma unroll
-        for (int c = k + 1; c < PW; ++c) a[c] -= q[k] * Rs[k][c];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int c = 0; c < PW; ++c)
-        if (FULL || c < w) Vw[(size_t) c * ldv + r] = q[c];
-}
-
-// K4: second Cholesky pass + Householder reconstruction of the top block, one 16-wave workgroup (layout of hr_top_kernel:
-// lane r < 32 of wave g owns row r of the columns c = g + 16 q)
-__global__ __launch_bounds__(64 * HG) void hr2_kernel(const double* __restrict__ G2, const double* __restrict__ R1,
-                                                  double* __restrict__ Vw, int ldv, int w, double* __restrict__ A, int lda,
-                                                  double* __restrict__ tau, double* __restrict__ T, int ldt,
-                                                  double* __restrict__ Mout, int* __restrict__ guard)
-{
-    __shared__ double Bs[PW][PW + 1], R1s[PW][PW + 1], R2s[PW][PW + 1], R2i[PW][PW + 1], Qs[PW][PW + 1];
-    __shared__ double colb[2][PW];
-    __shared__ double Ss[PW];
-    __shared__ int flags[2];
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int r = lane;
-    const bool ra = r < w;
-    if (*guard != 0) return;                               // pass 1 already refused
-    if (threadIdx.x < 2) flags[threadIdx.x] = 0;
-    __syncthreads();
-    for (int el = threadIdx.x; el < PW * PW; el += 64 * HG) {
-        const int i = el % PW, c = el / PW;
-        const bool in = (i < w && c < w);
-        R1s[i][c] = (in && i <= c) ? R1[c * PW + i] : 0.0;
-        Qs[i][c] = in ? Vw[(size_t) c * ldv + i] : 0.0;
-        if (in) {
-            const double d = G2[(size_t) c * PW + i] - (i == c ? 1.0 : 0.0);
-            if (!(fabs(d) <= QRD_GUARD_THR)) flags[0] = 1;  // also catches NaN
-        }
-    }
-    __syncthreads();
-    if (flags[0]) { if (threadIdx.x == 0) *guard = 1; return; }
-    if (g == 0) {
-        const bool ok = chol_wave(G2, w, lane, R2s);
-        if (!ok && lane == 0) flags[1] = 1;
-    }
-    __syncthreads();
-    if (flags[1]) { if (threadIdx.x == 0) *guard = 1; return; }
-    if (g == 0) triu_inv_wave(R2s, lane, R2i);
-    __syncthreads();
-    double b[HQ], rt[HQ];
-#pragma unroll
-    for (int q = 0; q < HQ; ++q) {
-        const int c = g + HG * q;
-        double acc = 0.0, acr = 0.0;
-        if (ra && c < w) {
-            for (int k = 0; k <= c; ++k) acc += Qs[r][k] * R2i[k][c];             // Q1_top = Q_top R2^-1
-            for (int k = r; k <= c; ++k) acr += R2s[r][k] * R1s[k][c];            // R~ = R2 R1
-        }
-        b[q] = acc; rt[q] = acr;
-    }
-    HrStep<0>::lu(b, r, g, w, colb, Ss);
-    __syncthreads();
-    if (r < PW) {
-#pragma unroll
-        for (int q = 0; q < HQ; ++q) Bs[r][g + HG * q] = b[q];
-    }
-    __syncthreads();
-    double x[HQ], ui[HQ];
-#pragma unroll
-    for (int q = 0; q < HQ; ++q) {
-        const int c = g + HG * q;
-        x[q] = (ra && c <= r) ? -Ss[r] * Bs[c][r] : 0.0;          // -S U^T
-        ui[q] = (ra && r == c) ? 1.0 : 0.0;
-    }
-    HrStep<0>::xsolve(x, r, w, Bs);
-    HrStep<PW - 1>::uinv(ui, r, w, Bs);
-    __syncthreads();                                              // everyone is done with Qs
-    if (r < PW) {
-#pragma unroll
-        for (int q = 0; q < HQ; ++q) Qs[r][g + HG * q] = (ra && g + HG * q >= r) ? ui[q] : 0.0;     // Qs := U^-1
-    }
-    __syncthreads();
-    if (!ra) return;
-#pragma unroll
-    for (int q = 0; q < HQ; ++q) {
-        const int c = g + HG * q;
-        if (c < w) {
-            double m = 0.0;
-            for (int k = r; k <= c; ++k) m += R2i[r][k] * Qs[k][c];            // M = R2^-1 U^-1 (upper)
-            Mout[c * PW + r] = (c >= r) ? m : 0.0;
-            T[(size_t) r * ldt + c] = x[q];                                        // T(c, r) = X(r, c)
-            A[(size_t) c * lda + r] = (c >= r) ? Ss[r] * rt[q] : b[q];
-            Vw[(size_t) c * ldv + r] = (c < r) ? b[q] : (c == r ? 1.0 : 0.0);
-            if (c == r) tau[r] = x[q];
-        }
-    }
-}
-
-// K5: rows >= w of V = Q M, written into Vw and below the diagonal block of the panel
-template <bool FULL>
-__global__ __launch_bounds__(PT) void final2_kernel(double* __restrict__ Vw, int ldv, int mk, int w, const double* __restrict__ Mm,
-                                                    double* __restrict__ A, int lda, const int* __restrict__ guard)
-{
-    __shared__ double Ms[PW][PW + 1];
-    if (*guard != 0) return;
-    const int tid = threadIdx.x, r = blockIdx.x * PT + tid;
-    for (int el = tid; el < PW * PW; el += PT) {
-        const int i = el % PW, c = el / PW;
-        Ms[i][c] = (i < w && c < w && i <= c) ? Mm[c * PW + i] : 0.0;
-    }
-    double q[PW], v[PW];
-    {
-        const double* p = Vw + min(r, mk - 1);
-#pragma unroll
-        for (int c = 0; c < PW; ++c) { q[c] = (FULL || c < w) ? p[(size_t) c * ldv] : 0.0; v[c] = 0.0; }
-    }
-    __syncthreads();
-    if (r < w || r >= mk) return;
-#pragma unroll
-    for (int k = 0; k < PW; ++k) {
-#pragma unroll
-        for (int c = k; c < PW; ++c) v[c] += q[k] * Ms[k][c];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int c = 0; c < PW; ++c)
-        if (FULL || c < w) { Vw[(size_t) c * ldv + r] = v[c]; A[(size_t) c * lda + r] = v[c]; }
-}
-
-
 // =========================================================================================================
 // Second-generation CholeskyQR2 leaf: the same mathematics in 4 launches instead of 7 (plus the guard launches).
 //   gram32_kernel          G1 slabs (at most CQ2_MAXSLAB of them, so that a consumer can sum them itself)
@@ -2082,7 +1915,7 @@ static int nt_for(int rows) { return rows <= 64 ? 64 : (rows <= 128 ? 128 : (row
 // of two and the cross-wave sum has 4 partials instead of 8
 static int leaf_waves(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_LEAF_WAVES"); int v_ = (e && atoi(e) == 8) ? 8 : 4; return v_; }();
+    static const int v = 4;
     return v;
 }
 
@@ -2184,7 +2017,7 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     lv_rows[0] = mk; lv_chunk[0] = 0; lv_nblk[0] = (mk + brows0 - 1) / brows0; lv_off[0] = 0; lv_tau[0] = 0;
     // final3_u: the caller's last CholeskyQR2 launch (final3_kernel<true> with this U') is still to be issued -- fused with the
     // one-launch guard route where that exists (same grid), on its own otherwise
-    static const int fuse = [] { const char* e = getenv("MI355XQR_FUSE_GUARD"); int v_ = (e && atoi(e) == 0) ? 0 : 1; return v_; }();
+    static const int fuse = 1;
     const bool coop = guard && bar && coop_enabled() && lv_nblk[0] * w <= PT;
     const EpArgs ep0 = ep ? *ep : EpArgs{};
     const size_t ep_shm = ep ? EP_SMEM_BYTES : 0;
@@ -2196,7 +2029,7 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
     };
     if (final3_u && coop && fuse && brows0 == PT && w == PW) {
         if (gen == 3) {
-            static const int half_wg = [] { const char* e = getenv("MI355XQR_LEAF_HALFWG"); return e ? (int) (atoi(e) != 0) : 1; }();
+            static const int half_wg = 1;
             const int rows_wg = half_wg ? PT / 2 : PT;
             hipLaunchKernelGGL(final4_coop_kernel, dim3(half_wg ? (mk + rows_wg - 1) / rows_wg : lv_nblk[0]), dim3(PT), ep_shm, s, final3_u, lv_nblk[0],
                                brows0 / PT, mk, w, Vloc1, taus, Ts, stacks, Rt, Cup, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, rows_wg,
@@ -2208,7 +2041,7 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
         return (int) hipGetLastError();
     }
     // tall leaf behind a CholeskyQR2 attempt (second-generation kernels): final3 and the whole multi-level guard route in one launch
-    static const int tall_coop = [] { const char* e = getenv("MI355XQR_TALL_COOP"); return e ? (int) (atoi(e) != 0) : 1; }();
+    static const int tall_coop = 1;
     if (final3_u && gen == 2 && guard && bar && !coop && coop_enabled() && tall_coop && fuse && w == PW && brows0 == 2 * PT) {
         TallTree t{};
         t.nblk0 = lv_nblk[0]; t.halves = brows0 / PT;
@@ -2228,7 +2061,7 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
             t.L = Lv; t.top_off = off; t.top_rows = cur_rows;
             // participants: the launch is a no-op nearly always, and what a no-op costs is dispatching its workgroups (140 KB of LDS
             // each) -- 64 are gone in ~5 us; on the guard route they walk their blocks grid-stride (MI355XQR_TALL_COOP_G to change)
-            static const int gcap = [] { const char* e = getenv("MI355XQR_TALL_COOP_G"); const int v = e ? atoi(e) : 64; return v < 1 ? 64 : v; }();
+            static const int gcap = 64;
             int G = qrd_stream_cus(stream);
             if (G > gcap) G = gcap;
             if (G > t.nblk0) G = t.nblk0;
@@ -2236,7 +2069,7 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
             const int fblocks = (mk + PT - 1) / PT;
             // MI355XQR_TALL_COOP_FUSE=0: final3 always as its own launch (measured equal within noise at 65536 / 131072 rows:
             // 1.04 / 1.46 ms against 1.03 / 1.43 fused)
-            static const int fuse_tall = [] { const char* e = getenv("MI355XQR_TALL_COOP_FUSE"); return e ? (int) (atoi(e) != 0) : 1; }();
+            static const int fuse_tall = 1;
             if (fuse_tall && fblocks <= qrd_stream_cus(stream))
                 hipLaunchKernelGGL(final3_coop_tall_kernel, dim3(fblocks > G ? fblocks : G), dim3(PT), ep_shm, s, final3_u, t, G, mk, w, Vloc1, Vup,
                                    taus, Ts, stacks, Cup, Rt, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, ep ? 1 : 0, epw, ep0);
@@ -2303,11 +2136,11 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
 // Leaf = CholeskyQR2 + Householder reconstruction, guarded: 7 short launches, then the Householder-TSQR leaf above as
 // launches that return at once unless the guard word says the Cholesky route was refused for this leaf.
 // cws: QRD_CHOLQR_WS doubles (G1, G2, R1, M, guard word).
-// MI355XQR_LEAF=1 selects the first-generation launch sequence (7 launches + guards), 2 the second (4 launches, row solves on
+// MI355XQR_LEAF=2 selects the second-generation launch sequence (4 launches, row solves on
 // the vector ALUs), default 3 (4 launches, row solves as matrix-core products with explicit triangular inverses; short leaves)
 static int leaf_gen(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_LEAF"); int v_ = e ? atoi(e) : 3; if (v_ < 1 || v_ > 3) v_ = 3; return v_; }();
+    static const int v = [] { const char* e = getenv("MI355XQR_LEAF"); int v_ = e ? atoi(e) : 3; if (v_ < 2 || v_ > 3) v_ = 3; return v_; }();
     return v;
 }
 
@@ -2378,7 +2211,7 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
         // The fused launch has one 4-wave product workgroup per compute unit (~2 TB/s on a tall leaf) where the separate launch streams
         // at 3.3 TB/s; it wins while the product is shorter than that difference plus the reconstruction it hides (~28 us): up to
         // ~128 MB of operands (65536 x 256: 1.17 -> 1.11 ms; 262144 x 512: 6.96 -> 7.09, hence not there)
-        static const long long ep_max_mb = [] { const char* e = getenv("MI355XQR_EP_MAX_MB"); return (long long) (e ? atoi(e) : 128); }();
+        static const long long ep_max_mb = 128;
         if (N > 0 && 8LL * mk * (32 + N) <= ep_max_mb * 1000000LL &&
             eph->N1 % 32 == 0 && eph->N2 % 32 == 0 && mk % BK == 0 && mk >= BK && ep_vec_ok(Vw, ldv) &&
             (eph->N1 == 0 || ep_vec_ok(eph->B1, eph->ldb1)) && (eph->N2 == 0 || ep_vec_ok(eph->B2, eph->ldb2)) && eph->slabs &&
@@ -2424,7 +2257,7 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
         int nblk2 = nblk;                                   // workgroups of cholq2_kernel = slabs of G2
         if (nblk <= CQ2_MAXSLAB) {
             // short leaf (square problems): at most CQ2_MAXSLAB Gram slabs of >= 128 rows, summed by their consumers
-            static const int gslab_max = [] { const char* e = getenv("MI355XQR_GRAM_SLABS"); int v_ = e ? atoi(e) : CQ2_MAXSLAB; if (v_ < 1 || v_ > CQ2_MAXSLAB) v_ = CQ2_MAXSLAB; return v_; }();
+            static const int gslab_max = CQ2_MAXSLAB;
             int rows_per = ((mk + gslab_max - 1) / gslab_max + GKB - 1) / GKB * GKB;
             if (rows_per < 2 * GKB) rows_per = 2 * GKB;
             int nslab = (mk + rows_per - 1) / rows_per;
@@ -2433,7 +2266,7 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
             // 256-row workgroups where that keeps the partial Grams of G2 within CQ2_MAXSLAB (mk <= 8192, the chain-bound part of a
             // square factorisation): the kernel is bound by its 128 matrix-core instructions per wave -- at two waves per SIMD 7.4 us
             // of its 25 -- and half-size workgroups put them on twice the compute units
-            static const int half_wg = [] { const char* e = getenv("MI355XQR_LEAF_HALFWG"); int v_ = e ? atoi(e) != 0 : 1; return v_; }();
+            static const int half_wg = 1;
             if (gen == 3 && half_wg && (mk + 255) / 256 <= CQ2_MAXSLAB) {
                 nblk2 = (mk + 255) / 256;
                 hipLaunchKernelGGL((cholq3_kernel<256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk,
@@ -2449,7 +2282,7 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
             // 256-row workgroups, three to a compute unit
             // two row blocks per workgroup where that still leaves >= 1.5 workgroups per compute unit (262144 rows: 7.58 -> 7.31 ms
             // for the 512-column shard; 65536 rows: 2 % slower, half the chip would idle)
-            static const int rb_env = [] { const char* e = getenv("MI355XQR_TALL_RB"); int v_ = e ? atoi(e) : 0; return v_; }();
+            static const int rb_env = 0;
             const bool rb2 = rb_env == 2 || (rb_env != 1 && (mk + 511) / 512 >= 384);
             nblk2 = rb2 ? (mk + 511) / 512 : (mk + 255) / 256;
             if (gram_nslab > 0 && (size_t) gram_nslab * PW * PW <= slab_cap - (size_t) nblk2 * PW * PW)
@@ -2458,10 +2291,10 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
                 rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
             if (rc) return rc;
             slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
-            static const int tall_q = [] { const char* e = getenv("MI355XQR_TALL_Q"); int v_ = e ? atoi(e) : 4; return v_; }();
+            static const int tall_q = 4;
             if (tall_q == 4 && (mk & 3) == 0 && w == PW) {
                 // streaming form: one-wave Cholesky (R1, R1^-1 -> Mm, which hr3 overwrites later), then the matrix-core pass
-                static const int gq_max = [] { const char* e = getenv("MI355XQR_TALL_QGRID"); int v_ = e ? atoi(e) : 512; if (v_ < 32 || v_ > 2048) v_ = 512; return v_; }();
+                static const int gq_max = 512;
                 int gq = (mk + PT - 1) / PT;
                 if (gq > gq_max) gq = gq_max;
                 nblk2 = gq;
@@ -2496,16 +2329,8 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
         else
             hipLaunchKernelGGL(hr3_kernel<false>, dim3(1), dim3(64 * H3G), 0, s, g2src, g2n, R1, Vw, ldv, P, ld, tau, T, ldt, Mm, guard, bar);
         have_bar = true;                                    // final3_kernel<true>: issued by panel_tsqr_impl, fused with the guard route where it can
-    } else {
-        use_ep = false;                                     // first-generation launch sequence: the product stays a separate launch
-        rc = gram32(s, P, ld, mk, G1, slabs, slab_cap);
-        if (rc) return rc;
-        hipLaunchKernelGGL(cholq_kernel<true>, dim3(nblk), dim3(PT), 0, s, P, ld, mk, w, G1, R1, Vw, ldv, guard);
-        rc = gram32(s, Vw, ldv, mk, G2, slabs, slab_cap);
-        if (rc) return rc;
-        hipLaunchKernelGGL(hr2_kernel, dim3(1), dim3(64 * HG), 0, s, G2, R1, Vw, ldv, w, P, ld, tau, T, ldt, Mm, guard);
-        hipLaunchKernelGGL(final2_kernel<true>, dim3(nblk), dim3(PT), 0, s, Vw, ldv, mk, w, Mm, P, ld, guard);
-    }
+    } else
+        return panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, nullptr);     // unaligned operands: Householder route directly
     rc = (int) hipGetLastError();
     if (rc) return rc;
     rc = panel_tsqr_impl(stream, P, ld, mk, w, tau, T, ldt, Vw, ldv, ws, m_cap, guard, have_bar ? bar : nullptr, have_bar ? Mm : nullptr,

@@ -170,15 +170,6 @@ int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* 
 int qrd_gemm_nt(void* s, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt, double* C, int ldc, int gm,
                 unsigned long long* st)
 { (void) s; (void) sign; (void) gm; (void) st; chk("gemm_nt A", A, lda, M, K); chk("gemm_nt Bt", Bt, ldbt, N, K); chk("gemm_nt C", C, ldc, M, N); return 0; }
-int qrd_gemm_tnt(void* s, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* Ct, int ldct, double* slabs,
-                 size_t cap, int ks, int cus, int gm)
-{ (void) s; (void) ks; (void) cus; (void) gm; (void) slabs; (void) cap; chk("tnt A", A, lda, K, M); chk("tnt B", B, ldb, K, N); chk("tnt Ct", Ct, ldct, N, M); return 0; }
-int qrd_gemm_nn_batch(void* s, int M, int N, int K, double al, const double* A, int lda, size_t sA, const double* B, int ldb, size_t sB,
-                      double be, double* C, int ldc, size_t sC, int batch)
-{
-    for (int b = 0; b < batch; ++b) qrd_gemm_nn(s, M, N, K, al, A + sA * b, lda, B + sB * b, ldb, be, C + sC * b, ldc);
-    return 0;
-}
 static void leaf_chk(const char* w, double* P, int ld, int mk, int wd, double* tau, double* T, int ldt, double* Vw, int ldv)
 { chk(w, P, ld, mk, wd); chk(w, tau, wd, wd, 1); chk(w, T, ldt, wd, wd); chk(w, Vw, ldv, mk, wd); }
 int qrd_leaf_panel(void* s, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* scratch)
@@ -220,7 +211,7 @@ int qrd_panel_fused(void* s, double* A, int lda, int mk, int wh, double* tau, do
 {
     if (!qrd_panel_fused_ok(s, A, lda, mk, wh, Vw, ldv)) return -7;
     leaf_chk("panel_fused", A, lda, mk, wh, tau, T, ldt, Vw, ldv);
-    chk("panel_fused G", G, ldg, wh, wh);
+    if (G) chk("panel_fused G", G, ldg, wh, wh);           /* NULL: the caller forms V^T V itself */
     chkb("panel_fused ws", ws, sizeof(double) * qrd_panel_fused_ws_doubles());
     chkb("panel_fused status", status, 4 * sizeof(int));
     *epoch += 1024u;

@@ -306,11 +306,26 @@ def main():
             ts.factor(bufs[i % nbuf])
             ts.sync()
         lat_ms = (time.perf_counter() - t1) / reps * 1e3
-        lat = torch.tensor([lat_ms, loc_ms], dtype=torch.float64, device=coll_dev)
+        # the library's own timestamps of the last factorisation's gathers (stacked stream past its wait for the local panel ->
+        # collective done, summed over the block columns): what the exchange costs on THIS node, max over ranks
+        gs, gs_src = (be.tp.gather_stats(), "ncclAllGather per block column (RCCL)") if be.transport == "rccl" else (None, None)
+        if gs is None and be.tp.is_pipelined():
+            # bring-up transports (R factors through torch.distributed): the same pipelined schedule with this rank's own factor
+            # copied into every slot -- the fields exist and the event plumbing has run before the first RCCL run reads them
+            for i in range(3):
+                be.tp.factor_selfgather(bufs[i % nbuf], m_local, be.R)
+            gs, gs_src = be.tp.gather_stats(), "self-gather: device copies in place of the collective (transport %s)" % be.transport
+        lat = torch.tensor([lat_ms, loc_ms] + ([gs["gather_ms"], gs["gather_max_ms"], gs["call_ms"]] if gs else [0.0, 0.0, 0.0]),
+                           dtype=torch.float64, device=coll_dev)
         dist.all_reduce(lat, op=dist.ReduceOp.MAX)
         lat_ms, loc_ms = float(lat[0].item()), float(lat[1].item())
         tsqr_split = {"unpipelined_latency_ms": lat_ms, "local_qr_ms": loc_ms,
                       "exchange_and_stacked_qr_ms": lat_ms - loc_ms,
+                      "gather_ms": float(lat[2].item()) if gs else None,
+                      "gather_max_ms": float(lat[3].item()) if gs else None,
+                      "gather_call_ms": float(lat[4].item()) if gs else None,
+                      "fell_back_to_one_collective": bool(gs["fell_back"]) if gs else None,
+                      "gather_source": gs_src,
                       "pipelined_ms_per_step": dt / K * 1e3,
                       "panel_pipelined_exchange": bool(be.transport == "rccl" and be.tp.is_pipelined()),
                       "unpipelined_gflops": flops(m_total, n) / (lat_ms * 1e-3) / 1e9,

@@ -87,6 +87,7 @@ _sig("qr_tsqr_local_dev", C.c_int, _vp, _vp, C.c_int)
 _sig("qr_tsqr_exchange_buffers", C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp))
 _sig("qr_tsqr_stacked_dev", C.c_int, _vp, _vp)
 _sig("qr_tsqr_is_pipelined", C.c_int, _vp)
+_sig("qr_tsqr_gather_stats", C.c_int, _vp, C.POINTER(C.c_double))
 _sig("qr_tsqr_factor_virtual_dev", C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp))
 _sig("qr_tsqr_factor_selfgather_dev", C.c_int, _vp, _vp, C.c_int, _vp)
 _sig("qr_tsqr_sync", C.c_int, _vp)
@@ -477,7 +478,7 @@ class TsqrPlan:
         self.stacked = Plan(nranks * n, n, borrowed=sp) if sp else None
 
     def close(self):
-        if self.h:
+        if self.h and lib is not None:      # (at interpreter shutdown the module's globals may already be gone)
             lib.qr_tsqr_plan_destroy(self.h)
             self.h = None
 
@@ -494,6 +495,12 @@ class TsqrPlan:
 
     def is_pipelined(self):
         return bool(lib.qr_tsqr_is_pipelined(self.h))
+
+    def gather_stats(self):
+        """the exchange of the last pipelined factor(): per-gather intervals from the stacked stream's events (include/mi355x_qr.h)"""
+        out = (C.c_double * 5)()
+        check(lib.qr_tsqr_gather_stats(self.h, out), "qr_tsqr_gather_stats")
+        return {"gather_ms": out[0], "gather_max_ms": out[1], "call_ms": out[2], "pipelined": bool(out[3]), "fell_back": bool(out[4])}
 
     def local_factor(self, dA, lda):
         check(lib.qr_tsqr_local_dev(self.h, _dptr(dA), lda), "qr_tsqr_local_dev")

@@ -279,7 +279,9 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
      * trailing matrix.  "0" = no partition (shared CUs, stream priority only).  MI355XQR_PANEL_CUS=c is the
      * one-phase form.  Default: partition when there is a wide update worth overlapping with (n >= 2048);
      * tall-skinny problems are all panel, so they keep the whole chip on one stream set. */
-    int rc = qrd_stream_create(&p->s_main, 1);
+    /* (a multi-rank TSQR's local plan takes a normal-priority stream: the stacked plan's high-priority stream, which carries the exchange
+     * and the short stacked panels everyone is waiting for, goes first whenever both have work queued) */
+    int rc = qrd_stream_create(&p->s_main, !tsqr_local);
     p->stream = p->s_main;
     p->pair_cur = -1;
     if (!rc && p->lookahead) {
@@ -1605,9 +1607,16 @@ struct qr_tsqr_plan {
     double *drecv;                  /* nranks blocks of n x nb: one gathered block column (reused panel after panel, stream order) */
     double *Vst, *Tst;              /* explicit V (ldv2 x nb) and T (ldt x nb) of every stacked panel: later panels apply them */
     void *ev_pan[QR_TSQR_MAXPAN];   /* local panel k factored, its block column of R packed (local stream) */
-    void *ev_sent[QR_TSQR_MAXPAN];  /* the exchange has consumed send block k (stacked stream) */
+    void *ev_sent[QR_TSQR_MAXPAN];  /* the exchange has consumed send block k (stacked stream; with timing: end of gather k) */
+    void *ev_g0[QR_TSQR_MAXPAN];    /* the stacked stream is past its wait for local panel k: gather k starts (timing) */
+    void *ev_t0, *ev_t1;            /* first launch of a pipelined call (local stream) / its last (stacked stream) */
     int sent_pending[QR_TSQR_MAXPAN];
+    /* what the exchange costs on THIS node is not known before the first multi-rank run: the gathers are timed (qr_tsqr_gather_stats),
+     * and with MI355XQR_TSQR_PIPE unset the ranks decide TOGETHER, once, whether to keep the pipelined form (tsqr_decide) */
+    int pipe_auto, pipe_calls, pipe_fell_back, stats_valid;
+    double *dstat;                  /* 2 + 2 * nranks doubles: this rank's {gather sum, step} ms, then every rank's */
 };
+#define QR_TSQR_DECIDE_CALL 2       /* the decision is taken before this pipelined call (0-based): call 0 pays RCCL's lazy set-up, call 1 is warm */
 
 int qr_tsqr_unique_id(void* id128)
 {
@@ -1636,7 +1645,8 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
         if (!rc) rc = qrd_malloc((void**) &t->dQt, sizeof(double) * (size_t) t->sm * n);      /* not on first use: no hipMalloc beside running collectives */
         /* panel-pipelined exchange: MI355XQR_TSQR_PIPE=0 keeps the one-collective form */
         const int pnb = rc ? 0 : t->p->nb;
-        if (!rc && env_int("MI355XQR_TSQR_PIPE", 1) != 0 && !t->p->lookahead && !t->p2->lookahead && pnb == t->p2->nb && n % pnb == 0 &&
+        t->pipe_auto = getenv("MI355XQR_TSQR_PIPE") == NULL || strcmp(getenv("MI355XQR_TSQR_PIPE"), "auto") == 0;
+        if (!rc && (t->pipe_auto || env_int("MI355XQR_TSQR_PIPE", 1) != 0) && !t->p->lookahead && !t->p2->lookahead && pnb == t->p2->nb && n % pnb == 0 &&
             n / pnb >= 2 && n / pnb + 1 <= QR_TSQR_MAXPAN) {
             t->npan = n / pnb;
             for (int k = 0; k <= t->npan; ++k) t->pan_k[k] = k * pnb;
@@ -1653,8 +1663,12 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
             if (!rc) rc = qrd_memset(t->p2->s_main, t->Tst, 0, sizeof(double) * (size_t) t->npan * t->p2->ldt * pnb);
             for (int k = 0; k < t->npan && !rc; ++k) {
                 rc = qrd_event_create_notiming(&t->ev_pan[k]);
-                if (!rc) rc = qrd_event_create_notiming(&t->ev_sent[k]);
+                if (!rc) rc = qrd_event_create(&t->ev_sent[k]);
+                if (!rc) rc = qrd_event_create(&t->ev_g0[k]);
             }
+            if (!rc) rc = qrd_event_create(&t->ev_t0);
+            if (!rc) rc = qrd_event_create(&t->ev_t1);
+            if (!rc) rc = qrd_malloc((void**) &t->dstat, sizeof(double) * (size_t) (2 + 2 * nranks));
             if (!rc) rc = qrd_stream_sync(t->p2->s_main);
             t->pipe_ok = !rc;
         }
@@ -1691,11 +1705,14 @@ int qr_tsqr_plan_destroy(qr_tsqr_plan* t)
     if (t->ev_stacked) qrd_event_destroy(t->ev_stacked);
     if (t->ev_q) qrd_event_destroy(t->ev_q);
     qrd_free(t->dtau); qrd_free(t->dtau2); qrd_free(t->dRp); qrd_free(t->dRall); qrd_free(t->dS); qrd_free(t->dQt);
-    qrd_free(t->dsend); qrd_free(t->drecv); qrd_free(t->Vst); qrd_free(t->Tst);
+    qrd_free(t->dsend); qrd_free(t->drecv); qrd_free(t->Vst); qrd_free(t->Tst); qrd_free(t->dstat);
     for (int k = 0; k < QR_TSQR_MAXPAN; ++k) {
         if (t->ev_pan[k]) qrd_event_destroy(t->ev_pan[k]);
         if (t->ev_sent[k]) qrd_event_destroy(t->ev_sent[k]);
+        if (t->ev_g0[k]) qrd_event_destroy(t->ev_g0[k]);
     }
+    if (t->ev_t0) qrd_event_destroy(t->ev_t0);
+    if (t->ev_t1) qrd_event_destroy(t->ev_t1);
     qr_plan_destroy(t->p); qr_plan_destroy(t->p2);
     if (t->own_comm && t->comm) qrd_comm_destroy(t->comm);
     free(t);
@@ -1816,13 +1833,78 @@ static int tsqr_stacked_panel(qr_tsqr_plan* t, int pi)
     return rc;
 }
 
+/* the last pipelined call's gathers, from its events (both streams drained by the caller): sum and longest of ev_g0 -> ev_sent, and
+ * the whole call ev_t0 -> ev_t1.  A gather's interval starts when the stacked stream is past its wait for the LOCAL panel, so it holds
+ * the collective itself plus the wait for the slowest rank's panel -- what pipelining has to hide */
+static int tsqr_read_stats(qr_tsqr_plan* t, double* sum_ms, double* max_ms, double* step_ms)
+{
+    *sum_ms = *max_ms = *step_ms = 0.0;
+    if (!t->stats_valid) return 0;
+    for (int pi = 0; pi < t->npan; ++pi) {
+        float ms = 0.0f;
+        CHECK(qrd_event_elapsed_ms(t->ev_g0[pi], t->ev_sent[pi], &ms));
+        *sum_ms += ms;
+        if (ms > *max_ms) *max_ms = ms;
+    }
+    float st = 0.0f;
+    CHECK(qrd_event_elapsed_ms(t->ev_t0, t->ev_t1, &st));
+    *step_ms = st;
+    return 0;
+}
+
+/* out[0] = sum of the gathers' intervals (ms), out[1] = the longest, out[2] = the whole call, out[3] = 1 pipelined / 0 one collective,
+ * out[4] = 1 when the ranks' joint decision (MI355XQR_TSQR_PIPE unset) fell back to one collective.  Drains the plan's streams. */
+int qr_tsqr_gather_stats(qr_tsqr_plan* t, double* out5)
+{
+    if (!t || !out5) return QR_E_ARG;
+    CHECK(qr_tsqr_sync(t));
+    out5[3] = (t->pipe_ok && t->nranks > 1) ? 1.0 : 0.0;
+    out5[4] = t->pipe_fell_back ? 1.0 : 0.0;
+    return tsqr_read_stats(t, &out5[0], &out5[1], &out5[2]);
+}
+
+/* MI355XQR_TSQR_PIPE unset: before pipelined call QR_TSQR_DECIDE_CALL every rank puts {sum of its gathers, its step} of the previous
+ * (warm) call into ONE more all-gather, and every rank applies the same rule to the same 2 P numbers: if the slowest rank's gathers
+ * took more than half of the fastest rank's step, n / nb small collectives cannot hide behind the local factorisation on this node,
+ * and all ranks go back to the one-collective form from this call on -- together, because a rank that kept the pipelined order
+ * would wait for ever in a collective the others never issue.  (A fixed call index, no timing-dependent branch before it.) */
+static int tsqr_decide(qr_tsqr_plan* t, int self_gather)
+{
+    const int P = t->nranks;
+    double mine[2], step_ms = 0.0, mx = 0.0;
+    CHECK(qr_tsqr_sync(t));
+    CHECK(tsqr_read_stats(t, &mine[0], &mx, &step_ms));
+    mine[1] = step_ms;
+    double all[2 * 64];
+    if (P > 64) return 0;
+    if (self_gather || !t->comm) {
+        for (int q = 0; q < P; ++q) { all[2 * q] = mine[0]; all[2 * q + 1] = mine[1]; }
+    } else {
+        void* s2 = t->p2->s_main;
+        CHECK(qrd_h2d(s2, t->dstat, mine, sizeof mine));
+        CHECK(qrd_allgather_f64(t->comm, s2, t->dstat, t->dstat + 2, 2));
+        CHECK(qrd_d2h(s2, all, t->dstat + 2, sizeof(double) * 2 * (size_t) P));
+        CHECK(qrd_stream_sync(s2));
+    }
+    double gmax = 0.0, smin = 1e300;
+    for (int q = 0; q < P; ++q) {
+        if (all[2 * q] > gmax) gmax = all[2 * q];
+        if (all[2 * q + 1] < smin) smin = all[2 * q + 1];
+    }
+    if (gmax > 0.5 * smin) { t->pipe_ok = 0; t->pipe_fell_back = 1; t->stats_valid = 0; }
+    return 0;
+}
+
 static int tsqr_factor_pipelined(qr_tsqr_plan* t, double* dA, int lda, double* dR, int self_gather)
 {
     const int n = t->n;
     void* s2 = t->p2->s_main;
+    ++t->pipe_calls;
+    CHECK(qrd_event_record(t->ev_t0, t->p->s_main));
     for (int pi = 0; pi < t->npan; ++pi) {
         CHECK(tsqr_local_panel(t, dA, lda, pi));
         CHECK(qrd_stream_wait_event(s2, t->ev_pan[pi]));
+        CHECK(qrd_event_record(t->ev_g0[pi], s2));
         /* exactly the block column's own n x wout doubles (the half blocks at the end used to send a full n x nb from their start: the
          * tail of that range is the next block's, which the local stream may be repacking -- discarded by the receivers, but an
          * unordered read all the same) */
@@ -1838,6 +1920,8 @@ static int tsqr_factor_pipelined(qr_tsqr_plan* t, double* dA, int lda, double* d
     }
     CHECK(qr_extract_r_dev(t->p2, t->dS, t->sm, n, t->sm, dR, n, n));
     CHECK(qrd_event_record(t->ev_stacked, s2));
+    CHECK(qrd_event_record(t->ev_t1, s2));
+    t->stats_valid = 1;
     t->stacked_pending = 1;
     t->local_done = 0;
     return 0;
@@ -1881,6 +1965,7 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
 int qr_tsqr_factor_selfgather_dev(qr_tsqr_plan* t, double* dA, int lda, double* dR)
 {
     if (!t || !dA || !dR || lda < t->m_local || t->nranks < 2) return QR_E_ARG;
+    if (t->pipe_ok && t->pipe_auto && t->pipe_calls == QR_TSQR_DECIDE_CALL) CHECK(tsqr_decide(t, 1));
     if (t->pipe_ok) return tsqr_factor_pipelined(t, dA, lda, dR, 1);
     CHECK(qr_tsqr_local_dev(t, dA, lda));
     for (int q = 0; q < t->nranks; ++q)
@@ -1896,6 +1981,7 @@ int qr_tsqr_factor_dev(qr_tsqr_plan* t, double* dA, int lda, double* dR)
 {
     if (!t || !dA || !dR || lda < t->m_local) return QR_E_ARG;
     if (t->nranks > 1 && !t->comm) return QR_E_ARG;      /* plan made for an external transport: use local / exchange_buffers / stacked */
+    if (t->nranks > 1 && t->pipe_ok && t->pipe_auto && t->pipe_calls == QR_TSQR_DECIDE_CALL) CHECK(tsqr_decide(t, 0));
     if (t->nranks > 1 && t->pipe_ok) return tsqr_factor_pipelined(t, dA, lda, dR, 0);
     CHECK(qr_tsqr_local_dev(t, dA, lda));
     if (t->nranks > 1)

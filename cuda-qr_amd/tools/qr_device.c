@@ -6,11 +6,16 @@
  * figure times the whole host-pointer call.  The second figure is the same factorisation with the matrix already
  * resident in HBM (what bench.py reports).  The reference silently rounds m and n to fit its window ladder
  * (qr.cu:722-734); this library takes any m >= n, so the sizes are used as given.
+ *
+ * `./qr_device m n --compare` adds the vendor line the reference prints under ENABLE_MAGMA (qr.cu:790-806, "MAGMA ran QR on ..."):
+ * rocSOLVER's dgeqrf on the same matrix, resident in HBM.  rocSOLVER / rocBLAS are dlopen()ed by THIS tool only when the flag is
+ * given: the library never links or loads them.
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <dlfcn.h>
 
 #include "mi355x_qr.h"
 
@@ -23,9 +28,39 @@ static double now(void)
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+/* the comparator (qr.cu:555-565 magmaQR, timed at qr.cu:790-806): rocsolver_dgeqrf(handle, m, n, dA, lda, dtau), column-major in place */
+static int vendor_line(const double* A, double* dA, double* dtau, int m, int n, double flops)
+{
+    void* hb = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!hb) hb = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    void* hs = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!hs) hs = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    void* hh = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!hb || !hs || !hh) { printf("rocSOLVER not available on this machine (%s)\n", dlerror()); return 0; }
+    int (*create)(void**) = (int (*)(void**)) dlsym(hb, "rocblas_create_handle");
+    int (*destroy)(void*) = (int (*)(void*)) dlsym(hb, "rocblas_destroy_handle");
+    int (*geqrf)(void*, int, int, double*, int, double*) = (int (*)(void*, int, int, double*, int, double*)) dlsym(hs, "rocsolver_dgeqrf");
+    int (*devsync)(void) = (int (*)(void)) dlsym(hh, "hipDeviceSynchronize");
+    void* handle = NULL;
+    if (!create || !destroy || !geqrf || !devsync || create(&handle)) { printf("rocSOLVER not usable on this machine\n"); return 0; }
+    double el = 0.0;
+    for (int t = -1; t < TRIALS; t++) {             /* t = -1: untimed first call (workspace, kernel loading) */
+        if (qr_copy_to_device(dA, A, sizeof(double) * (size_t) m * n)) return 1;
+        devsync();
+        const double t0 = now();
+        if (geqrf(handle, m, n, dA, m, dtau) || devsync()) { fprintf(stderr, "rocsolver_dgeqrf failed\n"); destroy(handle); return 1; }
+        if (t >= 0) el += now() - t0;
+    }
+    destroy(handle);
+    printf("rocSOLVER ran QR on %dx%d matrix in %f s (avg over %d)   [matrix resident in HBM, %.1f GFLOP/s fp64]\n",
+           m, n, el / TRIALS, TRIALS, flops / (el / TRIALS) / 1e9);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
-    if (argc < 3) { puts("Usage: ./qr_device m n"); return 1; }
+    if (argc < 3) { puts("Usage: ./qr_device m n [--compare]"); return 1; }
+    const int compare = argc > 3 && strcmp(argv[3], "--compare") == 0;
     const int m = atoi(argv[1]), n = atoi(argv[2]);
     if (m < 1 || n < 1 || m < n) { fprintf(stderr, "need m >= n >= 1\n"); return 1; }
     printf("Exact problem size: %dx%d\n", m, n);
@@ -68,6 +103,7 @@ int main(int argc, char** argv)
     }
     printf(" MMQR ran QR on %dx%d matrix in %f s (avg over %d)   [matrix resident in HBM, %.1f GFLOP/s fp64]\n",
            m, n, el / TRIALS, TRIALS, flops / (el / TRIALS) / 1e9);
+    if (compare && vendor_line(A, dA, dtau, m, n, flops)) return 1;
     qr_device_free(dA); qr_device_free(dtau);
     qr_plan_destroy(p);
     free(A); free(RV);

@@ -145,6 +145,13 @@ int qr_tsqr_stacked_dev(qr_tsqr_plan* tp, double* dR);
  * qr_tsqr_factor_selfgather_dev: one rank's complete step with its own factor copied into every rank slot: the launches, streams and
  * events of a real rank minus the network (latency measurements on one GPU). */
 int qr_tsqr_is_pipelined(qr_tsqr_plan* tp);
+/* The exchange of the last pipelined qr_tsqr_factor_dev, from events on the stacked plan's stream (drains the plan's streams):
+ * out5[0] = sum over the block columns of [stacked stream past its wait for the local panel -> gather done] in ms, out5[1] = the longest
+ * of them, out5[2] = the whole call, out5[3] = 1 pipelined / 0 one collective, out5[4] = 1 when the ranks fell back together.
+ * With MI355XQR_TSQR_PIPE unset (or "auto") every rank contributes {out5[0], out5[2]} of its second call to one more all-gather before
+ * its third and all apply the same rule: slowest rank's gathers > half of the fastest rank's step -> one collective from then on
+ * (MI355XQR_TSQR_PIPE=1 keeps the pipelined form, =0 never uses it). */
+int qr_tsqr_gather_stats(qr_tsqr_plan* tp, double* out5);
 int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int nranks, double** dA_shards, int lda, double** dR);
 int qr_tsqr_factor_selfgather_dev(qr_tsqr_plan* tp, double* dA_shard, int lda, double* dR);
 int qr_tsqr_sync(qr_tsqr_plan* tp);

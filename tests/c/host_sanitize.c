@@ -38,6 +38,46 @@ static void factor_once(int pm, int pn, int nb, int m, int n, int with_q, int pr
     OK(qr_plan_destroy(p));
 }
 
+/* one rank of a multi-rank TSQR over the stub's thread communicators: four steps, the joint fall-back decision before the third */
+int qrd_comm_init_all(void** comms, int n, const int* devs);
+int qrd_comm_destroy(void* comm);
+typedef struct { void* comm; int rank, P, expect_fallback, bad; } tsqr_rank_arg;
+static void* tsqr_rank(void* arg)
+{
+    tsqr_rank_arg* a = (tsqr_rank_arg*) arg;
+    const int ml = 8192, n = 256;
+    qr_tsqr_plan* t = NULL;
+    double *dA = NULL, *dR = NULL, st[5];
+    OK(qr_tsqr_plan_create_comm(&t, a->comm, a->P, a->rank, ml, n, 64));
+    OK(qr_device_malloc((void**) &dA, sizeof(double) * (size_t) ml * n));
+    OK(qr_device_malloc((void**) &dR, sizeof(double) * (size_t) n * n));
+    if (!qr_tsqr_is_pipelined(t)) a->bad = 1;
+    for (int it = 0; it < 4; ++it) OK(qr_tsqr_factor_dev(t, dA, ml, dR));
+    OK(qr_tsqr_gather_stats(t, st));
+    if ((int) st[4] != a->expect_fallback || qr_tsqr_is_pipelined(t) == a->expect_fallback) a->bad = 2;
+    if (!a->expect_fallback && !(st[0] > 0.0 && st[1] > 0.0 && st[2] > st[0])) a->bad = 3;
+    OK(qr_tsqr_plan_destroy(t));
+    OK(qr_device_free(dA)); OK(qr_device_free(dR));
+    return NULL;
+}
+static int tsqr_ranks_run(int expect_fallback)
+{
+    enum { P = 3 };
+    void* comms[P];
+    const int devs[P] = {0, 1, 2};
+    pthread_t th[P];
+    tsqr_rank_arg args[P];
+    OK(qrd_comm_init_all(comms, P, devs));
+    for (int r = 0; r < P; ++r) {
+        args[r] = (tsqr_rank_arg){comms[r], r, P, expect_fallback, 0};
+        pthread_create(&th[r], NULL, tsqr_rank, &args[r]);
+    }
+    int bad = 0;
+    for (int r = 0; r < P; ++r) { pthread_join(th[r], NULL); if (args[r].bad) bad = args[r].bad; }
+    for (int r = P - 1; r >= 0; --r) qrd_comm_destroy(comms[r]);
+    return bad;
+}
+
 static void* host_caller(void* arg)
 {
     const int id = (int) (long) arg;
@@ -165,6 +205,21 @@ int main(void)
         OK(qr_tsqr_factor_selfgather_dev(tps[1], dA[1], ml, dR[1]));
         OK(qr_tsqr_formq_dev(tps[1], dA[1], ml, dA[0], ml));
         for (int r = 0; r < P; ++r) { OK(qr_tsqr_plan_destroy(tps[r])); OK(qr_device_free(dA[r])); OK(qr_device_free(dR[r])); }
+    }
+
+    /* 4c. three ranks (threads) over the stub communicators: the gathers are timed, and with MI355XQR_TSQR_PIPE unset the ranks
+     * decide together before their third step -- keep the pipelined exchange when the gathers are short, one collective when slow */
+    {
+        unsetenv("MI355XQR_TSQR_PIPE");
+        if (tsqr_ranks_run(0)) return 10;
+        setenv("QRD_STUB_GATHER_MS", "50", 1);
+        if (tsqr_ranks_run(1)) return 11;
+        unsetenv("QRD_STUB_GATHER_MS");
+        setenv("MI355XQR_TSQR_PIPE", "1", 1);                              /* forced on: no decision, slow gathers or not */
+        setenv("QRD_STUB_GATHER_MS", "50", 1);
+        if (tsqr_ranks_run(0)) return 12;
+        unsetenv("QRD_STUB_GATHER_MS");
+        unsetenv("MI355XQR_TSQR_PIPE");
     }
 
     /* 5. legacy-layout shim: argument checks and buffer sizes of the sliding-window path */

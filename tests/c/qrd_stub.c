@@ -111,10 +111,21 @@ int qrd_graph_destroy(void* exec) { free(exec); return 0; }
 int qrd_event_create(void** e) { *e = calloc(1, 8); return *e ? 0 : 2; }
 int qrd_event_create_notiming(void** e) { return qrd_event_create(e); }
 int qrd_event_destroy(void* e) { free(e); return 0; }
-int qrd_event_record(void* e, void* s) { (void) s; return e ? 0 : 1; }
+/* a record stamps the event with a process-wide tick (0.01 "ms" apart, or QRD_STUB_GATHER_MS after a collective: the joint fall-back
+ * decision of the pipelined exchange can be driven from a test), so that elapsed times are ordered like the records */
+static __thread double g_stub_tick = 0.0, g_stub_after_gather = 0.0;      /* per host thread = per rank */
+int qrd_event_record(void* e, void* s)
+{
+    (void) s;
+    if (!e) return 1;
+    g_stub_tick += 0.01 + g_stub_after_gather;
+    g_stub_after_gather = 0.0;
+    *(double*) e = g_stub_tick;
+    return 0;
+}
 int qrd_event_sync(void* e) { return e ? 0 : 1; }
 int qrd_stream_wait_event(void* s, void* e) { (void) s; return e ? 0 : 1; }
-int qrd_event_elapsed_ms(void* a, void* b, float* ms) { if (!a || !b) return 1; *ms = 0.125f; return 0; }
+int qrd_event_elapsed_ms(void* a, void* b, float* ms) { if (!a || !b) return 1; *ms = (float) (*(double*) b - *(double*) a); return 0; }
 int qrd_device_count(int* n) { const char* e = getenv("QRD_STUB_NDEV"); *n = e ? atoi(e) : 4; return 0; }
 int qrd_set_device(int d) { t_dev = d; return 0; }
 int qrd_get_device(int* d) { *d = t_dev; return 0; }
@@ -299,5 +310,6 @@ int qrd_allgather_f64(void* comm, void* stream, const double* send, double* recv
     pthread_barrier_wait(&c->w->bar);
     for (int q = 0; q < c->w->n; ++q) memcpy(recv + (size_t) q * count, c->w->send[q], count * sizeof(double));
     pthread_barrier_wait(&c->w->bar);
+    { const char* e = getenv("QRD_STUB_GATHER_MS"); if (e) g_stub_after_gather = atof(e); }
     return 0;
 }

@@ -487,6 +487,10 @@ def test_qr_device_cli_like_reference_harness(qr):
     assert m and 0.0 < float(m.group(1)) < 5.0
     usage = subprocess.run([exe], capture_output=True, text=True)
     assert usage.returncode == 1 and "Usage: ./qr_device m n" in usage.stdout
+    # --compare: the vendor line the reference prints under ENABLE_MAGMA (qr.cu:790-806), here rocSOLVER's dgeqrf
+    out = subprocess.run([exe, "2048", "256", "--compare"], check=True, capture_output=True, text=True).stdout
+    v = re.search(r"rocSOLVER ran QR on 2048x256 matrix in (\S+) s \(avg over 3\)", out)
+    assert (v and 0.0 < float(v.group(1)) < 5.0) or "rocSOLVER not" in out
 
 
 @pytest.mark.parametrize("m,n", [(1024, 1024), (2048, 2048), (1536, 1100)])

@@ -166,6 +166,10 @@ def test_bench_bringup_two_ranks_on_one_gpu_through_the_c_abi_plan(tmp_path):
     sp = line["tsqr_step_split"]
     assert sp["unpipelined_latency_ms"] >= sp["local_qr_ms"] > 0 and sp["pipelined_ms_per_step"] > 0
     assert line["config"]["collective"].startswith("1 all_gather")
+    # the exchange's own timestamps (here from the self-gather form: the transport is not RCCL) and the joint fall-back flag
+    print("tsqr_step_split:", {k: sp[k] for k in ("gather_ms", "gather_max_ms", "gather_call_ms", "fell_back_to_one_collective", "gather_source")})
+    assert sp["gather_ms"] > 0 and sp["gather_call_ms"] > sp["gather_max_ms"] > 0 and sp["fell_back_to_one_collective"] is False
+    assert "self-gather" in sp["gather_source"]
     one = line["same_problem_1gpu"]           # the same 262144 x 256 matrix on rank 0's GPU alone: the strong-scaling denominator
     assert one["ms"] > 0 and one["speedup_latency"] > 0 and one["speedup_throughput"] > 0
 

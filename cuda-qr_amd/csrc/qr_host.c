@@ -77,6 +77,7 @@ struct qr_plan {
     int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height;
                                  * 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
     double* chol_ws;
+    double* cq_ws; int* cq_status;   /* small-factor workspace and guard flag of the full-width tall panel (qr_panel_cqr.hip); NULL: not used */
     double* pf_ws;              /* exchange workspace of the one-launch panel (qr_panel_fused.hip); NULL: not used */
     unsigned pf_epoch;          /* its epoch counter: the workspace's epoch words never exceed it */
     int* pf_status;             /* device: [0] leaves that took the Householder route inside a one-launch panel, [1] a wait timed out */
@@ -116,6 +117,7 @@ typedef struct qr_knobs {
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
     int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
+    int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: tall panels (<= 128 columns) of at least this many rows at full width (0 = never) */
     int fused_gram;                                         /* MI355XQR_FUSED_GRAM: the panel's Gram blocks V_prev^T V_l inside that launch (else one launch after it) */
 } qr_knobs;
 static qr_knobs g_knobs;
@@ -138,6 +140,7 @@ static void knobs_init(void)
     k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
     k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
     k->fused_gram = env_int("MI355XQR_FUSED_GRAM", 0) != 0;
+    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 1 << 20);
 }
 
 static const qr_knobs* knobs(void)
@@ -395,7 +398,11 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         rc = qrd_malloc((void**) &p->slabs_ep, sizeof(double) * p->slab_ep_cap);
     }
     if (!rc && p->panel_tsqr == 3 && knobs()->fused_panel) {
-        rc = qrd_malloc((void**) &p->pf_ws, sizeof(double) * qrd_panel_fused_ws_doubles());
+        if (knobs()->cqr_min_rows > 0 && m >= knobs()->cqr_min_rows) {
+            rc = qrd_malloc((void**) &p->cq_ws, sizeof(double) * qrd_panel_cqr_ws_doubles());
+            if (!rc) rc = qrd_malloc((void**) &p->cq_status, 4 * sizeof(int));
+        }
+        if (!rc) rc = qrd_malloc((void**) &p->pf_ws, sizeof(double) * qrd_panel_fused_ws_doubles());
         if (!rc) rc = qrd_memset(p->stream, p->pf_ws, 0, sizeof(double) * qrd_panel_fused_ws_doubles());
         if (!rc) rc = qrd_malloc((void**) &p->pf_status, 4 * sizeof(int));
         if (!rc) rc = qrd_memset(p->stream, p->pf_status, 0, 4 * sizeof(int));
@@ -432,7 +439,7 @@ int qr_plan_destroy(qr_plan* p)
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
     qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
-    qrd_free(p->pf_ws); qrd_free(p->pf_status);
+    qrd_free(p->pf_ws); qrd_free(p->pf_status); qrd_free(p->cq_ws); qrd_free(p->cq_status);
     if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
     return 0;
@@ -621,6 +628,23 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
     return rc;
 }
 
+/* A tall half (mkh x wh, wh <= 128) at its full width: CholeskyQR2 + Householder reconstruction in six passes instead of the leaf chain's
+ * twelve (qr_panel_cqr.hip); T of the half comes out complete.  Returns 1 when the guard refused the panel (ill-conditioned: A is
+ * untouched, the caller runs the leaf chain), 0 when done.  The guard's verdict is read on the host: one drain of the stream per tall
+ * panel (~20 us beside a ~0.6 ms panel), never under stream capture. */
+static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, double* tauh, double* Th, int ldt, double* Vh, int ldv)
+{
+    CHECK(qrd_memset(p->stream, p->cq_status, 0, 4 * sizeof(int)));
+    CHECK(tn(p, wh, wh, mkh, Ah, lda, Ah, lda, qrd_panel_cqr_g1(p->cq_ws), 128, NULL));
+    CHECK(qrd_panel_cqr_stage1(p->stream, Ah, lda, mkh, wh, Vh, ldv, p->cq_ws, p->cq_status));
+    CHECK(tn(p, wh, wh, mkh, Vh, ldv, Vh, ldv, qrd_panel_cqr_g2(p->cq_ws), 128, NULL));
+    CHECK(qrd_panel_cqr_stage2(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status));
+    int st[4] = {0, 0, 0, 0};
+    CHECK(qrd_d2h(p->stream, st, p->cq_status, sizeof st));
+    CHECK(qrd_stream_sync(p->stream));
+    return st[0] != 0;
+}
+
 static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t, void* half_ready)
 {
     const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt, nb = p->nb;
@@ -652,7 +676,14 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         }
         /* the whole half in ONE launch (qr_panel_fused.hip: every leaf, its in-panel product and update; leaf T blocks, tau, V and
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
-        const int fused_half = p->pf_ws && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
+        int cqr_done = 0;
+        if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= kn->cqr_min_rows && wh >= 64 && qrd_panel_cqr_ok(mk - c0, wh)) {
+            const int rc = panel_cqr_half(p, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
+                                          p->Vw + (size_t) c0 * ldv + c0, ldv);
+            if (rc < 0) return rc;
+            cqr_done = rc == 0;
+        }
+        const int fused_half = !cqr_done && p->pf_ws && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
                                qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);
         if (fused_half) {
             CHECK(qrd_panel_fused(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
@@ -660,7 +691,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
                                   &p->pf_epoch, p->pf_status));
             gram_done = need_t && kn->fused_gram;
         }
-        for (int c = c0; c < cend && !fused_half; c += ib) {
+        for (int c = c0; c < cend && !fused_half && !cqr_done; c += ib) {
             const int w = imin(ib, cend - c), mkl = mk - c;
             double* P = Ak + (size_t) c * lda + c;
             double* Vl = p->Vw + (size_t) c * ldv + c;
@@ -713,7 +744,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         if (p->v_ready && nhalf == 1) CHECK(qrd_event_record(p->v_ready, p->stream));   /* V done; what follows only builds T */
         double* Vh = p->Vw + (size_t) c0 * ldv + c0;          /* this half's V: rows from c0 (zero above) */
         double* Thh = p->T + (size_t) c0 * ldt + c0;
-        if (wh > ib) {
+        if (wh > ib && !cqr_done) {
             double* Ghh = p->G + (size_t) c0 * nb + c0;
             if (!gram_done) CHECK(tn(p, wh, wh, mk - c0, Vh, ldv, Vh, ldv, Ghh, nb, NULL));       /* Gram of the half */
             /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the

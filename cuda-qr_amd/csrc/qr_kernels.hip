@@ -828,6 +828,7 @@ int qrd_init(void)
     rc |= qrd_panel_tsqr_init();
     rc |= qrd_leaf_fused_init();
     rc |= qrd_panel_fused_init();
+    rc |= qrd_panel_cqr_init();
     return rc;
 }
 

@@ -108,6 +108,7 @@ int main(void)
     factor_once(4096, 1024, 512, 4096, 1000, 1, 1);
     factor_once(70000, 96, 32, 70000, 96, 1, 0);
     factor_once(16384, 2048, 256, 4096, 2048, 0, 0);
+    factor_once(65536, 256, 128, 65536, 256, 1, 0);       /* tall panels at full width (qr_panel_cqr): accepted at 65536 rows, refused by the stub's guard at 65408 */
     setenv("MI355XQR_LOOKAHEAD", "1", 1);
     factor_once(3000, 2100, 128, 3000, 2100, 1, 1);
     factor_once(2304, 2304, 512, 2304, 2304, 0, 0);

@@ -208,6 +208,28 @@ int qrd_panel_cholqr_ep(void* s, double* P, int ld, int mk, int w, double* tau, 
     *did = (mk & 64) ? 0 : 1;          /* both outcomes are exercised */
     return 0;
 }
+/* the full-width tall panel: same shape rule as the real layer; panels whose height has bit 12 set are REFUSED by the (stub) guard, so
+ * that the host's fall-back to the leaf chain on the untouched panel is exercised as well */
+size_t qrd_panel_cqr_ws_doubles(void) { return 11 * 128 * 128 + 128; }
+int qrd_panel_cqr_init(void) { return 0; }
+int qrd_panel_cqr_ok(int mk, int w) { return w >= 32 && w <= 128 && w % 32 == 0 && mk >= 2 * w; }
+double* qrd_panel_cqr_g1(double* ws) { return ws; }
+double* qrd_panel_cqr_g2(double* ws) { return ws + 128 * 128; }
+int qrd_panel_cqr_stage1(void* s, const double* A, int lda, int mk, int w, double* Vw, int ldv, double* ws, int* status)
+{
+    (void) s;
+    chk("cqr stage1 A", A, lda, mk, w); chk("cqr stage1 Vw", Vw, ldv, mk, w);
+    chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); chkb("cqr status", status, 4 * sizeof(int));
+    if (mk & 4096) status[0] = 1;
+    return 0;
+}
+int qrd_panel_cqr_stage2(void* s, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)
+{
+    (void) s;
+    leaf_chk("cqr stage2", A, lda, mk, w, tau, T, ldt, Vw, ldv);
+    chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); chkb("cqr status", status, 4 * sizeof(int));
+    return 0;
+}
 size_t qrd_panel_fused_ws_doubles(void) { return 700000; }
 /* same shape rules as the real launch layer (whole leaves, <= 256 columns, <= 32 x 256 rows, rows a multiple of 4, aligned operands);
  * heights with bit 9 set are declined so that both routes of factor_panel are exercised */

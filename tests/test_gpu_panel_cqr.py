@@ -1,0 +1,138 @@
+"""-m gpu: the full-width tall panel (qr_panel_cqr.hip) against numpy -- CholeskyQR2 + Householder reconstruction of a whole panel of up
+to 128 columns in six passes.  Checked as a compact-WY panel: V unit lower trapezoidal and equal to the in-place tails, T upper
+triangular with tau on its diagonal and T^-1 + T^-T = V^T V, (I - V T V^T)^T P = [R; 0], R equal to LAPACK's up to the signs of its
+rows; ill-conditioned panels are refused with A untouched; and the whole route inside qr_geqrf_dev / the TSQR shard."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, host, zeros
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def q(qr):
+    qr.check(qr.lib.qrd_init(), "qrd_init")
+    L = qr.lib
+    L.qrd_panel_cqr_ws_doubles.restype = C.c_size_t
+    L.qrd_panel_cqr_g1.restype = C.c_void_p
+    L.qrd_panel_cqr_g1.argtypes = [C.c_void_p]
+    L.qrd_panel_cqr_g2.restype = C.c_void_p
+    L.qrd_panel_cqr_g2.argtypes = [C.c_void_p]
+    L.qrd_panel_cqr_ok.argtypes = [C.c_int, C.c_int]
+    L.qrd_panel_cqr_stage1.restype = C.c_int
+    L.qrd_panel_cqr_stage1.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.qrd_panel_cqr_stage2.restype = C.c_int
+    L.qrd_panel_cqr_stage2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p]
+    L.qrd_gemm_tn.restype = C.c_int
+    L.qrd_gemm_tn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                              C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    return qr
+
+
+def run_panel(q, P, lda=None, ldv=None):
+    mk, w = P.shape
+    lda, ldv = lda or mk, ldv or mk
+    buf = np.full((lda, w), 7.0)
+    buf[:mk] = P
+    dA, dV = dev(buf), zeros(ldv, w)
+    dT, dtau = dev(np.full((w, w), np.nan)), zeros(w, 1)
+    ws = torch.zeros(int(q.lib.qrd_panel_cqr_ws_doubles()), dtype=torch.float64, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    cap = 1 << 22
+    slabs = torch.zeros(cap, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    L = q.lib
+    g1, g2 = L.qrd_panel_cqr_g1(ws.data_ptr()), L.qrd_panel_cqr_g2(ws.data_ptr())
+    assert L.qrd_gemm_tn(None, w, w, mk, 1.0, dA.data_ptr(), lda, dA.data_ptr(), lda, 0.0, g1, 128, slabs.data_ptr(), cap, None, 0) == 0
+    assert L.qrd_panel_cqr_stage1(None, dA.data_ptr(), lda, mk, w, dV.data_ptr(), ldv, ws.data_ptr(), status.data_ptr()) == 0
+    assert L.qrd_gemm_tn(None, w, w, mk, 1.0, dV.data_ptr(), ldv, dV.data_ptr(), ldv, 0.0, g2, 128, slabs.data_ptr(), cap, None, 0) == 0
+    assert L.qrd_panel_cqr_stage2(None, dA.data_ptr(), lda, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), ldv, ws.data_ptr(),
+                                  status.data_ptr()) == 0
+    q.check(L.qrd_device_sync(), "sync")
+    out = host(dA)
+    assert np.array_equal(out[mk:], buf[mk:]), "rows below the panel are never written"
+    return out[:mk], host(dV)[:mk], host(dT), host(dtau)[:, 0], status.cpu().numpy()
+
+
+def check_panel(P, out, V, T, tau):
+    mk, w = P.shape
+    assert np.isfinite(out).all() and np.isfinite(V).all() and np.isfinite(T).all() and np.isfinite(tau).all()
+    assert np.array_equal(np.triu(V[:w], 1), np.zeros((w, w))) and np.array_equal(np.diag(V[:w]), np.ones(w))
+    assert np.array_equal(np.tril(V, -1), np.tril(out, -1)), "explicit V and in-place tails must agree"
+    assert np.array_equal(np.tril(T, -1), np.zeros((w, w))) and np.array_equal(np.diag(T), tau)
+    Ti = np.linalg.inv(T)
+    assert np.abs(Ti + Ti.T - V.T @ V).max() < 1e-11 * max(1.0, np.abs(Ti).max())          # compact-WY identity
+    QtP = P - V @ (T.T @ (V.T @ P))
+    scale = np.abs(P).max()
+    assert np.abs(np.tril(QtP, -1)).max() < 1e-11 * np.sqrt(mk) * scale
+    assert np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-11 * np.sqrt(mk) * scale
+    R = np.triu(out[:w])
+    Rref = np.linalg.qr(P, mode="r")
+    S = np.sign(np.diag(R)) * np.sign(np.diag(Rref))
+    assert np.linalg.norm(S[:, None] * R - Rref) / np.linalg.norm(Rref) < 1e-12
+    # Householder's sign convention (reference qr.c:141-151): the diagonal of R has the sign opposite to the pivot it annihilates
+    assert R[0, 0] * P[0, 0] < 0
+
+
+@pytest.mark.parametrize("mk,w", [(4096, 128), (4096, 64), (5000, 96), (1000, 32), (20000, 128), (300, 128), (32768, 128), (40003, 64)])
+def test_panel_cqr_well_conditioned(q, mk, w):
+    P = np.random.default_rng(mk + w).random((mk, w))
+    out, V, T, tau, st = run_panel(q, P, lda=mk + 6, ldv=mk + 2)
+    assert st[0] == 0, "the guard refused a well-conditioned panel"
+    check_panel(P, out, V, T, tau)
+
+
+def test_panel_cqr_moderately_conditioned_takes_the_second_cholesky(q):
+    """cond ~ 3e5: |Q^T Q - I| after one pass is far above 1e-9 (second Cholesky instead of the first-order factor), still below 1/64"""
+    rng = np.random.default_rng(3)
+    mk, w = 8192, 128
+    U, _ = np.linalg.qr(rng.standard_normal((mk, w)))
+    W, _ = np.linalg.qr(rng.standard_normal((w, w)))
+    P = (U * np.logspace(0, -5.5, w)) @ W.T
+    out, V, T, tau, st = run_panel(q, P)
+    assert st[0] == 0
+    check_panel(P, out, V, T, tau)
+
+
+@pytest.mark.parametrize("kind", ["rank_deficient", "cond_1e9", "nan"])
+def test_panel_cqr_refuses_and_leaves_the_panel_untouched(q, kind):
+    rng = np.random.default_rng(11)
+    mk, w = 4096, 128
+    P = rng.random((mk, w))
+    if kind == "rank_deficient":
+        P[:, 77] = P[:, 3] + P[:, 5]
+    elif kind == "cond_1e9":
+        U, _ = np.linalg.qr(rng.standard_normal((mk, w)))
+        W, _ = np.linalg.qr(rng.standard_normal((w, w)))
+        P = (U * np.logspace(0, -9, w)) @ W.T
+    else:
+        P[100, 7] = np.nan
+    out, V, T, tau, st = run_panel(q, P)
+    assert st[0] == 1
+    assert np.array_equal(out, P, equal_nan=True), "a refused panel must be left exactly as it was"
+
+
+@pytest.mark.parametrize("m,n,nb", [(65536, 256, 128), (40000, 192, 64), (70001, 128, 128)])
+def test_geqrf_takes_the_full_width_route_on_tall_shapes(qr, m, n, nb):
+    """qr_geqrf_dev on tall shapes (with MI355XQR_CQR_MIN_ROWS=32768 in the environment every panel takes the full-width route; the default threshold is higher) against LAPACK"""
+    A = np.random.default_rng(m + n).random((m, n))
+    p = qr.Plan(m, n, nb, 32)
+    dA, dtau, dQ = dev(A), zeros(n, 1), zeros(m, n)
+    p.geqrf(dA, m, n, m, dtau)
+    p.sync()
+    F = host(dA)
+    p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+    p.sync()
+    Q = host(dQ)
+    p.close()
+    R = np.triu(F[:n])
+    Rref = np.linalg.qr(A, mode="r")
+    S = np.sign(np.diag(R)) * np.sign(np.diag(Rref))
+    assert np.linalg.norm(S[:, None] * R - Rref) / np.linalg.norm(Rref) < 1e-12
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12

@@ -39,12 +39,15 @@ constexpr int CQ_X1 = 7 * CQ_W * CQ_W;    // scratch operands, row-major
 constexpr int CQ_X2 = 8 * CQ_W * CQ_W;
 constexpr int CQ_RR = 9 * CQ_W * CQ_W;    // R = S R2 R1 row-major
 constexpr int CQ_TT = 10 * CQ_W * CQ_W;   // T row-major
-constexpr int CQ_SV = 11 * CQ_W * CQ_W;   // S (CQ_W doubles)
-constexpr int CQ_ST = 11 * CQ_W * CQ_W + CQ_W;   // 64 phase stamps of the one-workgroup kernels (CQ_STAMPS builds)
+constexpr int CQ_X3 = 11 * CQ_W * CQ_W;
+constexpr int CQ_SV = 12 * CQ_W * CQ_W;   // S (CQ_W doubles)
+constexpr int CQ_ST = 12 * CQ_W * CQ_W + CQ_W;   // 64 phase stamps of the one-workgroup kernels (CQ_STAMPS builds)
 constexpr int CQ_WS = CQ_ST + 64;
 
-__device__ __forceinline__ double cq_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cq_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Workspace traffic of the one-workgroup kernels: plain stores and loads.  Every workspace matrix is written ONCE per launch and read
+// only after cq_sync_global() (so no line of it can be in this compute unit's cache before it is written); agent-scope atomic stores
+// were measured at ~0.3 us EACH here (the compiler waits for every one of them: 64 per thread = 20 us per matrix written)
+__device__ __forceinline__ void cq_st(double* p, double v) { *p = v; }
 
 #ifdef CQ_STAMPS
 #define CQ_STAMP(n) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(ws + CQ_ST)[n] = wall_clock64(); } while (0)
@@ -54,14 +57,28 @@ __device__ __forceinline__ void cq_st(double* p, double v) { __hip_atomic_store(
 // barrier after which this workgroup's own global (workspace) stores can be read back by any of its threads
 __device__ __forceinline__ void cq_sync_global() { __threadfence(); __syncthreads(); }
 
+// Elementwise pass over the w x 128 index space (e -> (e >> 7, e & 127)) with the loads of 16 elements per thread requested together:
+// a rolled loop with a dependent global load per iteration costs the memory latency (~0.4 us) EVERY iteration -- 64 iterations = 25 us
+template <class FL, class FS>
+__device__ __forceinline__ void cq_elems(int w, int tid, FL load, FS store)
+{
+    const int n = w * CQ_W;
+    for (int base = tid; base < n; base += 16 * CQ_T) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int e = base + u * CQ_T; v[u] = load((e < n ? e : tid) >> 7, (e < n ? e : tid) & (CQ_W - 1)); }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int e = base + u * CQ_T; if (e < n) store(e >> 7, e & (CQ_W - 1), v[u]); }
+    }
+}
+
 // LDS of the one-workgroup kernels
 struct CqLds {
-    double* M;            // [CQ_LD][CQ_LD]: an upper-triangular matrix on and above the diagonal, its inverse X transposed strictly
-                          // below it (X(i, j) at M[j + 1][i])
-    double* row;          // [2][CQ_W] pivot row of the current / next elimination step
-    double* col;          // [2][CQ_W] pivot column
+    double* M;            // [CQ_LD][CQ_LD]: the working matrix; for the inverses an upper-triangular matrix on and above the diagonal and
+                          // its inverse X transposed strictly below it (X(i, j) at M[j + 1][i])
+    double* sb1;          // [32][33] block scratch: L11^-1 (R11^-T) of the current diagonal block
+    double* sb2;          // [32][33] block scratch: U'11^-1
     double* sv;           // [CQ_W] signs
-    double* sb;           // [32][33] block scratch of the inverse
     double* red;          // [CQ_T / 64] reduction scratch
     int* flag;            // [4]
 };
@@ -69,67 +86,14 @@ __device__ __forceinline__ CqLds cq_lds(double* sm)
 {
     CqLds L;
     L.M = sm;
-    L.row = L.M + CQ_LD * CQ_LD;
-    L.col = L.row + 2 * CQ_W;
-    L.sv = L.col + 2 * CQ_W;
-    L.sb = L.sv + CQ_W;
-    L.red = L.sb + 32 * 33;
+    L.sb1 = L.M + CQ_LD * CQ_LD;
+    L.sb2 = L.sb1 + 32 * 33;
+    L.sv = L.sb2 + 32 * 33;
+    L.red = L.sv + CQ_W;
     L.flag = reinterpret_cast<int*>(L.red + CQ_T / 64);
     return L;
 }
-constexpr size_t CQ_LDS_BYTES = sizeof(double) * (CQ_LD * CQ_LD + 4 * CQ_W + CQ_W + 32 * 33 + CQ_T / 64) + 64;
-
-// thread (ti, tj) of the 16 x 16 grid owns elements (ti + 16 a, tj + 16 b), a, b = 0 .. 7
-#define CQ_FOR_TILE for (int a = 0; a < CQ_E; ++a) for (int b = 0; b < CQ_E; ++b)
-
-// right-looking Cholesky of the symmetric matrix whose upper triangle sits in the register tiles: R (upper) -> L.M, row by row.
-// One barrier per column: the pivot row of step k + 1 is published by its owners at the end of step k.  Blocks of 16 x 16 elements
-// (one per thread and (a, b)) that lie entirely above the pivot row or below the diagonal are skipped by uniform branches.
-__device__ __forceinline__ bool cq_chol(double (&t)[CQ_E][CQ_E], const CqLds& L, int w, int ti, int tj, int tid)
-{
-    bool ok = true;
-    const int nbk = w >> 4;
-    if (ti == 0)
-#pragma unroll
-        for (int b = 0; b < CQ_E; ++b) L.row[tj + 16 * b] = t[0][b];
-    for (int k = 0; k < w; ++k) {
-        __syncthreads();
-        const double* rk = L.row + (k & 1) * CQ_W;
-        const double p = rk[k];
-        ok = ok && (p > 0.0);                                 // false for NaN as well
-        const double inv = rcp_newton(p);
-        if (tid < w) L.M[k * CQ_LD + tid] = (tid >= k) ? rk[tid] * rsqrt_newton(p) : 0.0;
-        const int a0 = k >> 4;                                // blocks a < a0 lie above the pivot row
-        double rj[CQ_E];
-#pragma unroll
-        for (int b = 0; b < CQ_E; ++b) rj[b] = (b >= a0 && b < nbk) ? rk[tj + 16 * b] : 0.0;
-#pragma unroll
-        for (int a = 0; a < CQ_E; ++a) {
-            if (a >= a0 && a < nbk) {
-                const int i = ti + 16 * a;
-                const double li = rk[i] * inv;
-#pragma unroll
-                for (int b = 0; b < CQ_E; ++b) {
-                    if (b >= a && b < nbk) {
-                        const int j = tj + 16 * b;
-                        if (i > k && j >= i) t[a][b] -= li * rj[b];
-                    }
-                }
-            }
-        }
-        const int kn = k + 1;
-        if (kn < w && ti == (kn & 15)) {
-            double* rn = L.row + (kn & 1) * CQ_W;
-#pragma unroll
-            for (int a = 0; a < CQ_E; ++a)
-                if (a == (kn >> 4))
-#pragma unroll
-                    for (int b = 0; b < CQ_E; ++b) rn[tj + 16 * b] = t[a][b];
-        }
-    }
-    __syncthreads();
-    return ok;
-}
+constexpr size_t CQ_LDS_BYTES = sizeof(double) * (CQ_LD * CQ_LD + 2 * 32 * 33 + CQ_W + CQ_T / 64) + 64;
 
 // one 16 x 16 tile of a product on the matrix cores: sum over k0 <= k < k1 (multiples of 4) of a(i0 + p, k) b(k, j0 + q).
 // Accumulator register r of a lane: row i0 + (lane >> 4) + 4 r, column j0 + (lane & 15)
@@ -138,8 +102,159 @@ __device__ __forceinline__ v4d cq_tile(FA a, FB b, int i0, int j0, int k0, int k
 {
     const int l15 = lane & 15, l4 = lane >> 4;
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
     for (int k = k0; k < k1; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(i0 + l15, k + l4), b(k + l4, j0 + l15), acc, 0, 0, 0);
     return acc;
+}
+
+// A list of 16 x 16 tiles dealt to the four waves; tile tl of a grid with ntc tile columns.  compute(i0, j0) -> accumulator,
+// store(i, j, value).  With `barrier` the stores wait until every wave has computed its tiles (in-place products whose operands
+// overlap the tiles written).  At most CQ_MAXT tiles per wave.
+constexpr int CQ_MAXT = 9;
+template <class FC, class FS>
+__device__ __forceinline__ void cq_tiles(int nt, int ntc, int r0, int c0, bool upper_only, bool barrier, int tid, FC compute, FS store)
+{
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    v4d acc[CQ_MAXT];
+#pragma unroll
+    for (int q = 0; q < CQ_MAXT; ++q) {
+        const int tl = wave + 4 * q, tr = tl / ntc, tc = tl - tr * ntc;
+        if (tl < nt && (!upper_only || tc >= tr)) acc[q] = compute(r0 + 16 * tr, c0 + 16 * tc);
+    }
+    if (barrier) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CQ_MAXT; ++q) {
+        const int tl = wave + 4 * q, tr = tl / ntc, tc = tl - tr * ntc;
+        if (tl < nt && (!upper_only || tc >= tr))
+#pragma unroll
+            for (int r = 0; r < 4; ++r) store(r0 + 16 * tr + l4 + 4 * r, c0 + 16 * tc + l15, acc[q][r]);
+    }
+    __syncthreads();
+}
+
+// Blocked right-looking Cholesky of the symmetric matrix whose upper triangle is in L.M: R (upper) in place.  Per block of 32 columns:
+// the diagonal block on wave 0 in registers (the leaves' CholAugStep: R11 on the lower lanes, R11^-T on the upper ones), then
+// R12 = R11^-T G12 and G22 -= R12^T R12 on the matrix cores.  Returns false on a non-positive pivot (uniform).
+__device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
+{
+    const int wave = tid >> 6;
+    auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
+    if (tid == 0) L.flag[0] = 1;
+    __syncthreads();
+    for (int o = 0; o < w; o += 32) {
+        if (wave == 0) {
+            int lane = tid & 63;
+            asm volatile("" : "+v"(lane));                    // keeps the unrolled recurrence's lane constants inside this iteration
+            const int c = lane & 31;
+            double g[PW];
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+                g[i] = (lane < PW) ? ((i <= c) ? L.M[(o + i) * CQ_LD + o + c] : L.M[(o + c) * CQ_LD + o + i]) : (i == c ? 1.0 : 0.0);
+            bool ok = true;
+            CholAugStep<0>::run(g, lane, ok);
+            if (!ok) L.flag[0] = 0;                            // (every lane of the wave saw the same pivots)
+            if (lane < PW) {
+#pragma unroll
+                for (int i = 0; i < PW; ++i) L.M[(o + i) * CQ_LD + o + c] = (i <= c) ? g[i] : 0.0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < PW; ++i) L.sb1[i * 33 + c] = (i >= c) ? g[i] : 0.0;      // sb1[i][k] = R11^-T(i, k)
+            }
+        }
+        __syncthreads();
+        const int rest = w - o - 32;
+        if (rest > 0) {
+            auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
+            cq_tiles(2 * (rest >> 4), rest >> 4, o, o + 32, false, true, tid,
+                     [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, tid & 63); },
+                     [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
+            auto Mt = [&](int i, int k) { return L.M[k * CQ_LD + i]; };
+            cq_tiles((rest >> 4) * (rest >> 4), rest >> 4, o + 32, o + 32, true, false, tid,
+                     [&](int i0, int j0) { return cq_tile(Mt, Mx, i0, j0, o, o + 32, tid & 63); },
+                     [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
+        }
+    }
+    return L.flag[0] != 0;
+}
+
+// Blocked modified LU of W - S R2 = L1 U' (W in L.M, whole; R2 row-major in global memory, zero below its diagonal), the sign of every
+// pivot chosen as Householder would (reference qr.c:141-151).  Per block of 32 columns: the diagonal block on wave 0 in registers (the
+// leaves' Hr3Lu: L11 \ U'11 on the lower lanes, L11^-1 on the upper ones) while wave 1 ... then U'11^-1 on wave 1, and on the matrix
+// cores U'12 = L11^-1 (W12 - S R2_12), L21 = W21 U'11^-1, W22 -= L21 U'12.  L1 \ U' in place, S -> L.sv.
+__device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const double* R2g, int tid)
+{
+    const int wave = tid >> 6;
+    auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
+    for (int o = 0; o < w; o += 32) {
+        if (wave == 0) {
+            int lane = tid & 63;
+            asm volatile("" : "+v"(lane));
+            const int c = lane & 31;
+            double b[PW], g[PW];
+#pragma unroll
+            for (int r = 0; r < PW; ++r) {
+                b[r] = (lane < PW) ? L.M[(o + r) * CQ_LD + o + c] : (r == c ? 1.0 : 0.0);
+                g[r] = (lane < PW && r <= c) ? R2g[(o + r) * CQ_W + o + c] : 0.0;
+            }
+            double sgn = 1.0;
+            Hr3Lu<0>::run(b, g, lane, sgn);
+            if (lane < PW) {
+#pragma unroll
+                for (int r = 0; r < PW; ++r) L.M[(o + r) * CQ_LD + o + c] = b[r];
+                L.sv[o + c] = sgn;
+            } else {
+#pragma unroll
+                for (int r = 0; r < PW; ++r) L.sb1[r * 33 + c] = (r >= c) ? b[r] : 0.0;      // sb1[i][k] = L11^-1(i, k)
+            }
+        }
+        __syncthreads();
+        const int rest = w - o - 32;
+        if (rest <= 0) break;
+        if (wave == 1) {                                       // U'11^-1 -> sb2, a column per lane in registers
+            const int lane = tid & 63, j = lane & 31;
+            const double dinv = rcp_newton(L.M[(o + j) * CQ_LD + o + j]);
+            double x[32];
+#pragma unroll
+            for (int i = 31; i >= 0; --i) {
+                double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = i + 1; k < 32; ++k) acc -= L.M[(o + i) * CQ_LD + o + k] * x[k];
+                x[i] = (i <= j) ? acc * readlane_f64(dinv, i) : 0.0;
+            }
+            if (lane < 32)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) L.sb2[i * 33 + j] = x[i];
+        }
+        // U'12 = L11^-1 (W12 - S R2_12): operands and result share W12 -> stores behind a barrier
+        auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
+        {   // W12 -= S R2_12 first, the R2 values of a thread requested together (element e: row o + (e >> 7), column o + 32 + (e & 127))
+            double r2[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + u * CQ_T, jj = e & (CQ_W - 1);
+                r2[u] = R2g[(o + (e >> 7)) * CQ_W + (jj < rest ? o + 32 + jj : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + u * CQ_T, k = o + (e >> 7), jj = e & (CQ_W - 1);
+                if (jj < rest) L.M[k * CQ_LD + o + 32 + jj] -= L.sv[k] * r2[u];
+            }
+            __syncthreads();
+        }
+        cq_tiles(2 * (rest >> 4), rest >> 4, o, o + 32, false, true, tid,
+                 [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, tid & 63); },
+                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
+        // L21 = W21 U'11^-1 (the barrier of the call above also published sb2)
+        auto Ui = [&](int k, int j) { return L.sb2[(k - o) * 33 + (j - o)]; };
+        cq_tiles((rest >> 4) * 2, 2, o + 32, o, false, true, tid,
+                 [&](int i0, int j0) { return cq_tile(Mx, Ui, i0, j0, o, o + 32, tid & 63); },
+                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
+        // W22 -= L21 U'12
+        cq_tiles((rest >> 4) * (rest >> 4), rest >> 4, o + 32, o + 32, false, false, tid,
+                 [&](int i0, int j0) { return cq_tile(Mx, Mx, i0, j0, o, o + 32, tid & 63); },
+                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
+    }
+    __syncthreads();
 }
 
 // inverse of the upper-triangular matrix in L.M (rows / columns < w, w a multiple of 32); the off-diagonal blocks of the matrix are
@@ -149,38 +264,59 @@ __device__ __forceinline__ v4d cq_tile(FA a, FB b, int i0, int j0, int k0, int k
 // column of X on distinct banks)
 __device__ __forceinline__ void cq_offdiag(const CqLds& L, int r0, int nr, int c0, int nc, int tid)
 {
-    // X(r0 : r0 + nr, c0 : c0 + nc) = -X(r0 .., r0 ..) (R(r0 .., c0 ..) X(c0 .., c0 ..)), nr, nc multiples of 16, c0 = r0 + nr
+    // X(r0 : r0 + nr, c0 : c0 + nc) = -X(r0 .., r0 ..) (R(r0 .., c0 ..) X(c0 .., c0 ..)), nr, nc multiples of 16 up to 64, c0 = r0 + nr.
+    // A wave owns a tile COLUMN (its B fragment is shared by the up to four tile rows, whose accumulators interleave on the matrix
+    // core: a chain of dependent f64 MFMAs issues one every ~70 cycles, four independent ones every 16)
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int ntc = nc >> 4, nt = (nr >> 4) * ntc;           // at most 16 tiles: up to four per wave
-    auto R = [&](int i, int k) { return L.M[i * CQ_LD + k]; };
-    auto X = [&](int k, int j) { return (k <= j) ? L.M[(j + 1) * CQ_LD + k] : 0.0; };
+    const int ntr = nr >> 4, ntc = nc >> 4;
+    const bool on = wave < ntc;
+    const int j0 = c0 + 16 * wave;
     v4d acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tl = wave + 4 * q;
-        if (tl < nt) acc[q] = cq_tile(R, X, r0 + 16 * (tl / ntc), c0 + 16 * (tl % ntc), c0, c0 + 16 * (tl % ntc) + 16, lane);   // X(c0 .., c0 ..) upper: k <= j
+    for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        // P = R(r0 .., c0 ..) X(c0 .., c0 ..): X upper triangular, k <= j
+#pragma unroll 2
+        for (int k = c0; k < j0 + 16; k += 4) {
+            const int kk = k + l4, j = j0 + l15;
+            const double b = (kk <= j) ? L.M[(j + 1) * CQ_LD + kk] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < ntr) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(L.M[(r0 + 16 * q + l15) * CQ_LD + kk], b, acc[q], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < ntr)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L.M[(r0 + 16 * q + l4 + 4 * r) * CQ_LD + j0 + l15] = acc[q][r];
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tl = wave + 4 * q, i0 = r0 + 16 * (tl / ntc), j0 = c0 + 16 * (tl % ntc);
-        if (tl < nt)
+    for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (on) {
+        // X12 = -X(r0 .., r0 ..) P: X upper triangular, k >= i (tile row q starts at k = r0 + 16 q)
+#pragma unroll 2
+        for (int k = r0; k < r0 + nr; k += 4) {
+            const int kk = k + l4;
+            const double b = L.M[kk * CQ_LD + j0 + l15];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) L.M[(i0 + l4 + 4 * r) * CQ_LD + j0 + l15] = acc[q][r];
+            for (int q = 0; q < 4; ++q)
+                if (q < ntr && k >= r0 + 16 * q) {
+                    const int i = r0 + 16 * q + l15;
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64((i <= kk) ? L.M[(kk + 1) * CQ_LD + i] : 0.0, b, acc[q], 0, 0, 0);
+                }
+        }
     }
     __syncthreads();
+    if (on) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tl = wave + 4 * q, i0 = r0 + 16 * (tl / ntc), j0 = c0 + 16 * (tl % ntc);
-        if (tl < nt) acc[q] = cq_tile(X, R, i0, j0, i0, r0 + nr, lane);                  // X(r0 .., r0 ..) upper: k >= i
-    }
-    __syncthreads();
+        for (int q = 0; q < 4; ++q)
+            if (q < ntr)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tl = wave + 4 * q, i0 = r0 + 16 * (tl / ntc), j0 = c0 + 16 * (tl % ntc);
-        if (tl < nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L.M[(j0 + l15 + 1) * CQ_LD + i0 + l4 + 4 * r] = -acc[q][r];
+                for (int r = 0; r < 4; ++r) L.M[(j0 + l15 + 1) * CQ_LD + r0 + 16 * q + l4 + 4 * r] = -acc[q][r];
     }
     __syncthreads();
 }
@@ -189,19 +325,28 @@ __device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int 
     (void) ti; (void) tj;
     const int nblk = w >> 5, wave = tid >> 6, lane = tid & 63;
     // the strictly lower part must read as zero where X has not been written
-    for (int e = tid; e < (w + 1) * w; e += CQ_T) {
-        const int r = e / w, c = e - r * w;
+    for (int e = tid; e < (w + 1) * CQ_W; e += CQ_T) {
+        const int r = e >> 7, c = e & (CQ_W - 1);
         if (c < r) L.M[r * CQ_LD + c] = 0.0;
     }
     __syncthreads();
-    if (wave < nblk && lane < 32) {
-        const int o = 32 * wave, j = lane;
-        double* xj = L.M + (o + j + 1) * CQ_LD + o;          // x(i) = X(o + i, o + j)
+    if (wave < nblk) {
+        // column j of the block's inverse in registers (static indices: the loops unroll); row i of R is a broadcast read
+        const int o = 32 * wave, j = lane & 31;
+        const double dinv = rcp_newton(L.M[(o + j) * CQ_LD + o + j]);
+        double x[32];
+#pragma unroll
         for (int i = 31; i >= 0; --i) {
             double acc = (i == j) ? 1.0 : 0.0;
-            for (int k = i + 1; k < 32; ++k) acc -= L.M[(o + i) * CQ_LD + o + k] * ((k <= j) ? xj[k] : 0.0);
-            const double x = acc * rcp_newton(L.M[(o + i) * CQ_LD + o + i]);
-            if (i <= j) xj[i] = x;
+#pragma unroll
+            for (int k = i + 1; k < 32; ++k) acc -= L.M[(o + i) * CQ_LD + o + k] * x[k];
+            x[i] = (i <= j) ? acc * readlane_f64(dinv, i) : 0.0;
+        }
+        if (lane < 32) {
+            double* xj = L.M + (o + j + 1) * CQ_LD + o;          // x(i) = X(o + i, o + j)
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i <= j) xj[i] = x[i];
         }
     }
     __syncthreads();
@@ -213,73 +358,81 @@ __device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int 
 // the inverse out of L.M into a row-major global matrix (zero below the diagonal)
 __device__ __forceinline__ void cq_inv_out(const CqLds& L, double* X, int w, int tid)
 {
-    for (int e = tid; e < w * w; e += CQ_T) {
-        const int i = e / w, j = e - i * w;
+    for (int e = tid; e < w * CQ_W; e += CQ_T) {
+        const int i = e >> 7, j = e & (CQ_W - 1);
+        if (j >= w) continue;
         cq_st(X + i * CQ_W + j, (j >= i) ? L.M[(j + 1) * CQ_LD + i] : 0.0);
     }
 }
 
-// C = A B for upper-triangular A (in L.M, on and above the diagonal) and upper-triangular B (row-major, global), on the matrix cores:
-// wave v owns tile rows v and v + 4 and all eight tile columns; c[q] (accumulator layout of cq_tile) is tile (v + 4 (q >> 3), q & 7)
-__device__ __forceinline__ void cq_upper_product(v4d (&c)[16], const CqLds& L, const double* B, int w, int tid)
-{
-    const int wave = tid >> 6, lane = tid & 63;
-    auto A = [&](int i, int k) { return (k >= i) ? L.M[i * CQ_LD + k] : 0.0; };
-    auto Bg = [&](int k, int j) { return cq_ld(B + k * CQ_W + j); };
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int tr = wave + 4 * (q >> 3), tc = q & 7;
-        c[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-        if (tc >= tr && 16 * tc < w && 16 * tr < w) c[q] = cq_tile(A, Bg, 16 * tr, 16 * tc, 16 * tr, 16 * tc + 16, lane);
-    }
-}
-// visit the elements of the wave's product tiles: f(i, j, value)
+// C = A diag(d) B for upper-triangular A (L.M, on and above the diagonal) and upper-triangular B (transposed strictly below the
+// diagonal of L.M, where the inverses leave their result: B(k, j) at M[j + 1][k]); d = NULL: no scaling.  A wave owns two tile ROWS
+// (tr and 7 - tr: nine tiles on and above the diagonal each at w = 128): the A fragment of a k-step is shared by the row's tiles and
+// their accumulators interleave on the matrix core.  f(i, j, value) for every element on and above the tile diagonal.
 template <class F>
-__device__ __forceinline__ void cq_product_visit(const v4d (&c)[16], int w, int tid, F f)
+__device__ __forceinline__ void cq_upper_product(const CqLds& L, const double* d, int w, int tid, F f)
 {
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, nt = w >> 4;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int tr = half ? 7 - wave : wave;
+        if (tr >= nt) continue;
+        v4d acc[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int tr = wave + 4 * (q >> 3), tc = q & 7;
-        if (16 * tc < w && 16 * tr < w)
+        for (int q = 0; q < 8; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const int i = 16 * tr + l15;
+#pragma unroll 2
+        for (int k = 16 * tr; k < w; k += 4) {
+            const int kk = k + l4;
+            const double a = (kk >= i) ? L.M[i * CQ_LD + kk] * (d ? d[kk] : 1.0) : 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) f(16 * tr + l4 + 4 * r, 16 * tc + l15, c[q][r]);
+            for (int q = 0; q < 8; ++q) {
+                if (q >= tr && q < nt && k < 16 * q + 16) {       // B(k, j) = 0 for k > j
+                    const int j = 16 * q + l15;
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (kk <= j) ? L.M[(j + 1) * CQ_LD + kk] : 0.0, acc[q], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q >= tr && q < nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f(16 * tr + l4 + 4 * r, 16 * q + l15, acc[q][r]);
     }
 }
 
-__device__ __forceinline__ void cq_tile_to_lds_upper(const double (&t)[CQ_E][CQ_E], const CqLds& L, int w, int ti, int tj)
+// a row-major global upper-triangular matrix into the transposed slots strictly below the diagonal of L.M (operand B of cq_upper_product)
+__device__ __forceinline__ void cq_load_lowerT(const CqLds& L, const double* G, int w, int tid)
 {
-#pragma unroll
-    CQ_FOR_TILE {
-        const int i = ti + 16 * a, j = tj + 16 * b;
-        if (i < w && j < w && j >= i) L.M[i * CQ_LD + j] = t[a][b];
-    }
+    cq_elems(w, tid, [&](int k, int j) { return G[k * CQ_W + j]; }, [&](int k, int j, double v) { if (j < w && j >= k) L.M[(j + 1) * CQ_LD + k] = v; });
+}
+
+// a row-major global matrix (upper triangle) into L.M
+__device__ __forceinline__ void cq_load_upper(const CqLds& L, const double* G, int w, int tid)
+{
+    cq_elems(w, tid, [&](int i, int j) { return G[i * CQ_W + j]; }, [&](int i, int j, double v) { if (j < w && j >= i) L.M[i * CQ_LD + j] = v; });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// R1 = chol(G1), R1^-1.  G: column-major ld CQ_W (upper triangle read).  status[0] |= 1 on a non-positive pivot.
+// R1 = chol(G1), R1^-1.  G: column-major ld CQ_W, symmetric (read along its rows).  status[0] |= 1 on a non-positive pivot.
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* status)
 {
     extern __shared__ double sm[];
     const CqLds L = cq_lds(sm);
-    const int tid = threadIdx.x, tj = tid & 15, ti = tid >> 4;
-    double t[CQ_E][CQ_E];
-#pragma unroll
-    CQ_FOR_TILE {
-        const int i = ti + 16 * a, j = tj + 16 * b;
-        t[a][b] = (i < w && j < w && j >= i) ? ws[CQ_G1 + i + CQ_W * j] : 0.0;
-    }
+    const int tid = threadIdx.x;
+    // G(i, j) = G(j, i): consecutive lanes read consecutive addresses
+    cq_elems(w, tid, [&](int i, int j) { return ws[CQ_G1 + j + CQ_W * i]; }, [&](int i, int j, double v) { if (j < w && j >= i) L.M[i * CQ_LD + j] = v; });
     CQ_STAMP(0);
-    const bool ok = cq_chol(t, L, w, ti, tj, tid);
+    const bool ok = cq_chol_blocked(L, w, tid);
     CQ_STAMP(1);
-    if (!ok) { if (tid == 0) status[0] = 1; return; }         // uniform: every thread read the same pivots
-    for (int e = tid; e < w * w; e += CQ_T) {
-        const int i = e / w, j = e - i * w;
-        cq_st(ws + CQ_R1 + i * CQ_W + j, (j >= i) ? L.M[i * CQ_LD + j] : 0.0);
+    if (!ok) { if (tid == 0) status[0] = 1; return; }
+    for (int e = tid; e < w * CQ_W; e += CQ_T) {
+        const int i = e >> 7, j = e & (CQ_W - 1);
+        if (j < w) cq_st(ws + CQ_R1 + i * CQ_W + j, (j >= i) ? L.M[i * CQ_LD + j] : 0.0);
     }
     CQ_STAMP(2);
-    cq_upper_inv(L, w, ti, tj, tid);
+    cq_upper_inv(L, w, 0, 0, tid);
     CQ_STAMP(3);
     cq_inv_out(L, ws + CQ_R1I, w, tid);
     CQ_STAMP(4);
@@ -293,23 +446,18 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
 {
     extern __shared__ double sm[];
     const CqLds L = cq_lds(sm);
-    const int tid = threadIdx.x, tj = tid & 15, ti = tid >> 4;
+    const int tid = threadIdx.x;
     if (status[0]) return;                                    // the first Cholesky failed
-    double t[CQ_E][CQ_E];
     CQ_STAMP(8);
-    // ---- G2: its distance from I decides between the first-order factor, the Cholesky and the refusal
+    // ---- G2 -> L.M (upper); its distance from I decides between the first-order factor, the Cholesky and the refusal
     double dmax = 0.0;
-    bool nan = false;
-#pragma unroll
-    CQ_FOR_TILE {
-        const int i = ti + 16 * a, j = tj + 16 * b;
-        const bool in = i < w && j < w && j >= i;
-        t[a][b] = in ? ws[CQ_G2 + i + CQ_W * j] : 0.0;
-        const double d = in ? fabs(t[a][b] - (i == j ? 1.0 : 0.0)) : 0.0;
-        nan = nan || !(d == d);
-        dmax = fmax(dmax, d);
-    }
-    if (nan) dmax = 1e300;
+    cq_elems(w, tid, [&](int i, int j) { return ws[CQ_G2 + j + CQ_W * i]; }, [&](int i, int j, double g) {
+        if (j < w && j >= i) {
+            L.M[i * CQ_LD + j] = g;
+            const double d = fabs(g - (i == j ? 1.0 : 0.0));
+            dmax = (d == d) ? fmax(dmax, d) : 1e300;
+        }
+    });
     for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
     if ((tid & 63) == 0) L.red[tid >> 6] = dmax;
     __syncthreads();
@@ -319,157 +467,86 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     const bool first_order = dmax <= QRD_CHOL1_THR;
     if (first_order) {
         // G2 = I + E, |E| <= 1e-9: R2 = I + triu(E, 1) + diag(E) / 2 to ~1e-18
-        for (int e = tid; e < w * w; e += CQ_T) L.M[(e / w) * CQ_LD + (e % w)] = 0.0;
-        __syncthreads();
-#pragma unroll
-        CQ_FOR_TILE {
-            const int i = ti + 16 * a, j = tj + 16 * b;
-            if (i < w && j < w && j >= i) L.M[i * CQ_LD + j] = (i == j) ? 1.0 + 0.5 * (t[a][b] - 1.0) : t[a][b];
-        }
+        if (tid < w) L.M[tid * CQ_LD + tid] = 1.0 + 0.5 * (L.M[tid * CQ_LD + tid] - 1.0);
         __syncthreads();
     } else {
-        const bool ok = cq_chol(t, L, w, ti, tj, tid);
+        const bool ok = cq_chol_blocked(L, w, tid);
         if (!ok) { if (tid == 0) status[0] = 1; return; }
     }
-    for (int e = tid; e < w * w; e += CQ_T) {
-        const int i = e / w, j = e - i * w;
-        cq_st(ws + CQ_R2 + i * CQ_W + j, (j >= i) ? L.M[i * CQ_LD + j] : 0.0);
+    // R2 -> global (the LU and two products read it from there); R2^-1 -> X1 (first order: 2 I - R2)
+    for (int e = tid; e < w * CQ_W; e += CQ_T) {
+        const int i = e >> 7, j = e & (CQ_W - 1);
+        if (j >= w) continue;
+        const double r = (j >= i) ? L.M[i * CQ_LD + j] : 0.0;
+        cq_st(ws + CQ_R2 + i * CQ_W + j, r);
+        if (first_order) cq_st(ws + CQ_X1 + i * CQ_W + j, (j > i) ? -r : (j == i ? 2.0 - r : 0.0));
     }
-    CQ_STAMP(9);
-    // ---- modified LU of Q_top - S R2 (R2 in L.M), the sign of every pivot chosen as Householder would (reference qr.c:141-151)
-#pragma unroll
-    CQ_FOR_TILE {
-        const int i = ti + 16 * a, j = tj + 16 * b;
-        t[a][b] = (i < w && j < w) ? Vw[i + (size_t) ldv * j] : 0.0;
-    }
-    if (ti == 0)
-#pragma unroll
-        for (int b = 0; b < CQ_E; ++b) L.row[tj + 16 * b] = t[0][b];
-    if (tj == 0)
-#pragma unroll
-        for (int a = 0; a < CQ_E; ++a) L.col[ti + 16 * a] = t[a][0];
-    const int nbk = w >> 4;
-    for (int I = 0; I < w; ++I) {
+    if (!first_order) {
         __syncthreads();
-        const double* rI = L.row + (I & 1) * CQ_W;
-        const double* cI = L.col + (I & 1) * CQ_W;
-        const double x = rI[I];
-        const double S = (x >= 0.0) ? -1.0 : 1.0;
-        const double piv = x - S * L.M[I * CQ_LD + I];        // |piv| >= R2(I, I) > 0
-        const double inv = rcp_newton(piv);
-        if (tid == 0) L.sv[I] = S;
-        const int a0 = I >> 4;                                // blocks a < a0 (b < a0) lie above (left of) the pivot
-        double uj[CQ_E];
-#pragma unroll
-        for (int b = 0; b < CQ_E; ++b) {
-            const int j = tj + 16 * b;
-            uj[b] = (b >= a0 && b < nbk && j >= I) ? rI[j] - S * L.M[I * CQ_LD + j] : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < CQ_E; ++a) {
-            if (a >= a0 && a < nbk) {
-                const int i = ti + 16 * a;
-                const double li = cI[i] * inv;
-#pragma unroll
-                for (int b = 0; b < CQ_E; ++b) {
-                    if (b >= a0 && b < nbk) {
-                        const int j = tj + 16 * b;
-                        if (i == I) { if (j >= I) t[a][b] = uj[b]; }
-                        else if (i > I) {
-                            if (j == I) t[a][b] = li;
-                            else if (j > I) t[a][b] -= li * uj[b];
-                        }
-                    }
-                }
-            }
-        }
-        const int In = I + 1;
-        if (In < w) {
-            if (ti == (In & 15)) {
-                double* rn = L.row + (In & 1) * CQ_W;
-#pragma unroll
-                for (int a = 0; a < CQ_E; ++a)
-                    if (a == (In >> 4))
-#pragma unroll
-                        for (int b = 0; b < CQ_E; ++b) rn[tj + 16 * b] = t[a][b];
-            }
-            if (tj == (In & 15)) {
-                double* cn = L.col + (In & 1) * CQ_W;
-#pragma unroll
-                for (int b = 0; b < CQ_E; ++b)
-                    if (b == (In >> 4))
-#pragma unroll
-                        for (int a = 0; a < CQ_E; ++a) cn[ti + 16 * a] = t[a][b];
-            }
-        }
+        cq_upper_inv(L, w, 0, 0, tid);
+        cq_inv_out(L, ws + CQ_X1, w, tid);
     }
+    cq_sync_global();
+    CQ_STAMP(9);
+    // ---- W = Q_top -> L.M (whole), blocked modified LU
+    // (consecutive lanes: consecutive rows of a column)
+    cq_elems(w, tid, [&](int j, int i) { return Vw[(i < w ? i : w - 1) + (size_t) ldv * j]; }, [&](int j, int i, double v) { if (i < w) L.M[i * CQ_LD + j] = v; });
     __syncthreads();
+    cq_lu_blocked(L, w, ws + CQ_R2, tid);
     CQ_STAMP(10);
     // L1 \ U' and S out; Q_top - S R2 back into Vw (the last pass multiplies it by U'^-1 like every other row: it becomes L1)
+    for (int e = tid; e < w * CQ_W; e += CQ_T) {
+        const int i = e >> 7, j = e & (CQ_W - 1);
+        if (j < w) cq_st(ws + CQ_LU + i * CQ_W + j, L.M[i * CQ_LD + j]);
+    }
+    {   // (W in L.M has been overwritten: Q_top is read again, with R2, both requested 8 elements ahead)
+        const int n = w * CQ_W;
+        for (int base = tid; base < n; base += 8 * CQ_T) {
+            double qv[8], rv[8];
 #pragma unroll
-    CQ_FOR_TILE {
-        const int i = ti + 16 * a, j = tj + 16 * b;
-        if (i < w && j < w) {
-            cq_st(ws + CQ_LU + i * CQ_W + j, t[a][b]);
-            if (j >= i) Vw[i + (size_t) ldv * j] -= L.sv[i] * L.M[i * CQ_LD + j];
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * CQ_T, ee = e < n ? e : tid, j = ee >> 7, i = ee & (CQ_W - 1), ic = i < w ? i : w - 1;
+                qv[u] = Vw[ic + (size_t) ldv * j];
+                rv[u] = ws[CQ_R2 + ic * CQ_W + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * CQ_T, j = e >> 7, i = e & (CQ_W - 1);
+                if (e < n && i < w && j >= i) Vw[i + (size_t) ldv * j] = qv[u] - L.sv[i] * rv[u];
+            }
         }
     }
     if (tid < w) cq_st(ws + CQ_SV + tid, L.sv[tid]);
     CQ_STAMP(11);
-    // ---- R = S R2 R1 (R2 still in L.M)
-    v4d c[16];
-    cq_upper_product(c, L, ws + CQ_R1, w, tid);
-    cq_product_visit(c, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_RR + i * CQ_W + j, (j >= i) ? L.sv[i] * v : 0.0); });
+    // ---- U = U' R2^-1 -> X2 (U' is the upper triangle of L.M; R2^-1 goes transposed below the diagonal, over L1: it is in ws + CQ_LU)
+    cq_load_lowerT(L, ws + CQ_X1, w, tid);
+    __syncthreads();
+    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_X2 + i * CQ_W + j, (j >= i) ? v : 0.0); });
+    __syncthreads();
     CQ_STAMP(12);
-    // ---- R2^-1 -> X1 (first order: 2 I - R2)
-    if (first_order) {
-        for (int e = tid; e < w * w; e += CQ_T) {
-            const int i = e / w, j = e - i * w;
-            cq_st(ws + CQ_X1 + i * CQ_W + j, (j > i) ? -L.M[i * CQ_LD + j] : (j == i ? 2.0 - L.M[i * CQ_LD + j] : 0.0));
-        }
-        cq_sync_global();
-    } else {
-        __syncthreads();                                      // (the product above still reads R2's off-diagonal blocks)
-        cq_upper_inv(L, w, ti, tj, tid);
-        cq_inv_out(L, ws + CQ_X1, w, tid);
-        cq_sync_global();
-    }
-    CQ_STAMP(13);
-    // ---- U' -> L.M; U = U' R2^-1 -> X2; U'^-1 -> UI
-    cq_tile_to_lds_upper(t, L, w, ti, tj);
-    __syncthreads();
-    cq_upper_product(c, L, ws + CQ_X1, w, tid);
-    cq_product_visit(c, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_X2 + i * CQ_W + j, (j >= i) ? v : 0.0); });
-    __syncthreads();
-    CQ_STAMP(14);
-    cq_upper_inv(L, w, ti, tj, tid);
-    CQ_STAMP(15);
+    // ---- U'^-1 -> UI
+    cq_upper_inv(L, w, 0, 0, tid);
     cq_inv_out(L, ws + CQ_UI, w, tid);
-    __syncthreads();
-    CQ_STAMP(16);
-    // ---- L1^-T: the inverse of the unit upper-triangular L1^T, rows scaled by S on the way out: X1 = S L1^-T
-#pragma unroll
-    CQ_FOR_TILE {
-        const int i = ti + 16 * a, j = tj + 16 * b;
-        if (i < w && j < w && i >= j) L.M[j * CQ_LD + i] = (i == j) ? 1.0 : t[a][b];         // (L1^T)(j, i) = L1(i, j)
-    }
-    __syncthreads();
-    cq_upper_inv(L, w, ti, tj, tid);
-    for (int e = tid; e < w * w; e += CQ_T) {
-        const int i = e / w, j = e - i * w;
-        cq_st(ws + CQ_X1 + i * CQ_W + j, (j >= i) ? L.sv[i] * L.M[(j + 1) * CQ_LD + i] : 0.0);
-    }
     cq_sync_global();
-    CQ_STAMP(17);
-    // ---- T = -U (S L1^-T): U (X2) -> L.M
-    for (int e = tid; e < w * w; e += CQ_T) {
-        const int i = e / w, j = e - i * w;
-        if (j >= i) L.M[i * CQ_LD + j] = cq_ld(ws + CQ_X2 + i * CQ_W + j);
-    }
+    CQ_STAMP(13);
+    // ---- L1^-T: the inverse of the unit upper-triangular L1^T stays below the diagonal of L.M
+    // (L1^T)(j, i) = L1(i, j): row i of LU read along j
+    cq_elems(w, tid, [&](int i, int j) { return ws[CQ_LU + i * CQ_W + j]; }, [&](int i, int j, double v) { if (j < w && i >= j) L.M[j * CQ_LD + i] = (i == j) ? 1.0 : v; });
     __syncthreads();
-    cq_upper_product(c, L, ws + CQ_X1, w, tid);
-    cq_product_visit(c, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
-    CQ_STAMP(18);
+    cq_upper_inv(L, w, 0, 0, tid);
+    CQ_STAMP(14);
+    // ---- T = -U S L1^-T: U (X2) -> the upper triangle of L.M, S folded into U's columns
+    cq_load_upper(L, ws + CQ_X2, w, tid);
+    __syncthreads();
+    cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
+    __syncthreads();
+    CQ_STAMP(15);
+    // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
+    cq_load_upper(L, ws + CQ_R2, w, tid);
+    cq_load_lowerT(L, ws + CQ_R1, w, tid);
+    __syncthreads();
+    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_RR + i * CQ_W + j, (j >= i) ? L.sv[i] * v : 0.0); });
+    CQ_STAMP(16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -487,8 +564,8 @@ __global__ __launch_bounds__(CR_THREADS) void cqr_rows_kernel(const double* __re
     extern __shared__ double sm[];                           // X^T? no: X row-major [k][j], stride CQ_LD
     if (MODE == 1 && status[0]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    for (int e = tid; e < w * w; e += CR_THREADS) {
-        const int k = e / w, j = e - k * w;
+    for (int e = tid; e < w * CQ_W; e += CR_THREADS) {
+        const int k = e >> 7, j = e & (CQ_W - 1);
         sm[k * CQ_LD + j] = X[k * CQ_W + j];
     }
     __syncthreads();
@@ -534,7 +611,7 @@ __global__ __launch_bounds__(256) void cqr_top_kernel(const double* ws, int w, d
         const double lu = ws[CQ_LU + i * CQ_W + j];
         A[i + (size_t) lda * j] = (j >= i) ? ws[CQ_RR + i * CQ_W + j] : lu;
         Vw[i + (size_t) ldv * j] = (j < i) ? lu : (j == i ? 1.0 : 0.0);
-        const double tv = ws[CQ_TT + i * CQ_W + j];
+        const double tv = (j >= i) ? ws[CQ_TT + i * CQ_W + j] : 0.0;      // (tiles below the tile diagonal are never written)
         T[i + (size_t) ldt * j] = tv;
         if (i == j) tau[i] = tv;
     }

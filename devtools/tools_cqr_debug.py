@@ -48,13 +48,13 @@ L.qrd_device_sync()
 print("status", status.cpu().numpy())
 R2 = np.linalg.cholesky(G2).T
 print("R2 err", err(mat(5), R2))
-LU, S = mat(6), ws.cpu().numpy()[11 * 128 * 128:11 * 128 * 128 + w]
+LU, S = mat(6), ws.cpu().numpy()[12 * 128 * 128:12 * 128 * 128 + w]
 L1, Up = np.tril(LU, -1) + np.eye(w), np.triu(LU)
 print("LU err", err(L1 @ Up, Q[:w] - S[:, None] * mat(5)))
 print("Uinv err", err(mat(4), np.linalg.inv(Up)))
-print("R err", err(mat(9), S[:, None] * mat(5) @ mat(2)))
+print("R err", err(np.triu(mat(9)), S[:, None] * mat(5) @ mat(2)))
 U = Up @ np.linalg.inv(mat(5))
-print("T err", err(mat(10), -U @ np.diag(S) @ np.linalg.inv(L1).T))
+print("T err", err(np.triu(mat(10)), -U @ np.diag(S) @ np.linalg.inv(L1).T))
 V = host(dV)
 out = host(dA)
 print("V err", err(V[w:], (Q[w:]) @ np.linalg.inv(Up)), " top", err(V[:w], L1))
@@ -62,9 +62,9 @@ T = host(dT)
 QtP = P - V @ (T.T @ (V.T @ P))
 print("below-diagonal of Q^T P", np.abs(np.tril(QtP, -1)).max(), " R match", err(np.triu(QtP[:w]), np.triu(out[:w])))
 if len(sys.argv) > 3:
-    st = ws.cpu().numpy()[11 * 128 * 128 + 128:11 * 128 * 128 + 128 + 64].view(np.uint64)
-    names = {0: "chol start", 1: "chol loop", 2: "R1 out", 3: "inverse", 4: "inverse out", 8: "lu start", 9: "G2 / R2", 10: "LU loop", 11: "LU out", 12: "R product",
-             13: "R2 inverse", 14: "U product", 15: "U' inverse", 16: "UI out", 17: "L1^-T inverse", 18: "T product"}
-    for a, b in ((0, 5), (8, 19)):
+    st = ws.cpu().numpy()[12 * 128 * 128 + 128:12 * 128 * 128 + 128 + 64].view(np.uint64)
+    names = {1: "chol", 2: "R1 out", 3: "inverse", 4: "inverse out", 9: "G2 -> R2, R2^-1", 10: "W load + LU", 11: "LU out", 12: "U product",
+             13: "U' inverse", 14: "L1^-T inverse", 15: "T product", 16: "R product"}
+    for a, b in ((0, 5), (8, 17)):
         for i in range(a + 1, b):
             print("  %-16s %8.1f us" % (names.get(i, i), (int(st[i]) - int(st[i - 1])) * 0.01))

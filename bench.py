@@ -412,6 +412,10 @@ def main():
                 "cu_partition_note": ("with look-ahead the wide update runs on the update stream's compute units "
                                       "(16384^2: 224 of 256, the panel chain owns 32 = 4 compute units of every XCD; smaller problems 192 / 64)"),
                 "update_stream_cus": cus_u,
+                # the same rate against the peak of the compute units the kernel actually runs on (`frac` above stays against the whole
+                # chip, as the contract asks): what the kernel itself leaves on the table, apart from the schedule's CU partition
+                "cus": cus_u,
+                "frac_of_cus_used": (ach / (FP64_MATRIX_PEAK_TFLOPS * cus_u / float(qr.device_info()["compute_units"] or 256))) if cus_u else None,
                 "rocprof_pmc": "profiles/r03_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
                 "measured_probe": measured,
                 "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],

@@ -65,13 +65,14 @@ double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx);
 int qrd_diff_norm(void* stream, const double* X, int ldx, const double* Y, int ldy, long long rows, int cols,
                   long long row_off, long long total_rows, unsigned long long seed, int sub_identity, double* out);
 
-/* a TALL panel (<= 128 columns) at its full width: CholeskyQR2 + Householder reconstruction in six passes (qr_panel_cqr.hip).  The caller
- * puts G1 = A^T A into qrd_panel_cqr_g1(ws) (column-major, ld 128), calls stage1 (R1, Q = A R1^-1 -> Vw), puts G2 = Q^T Q into
- * qrd_panel_cqr_g2(ws), calls stage2 (V -> Vw and A, R, T, tau).  status[0] (device, zeroed by the caller) = 1: the guard refused the
- * panel and A is untouched */
+/* a TALL panel (<= 128 columns) at its full width: CholeskyQR2 + Householder reconstruction in three passes over the panel
+ * (qr_panel_cqr.hip): V -> Vw and below the diagonal of A, R, T (complete), tau.  status: 4 device ints, zeroed by the call;
+ * status[0] = 1 afterwards: the guard refused the panel and A is untouched.  -7: shape not taken (qrd_panel_cqr_ok).
+ * stage1 / stage2 + g1 / g2: the same in two halves with the Gram matrices supplied by the caller (development checks) */
 size_t qrd_panel_cqr_ws_doubles(void);
 int qrd_panel_cqr_init(void);
 int qrd_panel_cqr_ok(int mk, int w);
+int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status);
 double* qrd_panel_cqr_g1(double* ws);
 double* qrd_panel_cqr_g2(double* ws);
 int qrd_panel_cqr_stage1(void* stream, const double* A, int lda, int mk, int w, double* Vw, int ldv, double* ws, int* status);

@@ -117,8 +117,9 @@ typedef struct qr_knobs {
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
     int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
-    int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: tall panels (<= 128 columns) of at least this many rows at full width (0 = never) */
-    int fused_gram;                                         /* MI355XQR_FUSED_GRAM: the panel's Gram blocks V_prev^T V_l inside that launch (else one launch after it) */
+    int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: 128-column panels of at least this many rows at full width (0 = never).  Measured
+                                                             * (devtools/r4_cqr.sh): 262144 rows 6.85 against 6.74 ms, 524288 4.36 against 4.78, 2^20 2.96 against 5.64 */
+    int fused_gram;                                         /* the panel's Gram blocks V_prev^T V_l inside the one-launch panel (else one launch after it): constant 0 */
 } qr_knobs;
 static qr_knobs g_knobs;
 static pthread_once_t g_knobs_once = PTHREAD_ONCE_INIT;
@@ -139,8 +140,8 @@ static void knobs_init(void)
     k->early_product = env_int("MI355XQR_EP", 1) != 0;
     k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
     k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
-    k->fused_gram = env_int("MI355XQR_FUSED_GRAM", 0) != 0;
-    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 1 << 20);
+    k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
+    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 393216);
 }
 
 static const qr_knobs* knobs(void)
@@ -628,17 +629,13 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
     return rc;
 }
 
-/* A tall half (mkh x wh, wh <= 128) at its full width: CholeskyQR2 + Householder reconstruction in six passes instead of the leaf chain's
+/* A tall half (mkh x wh, wh <= 128) at its full width: CholeskyQR2 + Householder reconstruction in three passes instead of the leaf chain's
  * twelve (qr_panel_cqr.hip); T of the half comes out complete.  Returns 1 when the guard refused the panel (ill-conditioned: A is
  * untouched, the caller runs the leaf chain), 0 when done.  The guard's verdict is read on the host: one drain of the stream per tall
  * panel (~20 us beside a ~0.6 ms panel), never under stream capture. */
 static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, double* tauh, double* Th, int ldt, double* Vh, int ldv)
 {
-    CHECK(qrd_memset(p->stream, p->cq_status, 0, 4 * sizeof(int)));
-    CHECK(tn(p, wh, wh, mkh, Ah, lda, Ah, lda, qrd_panel_cqr_g1(p->cq_ws), 128, NULL));
-    CHECK(qrd_panel_cqr_stage1(p->stream, Ah, lda, mkh, wh, Vh, ldv, p->cq_ws, p->cq_status));
-    CHECK(tn(p, wh, wh, mkh, Vh, ldv, Vh, ldv, qrd_panel_cqr_g2(p->cq_ws), 128, NULL));
-    CHECK(qrd_panel_cqr_stage2(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status));
+    CHECK(qrd_panel_cqr(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status));
     int st[4] = {0, 0, 0, 0};
     CHECK(qrd_d2h(p->stream, st, p->cq_status, sizeof st));
     CHECK(qrd_stream_sync(p->stream));
@@ -677,7 +674,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         /* the whole half in ONE launch (qr_panel_fused.hip: every leaf, its in-panel product and update; leaf T blocks, tau, V and
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
         int cqr_done = 0;
-        if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= kn->cqr_min_rows && wh >= 64 && qrd_panel_cqr_ok(mk - c0, wh)) {
+        if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= kn->cqr_min_rows && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
             const int rc = panel_cqr_half(p, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
                                           p->Vw + (size_t) c0 * ldv + c0, ldv);
             if (rc < 0) return rc;

@@ -42,7 +42,8 @@ constexpr int CQ_TT = 10 * CQ_W * CQ_W;   // T row-major
 constexpr int CQ_X3 = 11 * CQ_W * CQ_W;
 constexpr int CQ_SV = 12 * CQ_W * CQ_W;   // S (CQ_W doubles)
 constexpr int CQ_ST = 12 * CQ_W * CQ_W + CQ_W;   // 64 phase stamps of the one-workgroup kernels (CQ_STAMPS builds)
-constexpr int CQ_WS = CQ_ST + 64;
+constexpr int CQ_SL = CQ_ST + 64;                  // Gram partials of the streaming passes: 256 workgroups x 36 tiles x 256
+constexpr int CQ_WS = CQ_SL + 1024 * 36 * 256;
 
 // Workspace traffic of the one-workgroup kernels: plain stores and loads.  Every workspace matrix is written ONCE per launch and read
 // only after cq_sync_global() (so no line of it can be in this compute unit's cache before it is written); agent-scope atomic stores
@@ -550,54 +551,157 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The streaming passes: dst rows = src rows times an upper-triangular w x w matrix X (row-major in ws).  Matrix cores with the
-// product transposed -- D(col, row) = sum_k X(k, col) src(row, k) -- so that the accumulator registers of a lane are four columns of
-// 16 CONSECUTIVE ROWS: loads and stores are both whole 128-byte lines of a column.  A wave takes 16 rows at a time: the 16 x w row
-// block sits in 32 operand registers, column tile jt needs only k < 16 (jt + 1).
-//   MODE 0: Q = A R1^-1 (src A, dst Vw).    MODE 1: V = Q' U'^-1 (src Vw, dst Vw and A); returns at once when status[0] is set.
+// The streaming passes, one kernel template:
+//   MULT: dst rows = src rows times an upper-triangular w x w matrix X (row-major in ws).  Matrix cores with the product transposed
+//         -- D(col, row) = sum_k X(k, col) src(row, k) -- so that the accumulator registers of a lane are four columns of 16
+//         CONSECUTIVE ROWS: loads and stores are both whole 128-byte lines of a column.  A wave takes 16 rows at a time: the 16 x w
+//         row block sits in 32 operand registers, column tile jt needs only k < 16 (jt + 1).  X sits in LDS as its 36 upper
+//         16 x 16 blocks (72 KB instead of 132).
+//   GRAM: the Gram matrix of the rows this wave has produced (MULT) or read (!MULT) accumulates in 36 accumulator tiles: the 16 x w
+//         block goes through a wave-private LDS tile to change from "lane = row" to "lane = column", then 144 matrix-core
+//         instructions per block -- the separate V^T V pass over the panel (gemm_tn: 176 us at 262144 x 128) disappears.  Per-workgroup
+//         partials go to `slabs`, summed by cqr_gram_reduce_kernel in a fixed order (deterministic).
+//   pass 1: !MULT, GRAM  (G1 = A^T A)     pass 2: MULT, GRAM  (Q = A R1^-1 -> Vw, G2 = Q^T Q)     pass 3: MULT, DST2  (V -> Vw and A)
+// The next block's rows are requested before the current block's matrix-core work.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int CR_THREADS = 256;
-template <int MODE>
-__global__ __launch_bounds__(CR_THREADS) void cqr_rows_kernel(const double* __restrict__ X, int w, int mk, const double* src, int lds_,
-                                                                double* dst, int ldd, double* dst2, int ldd2, const int* status)
+constexpr int CS_THREADS = 256;
+constexpr int CS_QLD = 130;                                    // row stride of the workgroup's block in LDS (accumulator-order writes conflict-free, operand reads 2-way)
+constexpr int CS_XC = 36 * 256;                                // doubles of the compact X
+constexpr int CS_NWG = 256;                                    // workgroups of the passes that hold X in LDS (one per compute unit)
+constexpr int CS_NWG_GRAM = 1024;                              // workgroups (= partials) of the Gram-only pass
+constexpr size_t CS_LDS_BYTES = sizeof(double) * (CS_XC + 4 * 16 * CS_QLD);
+constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass: four workgroups fit a compute unit
+__device__ __forceinline__ int cs_blk(int kb, int jb) { return (jb * (jb + 1) / 2 + kb) * 256; }
+
+template <bool MULT, bool GRAM, bool DST2>
+__global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __restrict__ X, int w, int mk, const double* src, int lds_, double* dst,
+                                                                 int ldd, double* dst2, int ldd2, double* slabs, const int* status)
 {
-    extern __shared__ double sm[];                           // X^T? no: X row-major [k][j], stride CQ_LD
-    if (MODE == 1 && status[0]) return;
+    extern __shared__ double sm[];
+    if (DST2 && status[0]) return;
+    double* Xc = sm;
+    double* Qall = sm + (MULT ? CS_XC : 0);                   // the workgroup's 64 x w block, rows of wave v at 16 v
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    for (int e = tid; e < w * CQ_W; e += CR_THREADS) {
-        const int k = e >> 7, j = e & (CQ_W - 1);
-        sm[k * CQ_LD + j] = X[k * CQ_W + j];
+    double* Qt = Qall + wave * 16 * CS_QLD;
+    const int nct = w >> 4;
+    if (MULT) {
+        for (int e = tid; e < w * CQ_W; e += CS_THREADS) {
+            const int k = e >> 7, j = e & (CQ_W - 1);
+            if (j < w && j >= (k & ~15)) Xc[cs_blk(k >> 4, j >> 4) + (k & 15) * 16 + (j & 15)] = X[k * CQ_W + j];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const int ntile = (mk + 15) >> 4, nct = w >> 4;
-    for (int tile = blockIdx.x * (CR_THREADS / 64) + wave; tile < ntile; tile += gridDim.x * (CR_THREADS / 64)) {
-        const int r0 = 16 * tile, row = r0 + l15;
+    // GRAM: a wave owns the tile rows `wave` and 7 - wave of the Gram matrix (nine tiles on and above the diagonal at w = 128) over ALL
+    // 64 rows of the workgroup's block: 72 accumulator registers instead of the 288 of a whole Gram matrix per wave
+    v4d g0[8], g1[8];
+    if (GRAM)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { g0[t] = (v4d){0.0, 0.0, 0.0, 0.0}; g1[t] = g0[t]; }
+    const int ntile = (mk + 15) >> 4, nblk = (ntile + 3) >> 2;
+    double q[32], qn[32];
+    auto load = [&](double (&x)[32], int t) {
+        const int row = 16 * t + l15;
         const bool rin = row < mk;
         const double* sp = src + (rin ? row : mk - 1);
-        double q[32];
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) q[ks] = (4 * ks + l4 < w) ? sp[(size_t) (4 * ks + l4) * lds_] : 0.0;
+        for (int ks = 0; ks < 32; ++ks) x[ks] = (4 * ks + l4 < w && t < ntile) ? sp[(size_t) (4 * ks + l4) * lds_] : 0.0;
         if (!rin) {
 #pragma unroll
-            for (int ks = 0; ks < 32; ++ks) q[ks] = 0.0;
+            for (int ks = 0; ks < 32; ++ks) x[ks] = 0.0;
         }
+    };
+    int blk = blockIdx.x;
+    if (blk < nblk) load(q, 4 * blk + wave);
+    for (; blk < nblk; blk += gridDim.x) {
+        const int tile = 4 * blk + wave;
+        // the next block's rows are requested before this block's matrix-core work
+        load(qn, tile + 4 * gridDim.x);                       // (a tile beyond the end loads nothing: predicate in load)
+        const int row = 16 * tile + l15;
+        const bool rin = row < mk;
+        if (MULT) {
 #pragma unroll
-        for (int jt = 0; jt < 8; ++jt) {
-            if (jt < nct) {
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int jt = 0; jt < 8; ++jt) {
+                if (jt < nct) {
+                    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ks = 0; ks < 4 * (jt + 1); ++ks)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[(4 * ks + l4) * CQ_LD + 16 * jt + l15], q[ks], acc, 0, 0, 0);
-                if (rin) {
+                    for (int ks = 0; ks < 4 * (jt + 1); ++ks)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xc[cs_blk(ks >> 2, jt) + (4 * (ks & 3) + l4) * 16 + l15], q[ks], acc, 0, 0, 0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int colj = 16 * jt + l4 + 4 * r;
-                        dst[row + (size_t) colj * ldd] = acc[r];
-                        if (MODE == 1) dst2[row + (size_t) colj * ldd2] = acc[r];
+                        if (rin) {
+                            dst[row + (size_t) colj * ldd] = acc[r];
+                            if (DST2) dst2[row + (size_t) colj * ldd2] = acc[r];
+                        }
+                        if (GRAM) Qt[l15 * CS_QLD + colj] = rin ? acc[r] : 0.0;
                     }
                 }
             }
+        } else if (GRAM) {
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks)
+                if (4 * ks < w) Qt[l15 * CS_QLD + 4 * ks + l4] = q[ks];
         }
+        if (GRAM) {
+            __syncthreads();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int tr = half ? 7 - wave : wave;
+                if (tr < nct) {
+#pragma unroll 4
+                    for (int k = 0; k < 64; k += 4) {
+                        const double* qr = Qall + (k + l4) * CS_QLD + l15;
+                        const double a = qr[16 * tr];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            if (t >= tr && t < nct) {
+                                if (half) g1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qr[16 * t], g1[t], 0, 0, 0);
+                                else g0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qr[16 * t], g0[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                  // the block is free for the next one's writes
+        }
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) q[ks] = qn[ks];
+    }
+    if (GRAM) {
+        double* out = slabs + (size_t) blockIdx.x * 36 * 256;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tr = half ? 7 - wave : wave;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (tr < nct && t >= tr && t < nct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[(t * (t + 1) / 2 + tr) * 256 + r * 64 + lane] = half ? g1[t][r] : g0[t][r];
+        }
+    }
+}
+
+// G (column-major ld CQ_W, both triangles) = sum over the workgroup partials, in slab order.  Tile t = (ti <= tj), accumulator
+// register r of lane l: element (16 ti + (l >> 4) + 4 r, 16 tj + (l & 15)).  Grid: (tiles, 8 chunks of 32 elements).
+__global__ __launch_bounds__(256) void cqr_gram_reduce_kernel(const double* __restrict__ slabs, int nslab, double* G)
+{
+    __shared__ double part[8][33];
+    const int t = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, el = tid & 31, grp = tid >> 5;
+    const int e = chunk * 32 + el;
+    double s = 0.0;
+    for (int q = grp; q < nslab; q += 8) s += slabs[(size_t) q * 36 * 256 + t * 256 + e];       // fixed order per group
+    part[grp][el] = s;
+    __syncthreads();
+    if (grp == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < 8; ++q2) v += part[q2][el];
+        int tj = 0;
+        while ((tj + 1) * (tj + 2) / 2 <= t) ++tj;
+        const int ti = t - tj * (tj + 1) / 2;
+        const int r = e >> 6, l = e & 63, i = 16 * ti + (l >> 4) + 4 * r, j = 16 * tj + (l & 15);
+        G[i + CQ_W * j] = v;
+        G[j + CQ_W * i] = v;
     }
 }
 
@@ -626,35 +730,59 @@ int qrd_panel_cqr_init(void)
 {
     hipError_t e = hipFuncSetAttribute((const void*) cqr_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
-    const int rows_lds = (int) (sizeof(double) * CQ_W * CQ_LD);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     return (int) e;
 }
 
 // shapes this route takes: w a multiple of 32 up to 128, at least 2 w rows
 int qrd_panel_cqr_ok(int mk, int w) { return w >= 32 && w <= CQ_W && (w & 31) == 0 && mk >= 2 * w; }
 
-// stage 1 (after G1 = A^T A has been put into ws + CQ_G1, column-major ld 128): R1, R1^-1, Q = A R1^-1 -> Vw
+static int cs_grid(int mk, int cap = CS_NWG) { const int g = (mk + 63) / 64; return g < cap ? g : cap; }
+
+// The whole panel: six launches + two small reductions on `stream`.  status (device, 4 ints) is zeroed here; status[0] = 1 afterwards:
+// the guard refused the panel and A is untouched.
+int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)
+{
+    if (!qrd_panel_cqr_ok(mk, w)) return -7;
+    hipStream_t s = (hipStream_t) stream;
+    hipError_t e = hipMemsetAsync(status, 0, 4 * sizeof(int), s);
+    if (e != hipSuccess) return (int) e;
+    const int grid = cs_grid(mk), ggrid = cs_grid(mk, CS_NWG_GRAM), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
+    hipLaunchKernelGGL((cqr_stream_kernel<false, true, false>), dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, (const double*) nullptr, w, mk, A, lda,
+                       (double*) nullptr, 0, (double*) nullptr, 0, ws + CQ_SL, status);
+    hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
+    hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
+    hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Vw, ldv,
+                       (double*) nullptr, 0, ws + CQ_SL, status);
+    hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
+    hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Vw, ldv, status);
+    hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
+                       (double*) nullptr, status);
+    hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+    return (int) hipGetLastError();
+}
+
+// the two halves with the Gram matrices supplied by the caller (G1 in qrd_panel_cqr_g1(ws) before stage 1, G2 = Q^T Q in
+// qrd_panel_cqr_g2(ws) before stage 2; column-major ld 128): kept for the stage-by-stage checks of devtools/tools_cqr_debug.py
 int qrd_panel_cqr_stage1(void* stream, const double* A, int lda, int mk, int w, double* Vw, int ldv, double* ws, int* status)
 {
     hipStream_t s = (hipStream_t) stream;
     hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
-    const int ntile = (mk + 15) / 16, grid = ((ntile + 3) / 4 < 256) ? (ntile + 3) / 4 : 256;
-    hipLaunchKernelGGL(cqr_rows_kernel<0>, dim3(grid), dim3(CR_THREADS), sizeof(double) * CQ_W * CQ_LD, s, ws + CQ_R1I, w, mk, A, lda, Vw, ldv,
-                       (double*) nullptr, 0, status);
+    hipLaunchKernelGGL((cqr_stream_kernel<true, false, false>), dim3(cs_grid(mk)), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Vw, ldv,
+                       (double*) nullptr, 0, (double*) nullptr, status);
     return (int) hipGetLastError();
 }
 
-// stage 2 (after G2 = Q^T Q has been put into ws + CQ_G2): the small factors, V -> Vw and A, the top block, T, tau
 int qrd_panel_cqr_stage2(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws,
                          int* status)
 {
     hipStream_t s = (hipStream_t) stream;
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Vw, ldv, status);
-    const int ntile = (mk + 15) / 16, grid = ((ntile + 3) / 4 < 256) ? (ntile + 3) / 4 : 256;
-    hipLaunchKernelGGL(cqr_rows_kernel<1>, dim3(grid), dim3(CR_THREADS), sizeof(double) * CQ_W * CQ_LD, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
-                       status);
+    hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(cs_grid(mk)), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
+                       (double*) nullptr, status);
     hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
     return (int) hipGetLastError();
 }

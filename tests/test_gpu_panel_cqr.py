@@ -28,13 +28,15 @@ def q(qr):
     L.qrd_panel_cqr_stage2.restype = C.c_int
     L.qrd_panel_cqr_stage2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p]
+    L.qrd_panel_cqr.restype = C.c_int
+    L.qrd_panel_cqr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.qrd_gemm_tn.restype = C.c_int
     L.qrd_gemm_tn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                               C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     return qr
 
 
-def run_panel(q, P, lda=None, ldv=None):
+def run_panel(q, P, lda=None, ldv=None, two_stage=False):
     mk, w = P.shape
     lda, ldv = lda or mk, ldv or mk
     buf = np.full((lda, w), 7.0)
@@ -47,12 +49,15 @@ def run_panel(q, P, lda=None, ldv=None):
     slabs = torch.zeros(cap, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     L = q.lib
-    g1, g2 = L.qrd_panel_cqr_g1(ws.data_ptr()), L.qrd_panel_cqr_g2(ws.data_ptr())
-    assert L.qrd_gemm_tn(None, w, w, mk, 1.0, dA.data_ptr(), lda, dA.data_ptr(), lda, 0.0, g1, 128, slabs.data_ptr(), cap, None, 0) == 0
-    assert L.qrd_panel_cqr_stage1(None, dA.data_ptr(), lda, mk, w, dV.data_ptr(), ldv, ws.data_ptr(), status.data_ptr()) == 0
-    assert L.qrd_gemm_tn(None, w, w, mk, 1.0, dV.data_ptr(), ldv, dV.data_ptr(), ldv, 0.0, g2, 128, slabs.data_ptr(), cap, None, 0) == 0
-    assert L.qrd_panel_cqr_stage2(None, dA.data_ptr(), lda, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), ldv, ws.data_ptr(),
-                                  status.data_ptr()) == 0
+    if not two_stage:
+        assert L.qrd_panel_cqr(None, dA.data_ptr(), lda, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), ldv, ws.data_ptr(), status.data_ptr()) == 0
+    else:          # the development form: Gram matrices from the library's general product
+        g1, g2 = L.qrd_panel_cqr_g1(ws.data_ptr()), L.qrd_panel_cqr_g2(ws.data_ptr())
+        assert L.qrd_gemm_tn(None, w, w, mk, 1.0, dA.data_ptr(), lda, dA.data_ptr(), lda, 0.0, g1, 128, slabs.data_ptr(), cap, None, 0) == 0
+        assert L.qrd_panel_cqr_stage1(None, dA.data_ptr(), lda, mk, w, dV.data_ptr(), ldv, ws.data_ptr(), status.data_ptr()) == 0
+        assert L.qrd_gemm_tn(None, w, w, mk, 1.0, dV.data_ptr(), ldv, dV.data_ptr(), ldv, 0.0, g2, 128, slabs.data_ptr(), cap, None, 0) == 0
+        assert L.qrd_panel_cqr_stage2(None, dA.data_ptr(), lda, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), ldv, ws.data_ptr(),
+                                      status.data_ptr()) == 0
     q.check(L.qrd_device_sync(), "sync")
     out = host(dA)
     assert np.array_equal(out[mk:], buf[mk:]), "rows below the panel are never written"
@@ -87,6 +92,20 @@ def test_panel_cqr_well_conditioned(q, mk, w):
     check_panel(P, out, V, T, tau)
 
 
+def test_panel_cqr_two_stage_form_with_external_gram_matrices(q):
+    P = np.random.default_rng(77).random((9000, 128))
+    out, V, T, tau, st = run_panel(q, P, two_stage=True)
+    assert st[0] == 0
+    check_panel(P, out, V, T, tau)
+
+
+def test_panel_cqr_is_bitwise_reproducible(q):
+    P = np.random.default_rng(78).random((50000, 96))
+    a = run_panel(q, P)
+    b = run_panel(q, P)
+    assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4]))
+
+
 def test_panel_cqr_moderately_conditioned_takes_the_second_cholesky(q):
     """cond ~ 3e5: |Q^T Q - I| after one pass is far above 1e-9 (second Cholesky instead of the first-order factor), still below 1/64"""
     rng = np.random.default_rng(3)
@@ -117,9 +136,9 @@ def test_panel_cqr_refuses_and_leaves_the_panel_untouched(q, kind):
     assert np.array_equal(out, P, equal_nan=True), "a refused panel must be left exactly as it was"
 
 
-@pytest.mark.parametrize("m,n,nb", [(65536, 256, 128), (40000, 192, 64), (70001, 128, 128)])
+@pytest.mark.parametrize("m,n,nb", [(458752, 256, 128), (400001, 128, 128)])
 def test_geqrf_takes_the_full_width_route_on_tall_shapes(qr, m, n, nb):
-    """qr_geqrf_dev on tall shapes (with MI355XQR_CQR_MIN_ROWS=32768 in the environment every panel takes the full-width route; the default threshold is higher) against LAPACK"""
+    """qr_geqrf_dev on tall shapes (128-column panels of at least MI355XQR_CQR_MIN_ROWS = 393216 rows: the full-width route) against LAPACK"""
     A = np.random.default_rng(m + n).random((m, n))
     p = qr.Plan(m, n, nb, 32)
     dA, dtau, dQ = dev(A), zeros(n, 1), zeros(m, n)

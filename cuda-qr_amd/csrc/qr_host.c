@@ -118,7 +118,8 @@ typedef struct qr_knobs {
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
     int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
     int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: 128-column panels of at least this many rows at full width (0 = never).  Measured
-                                                             * (devtools/r4_cqr.sh): 262144 rows 6.85 against 6.74 ms, 524288 4.36 against 4.78, 2^20 2.96 against 5.64 */
+                                                             * (devtools/r4_cqr.sh, whole factorisations): 131072 x 256 1.69 against 1.44 ms, 262144 x 512 6.06 against 6.61, 524288 x 256 3.77
+                                                             * against 5.04, 2^20 x 128 2.51 against 5.67 */
     int fused_gram;                                         /* the panel's Gram blocks V_prev^T V_l inside the one-launch panel (else one launch after it): constant 0 */
 } qr_knobs;
 static qr_knobs g_knobs;
@@ -141,7 +142,7 @@ static void knobs_init(void)
     k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
     k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
     k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
-    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 393216);
+    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 196608);
 }
 
 static const qr_knobs* knobs(void)

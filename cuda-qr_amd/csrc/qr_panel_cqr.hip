@@ -21,6 +21,10 @@
 
 namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
+// The wave index is taken through readfirstlane everywhere below: as `tid >> 6` it is a VECTOR value to the compiler, every
+// "this wave owns that tile" test became an exec-mask block of its own and each matrix-core instruction sat behind its private
+// `ds_read; s_waitcnt lgkmcnt(0)` -- the Gram pass ran at 11.6 us per 64-row block where the instructions account for 4
+
 
 constexpr int CQ_W = 128;                 // widest panel
 constexpr int CQ_LD = 129;                // row stride of the LDS matrix
@@ -52,24 +56,26 @@ __device__ __forceinline__ void cq_st(double* p, double v) { *p = v; }
 
 #ifdef CQ_STAMPS
 #define CQ_STAMP(n) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(ws + CQ_ST)[n] = wall_clock64(); } while (0)
+#define CQ_STAMP_L(n) do { if (threadIdx.x == 0 && L.wsdbg) reinterpret_cast<unsigned long long*>(L.wsdbg + CQ_ST)[n] = wall_clock64(); } while (0)
 #else
 #define CQ_STAMP(n) do { } while (0)
+#define CQ_STAMP_L(n) do { } while (0)
 #endif
 // barrier after which this workgroup's own global (workspace) stores can be read back by any of its threads
 __device__ __forceinline__ void cq_sync_global() { __threadfence(); __syncthreads(); }
 
-// Elementwise pass over the w x 128 index space (e -> (e >> 7, e & 127)) with the loads of 16 elements per thread requested together:
+// Elementwise pass over the w x 128 index space (e -> (e >> 7, e & 127)) with the loads of 32 elements per thread requested together:
 // a rolled loop with a dependent global load per iteration costs the memory latency (~0.4 us) EVERY iteration -- 64 iterations = 25 us
 template <class FL, class FS>
 __device__ __forceinline__ void cq_elems(int w, int tid, FL load, FS store)
 {
     const int n = w * CQ_W;
-    for (int base = tid; base < n; base += 16 * CQ_T) {
-        double v[16];
+    for (int base = tid; base < n; base += 32 * CQ_T) {
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int e = base + u * CQ_T; v[u] = load((e < n ? e : tid) >> 7, (e < n ? e : tid) & (CQ_W - 1)); }
+        for (int u = 0; u < 32; ++u) { const int e = base + u * CQ_T; v[u] = load((e < n ? e : tid) >> 7, (e < n ? e : tid) & (CQ_W - 1)); }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int e = base + u * CQ_T; if (e < n) store(e >> 7, e & (CQ_W - 1), v[u]); }
+        for (int u = 0; u < 32; ++u) { const int e = base + u * CQ_T; if (e < n) store(e >> 7, e & (CQ_W - 1), v[u]); }
     }
 }
 
@@ -82,6 +88,7 @@ struct CqLds {
     double* sv;           // [CQ_W] signs
     double* red;          // [CQ_T / 64] reduction scratch
     int* flag;            // [4]
+    double* wsdbg;        // workspace (phase stamps of CQ_STAMPS builds)
 };
 __device__ __forceinline__ CqLds cq_lds(double* sm)
 {
@@ -92,6 +99,7 @@ __device__ __forceinline__ CqLds cq_lds(double* sm)
     L.sv = L.sb2 + 32 * 33;
     L.red = L.sv + CQ_W;
     L.flag = reinterpret_cast<int*>(L.red + CQ_T / 64);
+    L.wsdbg = nullptr;
     return L;
 }
 constexpr size_t CQ_LDS_BYTES = sizeof(double) * (CQ_LD * CQ_LD + 2 * 32 * 33 + CQ_W + CQ_T / 64) + 64;
@@ -115,7 +123,7 @@ constexpr int CQ_MAXT = 9;
 template <class FC, class FS>
 __device__ __forceinline__ void cq_tiles(int nt, int ntc, int r0, int c0, bool upper_only, bool barrier, int tid, FC compute, FS store)
 {
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     v4d acc[CQ_MAXT];
 #pragma unroll
     for (int q = 0; q < CQ_MAXT; ++q) {
@@ -138,7 +146,7 @@ __device__ __forceinline__ void cq_tiles(int nt, int ntc, int r0, int c0, bool u
 // R12 = R11^-T G12 and G22 -= R12^T R12 on the matrix cores.  Returns false on a non-positive pivot (uniform).
 __device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
 {
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
     if (tid == 0) L.flag[0] = 1;
     __syncthreads();
@@ -184,7 +192,7 @@ __device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
 // cores U'12 = L11^-1 (W12 - S R2_12), L21 = W21 U'11^-1, W22 -= L21 U'12.  L1 \ U' in place, S -> L.sv.
 __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const double* R2g, int tid)
 {
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
     for (int o = 0; o < w; o += 32) {
         if (wave == 0) {
@@ -263,49 +271,59 @@ __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const doubl
 // X12 = -X11 (R12 X22) first inside each half of 64 columns and then between the halves, the products on the matrix cores with the
 // intermediate R12 X22 parked in R12's place.  X(i, j) goes to L.M[j + 1][i] (strictly below the diagonal: stride 129 keeps a
 // column of X on distinct banks)
-__device__ __forceinline__ void cq_offdiag(const CqLds& L, int r0, int nr, int c0, int nc, int tid)
+template <int NTR>
+__device__ __forceinline__ void cq_offdiag(const CqLds& L, int r0, int c0, int nc, int tid)
 {
-    // X(r0 : r0 + nr, c0 : c0 + nc) = -X(r0 .., r0 ..) (R(r0 .., c0 ..) X(c0 .., c0 ..)), nr, nc multiples of 16 up to 64, c0 = r0 + nr.
-    // A wave owns a tile COLUMN (its B fragment is shared by the up to four tile rows, whose accumulators interleave on the matrix
-    // core: a chain of dependent f64 MFMAs issues one every ~70 cycles, four independent ones every 16)
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int ntr = nr >> 4, ntc = nc >> 4;
+    // X(r0 : r0 + nr, c0 : c0 + nc) = -X(r0 .., r0 ..) (R(r0 .., c0 ..) X(c0 .., c0 ..)), nr = 16 NTR, nc a multiple of 16 up to 64, c0 = r0 + nr.
+    // A wave owns a tile COLUMN (its B fragment is shared by the NTR tile rows, whose accumulators interleave on the matrix core: a
+    // chain of dependent f64 MFMAs issues one every ~70 cycles, independent ones every 64); static tile-row count, operands of the next
+    // k-step requested before this one's instructions
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    constexpr int nr = 16 * NTR;
+    const int ntc = nc >> 4;
     const bool on = wave < ntc;
-    const int j0 = c0 + 16 * wave;
-    v4d acc[4];
+    const int j0 = c0 + 16 * wave, j = j0 + l15;
+    v4d acc[NTR];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NTR; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
     if (on) {
         // P = R(r0 .., c0 ..) X(c0 .., c0 ..): X upper triangular, k <= j
-#pragma unroll 2
-        for (int k = c0; k < j0 + 16; k += 4) {
-            const int kk = k + l4, j = j0 + l15;
-            const double b = (kk <= j) ? L.M[(j + 1) * CQ_LD + kk] : 0.0;
+        double a[NTR], an[NTR], b, bn = 0.0;
+        auto ld = [&](int k, double (&av)[NTR], double& bv) {
+            const int kk = k + l4;
+            bv = (kk <= j) ? L.M[(j + 1) * CQ_LD + kk] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < ntr) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(L.M[(r0 + 16 * q + l15) * CQ_LD + kk], b, acc[q], 0, 0, 0);
+            for (int q = 0; q < NTR; ++q) av[q] = L.M[(r0 + 16 * q + l15) * CQ_LD + kk];
+        };
+        ld(c0, a, b);
+        for (int k = c0; k < j0 + 16; k += 4) {
+            if (k + 4 < j0 + 16) ld(k + 4, an, bn);
+#pragma unroll
+            for (int q = 0; q < NTR; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b, acc[q], 0, 0, 0);
+            b = bn;
+#pragma unroll
+            for (int q = 0; q < NTR; ++q) a[q] = an[q];
         }
     }
     __syncthreads();
     if (on) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < ntr)
+        for (int q = 0; q < NTR; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) L.M[(r0 + 16 * q + l4 + 4 * r) * CQ_LD + j0 + l15] = acc[q][r];
+            for (int r = 0; r < 4; ++r) L.M[(r0 + 16 * q + l4 + 4 * r) * CQ_LD + j0 + l15] = acc[q][r];
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NTR; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
     if (on) {
         // X12 = -X(r0 .., r0 ..) P: X upper triangular, k >= i (tile row q starts at k = r0 + 16 q)
-#pragma unroll 2
-        for (int k = r0; k < r0 + nr; k += 4) {
-            const int kk = k + l4;
+#pragma unroll
+        for (int ks = 0; ks < 4 * NTR; ++ks) {
+            const int kk = r0 + 4 * ks + l4;
             const double b = L.M[kk * CQ_LD + j0 + l15];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < ntr && k >= r0 + 16 * q) {
+            for (int q = 0; q < NTR; ++q)
+                if (4 * ks >= 16 * q) {
                     const int i = r0 + 16 * q + l15;
                     acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64((i <= kk) ? L.M[(kk + 1) * CQ_LD + i] : 0.0, b, acc[q], 0, 0, 0);
                 }
@@ -314,23 +332,23 @@ __device__ __forceinline__ void cq_offdiag(const CqLds& L, int r0, int nr, int c
     __syncthreads();
     if (on) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < ntr)
+        for (int q = 0; q < NTR; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) L.M[(j0 + l15 + 1) * CQ_LD + r0 + 16 * q + l4 + 4 * r] = -acc[q][r];
+            for (int r = 0; r < 4; ++r) L.M[(j0 + l15 + 1) * CQ_LD + r0 + 16 * q + l4 + 4 * r] = -acc[q][r];
     }
     __syncthreads();
 }
 __device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int tj, int tid)
 {
     (void) ti; (void) tj;
-    const int nblk = w >> 5, wave = tid >> 6, lane = tid & 63;
+    const int nblk = w >> 5, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // the strictly lower part must read as zero where X has not been written
     for (int e = tid; e < (w + 1) * CQ_W; e += CQ_T) {
         const int r = e >> 7, c = e & (CQ_W - 1);
         if (c < r) L.M[r * CQ_LD + c] = 0.0;
     }
     __syncthreads();
+    CQ_STAMP_L(20);
     if (wave < nblk) {
         // column j of the block's inverse in registers (static indices: the loops unroll); row i of R is a broadcast read
         const int o = 32 * wave, j = lane & 31;
@@ -351,9 +369,12 @@ __device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int 
         }
     }
     __syncthreads();
-    if (w >= 64) cq_offdiag(L, 0, 32, 32, 32, tid);
-    if (w == 128) cq_offdiag(L, 64, 32, 96, 32, tid);
-    if (w > 64) cq_offdiag(L, 0, 64, 64, w - 64, tid);
+    CQ_STAMP_L(21);
+    if (w >= 64) cq_offdiag<2>(L, 0, 32, 32, tid);
+    if (w == 128) cq_offdiag<2>(L, 64, 96, 32, tid);
+    CQ_STAMP_L(22);
+    if (w > 64) cq_offdiag<4>(L, 0, 64, w - 64, tid);
+    CQ_STAMP_L(23);
 }
 
 // the inverse out of L.M into a row-major global matrix (zero below the diagonal)
@@ -370,36 +391,58 @@ __device__ __forceinline__ void cq_inv_out(const CqLds& L, double* X, int w, int
 // diagonal of L.M, where the inverses leave their result: B(k, j) at M[j + 1][k]); d = NULL: no scaling.  A wave owns two tile ROWS
 // (tr and 7 - tr: nine tiles on and above the diagonal each at w = 128): the A fragment of a k-step is shared by the row's tiles and
 // their accumulators interleave on the matrix core.  f(i, j, value) for every element on and above the tile diagonal.
+template <int TR, bool FULL, class F>
+__device__ __forceinline__ void cq_product_row(const CqLds& L, const double* d, int nt, int l15, int l4, F f)
+{
+    if (!FULL && TR >= nt) return;
+    // tile row TR: tiles (TR, TR .. 7), k from 16 TR; tile q needs k < 16 q + 16.  Static ranges, the next k-step's operands requested
+    // before this one's matrix-core instructions
+    v4d acc[8];
+#pragma unroll
+    for (int q = TR; q < 8; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int i = 16 * TR + l15;
+    double a, an = 0.0, b[8], bn[8];
+    auto ld = [&](int k, double& av, double (&bv)[8]) {
+        const int kk = k + l4;
+        av = (kk >= i) ? L.M[i * CQ_LD + kk] * (d ? d[kk] : 1.0) : 0.0;
+#pragma unroll
+        for (int q = TR; q < 8; ++q)
+            if (k < 16 * q + 16) { const int j = 16 * q + l15; bv[q] = (kk <= j) ? L.M[(j + 1) * CQ_LD + kk] : 0.0; }
+    };
+    ld(16 * TR, a, b);
+#pragma unroll
+    for (int k = 16 * TR; k < 128; k += 4) {
+        if (!FULL && k >= 16 * nt) break;
+        if (k + 4 < 128) ld(k + 4, an, bn);
+#pragma unroll
+        for (int q = TR; q < 8; ++q)
+            if (k < 16 * q + 16 && (FULL || q < nt)) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[q], acc[q], 0, 0, 0);
+        a = an;
+#pragma unroll
+        for (int q = TR; q < 8; ++q) b[q] = bn[q];
+    }
+#pragma unroll
+    for (int q = TR; q < 8; ++q)
+        if (FULL || q < nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f(16 * TR + l4 + 4 * r, 16 * q + l15, acc[q][r]);
+}
+template <bool FULL, class F>
+__device__ __forceinline__ void cq_product_rows(const CqLds& L, const double* d, int nt, int wave, int l15, int l4, F f)
+{
+    switch (wave) {
+    case 0: cq_product_row<0, FULL>(L, d, nt, l15, l4, f); cq_product_row<7, FULL>(L, d, nt, l15, l4, f); break;
+    case 1: cq_product_row<1, FULL>(L, d, nt, l15, l4, f); cq_product_row<6, FULL>(L, d, nt, l15, l4, f); break;
+    case 2: cq_product_row<2, FULL>(L, d, nt, l15, l4, f); cq_product_row<5, FULL>(L, d, nt, l15, l4, f); break;
+    default: cq_product_row<3, FULL>(L, d, nt, l15, l4, f); cq_product_row<4, FULL>(L, d, nt, l15, l4, f); break;
+    }
+}
 template <class F>
 __device__ __forceinline__ void cq_upper_product(const CqLds& L, const double* d, int w, int tid, F f)
 {
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, nt = w >> 4;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int tr = half ? 7 - wave : wave;
-        if (tr >= nt) continue;
-        v4d acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const int i = 16 * tr + l15;
-#pragma unroll 2
-        for (int k = 16 * tr; k < w; k += 4) {
-            const int kk = k + l4;
-            const double a = (kk >= i) ? L.M[i * CQ_LD + kk] * (d ? d[kk] : 1.0) : 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (q >= tr && q < nt && k < 16 * q + 16) {       // B(k, j) = 0 for k > j
-                    const int j = 16 * q + l15;
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (kk <= j) ? L.M[(j + 1) * CQ_LD + kk] : 0.0, acc[q], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (q >= tr && q < nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) f(16 * tr + l4 + 4 * r, 16 * q + l15, acc[q][r]);
-    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, nt = w >> 4;
+    if (nt == 8) cq_product_rows<true>(L, d, nt, wave, l15, l4, f);
+    else cq_product_rows<false>(L, d, nt, wave, l15, l4, f);
 }
 
 // a row-major global upper-triangular matrix into the transposed slots strictly below the diagonal of L.M (operand B of cq_upper_product)
@@ -420,7 +463,10 @@ __device__ __forceinline__ void cq_load_upper(const CqLds& L, const double* G, i
 __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* status)
 {
     extern __shared__ double sm[];
-    const CqLds L = cq_lds(sm);
+    CqLds L = cq_lds(sm);
+#ifdef CQ_STAMPS
+    L.wsdbg = ws;
+#endif
     const int tid = threadIdx.x;
     // G(i, j) = G(j, i): consecutive lanes read consecutive addresses
     cq_elems(w, tid, [&](int i, int j) { return ws[CQ_G1 + j + CQ_W * i]; }, [&](int i, int j, double v) { if (j < w && j >= i) L.M[i * CQ_LD + j] = v; });
@@ -500,18 +546,18 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
         const int i = e >> 7, j = e & (CQ_W - 1);
         if (j < w) cq_st(ws + CQ_LU + i * CQ_W + j, L.M[i * CQ_LD + j]);
     }
-    {   // (W in L.M has been overwritten: Q_top is read again, with R2, both requested 8 elements ahead)
+    {   // (W in L.M has been overwritten: Q_top is read again, with R2, both requested 16 elements ahead)
         const int n = w * CQ_W;
-        for (int base = tid; base < n; base += 8 * CQ_T) {
-            double qv[8], rv[8];
+        for (int base = tid; base < n; base += 16 * CQ_T) {
+            double qv[16], rv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int e = base + u * CQ_T, ee = e < n ? e : tid, j = ee >> 7, i = ee & (CQ_W - 1), ic = i < w ? i : w - 1;
                 qv[u] = Vw[ic + (size_t) ldv * j];
                 rv[u] = ws[CQ_R2 + ic * CQ_W + j];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int e = base + u * CQ_T, j = e >> 7, i = e & (CQ_W - 1);
                 if (e < n && i < w && j >= i) Vw[i + (size_t) ldv * j] = qv[u] - L.sv[i] * rv[u];
             }
@@ -568,20 +614,67 @@ constexpr int CS_THREADS = 256;
 constexpr int CS_QLD = 130;                                    // row stride of the workgroup's block in LDS (accumulator-order writes conflict-free, operand reads 2-way)
 constexpr int CS_XC = 36 * 256;                                // doubles of the compact X
 constexpr int CS_NWG = 256;                                    // workgroups of the passes that hold X in LDS (one per compute unit)
-constexpr int CS_NWG_GRAM = 1024;                              // workgroups (= partials) of the Gram-only pass
+constexpr int CS_NWG_GRAM = 512;                               // workgroups (= partials) of the Gram-only pass (two per compute unit)
 constexpr size_t CS_LDS_BYTES = sizeof(double) * (CS_XC + 4 * 16 * CS_QLD);
 constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass: four workgroups fit a compute unit
 __device__ __forceinline__ int cs_blk(int kb, int jb) { return (jb * (jb + 1) / 2 + kb) * 256; }
 
-template <bool MULT, bool GRAM, bool DST2>
-__global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __restrict__ X, int w, int mk, const double* src, int lds_, double* dst,
-                                                                 int ldd, double* dst2, int ldd2, double* slabs, const int* status)
+// tile row TR of the Gram matrix of the workgroup's 64 x w block in LDS: tiles (TR, TR .. 7), 16 k-steps of 4 rows; the B operands of a
+// k-step are read together, unconditionally (the block's LDS rows are 130 doubles whatever w), then the matrix-core instructions
+template <int TR, bool FULL, bool PIPE>
+__device__ __forceinline__ void cs_gram_row(v4d (&g)[8], const double* Qall, int nct, int l15, int l4)
 {
-    extern __shared__ double sm[];
+    if (!FULL && TR >= nct) return;
+    const double* qr = Qall + l4 * CS_QLD + l15;
+    if (PIPE) {
+        // one wave per SIMD: nothing else hides the LDS latency -- fully unrolled, the next k-step's operands requested before this
+        // one's matrix-core instructions
+        double b[8], bn[8];
+#pragma unroll
+        for (int t = TR; t < 8; ++t) b[t] = qr[16 * t];
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+            if (k + 4 < 64)
+#pragma unroll
+                for (int t = TR; t < 8; ++t) bn[t] = qr[(k + 4) * CS_QLD + 16 * t];
+#pragma unroll
+            for (int t = TR; t < 8; ++t)
+                if (FULL || t < nct) g[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[TR], b[t], g[t], 0, 0, 0);
+#pragma unroll
+            for (int t = TR; t < 8; ++t) b[t] = bn[t];
+        }
+    } else {
+        // two waves per SIMD (the Gram-only pass): the other wave covers the latency, the registers go to the accumulators
+#pragma unroll 2
+        for (int k = 0; k < 64; k += 4) {
+            double b[8];
+#pragma unroll
+            for (int t = TR; t < 8; ++t) b[t] = qr[k * CS_QLD + 16 * t];
+#pragma unroll
+            for (int t = TR; t < 8; ++t)
+                if (FULL || t < nct) g[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[TR], b[t], g[t], 0, 0, 0);
+        }
+    }
+}
+template <bool FULL, bool PIPE>
+__device__ __forceinline__ void cs_gram_rows(v4d (&g0)[8], v4d (&g1)[8], const double* Qall, int nct, int wave, int l15, int l4)
+{
+    switch (wave) {                                           // (scalar: static tile ranges; FULL = 128 columns: no predicate around a matrix-core instruction)
+    case 0: cs_gram_row<0, FULL, PIPE>(g0, Qall, nct, l15, l4); cs_gram_row<7, FULL, PIPE>(g1, Qall, nct, l15, l4); break;
+    case 1: cs_gram_row<1, FULL, PIPE>(g0, Qall, nct, l15, l4); cs_gram_row<6, FULL, PIPE>(g1, Qall, nct, l15, l4); break;
+    case 2: cs_gram_row<2, FULL, PIPE>(g0, Qall, nct, l15, l4); cs_gram_row<5, FULL, PIPE>(g1, Qall, nct, l15, l4); break;
+    default: cs_gram_row<3, FULL, PIPE>(g0, Qall, nct, l15, l4); cs_gram_row<4, FULL, PIPE>(g1, Qall, nct, l15, l4); break;
+    }
+}
+
+template <bool MULT, bool GRAM, bool DST2>
+__device__ __forceinline__ void cqr_stream_body(double* sm, const double* __restrict__ X, int w, int mk, const double* src, int lds_, double* dst,
+                                                int ldd, double* dst2, int ldd2, double* slabs, const int* status)
+{
     if (DST2 && status[0]) return;
     double* Xc = sm;
     double* Qall = sm + (MULT ? CS_XC : 0);                   // the workgroup's 64 x w block, rows of wave v at 16 v
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
     double* Qt = Qall + wave * 16 * CS_QLD;
     const int nct = w >> 4;
     if (MULT) {
@@ -611,14 +704,18 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
         }
     };
     int blk = blockIdx.x;
-    if (blk < nblk) load(q, 4 * blk + wave);
+    if (MULT && blk < nblk) load(q, 4 * blk + wave);
     for (; blk < nblk; blk += gridDim.x) {
         const int tile = 4 * blk + wave;
-        // the next block's rows are requested before this block's matrix-core work
-        load(qn, tile + 4 * gridDim.x);                       // (a tile beyond the end loads nothing: predicate in load)
+        if (!MULT) load(q, tile);                             // (the Gram-only pass: two waves per SIMD cover each other's latency; no block kept in flight)
+        // the next block's rows are requested before this block's matrix-core work: with GRAM into q itself once the block has gone to
+        // LDS / through the product (the Gram instructions cover the latency, and a second buffer would cost the second wave per SIMD)
+        if (!GRAM) load(qn, tile + 4 * gridDim.x);            // (a tile beyond the end loads nothing: predicate in load)
         const int row = 16 * tile + l15;
         const bool rin = row < mk;
         if (MULT) {
+            // (one column tile at a time: with the k-step outermost -- eight interleaved accumulator chains -- the stores came in one burst
+            // at the end and the pass was 10 % slower)
 #pragma unroll
             for (int jt = 0; jt < 8; ++jt) {
                 if (jt < nct) {
@@ -643,29 +740,15 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
                 if (4 * ks < w) Qt[l15 * CS_QLD + 4 * ks + l4] = q[ks];
         }
         if (GRAM) {
+            if (MULT) load(q, tile + 4 * gridDim.x);
             __syncthreads();
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int tr = half ? 7 - wave : wave;
-                if (tr < nct) {
-#pragma unroll 4
-                    for (int k = 0; k < 64; k += 4) {
-                        const double* qr = Qall + (k + l4) * CS_QLD + l15;
-                        const double a = qr[16 * tr];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            if (t >= tr && t < nct) {
-                                if (half) g1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qr[16 * t], g1[t], 0, 0, 0);
-                                else g0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qr[16 * t], g0[t], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-            }
+            if (nct == 8) cs_gram_rows<true, MULT>(g0, g1, Qall, nct, wave, l15, l4);
+            else cs_gram_rows<false, MULT>(g0, g1, Qall, nct, wave, l15, l4);
             __syncthreads();                                  // the block is free for the next one's writes
         }
+        if (!GRAM)
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) q[ks] = qn[ks];
+            for (int ks = 0; ks < 32; ++ks) q[ks] = qn[ks];
     }
     if (GRAM) {
         double* out = slabs + (size_t) blockIdx.x * 36 * 256;
@@ -679,6 +762,21 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
                     for (int r = 0; r < 4; ++r) out[(t * (t + 1) / 2 + tr) * 256 + r * 64 + lane] = half ? g1[t][r] : g0[t][r];
         }
     }
+}
+
+template <bool MULT, bool GRAM, bool DST2>
+__global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __restrict__ X, int w, int mk, const double* src, int lds_, double* dst,
+                                                                 int ldd, double* dst2, int ldd2, double* slabs, const int* status)
+{
+    extern __shared__ double sm[];
+    cqr_stream_body<MULT, GRAM, DST2>(sm, X, w, mk, src, lds_, dst, ldd, dst2, ldd2, slabs, status);
+}
+// the Gram-only pass with TWO waves per SIMD (256 registers: 128 of accumulators, the row block, two k-steps of operands; 33 KB of LDS):
+// one workgroup's matrix-core phase runs under the other's loads and LDS transposition
+__global__ __launch_bounds__(CS_THREADS, 2) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs)
+{
+    extern __shared__ double sm[];
+    cqr_stream_body<false, true, false>(sm, nullptr, w, mk, src, lds_, nullptr, 0, nullptr, 0, slabs, nullptr);
 }
 
 // G (column-major ld CQ_W, both triangles) = sum over the workgroup partials, in slab order.  Tile t = (ti <= tj), accumulator
@@ -730,7 +828,6 @@ int qrd_panel_cqr_init(void)
 {
     hipError_t e = hipFuncSetAttribute((const void*) cqr_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
@@ -751,8 +848,7 @@ int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, 
     hipError_t e = hipMemsetAsync(status, 0, 4 * sizeof(int), s);
     if (e != hipSuccess) return (int) e;
     const int grid = cs_grid(mk), ggrid = cs_grid(mk, CS_NWG_GRAM), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
-    hipLaunchKernelGGL((cqr_stream_kernel<false, true, false>), dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, (const double*) nullptr, w, mk, A, lda,
-                       (double*) nullptr, 0, (double*) nullptr, 0, ws + CQ_SL, status);
+    hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
     hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
     hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Vw, ldv,

@@ -806,7 +806,7 @@ __device__ __forceinline__ void pf_householder_leaf(double (&ar)[4][8], const Pf
 __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, int nrow)
 {
     const PfLds L = pf_lds(sm);
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: "this wave owns that tile" tests become uniform branches, not exec-mask blocks)
     const int mk = P.mk, wh = P.wh, lda = P.lda, ldv = P.ldv;
     double* const A = P.A;
     double* const Vw = P.Vw;
@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
 __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nrow)
 {
     const PfLds L = pf_lds(sm);
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = 0;                                      // (stamps: this workgroup reports under its own stamp numbers)
     unsigned* const flags = reinterpret_cast<unsigned*>(P.ws);
     int nfallback = 0;

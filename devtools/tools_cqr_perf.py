@@ -6,7 +6,8 @@ import numpy as np, torch
 import cuda_qr_amd as qr
 mk, w = int(sys.argv[1]), int(sys.argv[2])
 pads = [int(x) for x in sys.argv[3:]] or [0]
-L = qr.lib
+L = qr.lib if not _os.environ.get('CQR_LIB') else C.CDLL(_os.path.abspath(_os.environ['CQR_LIB']))
+L.qrd_device_sync.restype = C.c_int
 qr.check(L.qrd_init(), "init")
 L.qrd_panel_cqr_ws_doubles.restype = C.c_size_t
 L.qrd_panel_cqr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

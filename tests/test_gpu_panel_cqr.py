@@ -138,7 +138,7 @@ def test_panel_cqr_refuses_and_leaves_the_panel_untouched(q, kind):
 
 @pytest.mark.parametrize("m,n,nb", [(458752, 256, 128), (400001, 128, 128)])
 def test_geqrf_takes_the_full_width_route_on_tall_shapes(qr, m, n, nb):
-    """qr_geqrf_dev on tall shapes (128-column panels of at least MI355XQR_CQR_MIN_ROWS = 393216 rows: the full-width route) against LAPACK"""
+    """qr_geqrf_dev on tall shapes (128-column panels of at least MI355XQR_CQR_MIN_ROWS = 196608 rows: the full-width route) against LAPACK"""
     A = np.random.default_rng(m + n).random((m, n))
     p = qr.Plan(m, n, nb, 32)
     dA, dtau, dQ = dev(A), zeros(n, 1), zeros(m, n)

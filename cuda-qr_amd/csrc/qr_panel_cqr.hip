@@ -610,11 +610,15 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
 //   pass 1: !MULT, GRAM  (G1 = A^T A)     pass 2: MULT, GRAM  (Q = A R1^-1 -> Vw, G2 = Q^T Q)     pass 3: MULT, DST2  (V -> Vw and A)
 // The next block's rows are requested before the current block's matrix-core work.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS only.  __syncthreads() is a release/acquire fence on EVERY address space: hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the barrier, i.e. the next block's global loads -- requested early precisely to run under this block's
+// matrix-core work -- had to land before the barrier: memory time and matrix-core time simply added up (Gram pass 132 us = 66 + 66)
+__device__ __forceinline__ void cs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int CS_THREADS = 256;
 constexpr int CS_QLD = 130;                                    // row stride of the workgroup's block in LDS (accumulator-order writes conflict-free, operand reads 2-way)
 constexpr int CS_XC = 36 * 256;                                // doubles of the compact X
 constexpr int CS_NWG = 256;                                    // workgroups of the passes that hold X in LDS (one per compute unit)
-constexpr int CS_NWG_GRAM = 512;                               // workgroups (= partials) of the Gram-only pass (two per compute unit)
+constexpr int CS_NWG_GRAM = 256;                               // workgroups (= partials) of the Gram-only pass
 constexpr size_t CS_LDS_BYTES = sizeof(double) * (CS_XC + 4 * 16 * CS_QLD);
 constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass: four workgroups fit a compute unit
 __device__ __forceinline__ int cs_blk(int kb, int jb) { return (jb * (jb + 1) / 2 + kb) * 256; }
@@ -704,10 +708,9 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
         }
     };
     int blk = blockIdx.x;
-    if (MULT && blk < nblk) load(q, 4 * blk + wave);
+    if (blk < nblk) load(q, 4 * blk + wave);
     for (; blk < nblk; blk += gridDim.x) {
         const int tile = 4 * blk + wave;
-        if (!MULT) load(q, tile);                             // (the Gram-only pass: two waves per SIMD cover each other's latency; no block kept in flight)
         // the next block's rows are requested before this block's matrix-core work: with GRAM into q itself once the block has gone to
         // LDS / through the product (the Gram instructions cover the latency, and a second buffer would cost the second wave per SIMD)
         if (!GRAM) load(qn, tile + 4 * gridDim.x);            // (a tile beyond the end loads nothing: predicate in load)
@@ -740,11 +743,11 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
                 if (4 * ks < w) Qt[l15 * CS_QLD + 4 * ks + l4] = q[ks];
         }
         if (GRAM) {
-            if (MULT) load(q, tile + 4 * gridDim.x);
-            __syncthreads();
-            if (nct == 8) cs_gram_rows<true, MULT>(g0, g1, Qall, nct, wave, l15, l4);
-            else cs_gram_rows<false, MULT>(g0, g1, Qall, nct, wave, l15, l4);
-            __syncthreads();                                  // the block is free for the next one's writes
+            load(q, tile + 4 * gridDim.x);
+            cs_lds_barrier();
+            if (nct == 8) cs_gram_rows<true, true>(g0, g1, Qall, nct, wave, l15, l4);
+            else cs_gram_rows<false, true>(g0, g1, Qall, nct, wave, l15, l4);
+            cs_lds_barrier();                                 // the block is free for the next one's writes
         }
         if (!GRAM)
 #pragma unroll
@@ -771,9 +774,8 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
     extern __shared__ double sm[];
     cqr_stream_body<MULT, GRAM, DST2>(sm, X, w, mk, src, lds_, dst, ldd, dst2, ldd2, slabs, status);
 }
-// the Gram-only pass with TWO waves per SIMD (256 registers: 128 of accumulators, the row block, two k-steps of operands; 33 KB of LDS):
-// one workgroup's matrix-core phase runs under the other's loads and LDS transposition
-__global__ __launch_bounds__(CS_THREADS, 2) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs)
+// the Gram-only pass (33 KB of LDS; two waves per SIMD were tried: no faster, and the block kept in flight then spills)
+__global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs)
 {
     extern __shared__ double sm[];
     cqr_stream_body<false, true, false>(sm, nullptr, w, mk, src, lds_, nullptr, 0, nullptr, 0, slabs, nullptr);

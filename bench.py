@@ -437,35 +437,33 @@ def main():
         # plus their in-panel updates, whose bytes are not in the counter file
         ptraffic, psrc = None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_panel_hbm.json")))
-            if m_local == 262144:
-                ptraffic = pj["hbm_bytes_per_leaf_streaming_kernels"] * (nb // 32)
-                psrc = {"file": "profiles/r03_pmc_panel_hbm.json", "per_leaf_kernels": pj["kernels"],
-                        "covers": "gram32 + cholq4_tall + final3 of the nb/32 leaves of one outer panel (%.0f MB per 67 MB leaf: %.1f passes); "
-                                  "not the in-panel updates, the Gram / T merge or the one-workgroup reconstruction kernel"
-                                  % (pj["hbm_bytes_per_leaf_streaming_kernels"] / 1e6, pj["hbm_bytes_per_leaf_streaming_kernels"] / 67.1e6),
-                        "method": pj["method"] + "; replayed from the committed file"}
+            # round 4: a 262144-row, 128-column panel takes the full-width route (qr_panel_cqr.hip): PMC passes over one such panel
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_panel_hbm.json")))
+            if m_local == pj["mk"] and nb == pj["w"]:
+                ptraffic = pj["hbm_bytes_per_panel"]
+                psrc = {"file": "profiles/r04_pmc_panel_hbm.json", "covers": pj["covers"], "method": pj["method"] + "; replayed from the committed file"}
         except Exception:
             pass
         # whole-factorisation HBM bytes of this shape (every dispatch: leaf kernels, in-panel products and updates, outer updates),
-        # PMC passes of devtools/scripts_r3_pmc_panel.sh -- replayed, not measured in this run
+        # PMC passes of devtools/scripts_r4_pmc.sh -- replayed, not measured in this run
         whole = None
         try:
-            wj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_tsqr_total_traffic.json")))
+            wj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_tsqr_total_traffic.json")))
             if m_local == wj["m"] and n == wj["n"]:
-                whole = {"file": "profiles/r03_pmc_tsqr_total_traffic.json", "hbm_bytes_per_factorisation": wj["hbm_bytes_per_factorisation"],
+                whole = {"file": "profiles/r04_pmc_tsqr_total_traffic.json", "hbm_bytes_per_factorisation": wj["hbm_bytes_per_factorisation"],
                          "algorithmic_bytes_16mn": wj["algorithmic_bytes_16mn"], "ratio": wj["ratio"],
                          "achieved_GBps_whole_step": wj["hbm_bytes_per_factorisation"] / (dt / K) / 1e9}
         except Exception:
             pass
-        roof = None if not pan["launches"] else {"bound": "hbm", "kernel": "panel factorisation (gram32 / chol1 / cholq4_tall / hr3 / final3 leaf kernels + guard launches, in-panel gemm_tn_dual / leaf_update_gram, Gram + T merge)",
+        roof = None if not pan["launches"] else {"bound": "hbm", "kernel": "panel factorisation: panels of >= 196608 rows x 128 columns at full width (qr_panel_cqr.hip: cqr_gram / cqr_chol / cqr_stream<Q,G2> / cqr_lu / cqr_stream<V> kernels), others by the leaf chain (gram32 / chol1 / cholq4_tall / hr3 / final3 + in-panel gemm_tn_dual / leaf_update_gram, Gram + T merge)",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": ptraffic, "traffic_source": psrc, "traffic_whole_factorisation": whole,
                 "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),
                 "profiled_steps_in_timed_region": len(range(0, K, stride)),
                 "algorithmic_bytes_per_launch": pan["bytes"] / max(pan["launches"], 1),
-                "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); the streaming leaf kernels run at 2.2-5.3 TB/s, "
-                        "the panel as a whole is bound by its ~9 dependent launches per leaf (DESIGN.md sections 3.1, 8)",
+                "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); a full-width panel moves 3.15x that in three passes "
+                        "(G1; Q + G2; V to two destinations) at 1.8 TB/s overall -- its passes cost memory time plus matrix-core time, and two "
+                        "one-workgroup factor kernels (0.33 ms) sit between them (DESIGN.md section 3.1c)",
                 "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None,
                 "measured_probe": measured}
 

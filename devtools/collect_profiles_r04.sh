@@ -20,6 +20,5 @@ cp $P/form_q_timing.txt $O/r04_form_q_timing.txt
 cp $P/qr_device_timing_table.txt $O/r04_qr_device_timing_table.txt
 cp $P/fuzz_parity.txt $O/r04_fuzz_parity.txt
 [ -f $M/tsqr_total_traffic_default.json ] && cp $M/tsqr_total_traffic_default.json $O/r04_pmc_tsqr_total_traffic.json
-[ -f $M/tsqr_total_traffic_cqr.json ] && cp $M/tsqr_total_traffic_cqr.json $O/r04_pmc_tsqr_total_traffic_full_width_panel.json
 [ -f $M/panel_kernels_hbm.txt ] && cp $M/panel_kernels_hbm.txt $O/r04_pmc_panel_kernels_hbm.txt
 ls $O | grep -c r04_

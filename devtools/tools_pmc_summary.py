@@ -7,7 +7,7 @@ tot = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(path)):
     if r.get("Counter_Name") != counter:
         continue
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:48]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:48]
     tot[name][0] += float(r["Counter_Value"]); tot[name][1] += 1
 print(f"{counter}: per-kernel totals (raw counter units) and per-dispatch average")
 for k, (v, c) in sorted(tot.items(), key=lambda x: -x[1][0]):

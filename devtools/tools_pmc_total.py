@@ -9,7 +9,7 @@ def per_kernel(path, counter):
     t = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(path)):
         if r.get("Counter_Name") != counter: continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:44]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:44]
         t[name][0] += float(r["Counter_Value"]) * 1024.0; t[name][1] += 1
     return t
 F, W = per_kernel(f, "FETCH_SIZE"), per_kernel(w, "WRITE_SIZE")

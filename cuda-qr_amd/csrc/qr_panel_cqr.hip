@@ -612,8 +612,15 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Workgroup barrier that orders LDS only.  __syncthreads() is a release/acquire fence on EVERY address space: hipcc puts
 // `s_waitcnt vmcnt(0)` in front of the barrier, i.e. the next block's global loads -- requested early precisely to run under this block's
-// matrix-core work -- had to land before the barrier: memory time and matrix-core time simply added up (Gram pass 132 us = 66 + 66)
-__device__ __forceinline__ void cs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// matrix-core work -- had to land before the barrier: memory time and matrix-core time simply added up (Gram pass 132 us = 66 + 66).
+// (An inline-asm `s_waitcnt lgkmcnt(0); s_barrier` does not help: the compiler puts its own vmcnt(0) in front of inline asm that
+// clobbers memory.  The fence builtin with an address-space argument compiles to exactly lgkmcnt(0) + s_barrier.)
+__device__ __forceinline__ void cs_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 constexpr int CS_THREADS = 256;
 constexpr int CS_QLD = 130;                                    // row stride of the workgroup's block in LDS (accumulator-order writes conflict-free, operand reads 2-way)
 constexpr int CS_XC = 36 * 256;                                // doubles of the compact X

@@ -627,7 +627,7 @@ constexpr int CS_XC = 36 * 256;                                // doubles of the
 constexpr int CS_NWG = 256;                                    // workgroups of the passes that hold X in LDS (one per compute unit)
 constexpr int CS_NWG_GRAM = 256;                               // workgroups (= partials) of the Gram-only pass
 constexpr size_t CS_LDS_BYTES = sizeof(double) * (CS_XC + 4 * 16 * CS_QLD);
-constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass: four workgroups fit a compute unit
+constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass
 __device__ __forceinline__ int cs_blk(int kb, int jb) { return (jb * (jb + 1) / 2 + kb) * 256; }
 
 // tile row TR of the Gram matrix of the workgroup's 64 x w block in LDS: tiles (TR, TR .. 7), 16 k-steps of 4 rows; the B operands of a
@@ -703,16 +703,13 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
         for (int t = 0; t < 8; ++t) { g0[t] = (v4d){0.0, 0.0, 0.0, 0.0}; g1[t] = g0[t]; }
     const int ntile = (mk + 15) >> 4, nblk = (ntile + 3) >> 2;
     double q[32], qn[32];
+    // unconditional, clamped loads: no select may consume a loaded register before its use (see cqr_gram_kernel).  Rows beyond the panel
+    // then hold copies of its last row: their products are never stored and their rows of the LDS block are zeroed (`rin`)
     auto load = [&](double (&x)[32], int t) {
         const int row = 16 * t + l15;
-        const bool rin = row < mk;
-        const double* sp = src + (rin ? row : mk - 1);
+        const double* sp = src + (row < mk ? row : mk - 1);
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) x[ks] = (4 * ks + l4 < w && t < ntile) ? sp[(size_t) (4 * ks + l4) * lds_] : 0.0;
-        if (!rin) {
-#pragma unroll
-            for (int ks = 0; ks < 32; ++ks) x[ks] = 0.0;
-        }
+        for (int ks = 0; ks < 32; ++ks) x[ks] = sp[(size_t) (4 * ks + l4 < w ? 4 * ks + l4 : 0) * lds_];
     };
     int blk = blockIdx.x;
     if (blk < nblk) load(q, 4 * blk + wave);
@@ -747,7 +744,7 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
         } else if (GRAM) {
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks)
-                if (4 * ks < w) Qt[l15 * CS_QLD + 4 * ks + l4] = q[ks];
+                if (4 * ks < w) Qt[l15 * CS_QLD + 4 * ks + l4] = rin ? q[ks] : 0.0;
         }
         if (GRAM) {
             load(q, tile + 4 * gridDim.x);
@@ -781,7 +778,10 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
     extern __shared__ double sm[];
     cqr_stream_body<MULT, GRAM, DST2>(sm, X, w, mk, src, lds_, dst, ldd, dst2, ldd2, slabs, status);
 }
-// the Gram-only pass (33 KB of LDS; two waves per SIMD were tried: no faster, and the block kept in flight then spills)
+// The Gram-only pass, G1 = A^T A (33 KB of LDS).  Tried and no faster: two waves per SIMD (132 us against 128), four workgroups per CU
+// (191 = 191 before the scalar wave index), two LDS block buffers with one barrier per block and the transposition of block i + 1
+// behind the matrix-core instructions of block i (143-145 us: memory time plus matrix-core time again, although the ISA has the waits
+// for the prefetched block behind the MFMAs)
 __global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs)
 {
     extern __shared__ double sm[];
@@ -837,6 +837,7 @@ int qrd_panel_cqr_init(void)
 {
     hipError_t e = hipFuncSetAttribute((const void*) cqr_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_GRAM);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);

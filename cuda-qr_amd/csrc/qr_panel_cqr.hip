@@ -343,6 +343,7 @@ __device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int 
     (void) ti; (void) tj;
     const int nblk = w >> 5, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // the strictly lower part must read as zero where X has not been written
+#pragma unroll 8
     for (int e = tid; e < (w + 1) * CQ_W; e += CQ_T) {
         const int r = e >> 7, c = e & (CQ_W - 1);
         if (c < r) L.M[r * CQ_LD + c] = 0.0;
@@ -353,6 +354,8 @@ __device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int 
         // column j of the block's inverse in registers (static indices: the loops unroll); row i of R is a broadcast read
         const int o = 32 * wave, j = lane & 31;
         const double dinv = rcp_newton(L.M[(o + j) * CQ_LD + o + j]);
+        // (dot-product form: a chain of 496 dependent FMAs, 7.5 us; the column (axpy) form with a residual vector in registers was
+        // measured at 17 us -- 64 more live registers spill in this kernel)
         double x[32];
 #pragma unroll
         for (int i = 31; i >= 0; --i) {
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
     const bool ok = cq_chol_blocked(L, w, tid);
     CQ_STAMP(1);
     if (!ok) { if (tid == 0) status[0] = 1; return; }
+#pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
         if (j < w) cq_st(ws + CQ_R1 + i * CQ_W + j, (j >= i) ? L.M[i * CQ_LD + j] : 0.0);
@@ -521,6 +525,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
         if (!ok) { if (tid == 0) status[0] = 1; return; }
     }
     // R2 -> global (the LU and two products read it from there); R2^-1 -> X1 (first order: 2 I - R2)
+#pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
         if (j >= w) continue;
@@ -542,6 +547,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     cq_lu_blocked(L, w, ws + CQ_R2, tid);
     CQ_STAMP(10);
     // L1 \ U' and S out; Q_top - S R2 back into Vw (the last pass multiplies it by U'^-1 like every other row: it becomes L1)
+#pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
         if (j < w) cq_st(ws + CQ_LU + i * CQ_W + j, L.M[i * CQ_LD + j]);

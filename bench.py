@@ -382,9 +382,8 @@ def main():
         tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
     except Exception:
         tj = None
-    gen = 1 if os.environ.get("MI355XQR_UPDATE") == "1" else 2
-    kname = ("gemm_nt_kernel<true, 0, 1> (trailing update A2 -= V*Wt^T, W kept transposed, direct-to-LDS tiles, v_mfma_f64_16x16x4_f64)"
-             if gen == 2 else "gemm_nn_w8_kernel<0> (trailing update A2 -= V*W, v_mfma_f64_16x16x4_f64)")
+    gen = 2
+    kname = "gemm_nt_kernel<true, 0, 1> (trailing update A2 -= V*Wt^T, W kept transposed, direct-to-LDS tiles, v_mfma_f64_16x16x4_f64)"
     if wl in ("c2", "c3") and upd["launches"]:
         ach = upd["flops"] / (upd["ms"] * 1e-3) / 1e12
         if tj and wl == "c3" and nb == tj.get("nb") and gen == 2 and "gemm_nt_kernel" in tj:

@@ -289,7 +289,7 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
     if (!qrd_gemm_nt_ok(M, N, K, A, lda, Bt, ldbt, C, ldc)) return -7;
     const int gx = M / 128, gy = N / 128;
     if (gm < 0) gm = nt_gm();
-    // MI355XQR_NT_SOLO=1 (measurement only): ask for 100 KB of LDS, so that ONE workgroup fits a compute unit
+    // (NT_SOLO, a measurement-only constant: ask for 100 KB of LDS, so that ONE workgroup fits a compute unit)
     static const int solo = 0;
     const size_t shm = solo ? (size_t) 100 * 1024 : 2 * NT_STAGE * sizeof(double);
     hipStream_t s = (hipStream_t) stream;

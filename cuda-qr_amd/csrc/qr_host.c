@@ -655,7 +655,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
     const qr_knobs* const kn = knobs();
     const int fuse_gram = 1;
     /* MI355XQR_FUSE_NN=0: in-panel update and the next leaf's Gram matrix as separate launches (gemm_nn + gram32_kernel);
-     * MI355XQR_FUSE_NN_MIN / _MAX: leaf heights the fused launch is used for (default: tall leaves only -- it saves a pass over
+     * QR_FUSE_NN_MIN_ROWS: leaf heights the fused launch is used for (tall leaves only -- it saves a pass over
      * the next leaf, 262144 x 512: 7.15 -> 7.08 ms; on the short leaves of square problems its 128 matrix-core instructions per
      * wave sit on 10-14 compute units and the launch takes 18 us where gemm_nn + gram32 take 14: 8192^2 32.4 -> 33.0 ms);
      * MI355XQR_FUSE_NN_GY: column pairs side by side on tall leaves (1 = every workgroup walks all columns, V read once) */

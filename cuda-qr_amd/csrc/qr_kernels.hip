@@ -833,7 +833,7 @@ int qrd_init(void)
 }
 
 // the wide trailing update A2 -= V*W: always the 128x128 tile, its own kernel name (TAG = 1) for the profiler
-// MI355XQR_NN_WAVES=4 selects the 4-wave kernel for the wide update (default 8, see gemm_nn_w8_kernel)
+// (the 8-wave kernel serves the wide update, see gemm_nn_w8_kernel; the knob that selected the 4-wave one was folded in round 4)
 static int nn_waves(void)
 {
     static const int v = 8;

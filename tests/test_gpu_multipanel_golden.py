@@ -92,7 +92,7 @@ np.save(sys.argv[1], O.sign_normalise(F))
     (128, {"MI355XQR_LEAF": "2"}),                                                    # second-generation CholeskyQR2 leaf (row solves on the vector ALUs)
     (128, {"MI355XQR_EP": "0"}),                                                      # in-panel product as a launch of its own (no early product)
     (256, {"MI355XQR_FUSED_MIN_ROWS": "0"}),                                          # round 4: every outer panel in ONE launch (qr_panel_fused.hip)
-    (128, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "0", "MI355XQR_FUSED_GRAM": "1"}),   # ... Gram blocks from inside the launch
+    (128, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "0"}),     # ... single-stream schedule
     (64, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0"}),   # ... on a 64-CU panel stream
     (512, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "0"}),               # ... two-level panels: each half one launch
     (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64:0.5,U", "MI355XQR_BALANCE": "14,44,0,0"}),   # late phase: panel chain on an unmasked stream

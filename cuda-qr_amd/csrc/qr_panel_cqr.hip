@@ -46,8 +46,8 @@ constexpr int CQ_TT = 10 * CQ_W * CQ_W;   // T row-major
 constexpr int CQ_X3 = 11 * CQ_W * CQ_W;
 constexpr int CQ_SV = 12 * CQ_W * CQ_W;   // S (CQ_W doubles)
 constexpr int CQ_ST = 12 * CQ_W * CQ_W + CQ_W;   // 64 phase stamps of the one-workgroup kernels (CQ_STAMPS builds)
-constexpr int CQ_SL = CQ_ST + 64;                  // Gram partials of the streaming passes: 256 workgroups x 36 tiles x 256
-constexpr int CQ_WS = CQ_SL + 1024 * 36 * 256;
+constexpr int CQ_SL = CQ_ST + 64;                  // Gram partials of the streaming passes: 256 workgroups x 36 tiles x 256 doubles (19 MB)
+constexpr int CQ_WS = CQ_SL + 256 * 36 * 256;
 
 // Workspace traffic of the one-workgroup kernels: plain stores and loads.  Every workspace matrix is written ONCE per launch and read
 // only after cq_sync_global() (so no line of it can be in this compute unit's cache before it is written); agent-scope atomic stores

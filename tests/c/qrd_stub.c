@@ -210,7 +210,7 @@ int qrd_panel_cholqr_ep(void* s, double* P, int ld, int mk, int w, double* tau, 
 }
 /* the full-width tall panel: same shape rule as the real layer; panels whose height has bit 12 set are REFUSED by the (stub) guard, so
  * that the host's fall-back to the leaf chain on the untouched panel is exercised as well */
-size_t qrd_panel_cqr_ws_doubles(void) { return 12 * 128 * 128 + 128 + 64 + 1024 * 36 * 256; }
+size_t qrd_panel_cqr_ws_doubles(void) { return 12 * 128 * 128 + 128 + 64 + 256 * 36 * 256; }
 int qrd_panel_cqr(void* s, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)
 {
     (void) s;

@@ -515,7 +515,7 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
                 pf_lds_row16(s1 + 64 + h * 32 + 16, *reinterpret_cast<double (*)[16]>(&vec[16]));
 #pragma unroll
                 for (int cc = 0; cc < 32; ++cc) wv += mcol[cc] * vec[cc];
-                pf_st(f.X4 + j * 32 + i, wv);
+                pf_st(f.X4 + j * 32 + i, -wv);                                           // -W: the updates then ADD V (-W) with no operation on a loaded value
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -549,7 +549,7 @@ __device__ __forceinline__ void pf_update_groups(double (&vr)[4][8], const doubl
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) w[ti][ks] = -pf_ld(X4 + (32 * jg + 16 * ti + l15) * 32 + 4 * ks + l4);
+            for (int ks = 0; ks < 8; ++ks) w[ti][ks] = pf_ld(X4 + (32 * jg + 16 * ti + l15) * 32 + 4 * ks + l4);      // X4 holds -W
     };
     auto cptr = [&](int jg, int ti) { return A + (size_t) (c + 32 + 32 * jg + 16 * ti + l4) * lda; };
     auto cload = [&](v4d (&cc)[4], const double* cp) {
@@ -632,7 +632,7 @@ __device__ __forceinline__ void pf_update0_finish(double (&vr)[4][8], v4d (&ca)[
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) aw[ti][ks] = -pf_ld(X4 + (16 * ti + l15) * 32 + 4 * ks + l4);
+        for (int ks = 0; ks < 8; ++ks) aw[ti][ks] = pf_ld(X4 + (16 * ti + l15) * 32 + 4 * ks + l4);                 // X4 holds -W
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -902,8 +902,10 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
                 for (int s4 = 0; s4 < 4; ++s4) {
                     const int row = wgrow0 + 16 * (4 * ch + s4) + 4 * l4, rowc = min(row, mk - 4);
                     const v2d lo = *reinterpret_cast<const v2d*>(xp + rowc), hi = *reinterpret_cast<const v2d*>(xp + rowc + 2);
-                    const bool on = row >= c && row < mk;            // rows of this leaf (Q is zero elsewhere; the Gram tiles need it)
-                    x[s4][0] = on ? lo[0] : 0.0; x[s4][1] = on ? lo[1] : 0.0; x[s4][2] = on ? hi[0] : 0.0; x[s4][3] = on ? hi[1] : 0.0;
+                    // no mask here: a select on a loaded value is a use of it, and the wait for the load would land in front of the MFMAs
+                    // the load is meant to run under.  Z needs none (Q is zero outside the leaf's rows, the operands there are finite);
+                    // the Gram tiles mask their operands where they are used (gmma)
+                    x[s4][0] = lo[0]; x[s4][1] = lo[1]; x[s4][2] = hi[0]; x[s4][3] = hi[1];
                 }
             };
             // G' = A_next^T A_next (the next leaf's columns as they are NOW, rows >= c), one 16 x 16 tile per wave beside its product:
@@ -912,11 +914,14 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
             // (the update is orthogonal on rows >= c): its all-to-all exchange and 200 KB sum disappear (pf_factor_wg)
             const bool want_g = f.nrest > 0;
             v4d gacc = (v4d){0.0, 0.0, 0.0, 0.0};
-            auto gmma = [&](const double (&xa)[4][4], const double (&xc)[4][4]) {
+            auto gmma = [&](const double (&xa)[4][4], const double (&xc)[4][4], int ch) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int row = wgrow0 + 16 * (4 * ch + s4) + 4 * l4;
+                    const bool on = row >= c && row < mk;            // rows of this leaf only
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) gacc = pf_mfma(xa[s4][kk], xc[s4][kk], gacc);
+                    for (int kk = 0; kk < 4; ++kk) gacc = pf_mfma(on ? xa[s4][kk] : 0.0, xc[s4][kk], gacc);
+                }
             };
             auto mma = [&](const double (&x)[4][4], int ch, v4d& acc0, v4d& acc1) {
 #pragma unroll
@@ -936,11 +941,11 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
                 v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
                 const double* xp = xptr(slot);
                 const bool gdiag = want_g && slot == 0 && wave < 2;       // wave-uniform
-                xload(xb[1], xp, 1); mma(xb[0], 0, acc0, acc1); if (gdiag) gmma(xb[0], xb[0]);
-                xload(xb[0], xp, 2); mma(xb[1], 1, acc0, acc1); if (gdiag) gmma(xb[1], xb[1]);
-                xload(xb[1], xp, 3); mma(xb[0], 2, acc0, acc1); if (gdiag) gmma(xb[0], xb[0]);
+                xload(xb[1], xp, 1); mma(xb[0], 0, acc0, acc1); if (gdiag) gmma(xb[0], xb[0], 0);
+                xload(xb[0], xp, 2); mma(xb[1], 1, acc0, acc1); if (gdiag) gmma(xb[1], xb[1], 1);
+                xload(xb[1], xp, 3); mma(xb[0], 2, acc0, acc1); if (gdiag) gmma(xb[0], xb[0], 2);
                 if (slot + 1 < nval) xload(xb[0], xptr(slot + 1), 0);
-                mma(xb[1], 3, acc0, acc1); if (gdiag) gmma(xb[1], xb[1]);
+                mma(xb[1], 3, acc0, acc1); if (gdiag) gmma(xb[1], xb[1], 3);
                 double* zp = X3g + (wave + 4 * slot) * 512 + 2 * lane;          // pf_zidx layout
                 pf_st2(zp, acc0[0], acc0[1]); pf_st2(zp + 128, acc0[2], acc0[3]);
                 pf_st2(zp + 256, acc1[0], acc1[1]); pf_st2(zp + 384, acc1[2], acc1[3]);
@@ -950,7 +955,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
                 const double* x0 = A + (size_t) (c + 32 + l15) * lda;
                 const double* x1 = x0 + (size_t) 16 * lda;
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) { xload(xb[0], x0, ch); xload(xc, x1, ch); gmma(xb[0], xc); }
+                for (int ch = 0; ch < 4; ++ch) { xload(xb[0], x0, ch); xload(xc, x1, ch); gmma(xb[0], xc, ch); }
             }
             if (want_g && wave < 3) {                            // accumulator order, as the Gram partials: tile 0, 2, 1 for wave 0, 1, 2
                 const int tile = (wave == 0) ? 0 : (wave == 1 ? 2 : 1);
@@ -1322,7 +1327,7 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
                 for (int q = 0; q < 4; ++q) {
                     const int e = tid + 256 * q, col = e >> 5, row = e & 31;
                     At[row][col] = at[q];                      // XT[col * 32 + row]
-                    Wn[row][col] = wn[q];                      // X4[j * 32 + i] = W(i, j)
+                    Wn[row][col] = -wn[q];                     // X4[j * 32 + i] = -W(i, j)
                 }
             }
             __syncthreads();

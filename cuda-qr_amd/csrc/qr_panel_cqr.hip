@@ -571,35 +571,49 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     }
     if (tid < w) cq_st(ws + CQ_SV + tid, L.sv[tid]);
     CQ_STAMP(11);
-    // ---- U = U' R2^-1 -> X2 (U' is the upper triangle of L.M; R2^-1 goes transposed below the diagonal, over L1: it is in ws + CQ_LU)
-    cq_load_lowerT(L, ws + CQ_X1, w, tid);
-    __syncthreads();
-    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_X2 + i * CQ_W + j, (j >= i) ? v : 0.0); });
-    __syncthreads();
-    CQ_STAMP(12);
-    // ---- U'^-1 -> UI
-    cq_upper_inv(L, w, 0, 0, tid);
-    cq_inv_out(L, ws + CQ_UI, w, tid);
-    cq_sync_global();
-    CQ_STAMP(13);
-    // ---- L1^-T: the inverse of the unit upper-triangular L1^T stays below the diagonal of L.M
-    // (L1^T)(j, i) = L1(i, j): row i of LU read along j
-    cq_elems(w, tid, [&](int i, int j) { return ws[CQ_LU + i * CQ_W + j]; }, [&](int i, int j, double v) { if (j < w && i >= j) L.M[j * CQ_LD + i] = (i == j) ? 1.0 : v; });
-    __syncthreads();
-    cq_upper_inv(L, w, 0, 0, tid);
-    CQ_STAMP(14);
-    // ---- T = -U S L1^-T: U (X2) -> the upper triangle of L.M, S folded into U's columns
-    cq_load_upper(L, ws + CQ_X2, w, tid);
-    __syncthreads();
-    cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
-    __syncthreads();
-    CQ_STAMP(15);
-    // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
-    cq_load_upper(L, ws + CQ_R2, w, tid);
-    cq_load_lowerT(L, ws + CQ_R1, w, tid);
-    __syncthreads();
-    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_RR + i * CQ_W + j, (j >= i) ? L.sv[i] * v : 0.0); });
-    CQ_STAMP(16);
+}
+
+// What follows the LU, on TWO workgroups side by side (four independent pieces were 120 us in a row on one):
+//   workgroup 0: U'^-1 -> UI (the operand of the V pass), then R = S R2 R1
+//   workgroup 1: U = U' R2^-1, the inverse of L1^T, T = -U S L1^-T
+// Operands from the workspace (written by cqr_lu_kernel / cqr_chol_kernel: an earlier launch); S from ws + CQ_SV.
+__global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const int* status)
+{
+    extern __shared__ double sm[];
+    const CqLds L = cq_lds(sm);
+    const int tid = threadIdx.x;
+    if (status[0]) return;
+    if (tid < w) L.sv[tid] = ws[CQ_SV + tid];
+    if (blockIdx.x == 0) {
+        // ---- U'^-1 -> UI
+        cq_load_upper(L, ws + CQ_LU, w, tid);
+        __syncthreads();
+        cq_upper_inv(L, w, 0, 0, tid);
+        cq_inv_out(L, ws + CQ_UI, w, tid);
+        __syncthreads();
+        // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
+        cq_load_upper(L, ws + CQ_R2, w, tid);
+        cq_load_lowerT(L, ws + CQ_R1, w, tid);
+        __syncthreads();
+        cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_RR + i * CQ_W + j, (j >= i) ? L.sv[i] * v : 0.0); });
+    } else {
+        // ---- U = U' R2^-1 -> X2 (U' above the diagonal, R2^-1 transposed below it)
+        cq_load_upper(L, ws + CQ_LU, w, tid);
+        cq_load_lowerT(L, ws + CQ_X1, w, tid);
+        __syncthreads();
+        cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_X2 + i * CQ_W + j, (j >= i) ? v : 0.0); });
+        __syncthreads();
+        // ---- L1^-T: the inverse of the unit upper-triangular L1^T stays below the diagonal of L.M
+        // (L1^T)(j, i) = L1(i, j): row i of LU read along j
+        cq_elems(w, tid, [&](int i, int j) { return ws[CQ_LU + i * CQ_W + j]; }, [&](int i, int j, double v) { if (j < w && i >= j) L.M[j * CQ_LD + i] = (i == j) ? 1.0 : v; });
+        __syncthreads();
+        cq_upper_inv(L, w, 0, 0, tid);
+        // ---- T = -U S L1^-T: U (X2) -> the upper triangle of L.M, S folded into U's columns
+        cq_sync_global();
+        cq_load_upper(L, ws + CQ_X2, w, tid);
+        __syncthreads();
+        cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -843,6 +857,7 @@ int qrd_panel_cqr_init(void)
 {
     hipError_t e = hipFuncSetAttribute((const void*) cqr_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_GRAM);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
@@ -871,6 +886,7 @@ int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, 
                        (double*) nullptr, 0, ws + CQ_SL, status);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Vw, ldv, status);
+    hipLaunchKernelGGL(cqr_post_kernel, dim3(2), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
     hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
                        (double*) nullptr, status);
     hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
@@ -893,6 +909,7 @@ int qrd_panel_cqr_stage2(void* stream, double* A, int lda, int mk, int w, double
 {
     hipStream_t s = (hipStream_t) stream;
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Vw, ldv, status);
+    hipLaunchKernelGGL(cqr_post_kernel, dim3(2), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
     hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(cs_grid(mk)), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
                        (double*) nullptr, status);
     hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);

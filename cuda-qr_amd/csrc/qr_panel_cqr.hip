@@ -164,10 +164,14 @@ __device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
             if (!ok) L.flag[0] = 0;                            // (every lane of the wave saw the same pivots)
             if (lane < PW) {
 #pragma unroll
-                for (int i = 0; i < PW; ++i) L.M[(o + i) * CQ_LD + o + c] = (i <= c) ? g[i] : 0.0;
+                for (int i = 0; i < PW; ++i)
+                    if (i <= c) L.M[(o + i) * CQ_LD + o + c] = g[i];       // (below the diagonal: the slots of the inverse, next branch)
             } else {
 #pragma unroll
-                for (int i = 0; i < PW; ++i) L.sb1[i * 33 + c] = (i >= c) ? g[i] : 0.0;      // sb1[i][k] = R11^-T(i, k)
+                for (int i = 0; i < PW; ++i) {
+                    L.sb1[i * 33 + c] = (i >= c) ? g[i] : 0.0;             // sb1[i][k] = R11^-T(i, k)
+                    if (i >= c) L.M[(o + i + 1) * CQ_LD + o + c] = g[i];   // X(c, i) = R11^-1(c, i) = R11^-T(i, c): the inverse's diagonal block
+                }
             }
         }
         __syncthreads();
@@ -338,18 +342,14 @@ __device__ __forceinline__ void cq_offdiag(const CqLds& L, int r0, int c0, int n
     }
     __syncthreads();
 }
-__device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int tj, int tid)
+__device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int have_diag, int, int tid)
 {
-    (void) ti; (void) tj;
+    // have_diag: the diagonal 32 x 32 blocks of the inverse are in their slots already (left by cq_chol_blocked).  Nothing below the
+    // diagonal needs to be zero beforehand: every read of an X slot is masked to the part that has been written
     const int nblk = w >> 5, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    // the strictly lower part must read as zero where X has not been written
-#pragma unroll 8
-    for (int e = tid; e < (w + 1) * CQ_W; e += CQ_T) {
-        const int r = e >> 7, c = e & (CQ_W - 1);
-        if (c < r) L.M[r * CQ_LD + c] = 0.0;
-    }
     __syncthreads();
     CQ_STAMP_L(20);
+    if (have_diag) goto offdiag;
     if (wave < nblk) {
         // column j of the block's inverse in registers (static indices: the loops unroll); row i of R is a broadcast read
         const int o = 32 * wave, j = lane & 31;
@@ -372,6 +372,7 @@ __device__ __forceinline__ void cq_upper_inv(const CqLds& L, int w, int ti, int 
         }
     }
     __syncthreads();
+offdiag:
     CQ_STAMP_L(21);
     if (w >= 64) cq_offdiag<2>(L, 0, 32, 32, tid);
     if (w == 128) cq_offdiag<2>(L, 64, 96, 32, tid);
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
         if (j < w) cq_st(ws + CQ_R1 + i * CQ_W + j, (j >= i) ? L.M[i * CQ_LD + j] : 0.0);
     }
     CQ_STAMP(2);
-    cq_upper_inv(L, w, 0, 0, tid);
+    cq_upper_inv(L, w, 1, 0, tid);                             // (diagonal blocks: from the Cholesky's augmented columns)
     CQ_STAMP(3);
     cq_inv_out(L, ws + CQ_R1I, w, tid);
     CQ_STAMP(4);
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     }
     if (!first_order) {
         __syncthreads();
-        cq_upper_inv(L, w, 0, 0, tid);
+        cq_upper_inv(L, w, 1, 0, tid);
         cq_inv_out(L, ws + CQ_X1, w, tid);
     }
     cq_sync_global();

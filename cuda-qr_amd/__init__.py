@@ -113,6 +113,8 @@ _sig("qr_copy_to_device", C.c_int, _vp, _vp, C.c_size_t)
 _sig("qr_copy_to_host", C.c_int, _vp, _vp, C.c_size_t)
 _sig("qr_plan_sync", C.c_int, _vp)
 _sig("qr_plan_stream", _vp, _vp)
+_sig("qr_plan_set_guard_mode", C.c_int, _vp, C.c_int)
+_sig("qr_plan_route_stats", C.c_int, _vp, C.POINTER(C.c_longlong))
 _sig("qr_plan_info", C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("qr_plan_update_cus", C.c_int, _vp)
 _sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)
@@ -392,6 +394,15 @@ class Plan:
 
     def sync(self):
         check(lib.qr_plan_sync(self.h), "qr_plan_sync")
+
+    def set_guard_mode(self, latch):
+        """latch = True: qr_geqrf_dev never waits for the device; a refused full-width tall panel is reported by sync() (QR_E_REFUSED)"""
+        check(lib.qr_plan_set_guard_mode(self.h, int(bool(latch))), "qr_plan_set_guard_mode")
+
+    def route_stats(self):
+        out = (C.c_longlong * 4)()
+        check(lib.qr_plan_route_stats(self.h, out), "qr_plan_route_stats")
+        return {"tall_panels": out[0], "tall_panels_refused": out[1], "fused_leaf_fallbacks": out[2], "fused_stalls": out[3]}
 
     @property
     def stream(self):

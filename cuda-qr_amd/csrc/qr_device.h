@@ -73,6 +73,11 @@ size_t qrd_panel_cqr_ws_doubles(void);
 int qrd_panel_cqr_init(void);
 int qrd_panel_cqr_ok(int mk, int w);
 int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status);
+/* the same with Q in a buffer of its own (Qb: mk x w, ld ldq): a refused panel then leaves Vw untouched as well; status[1] counts refused
+ * panels (sticky, never reset by the call); hflag (NULL: none): device address of a host word that receives 2 * seq + refused as soon as
+ * the verdict exists -- two thirds into the panel, so the host can decide what comes next while the last pass is still running */
+int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                    double* Qb, int ldq, unsigned* hflag, unsigned seq);
 double* qrd_panel_cqr_g1(double* ws);
 double* qrd_panel_cqr_g2(double* ws);
 int qrd_panel_cqr_stage1(void* stream, const double* A, int lda, int mk, int w, double* Vw, int ldv, double* ws, int* status);
@@ -135,6 +140,9 @@ int qrd_device_count(int* n);
 int qrd_set_device(int d);
 int qrd_get_device(int* d);
 int qrd_stream_cus(void* s);
+/* one 32-bit word of pinned host memory mapped into the device (kernels publish small verdicts into it with system scope) */
+int qrd_host_word_alloc(unsigned** host, unsigned** dev);
+int qrd_host_word_free(unsigned* host);
 int qrd_host_register(void* p, size_t bytes);
 int qrd_host_unregister(void* p);
 const char* qrd_error_string(int e);

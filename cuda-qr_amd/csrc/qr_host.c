@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/mi355x_qr.h"
 #include "qr_device.h"
@@ -77,7 +78,14 @@ struct qr_plan {
     int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height;
                                  * 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
     double* chol_ws;
-    double* cq_ws; int* cq_status;   /* small-factor workspace and guard flag of the full-width tall panel (qr_panel_cqr.hip); NULL: not used */
+    double* cq_ws; int* cq_status;   /* small-factor workspace and guard words of the full-width tall panel (qr_panel_cqr.hip); NULL: not used */
+    unsigned *cq_hword, *cq_hword_dev;   /* host word (mapped into the device) that receives a tall panel's verdict as soon as it exists */
+    unsigned cq_seq;            /* sequence number of the last tall panel issued */
+    int guard_latch;            /* 0: a refused tall panel is handed to the leaf chain (the host reads the verdict while the panel's last pass
+                                 * runs); 1: nothing is read inside qr_geqrf_dev, a refusal is reported by qr_plan_sync (QR_E_REFUSED) */
+    int cq_dirty, pf_dirty;     /* tall / one-launch panels have been issued since the status words were last read */
+    int fused_off;              /* 1: never the one-launch panel (set by the host-pointer entry points after a stalled hand-off, QR_E_STALL) */
+    long long n_cqr, n_cqr_refused, n_pf_leaf_fallback, n_pf_stall;   /* qr_plan_route_stats */
     double* pf_ws;              /* exchange workspace of the one-launch panel (qr_panel_fused.hip); NULL: not used */
     unsigned pf_epoch;          /* its epoch counter: the workspace's epoch words never exceed it */
     int* pf_status;             /* device: [0] leaves that took the Householder route inside a one-launch panel, [1] a wait timed out */
@@ -231,6 +239,8 @@ const char* qr_strerror(int status)
     case QR_E_ALLOC: return "host allocation failed";
     case QR_E_NODEVICE: return "no HIP device (this library has no CPU fallback)";
     case QR_E_INTERNAL: return "internal error";
+    case QR_E_STALL: return "a hand-off inside a one-launch panel timed out (its workgroups were not co-resident?): the factorisation is invalid";
+    case QR_E_REFUSED: return "latch mode: the guard refused a full-width tall panel (ill-conditioned or rank-deficient): the factorisation is invalid";
     case QRD_E_NORCCL: return "librccl.so could not be loaded (multi-GPU entry points need RCCL)";
     default:
         if (status > 0) return qrd_error_string(status);
@@ -403,6 +413,12 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         if (knobs()->cqr_min_rows > 0 && m >= knobs()->cqr_min_rows) {
             rc = qrd_malloc((void**) &p->cq_ws, sizeof(double) * qrd_panel_cqr_ws_doubles());
             if (!rc) rc = qrd_malloc((void**) &p->cq_status, 4 * sizeof(int));
+            if (!rc) rc = qrd_memset(p->stream, p->cq_status, 0, 4 * sizeof(int));
+            if (!rc) rc = qrd_host_word_alloc(&p->cq_hword, &p->cq_hword_dev);
+            {
+                const char* gm = getenv("MI355XQR_GUARD");      /* latch | host (default) */
+                p->guard_latch = gm != NULL && strcmp(gm, "latch") == 0;
+            }
         }
         if (!rc) rc = qrd_malloc((void**) &p->pf_ws, sizeof(double) * qrd_panel_fused_ws_doubles());
         if (!rc) rc = qrd_memset(p->stream, p->pf_ws, 0, sizeof(double) * qrd_panel_fused_ws_doubles());
@@ -442,9 +458,43 @@ int qr_plan_destroy(qr_plan* p)
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
     qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
     qrd_free(p->pf_ws); qrd_free(p->pf_status); qrd_free(p->cq_ws); qrd_free(p->cq_status);
+    qrd_host_word_free(p->cq_hword);
     if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
     return 0;
+}
+
+/* The status words the panel kernels leave on the device, read where the host waits anyway: a hand-off between the workgroups of a
+ * one-launch panel that timed out (the launch ended with garbage: QR_E_STALL), and -- latch mode only -- tall panels the guard refused
+ * (QR_E_REFUSED: the factorisation behind them is invalid).  Both are cleared by the read. */
+static int plan_read_status(qr_plan* p)
+{
+    int rc = 0;
+    if (p->pf_dirty && p->pf_status) {
+        int st[4] = {0, 0, 0, 0};
+        CHECK(qrd_d2h(p->s_main, st, p->pf_status, sizeof st));
+        CHECK(qrd_stream_sync(p->s_main));
+        p->pf_dirty = 0;
+        if (st[0] || st[1]) {
+            CHECK(qrd_memset(p->s_main, p->pf_status, 0, sizeof st));
+            CHECK(qrd_stream_sync(p->s_main));
+        }
+        p->n_pf_leaf_fallback += st[0];
+        if (st[1]) { p->n_pf_stall += 1; rc = QR_E_STALL; }
+    }
+    if (p->cq_dirty && p->cq_status && p->guard_latch) {
+        int st[4] = {0, 0, 0, 0};
+        CHECK(qrd_d2h(p->s_main, st, p->cq_status, sizeof st));
+        CHECK(qrd_stream_sync(p->s_main));
+        p->cq_dirty = 0;
+        if (st[1]) {
+            CHECK(qrd_memset(p->s_main, p->cq_status, 0, sizeof st));
+            CHECK(qrd_stream_sync(p->s_main));
+            p->n_cqr_refused += st[1];
+            if (!rc) rc = QR_E_REFUSED;
+        }
+    }
+    return rc;
 }
 
 int qr_plan_sync(qr_plan* p)
@@ -454,7 +504,22 @@ int qr_plan_sync(qr_plan* p)
         for (int j = 0; j < 2; ++j)
             if (p->s_pair[i][j]) CHECK(qrd_stream_sync(p->s_pair[i][j]));
     if (p->npairs == 0 && p->stream_u) CHECK(qrd_stream_sync(p->stream_u));
-    return p->s_main ? qrd_stream_sync(p->s_main) : 0;
+    if (p->s_main) CHECK(qrd_stream_sync(p->s_main));
+    return plan_read_status(p);
+}
+
+int qr_plan_set_guard_mode(qr_plan* p, int latch)
+{
+    if (!p || (latch != 0 && latch != 1)) return QR_E_ARG;
+    p->guard_latch = latch;
+    return 0;
+}
+
+int qr_plan_route_stats(qr_plan* p, long long* out4)
+{
+    if (!p || !out4) return QR_E_ARG;
+    out4[0] = p->n_cqr; out4[1] = p->n_cqr_refused; out4[2] = p->n_pf_leaf_fallback; out4[3] = p->n_pf_stall;
+    return 0;
 }
 void* qr_plan_stream(qr_plan* p) { return p ? p->s_main : NULL; }
 
@@ -631,15 +696,41 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
 }
 
 /* A tall half (mkh x wh, wh <= 128) at its full width: CholeskyQR2 + Householder reconstruction in three passes instead of the leaf chain's
- * twelve (qr_panel_cqr.hip); T of the half comes out complete.  Returns 1 when the guard refused the panel (ill-conditioned: A is
- * untouched, the caller runs the leaf chain), 0 when done.  The guard's verdict is read on the host: one drain of the stream per tall
- * panel (~20 us beside a ~0.6 ms panel), never under stream capture. */
-static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, double* tauh, double* Th, int ldt, double* Vh, int ldv)
+ * twelve (qr_panel_cqr.hip); T of the half comes out complete.  Q lives in Qh (the set's V*T buffer, free while its panel is being
+ * factored), so a refused panel leaves A AND Vh untouched.  Returns 1 when the guard refused the panel (the caller runs the leaf chain),
+ * 0 when done.
+ * The verdict exists two thirds into the panel (after the 128 x 128 reconstruction, before the last pass over the panel): the kernel
+ * that forms it publishes it into a host word, and the host reads THAT -- with the last pass still queued and running -- instead of
+ * draining the stream as round 4 did: whatever comes next is queued ~0.2 ms before the stream needs it, the GPU never idles.  The host
+ * thread does wait for that word; a caller that must not block inside qr_geqrf_dev sets the latch mode (qr_plan_set_guard_mode), in
+ * which nothing is read here and a refusal is reported by qr_plan_sync. */
+static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, double* tauh, double* Th, int ldt, double* Vh, int ldv, double* Qh)
 {
-    CHECK(qrd_panel_cqr(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status));
+    const unsigned seq = (++p->cq_seq) & 0x3fffffffu;
+    const int latch = p->guard_latch || !p->cq_hword;
+    CHECK(qrd_panel_cqr_q(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status, Qh, ldv, latch ? NULL : p->cq_hword_dev, seq));
+    p->n_cqr += 1;
+    p->cq_dirty = 1;
+    if (latch) return 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned v = __atomic_load_n(p->cq_hword, __ATOMIC_ACQUIRE);
+        if ((v >> 1) == seq) {
+            if (v & 1u) p->n_cqr_refused += 1;
+            return (int) (v & 1u);
+        }
+        if ((spins & 1023u) == 1023u) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) break;
+        }
+    }
+    /* the word never came (a fault in front of it?): drain the stream -- an error there is the caller's answer -- and read the device word */
+    CHECK(qrd_stream_sync(p->stream));
     int st[4] = {0, 0, 0, 0};
     CHECK(qrd_d2h(p->stream, st, p->cq_status, sizeof st));
     CHECK(qrd_stream_sync(p->stream));
+    if (st[0]) p->n_cqr_refused += 1;
     return st[0] != 0;
 }
 
@@ -677,16 +768,17 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         int cqr_done = 0;
         if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= kn->cqr_min_rows && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
             const int rc = panel_cqr_half(p, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
-                                          p->Vw + (size_t) c0 * ldv + c0, ldv);
+                                          p->Vw + (size_t) c0 * ldv + c0, ldv, p->VT + (size_t) c0 * ldv + c0);
             if (rc < 0) return rc;
             cqr_done = rc == 0;
         }
-        const int fused_half = !cqr_done && p->pf_ws && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
+        const int fused_half = !cqr_done && p->pf_ws && !p->fused_off && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
                                qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);
         if (fused_half) {
             CHECK(qrd_panel_fused(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
                                   p->Vw + (size_t) c0 * ldv + c0, ldv, (need_t && kn->fused_gram) ? p->G + (size_t) c0 * nb + c0 : NULL, nb, p->pf_ws,
                                   &p->pf_epoch, p->pf_status));
+            p->pf_dirty = 1;
             gram_done = need_t && kn->fused_gram;
         }
         for (int c = c0; c < cend && !fused_half && !cqr_done; c += ib) {
@@ -1347,8 +1439,18 @@ int mmqr_status(double* mat, double** tau, int m, int n)
     double* htau = (double*) calloc(ntau, sizeof(double));                    /* zero-filled like qr.c:61-62 */
     if (!htau) { slot_release(sl); return QR_E_ALLOC; }
     const size_t bytes = sizeof(double) * (size_t) m * n;
-    int rc = qrd_h2d(p->stream, sl->dA, mat, bytes);
-    if (!rc) rc = qr_geqrf_dev(p, sl->dA, m, n, m, sl->dtau);
+    int rc = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        rc = qrd_h2d(p->stream, sl->dA, mat, bytes);
+        if (!rc) rc = qr_geqrf_dev(p, sl->dA, m, n, m, sl->dtau);
+        /* the status words of the panel kernels, before the result replaces the caller's matrix: a stalled one-launch panel or (latch
+         * mode, MI355XQR_GUARD=latch) a refused tall panel is factored again from the host copy on the plain routes */
+        const int rs = qr_plan_sync(p);
+        if (!rc) rc = rs;
+        if (rc == QR_E_STALL && !p->fused_off) { p->fused_off = 1; continue; }
+        if (rc == QR_E_REFUSED && p->guard_latch) { p->guard_latch = 0; continue; }
+        break;
+    }
     if (!rc) rc = qrd_d2h(p->stream, mat, sl->dA, bytes);
     if (!rc) rc = qrd_d2h(p->stream, htau, sl->dtau, sizeof(double) * n);
     if (!rc) rc = qrd_stream_sync(p->stream);

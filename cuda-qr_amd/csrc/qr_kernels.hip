@@ -1373,6 +1373,19 @@ int qrd_event_elapsed_ms(void* a, void* b, float* ms) { return (int) hipEventEla
 int qrd_device_count(int* n) { return (int) hipGetDeviceCount(n); }
 int qrd_set_device(int d) { return (int) hipSetDevice(d); }
 int qrd_get_device(int* d) { return (int) hipGetDevice(d); }
+int qrd_host_word_alloc(unsigned** host, unsigned** dev)
+{
+    void* h = nullptr;
+    void* d = nullptr;
+    hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { if (h) hipHostFree(h); return (int) e; }
+    *reinterpret_cast<volatile unsigned*>(h) = 0u;
+    *host = (unsigned*) h;
+    *dev = (unsigned*) d;
+    return 0;
+}
+int qrd_host_word_free(unsigned* host) { return host ? (int) hipHostFree(host) : 0; }
 int qrd_host_register(void* p, size_t bytes) { return (int) hipHostRegister(p, bytes, hipHostRegisterDefault); }
 int qrd_host_unregister(void* p) { return (int) hipHostUnregister(p); }
 const char* qrd_error_string(int e) { return hipGetErrorString((hipError_t) e); }

@@ -494,12 +494,12 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
 // Everything between the two streaming passes, on one workgroup (see the header).  Q_top: the first w rows of Q in Vw.
 // Outputs: Vw top block <- Q_top - S R2; ws: U'^-1, L1 \ U', R, T, S; status[0] |= 1 when the panel is refused.
 // ---------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double* Vw, int ldv, int* status)
+// (the body returns true -- uniformly -- when the panel is refused; cqr_lu_kernel publishes the verdict)
+__device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double* Vw, int ldv, const int* status)
 {
-    extern __shared__ double sm[];
     const CqLds L = cq_lds(sm);
     const int tid = threadIdx.x;
-    if (status[0]) return;                                    // the first Cholesky failed
+    if (status[0]) return true;                               // the first Cholesky failed
     CQ_STAMP(8);
     // ---- G2 -> L.M (upper); its distance from I decides between the first-order factor, the Cholesky and the refusal
     double dmax = 0.0;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     __syncthreads();
     dmax = 0.0;
     for (int q = 0; q < CQ_T / 64; ++q) dmax = fmax(dmax, L.red[q]);
-    if (!(dmax <= QRD_GUARD_THR)) { if (tid == 0) status[0] = 1; return; }
+    if (!(dmax <= QRD_GUARD_THR)) return true;
     const bool first_order = dmax <= QRD_CHOL1_THR;
     if (first_order) {
         // G2 = I + E, |E| <= 1e-9: R2 = I + triu(E, 1) + diag(E) / 2 to ~1e-18
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
         __syncthreads();
     } else {
         const bool ok = cq_chol_blocked(L, w, tid);
-        if (!ok) { if (tid == 0) status[0] = 1; return; }
+        if (!ok) return true;
     }
     // R2 -> global (the LU and two products read it from there); R2^-1 -> X1 (first order: 2 I - R2)
 #pragma unroll 8
@@ -572,6 +572,24 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     }
     if (tid < w) cq_st(ws + CQ_SV + tid, L.sv[tid]);
     CQ_STAMP(11);
+    return false;
+}
+
+// status[0]: this panel was refused (the kernels behind this one return at once, A is untouched); status[1]: refused panels since the
+// host last cleared the word (sticky: the plan's latch mode reports it at qr_plan_sync); hflag (optional, host memory mapped into the
+// device): 2 * seq + refused, written with system scope as soon as the verdict exists -- the host reads it while the panel's last pass
+// is still running, so its decision (the leaf chain, or nothing) is queued long before the stream gets there
+__global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double* Vw, int ldv, int* status, unsigned* hflag, unsigned seq)
+{
+    extern __shared__ double sm[];
+    const bool refused = cq_lu_body(sm, ws, w, Vw, ldv, status);
+    if (threadIdx.x == 0) {
+        if (refused) { status[0] = 1; status[1] += 1; }
+        if (hflag) {
+            __threadfence_system();
+            __hip_atomic_store(hflag, 2u * seq + (refused ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // What follows the LU, on TWO workgroups side by side (four independent pieces were 120 us in a row on one):
@@ -703,7 +721,7 @@ template <bool MULT, bool GRAM, bool DST2>
 __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __restrict__ X, int w, int mk, const double* src, int lds_, double* dst,
                                                 int ldd, double* dst2, int ldd2, double* slabs, const int* status)
 {
-    if (DST2 && status[0]) return;
+    if (MULT && status && status[0]) return;                  // refused (pass 2: by the first Cholesky): nothing is written
     double* Xc = sm;
     double* Qall = sm + (MULT ? CS_XC : 0);                   // the workgroup's 64 x w block, rows of wave v at 16 v
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
@@ -871,27 +889,35 @@ int qrd_panel_cqr_ok(int mk, int w) { return w >= 32 && w <= CQ_W && (w & 31) ==
 
 static int cs_grid(int mk, int cap = CS_NWG) { const int g = (mk + 63) / 64; return g < cap ? g : cap; }
 
-// The whole panel: six launches + two small reductions on `stream`.  status (device, 4 ints) is zeroed here; status[0] = 1 afterwards:
-// the guard refused the panel and A is untouched.
-int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)
+// The whole panel: six launches + two small reductions on `stream`.  status (device, 4 ints): [0] is zeroed here and is 1 afterwards when the
+// guard refused the panel -- A is then untouched, and so is Vw when Q has a buffer of its own (Qb: mk x w, ld ldq; NULL = Q lives in
+// Vw, whose contents are then garbage after a refusal); [1] counts refused panels (never reset here).  hflag / seq: see cqr_lu_kernel.
+int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                    double* Qb, int ldq, unsigned* hflag, unsigned seq)
 {
     if (!qrd_panel_cqr_ok(mk, w)) return -7;
+    if (!Qb) { Qb = Vw; ldq = ldv; }
     hipStream_t s = (hipStream_t) stream;
-    hipError_t e = hipMemsetAsync(status, 0, 4 * sizeof(int), s);
+    hipError_t e = hipMemsetAsync(status, 0, sizeof(int), s);
     if (e != hipSuccess) return (int) e;
     const int grid = cs_grid(mk), ggrid = cs_grid(mk, CS_NWG_GRAM), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
     hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
     hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
-    hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Vw, ldv,
+    hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Qb, ldq,
                        (double*) nullptr, 0, ws + CQ_SL, status);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
-    hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Vw, ldv, status);
+    hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
     hipLaunchKernelGGL(cqr_post_kernel, dim3(2), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
-    hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
+    hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Qb, ldq, Vw, ldv, A, lda,
                        (double*) nullptr, status);
     hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
     return (int) hipGetLastError();
+}
+
+int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)
+{
+    return qrd_panel_cqr_q(stream, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, nullptr, 0, nullptr, 0u);
 }
 
 // the two halves with the Gram matrices supplied by the caller (G1 in qrd_panel_cqr_g1(ws) before stage 1, G2 = Q^T Q in
@@ -909,7 +935,7 @@ int qrd_panel_cqr_stage2(void* stream, double* A, int lda, int mk, int w, double
                          int* status)
 {
     hipStream_t s = (hipStream_t) stream;
-    hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Vw, ldv, status);
+    hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Vw, ldv, status, (unsigned*) nullptr, 0u);
     hipLaunchKernelGGL(cqr_post_kernel, dim3(2), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
     hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(cs_grid(mk)), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
                        (double*) nullptr, status);

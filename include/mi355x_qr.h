@@ -82,6 +82,8 @@ int explicitQR_legacy_status(double* A, double* tau, double* Q, double* R, int m
 #define QR_E_ALLOC    (-102)  /* host allocation failed */
 #define QR_E_NODEVICE (-103)  /* no HIP device visible: there is NO CPU fallback */
 #define QR_E_INTERNAL (-104)
+#define QR_E_STALL    (-105)  /* qr_plan_sync: a hand-off between the workgroups of a one-launch panel timed out; the factorisation is invalid */
+#define QR_E_REFUSED  (-106)  /* qr_plan_sync in latch mode (qr_plan_set_guard_mode): a full-width tall panel was refused; result invalid */
 const char* qr_strerror(int status);
 
 /* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 512, above 256 a multiple of 256;
@@ -219,7 +221,22 @@ int qr_copy_to_host(void* dst, const void* src, size_t bytes);
 qr_plan* qr_tsqr_local_plan(qr_tsqr_plan* tp);
 qr_plan* qr_tsqr_stacked_plan(qr_tsqr_plan* tp);
 
+/* Waits for everything queued on the plan's streams and reads the status words the panel kernels left on the device: QR_E_STALL /
+ * QR_E_REFUSED (above) report a factorisation issued since the last call that must not be used; both are cleared by the call. */
 int qr_plan_sync(qr_plan* plan);
+/* What happens when the device-side guard refuses a full-width tall panel (>= MI355XQR_CQR_MIN_ROWS rows x 128 columns: CholeskyQR2 at
+ * panel width needs cond(panel) < ~1e7 and full rank; no reference counterpart, the reference factors column by column, qr.c:109-235):
+ *   latch = 0 (default): the panel is handed to the Householder-guarded leaf chain, the result is as good as for any other input.  The
+ *              host thread reads the verdict from a host word the deciding kernel writes while the panel's last pass still runs: the GPU
+ *              does not idle, but qr_geqrf_dev waits for that word once per tall panel (it is not capturable into a graph);
+ *   latch = 1: qr_geqrf_dev never waits for the device (fully stream-ordered).  A refused panel makes the factorisation INVALID (the
+ *              matrix is overwritten with garbage from that panel on); qr_plan_sync / qr_tsqr_sync return QR_E_REFUSED and the caller
+ *              factors a fresh copy with latch = 0.  For pipelines that own their inputs and check a residual anyway.
+ * MI355XQR_GUARD=latch selects latch = 1 for every plan of the process. */
+int qr_plan_set_guard_mode(qr_plan* plan, int latch);
+/* out4: full-width tall panels issued, of them refused, leaves of one-launch panels that took their Householder route, one-launch
+ * panels whose hand-off stalled -- since the plan was created (refusals in latch mode and the last two are counted at qr_plan_sync) */
+int qr_plan_route_stats(qr_plan* plan, long long* out4);
 void* qr_plan_stream(qr_plan* plan);          /* the hipStream_t work is queued on */
 int qr_plan_update_cus(qr_plan* plan);        /* compute units the wide trailing update runs on (its share of the CU partition) */
 

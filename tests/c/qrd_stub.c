@@ -211,16 +211,31 @@ int qrd_panel_cholqr_ep(void* s, double* P, int ld, int mk, int w, double* tau, 
 /* the full-width tall panel: same shape rule as the real layer; panels whose height has bit 12 set are REFUSED by the (stub) guard, so
  * that the host's fall-back to the leaf chain on the untouched panel is exercised as well */
 size_t qrd_panel_cqr_ws_doubles(void) { return 12 * 128 * 128 + 128 + 64 + 256 * 36 * 256; }
-int qrd_panel_cqr(void* s, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)
+int qrd_panel_cqr_q(void* s, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                    double* Qb, int ldq, unsigned* hflag, unsigned seq)
 {
     (void) s;
     if (!qrd_panel_cqr_ok(mk, w)) return -7;
     leaf_chk("panel_cqr", A, lda, mk, w, tau, T, ldt, Vw, ldv);
+    if (Qb) chk("panel_cqr Q", Qb, ldq, mk, w);
     chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); chkb("cqr status", status, 4 * sizeof(int));
-    memset(status, 0, 4 * sizeof(int));
-    if (mk & 4096) status[0] = 1;
+    status[0] = 0;
+    if (mk & 4096) { status[0] = 1; status[1] += 1; }
+    if (hflag) __atomic_store_n(hflag, 2u * seq + (unsigned) status[0], __ATOMIC_RELEASE);
     return 0;
 }
+int qrd_panel_cqr(void* s, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)
+{
+    return qrd_panel_cqr_q(s, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, NULL, 0, NULL, 0u);
+}
+int qrd_host_word_alloc(unsigned** host, unsigned** dev)
+{
+    unsigned* w = (unsigned*) calloc(16, sizeof(unsigned));
+    if (!w) return 2;
+    *host = w; *dev = w;
+    return 0;
+}
+int qrd_host_word_free(unsigned* host) { free(host); return 0; }
 int qrd_panel_cqr_init(void) { return 0; }
 int qrd_panel_cqr_ok(int mk, int w) { return w >= 32 && w <= 128 && w % 32 == 0 && mk >= 2 * w; }
 double* qrd_panel_cqr_g1(double* ws) { return ws; }

@@ -30,26 +30,34 @@ def q(qr):
                                        C.c_void_p, C.c_void_p]
     L.qrd_panel_cqr.restype = C.c_int
     L.qrd_panel_cqr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.qrd_panel_cqr_q.restype = C.c_int
+    L.qrd_panel_cqr_q.argtypes = L.qrd_panel_cqr.argtypes + [C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
     L.qrd_gemm_tn.restype = C.c_int
     L.qrd_gemm_tn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                               C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     return qr
 
 
-def run_panel(q, P, lda=None, ldv=None, two_stage=False):
+def run_panel(q, P, lda=None, ldv=None, two_stage=False, qbuf=False, v0=0.0):
+    """qbuf: Q in a buffer of its own (what the library's schedule does); the workspace is POISONED with NaN either way (the plan's is
+    never zeroed), v0: what Vw holds before the call"""
     mk, w = P.shape
     lda, ldv = lda or mk, ldv or mk
     buf = np.full((lda, w), 7.0)
     buf[:mk] = P
-    dA, dV = dev(buf), zeros(ldv, w)
+    dA, dV = dev(buf), dev(np.full((ldv, w), v0))
     dT, dtau = dev(np.full((w, w), np.nan)), zeros(w, 1)
-    ws = torch.zeros(int(q.lib.qrd_panel_cqr_ws_doubles()), dtype=torch.float64, device="cuda")
+    ws = torch.full((int(q.lib.qrd_panel_cqr_ws_doubles()),), float("nan"), dtype=torch.float64, device="cuda")
     status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    dQ = dev(np.full((ldv, w), np.nan)) if qbuf else None
     cap = 1 << 22
     slabs = torch.zeros(cap, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     L = q.lib
-    if not two_stage:
+    if qbuf:
+        assert L.qrd_panel_cqr_q(None, dA.data_ptr(), lda, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), ldv, ws.data_ptr(), status.data_ptr(),
+                                 dQ.data_ptr(), ldv, None, 0) == 0
+    elif not two_stage:
         assert L.qrd_panel_cqr(None, dA.data_ptr(), lda, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(), ldv, ws.data_ptr(), status.data_ptr()) == 0
     else:          # the development form: Gram matrices from the library's general product
         g1, g2 = L.qrd_panel_cqr_g1(ws.data_ptr()), L.qrd_panel_cqr_g2(ws.data_ptr())
@@ -87,7 +95,7 @@ def check_panel(P, out, V, T, tau):
 @pytest.mark.parametrize("mk,w", [(4096, 128), (4096, 64), (5000, 96), (1000, 32), (20000, 128), (300, 128), (32768, 128), (40003, 64)])
 def test_panel_cqr_well_conditioned(q, mk, w):
     P = np.random.default_rng(mk + w).random((mk, w))
-    out, V, T, tau, st = run_panel(q, P, lda=mk + 6, ldv=mk + 2)
+    out, V, T, tau, st = run_panel(q, P, lda=mk + 6, ldv=mk + 2, qbuf=(mk % 3 == 0))
     assert st[0] == 0, "the guard refused a well-conditioned panel"
     check_panel(P, out, V, T, tau)
 
@@ -132,8 +140,13 @@ def test_panel_cqr_refuses_and_leaves_the_panel_untouched(q, kind):
     else:
         P[100, 7] = np.nan
     out, V, T, tau, st = run_panel(q, P)
-    assert st[0] == 1
+    assert st[0] == 1 and st[1] == 1
     assert np.array_equal(out, P, equal_nan=True), "a refused panel must be left exactly as it was"
+    # with Q in a buffer of its own (the library's schedule) the explicit V is untouched as well: the leaf chain that takes the panel over
+    # relies on the zeros above each leaf's diagonal block (round-4 advisor finding: Q used to be parked in Vw)
+    out, V, T, tau, st = run_panel(q, P, qbuf=True, v0=3.25)
+    assert st[0] == 1
+    assert np.array_equal(out, P, equal_nan=True) and np.array_equal(V, np.full_like(V, 3.25))
 
 
 @pytest.mark.parametrize("m,n,nb", [(458752, 256, 128), (400001, 128, 128)])
@@ -155,3 +168,96 @@ def test_geqrf_takes_the_full_width_route_on_tall_shapes(qr, m, n, nb):
     assert np.linalg.norm(S[:, None] * R - Rref) / np.linalg.norm(Rref) < 1e-12
     assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+
+
+def _ill_conditioned(kind, m, n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.random((m, n))
+    if kind == "cond_1e9":
+        U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+        W, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        A = (U * np.logspace(0, -9, n)) @ W.T
+    elif kind == "duplicated_column":
+        A[:, 200] = A[:, 131]            # inside the second 128-column panel
+        A[:, 17] = A[:, 3]               # and the first
+    elif kind == "zero_column":
+        A[:, 150] = 0.0
+    return A
+
+
+@pytest.mark.parametrize("kind", ["cond_1e9", "duplicated_column", "zero_column"])
+def test_geqrf_with_refused_tall_panels_is_householder_grade(qr, kind):
+    """qr_geqrf_dev on a tall shape whose 128-column panels the full-width route REFUSES (cond > 1e7, dependent or zero columns): the leaf
+    chain takes the untouched panel over and the result is as good as for any other input.  The plan is used for a well-conditioned
+    matrix FIRST, so that every workspace holds stale data (round-4 advisor finding: the fall-back ran on a V buffer polluted with Q)."""
+    m, n, nb = 200000, 256, 128
+    p = qr.Plan(m, n, nb, 32)
+    dtau, dQ = zeros(n, 1), zeros(m, n)
+    dA = dev(np.random.default_rng(1).random((m, n)))
+    p.geqrf(dA, m, n, m, dtau)
+    p.sync()
+    assert p.route_stats()["tall_panels"] == 2 and p.route_stats()["tall_panels_refused"] == 0
+    A = _ill_conditioned(kind, m, n, 5)
+    dA = dev(A)
+    p.geqrf(dA, m, n, m, dtau)
+    p.sync()
+    st = p.route_stats()
+    assert st["tall_panels"] == 4 and st["tall_panels_refused"] >= 1, st
+    F = host(dA)
+    p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+    p.sync()
+    Q = host(dQ)
+    p.close()
+    R = np.triu(F[:n])
+    assert np.isfinite(R).all() and np.isfinite(Q).all()
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+    if kind != "cond_1e9":
+        Rref = np.linalg.qr(A, mode="r")
+        dr, dref = np.abs(np.diag(R)), np.abs(np.diag(Rref))
+        assert np.allclose(dr[dref > 1e-8], dref[dref > 1e-8], rtol=1e-10)          # the well-determined part of R
+        assert (dr[dref <= 1e-8] < 1e-10).all()
+
+
+def test_latch_mode_reports_a_refused_panel_at_sync_and_never_blocks(qr):
+    """latch mode (qr_plan_set_guard_mode): qr_geqrf_dev is stream-ordered -- four tall factorisations are queued before the first has
+    finished -- and a refusal comes back from qr_plan_sync as QR_E_REFUSED (-106), once"""
+    import time
+    m, n, nb = 262144, 256, 128
+    p = qr.Plan(m, n, nb, 32)
+    p.set_guard_mode(True)
+    dtau = zeros(n, 1)
+    bufs = [dev(np.zeros((m, n))) for _ in range(4)]
+    for b in bufs:
+        p.fill_uniform(b, m, m, n, seed=12)
+    p.geqrf(bufs[0], m, n, m, dtau)          # warm-up
+    p.sync()
+    for b in bufs:
+        p.fill_uniform(b, m, m, n, seed=12)
+    p.sync()
+    t0 = time.perf_counter()
+    for b in bufs:
+        p.geqrf(b, m, n, m, dtau)
+    t_issue = time.perf_counter() - t0
+    p.sync()
+    t_all = time.perf_counter() - t0
+    assert t_issue < 0.5 * t_all, (t_issue, t_all)           # the host ran ahead of the device
+    assert p.route_stats()["tall_panels_refused"] == 0
+    A = _ill_conditioned("duplicated_column", m, n, 9)
+    dA = dev(A)
+    p.geqrf(dA, m, n, m, dtau)
+    with pytest.raises(qr.QRError, match="-106"):
+        p.sync()
+    p.sync()                                                # cleared by the read
+    assert p.route_stats()["tall_panels_refused"] >= 1
+    p.set_guard_mode(False)                                 # the documented recovery: a fresh copy, default mode
+    dA = dev(A)
+    dQ = zeros(m, n)
+    p.geqrf(dA, m, n, m, dtau)
+    p.sync()
+    R = np.triu(host(dA)[:n])
+    p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+    p.sync()
+    Q = host(dQ)
+    p.close()
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13 and np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12

@@ -76,7 +76,7 @@ __device__ __forceinline__ bool f32_chol4(double d00, double d01, double d02, do
 // Cholesky G = R^T R of a symmetric 32 x 32 matrix with X = R^-T, one wave.
 //   loadG(i, j)        G(i, j); called for every (i, j) of the tiles (0,0), (0,1), (1,1): entries below the diagonal must be FINITE (they are
 //                      multiplied by zeros), e.g. the mirrored value
-//   storeR(i, j, v)    R(i, j) for every j of the tile columns >= the row's tile (v = 0 left of the diagonal)
+//   storeR(i, j, v)    R(i, j) for every j < 32 (v = 0 left of the diagonal)
 //   storeX(i, j, v)    X(i, j) = R^-T(i, j) for every j < 32 (v = 0 right of the diagonal)
 // Each (i, j) is stored by exactly one lane.  Returns false (uniform) on a non-positive or NaN pivot; the outputs are then garbage.
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -117,6 +117,7 @@ struct F32CholStep {
             s1 = f32_mma(am, T[2][r], zero)[0];
             s1 = (16 + l15 >= row) ? s1 : 0.0;
             T[2] = f32_mms(s1, s1, T[2]);
+            storeR(row, l15, 0.0);
             storeR(row, 16 + l15, s1);
             const double y0 = f32_mma(am, X[1][r], zero)[0], y1 = f32_mma(am, X[2][r], zero)[0];
             X[1] = f32_mms(s1, y0, X[1]);
@@ -287,11 +288,25 @@ struct F32LuStep {
     }
 };
 
-template <class LW, class LR, class SLU, class SS, class SLI, class SUI>
-__device__ __forceinline__ void lu32_mfma(int lane, LW loadW, LR loadR2, SLU storeLU, SS storeS, SLI storeLi, SUI storeUit)
+// R2 in operand tiles (requested early by callers whose R2 comes from global memory: the loads then run under other work)
+template <class LR>
+__device__ __forceinline__ void lu32_load_r2(int lane, LR loadR2, v4d (&R2t)[3])
 {
     const int l15 = lane & 15, l4 = lane >> 4;
-    v4d Wt[4], Vt[4], R2t[3], XL[3], XU[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * r + l4;
+        R2t[0][r] = loadR2(i, l15);
+        R2t[1][r] = loadR2(i, 16 + l15);
+        R2t[2][r] = loadR2(16 + i, 16 + l15);
+    }
+}
+
+template <class LW, class SLU, class SS, class SLI, class SUI>
+__device__ __forceinline__ void lu32_mfma_r2(int lane, LW loadW, const v4d (&R2t)[3], SLU storeLU, SS storeS, SLI storeLi, SUI storeUit)
+{
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4d Wt[4], Vt[4], XL[3], XU[3];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * r + l4;
@@ -302,15 +317,20 @@ __device__ __forceinline__ void lu32_mfma(int lane, LW loadW, LR loadR2, SLU sto
                 Wt[2 * a + b][r] = loadW(16 * a + i, 16 * b + l15);
                 Vt[2 * a + b][r] = loadW(16 * b + l15, 16 * a + i);
             }
-        R2t[0][r] = loadR2(i, l15);
-        R2t[1][r] = loadR2(i, 16 + l15);
-        R2t[2][r] = loadR2(16 + i, 16 + l15);
         XL[0][r] = (i == l15) ? 1.0 : 0.0;
         XL[1][r] = 0.0;
         XL[2][r] = (i == l15) ? 1.0 : 0.0;
         XU[0][r] = XL[0][r]; XU[1][r] = 0.0; XU[2][r] = XL[2][r];
     }
     F32LuStep<0, SLU, SS, SLI, SUI>::run(Wt, Vt, R2t, XL, XU, lane, storeLU, storeS, storeLi, storeUit);
+}
+
+template <class LW, class LR, class SLU, class SS, class SLI, class SUI>
+__device__ __forceinline__ void lu32_mfma(int lane, LW loadW, LR loadR2, SLU storeLU, SS storeS, SLI storeLi, SUI storeUit)
+{
+    v4d R2t[3];
+    lu32_load_r2(lane, loadR2, R2t);
+    lu32_mfma_r2(lane, loadW, R2t, storeLU, storeS, storeLi, storeUit);
 }
 
 #endif

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64) void f32_chol_test_kernel(const double* __restr
     __shared__ double Gs[32][33], Rs[32][33], Xs[32][33];
     int lane = threadIdx.x;
     const double* g = G + (size_t) blockIdx.x * 1024;
-    for (int e = lane; e < 1024; e += 64) { Gs[e >> 5][e & 31] = g[e]; Rs[e >> 5][e & 31] = 0.0; Xs[e >> 5][e & 31] = 0.0; }
+    for (int e = lane; e < 1024; e += 64) { Gs[e >> 5][e & 31] = g[e]; Rs[e >> 5][e & 31] = 777.0; Xs[e >> 5][e & 31] = 777.0; }      // (poisoned: every entry must be written)
     __syncthreads();
     bool ok = true;
     const unsigned long long t0 = wall_clock64();
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void f32_lu_test_kernel(const double* __restric
     for (int e = lane; e < 1024; e += 64) {
         Ws[e >> 5][e & 31] = W[(size_t) blockIdx.x * 1024 + e];
         R2s[e >> 5][e & 31] = ((e & 31) >= (e >> 5)) ? R2[(size_t) blockIdx.x * 1024 + e] : 0.0;
-        Bs[e >> 5][e & 31] = 0.0; Ls[e >> 5][e & 31] = 0.0; Us[e >> 5][e & 31] = 0.0;
+        Bs[e >> 5][e & 31] = 777.0; Ls[e >> 5][e & 31] = 777.0; Us[e >> 5][e & 31] = 777.0;
     }
     __syncthreads();
     const unsigned long long t0 = wall_clock64();

@@ -18,6 +18,7 @@
 #include "qr_device.h"
 #include "qr_common.h"
 #include "qr_leaf_math.h"
+#include "qr_factor32.h"
 
 namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -89,6 +90,7 @@ struct CqLds {
     double* red;          // [CQ_T / 64] reduction scratch
     int* flag;            // [4]
     double* wsdbg;        // workspace (phase stamps of CQ_STAMPS builds)
+    double* dinv;         // global: per 32-block, U'11^-1 (row-major 32 x 32) then L11^-1; NULL: not kept
 };
 __device__ __forceinline__ CqLds cq_lds(double* sm)
 {
@@ -100,6 +102,7 @@ __device__ __forceinline__ CqLds cq_lds(double* sm)
     L.red = L.sv + CQ_W;
     L.flag = reinterpret_cast<int*>(L.red + CQ_T / 64);
     L.wsdbg = nullptr;
+    L.dinv = nullptr;
     return L;
 }
 constexpr size_t CQ_LDS_BYTES = sizeof(double) * (CQ_LD * CQ_LD + 2 * 32 * 33 + CQ_W + CQ_T / 64) + 64;
@@ -141,103 +144,136 @@ __device__ __forceinline__ void cq_tiles(int nt, int ntc, int r0, int c0, bool u
     __syncthreads();
 }
 
+// Trailing tiles of a block step dealt to waves 1 .. 3 while wave 0 factors the next diagonal block: the (tr, tc) grid of ntc x ntc
+// 16 x 16 tiles at (r0, r0), WITHOUT the four tiles of its leading 32 x 32 block (wave 0 has updated those itself); upper_only: tiles
+// on and above the tile diagonal.  compute(i0, j0) -> accumulator, store(i, j, value).  At most 11 tiles per wave (ntc <= 6).
+template <class FC, class FS>
+__device__ __forceinline__ void cq_tiles_rest(int ntc, int r0, bool upper_only, int wave, int lane, FC compute, FS store)
+{
+    constexpr int MAXT = 11;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4d acc[MAXT];
+    // (enumeration: tl over the full grid, the leading block's tiles and -- upper_only -- the lower tiles skipped; the counter of kept
+    // tiles is dealt round-robin to the three waves)
+    int kept = 0, mine = 0;
+    for (int tl = 0; tl < ntc * ntc; ++tl) {
+        const int tr = tl / ntc, tc = tl - tr * ntc;
+        if ((tr < 2 && tc < 2) || (upper_only && tc < tr)) continue;
+        if (kept % 3 == wave - 1) {
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q)
+                if (q == mine) acc[q] = compute(r0 + 16 * tr, r0 + 16 * tc);
+            ++mine;
+        }
+        ++kept;
+    }
+    kept = 0; mine = 0;
+    for (int tl = 0; tl < ntc * ntc; ++tl) {
+        const int tr = tl / ntc, tc = tl - tr * ntc;
+        if ((tr < 2 && tc < 2) || (upper_only && tc < tr)) continue;
+        if (kept % 3 == wave - 1) {
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q)
+                if (q == mine)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) store(r0 + 16 * tr + l4 + 4 * r, r0 + 16 * tc + l15, acc[q][r]);
+            ++mine;
+        }
+        ++kept;
+    }
+}
+
 // Blocked right-looking Cholesky of the symmetric matrix whose upper triangle is in L.M: R (upper) in place.  Per block of 32 columns:
-// the diagonal block on wave 0 in registers (the leaves' CholAugStep: R11 on the lower lanes, R11^-T on the upper ones), then
-// R12 = R11^-T G12 and G22 -= R12^T R12 on the matrix cores.  Returns false on a non-positive pivot (uniform).
+// the diagonal block on wave 0 on the matrix cores (chol32_mfma: R11 in place, R11^-T -> sb1 and, as the inverse's diagonal block
+// R11^-1, into the slots strictly below the diagonal: X(c, i) at M[i + 1][c]), then R12 = R11^-T G12 and G22 -= R12^T R12 on the matrix
+// cores.  Round 5, look-ahead inside the workgroup: wave 0 updates only the NEXT diagonal block and factors it while waves 1 - 3
+// update the rest of G22, so a block step costs max(diagonal block, trailing update) instead of their sum.
+// Returns false on a non-positive pivot (uniform).
+__device__ __forceinline__ void cq_chol_diag(const CqLds& L, int o, int tid)
+{
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));                            // keeps the unrolled steps' lane constants inside the caller's iteration
+    double* const Mo = L.M + o * CQ_LD + o;
+    const bool ok = chol32_mfma(lane, [&](int i, int j) { return (j >= i) ? Mo[i * CQ_LD + j] : Mo[j * CQ_LD + i]; },
+                                [&](int i, int j, double v) { if (j >= i) Mo[i * CQ_LD + j] = v; },
+                                [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; if (j <= i) Mo[(i + 1) * CQ_LD + j] = v; });
+    if (!ok) L.flag[0] = 0;
+}
+__device__ __forceinline__ void cq_wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
+    auto Mt = [&](int i, int k) { return L.M[k * CQ_LD + i]; };
     if (tid == 0) L.flag[0] = 1;
     __syncthreads();
-    for (int o = 0; o < w; o += 32) {
+    if (wave == 0) cq_chol_diag(L, 0, tid);
+    __syncthreads();
+    for (int o = 0; o + 32 < w; o += 32) {
+        const int rest = w - o - 32, ntc = rest >> 4;
+        auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
+        cq_tiles(2 * ntc, ntc, o, o + 32, false, true, tid,
+                 [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, lane); },
+                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
         if (wave == 0) {
-            int lane = tid & 63;
-            asm volatile("" : "+v"(lane));                    // keeps the unrolled recurrence's lane constants inside this iteration
-            const int c = lane & 31;
-            double g[PW];
+            // the next diagonal block's three upper tiles, then its factorisation (sb1 is free: the block row is solved)
+            const int n0 = o + 32;
+            const v4d a00 = cq_tile(Mt, Mx, n0, n0, o, o + 32, lane), a01 = cq_tile(Mt, Mx, n0, n0 + 16, o, o + 32, lane),
+                      a11 = cq_tile(Mt, Mx, n0 + 16, n0 + 16, o, o + 32, lane);
 #pragma unroll
-            for (int i = 0; i < PW; ++i)
-                g[i] = (lane < PW) ? ((i <= c) ? L.M[(o + i) * CQ_LD + o + c] : L.M[(o + c) * CQ_LD + o + i]) : (i == c ? 1.0 : 0.0);
-            bool ok = true;
-            CholAugStep<0>::run(g, lane, ok);
-            if (!ok) L.flag[0] = 0;                            // (every lane of the wave saw the same pivots)
-            if (lane < PW) {
-#pragma unroll
-                for (int i = 0; i < PW; ++i)
-                    if (i <= c) L.M[(o + i) * CQ_LD + o + c] = g[i];       // (below the diagonal: the slots of the inverse, next branch)
-            } else {
-#pragma unroll
-                for (int i = 0; i < PW; ++i) {
-                    L.sb1[i * 33 + c] = (i >= c) ? g[i] : 0.0;             // sb1[i][k] = R11^-T(i, k)
-                    if (i >= c) L.M[(o + i + 1) * CQ_LD + o + c] = g[i];   // X(c, i) = R11^-1(c, i) = R11^-T(i, c): the inverse's diagonal block
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = l4 + 4 * r;
+                L.M[(n0 + i) * CQ_LD + n0 + l15] -= a00[r];
+                L.M[(n0 + i) * CQ_LD + n0 + 16 + l15] -= a01[r];
+                L.M[(n0 + 16 + i) * CQ_LD + n0 + 16 + l15] -= a11[r];
             }
+            cq_wave_sync_lds();
+            cq_chol_diag(L, n0, tid);
+        } else {
+            cq_tiles_rest(ntc, o + 32, true, wave, lane, [&](int i0, int j0) { return cq_tile(Mt, Mx, i0, j0, o, o + 32, lane); },
+                          [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
         }
         __syncthreads();
-        const int rest = w - o - 32;
-        if (rest > 0) {
-            auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
-            cq_tiles(2 * (rest >> 4), rest >> 4, o, o + 32, false, true, tid,
-                     [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, tid & 63); },
-                     [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
-            auto Mt = [&](int i, int k) { return L.M[k * CQ_LD + i]; };
-            cq_tiles((rest >> 4) * (rest >> 4), rest >> 4, o + 32, o + 32, true, false, tid,
-                     [&](int i0, int j0) { return cq_tile(Mt, Mx, i0, j0, o, o + 32, tid & 63); },
-                     [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
-        }
     }
     return L.flag[0] != 0;
 }
 
 // Blocked modified LU of W - S R2 = L1 U' (W in L.M, whole; R2 row-major in global memory, zero below its diagonal), the sign of every
-// pivot chosen as Householder would (reference qr.c:141-151).  Per block of 32 columns: the diagonal block on wave 0 in registers (the
-// leaves' Hr3Lu: L11 \ U'11 on the lower lanes, L11^-1 on the upper ones) while wave 1 ... then U'11^-1 on wave 1, and on the matrix
-// cores U'12 = L11^-1 (W12 - S R2_12), L21 = W21 U'11^-1, W22 -= L21 U'12.  L1 \ U' in place, S -> L.sv.
+// pivot chosen as Householder would (reference qr.c:141-151).  Per block of 32 columns: the diagonal block on wave 0 on the matrix cores
+// (lu32_mfma: L11 \ U'11 in place, S, L11^-1 -> sb1, U'11^-1 -> sb2, and both into the workspace: they are the diagonal blocks of the
+// inverses cqr_post_kernel builds), then U'12 = L11^-1 (W12 - S R2_12), L21 = W21 U'11^-1, W22 -= L21 U'12 on the matrix cores --
+// with the same look-ahead as the Cholesky: wave 0 updates and factors the next diagonal block while waves 1 - 3 update the rest.
+__device__ __forceinline__ void cq_lu_r2(int o, const double* R2g, int tid, v4d (&R2t)[3])
+{
+    const double* const R2o = R2g + o * CQ_W + o;
+    lu32_load_r2(tid & 63, [&](int i, int j) { return (j >= i) ? R2o[i * CQ_W + j] : 0.0; }, R2t);
+}
+__device__ __forceinline__ void cq_lu_diag(const CqLds& L, int o, const v4d (&R2t)[3], int tid)
+{
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));
+    double* const Mo = L.M + o * CQ_LD + o;
+    double* const dinv = L.dinv ? L.dinv + (o >> 5) * 2048 : nullptr;
+    lu32_mfma_r2(lane, [&](int i, int j) { return Mo[i * CQ_LD + j]; }, R2t,
+                 [&](int i, int j, double v) { Mo[i * CQ_LD + j] = v; }, [&](int i, double v) { L.sv[o + i] = v; },
+                 [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; if (dinv) dinv[1024 + i * 32 + j] = v; },          // L11^-1(i, j)
+                 [&](int i, int j, double v) { L.sb2[j * 33 + i] = v; if (dinv) dinv[j * 32 + i] = v; });                // U'11^-1(j, i)
+}
 __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const double* R2g, int tid)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
-    for (int o = 0; o < w; o += 32) {
-        if (wave == 0) {
-            int lane = tid & 63;
-            asm volatile("" : "+v"(lane));
-            const int c = lane & 31;
-            double b[PW], g[PW];
-#pragma unroll
-            for (int r = 0; r < PW; ++r) {
-                b[r] = (lane < PW) ? L.M[(o + r) * CQ_LD + o + c] : (r == c ? 1.0 : 0.0);
-                g[r] = (lane < PW && r <= c) ? R2g[(o + r) * CQ_W + o + c] : 0.0;
-            }
-            double sgn = 1.0;
-            Hr3Lu<0>::run(b, g, lane, sgn);
-            if (lane < PW) {
-#pragma unroll
-                for (int r = 0; r < PW; ++r) L.M[(o + r) * CQ_LD + o + c] = b[r];
-                L.sv[o + c] = sgn;
-            } else {
-#pragma unroll
-                for (int r = 0; r < PW; ++r) L.sb1[r * 33 + c] = (r >= c) ? b[r] : 0.0;      // sb1[i][k] = L11^-1(i, k)
-            }
-        }
-        __syncthreads();
-        const int rest = w - o - 32;
-        if (rest <= 0) break;
-        if (wave == 1) {                                       // U'11^-1 -> sb2, a column per lane in registers
-            const int lane = tid & 63, j = lane & 31;
-            const double dinv = rcp_newton(L.M[(o + j) * CQ_LD + o + j]);
-            double x[32];
-#pragma unroll
-            for (int i = 31; i >= 0; --i) {
-                double acc = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = i + 1; k < 32; ++k) acc -= L.M[(o + i) * CQ_LD + o + k] * x[k];
-                x[i] = (i <= j) ? acc * readlane_f64(dinv, i) : 0.0;
-            }
-            if (lane < 32)
-#pragma unroll
-                for (int i = 0; i < 32; ++i) L.sb2[i * 33 + j] = x[i];
-        }
+    v4d r2t[3];                                                // wave 0: R2's diagonal block of the block it factors next, requested a phase early
+    if (wave == 0) { cq_lu_r2(0, R2g, tid, r2t); cq_lu_diag(L, 0, r2t, tid); }
+    __syncthreads();
+    for (int o = 0; o + 32 < w; o += 32) {
+        const int rest = w - o - 32, ntc = rest >> 4;
+        if (wave == 0) cq_lu_r2(o + 32, R2g, tid, r2t);
         // U'12 = L11^-1 (W12 - S R2_12): operands and result share W12 -> stores behind a barrier
         auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
         {   // W12 -= S R2_12 first, the R2 values of a thread requested together (element e: row o + (e >> 7), column o + 32 + (e & 127))
@@ -254,18 +290,34 @@ __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const doubl
             }
             __syncthreads();
         }
-        cq_tiles(2 * (rest >> 4), rest >> 4, o, o + 32, false, true, tid,
-                 [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, tid & 63); },
+        cq_tiles(2 * ntc, ntc, o, o + 32, false, true, tid,
+                 [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, lane); },
                  [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
         // L21 = W21 U'11^-1 (the barrier of the call above also published sb2)
         auto Ui = [&](int k, int j) { return L.sb2[(k - o) * 33 + (j - o)]; };
-        cq_tiles((rest >> 4) * 2, 2, o + 32, o, false, true, tid,
-                 [&](int i0, int j0) { return cq_tile(Mx, Ui, i0, j0, o, o + 32, tid & 63); },
+        cq_tiles(ntc * 2, 2, o + 32, o, false, true, tid,
+                 [&](int i0, int j0) { return cq_tile(Mx, Ui, i0, j0, o, o + 32, lane); },
                  [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
-        // W22 -= L21 U'12
-        cq_tiles((rest >> 4) * (rest >> 4), rest >> 4, o + 32, o + 32, false, false, tid,
-                 [&](int i0, int j0) { return cq_tile(Mx, Mx, i0, j0, o, o + 32, tid & 63); },
-                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
+        // W22 -= L21 U'12: wave 0 the next diagonal block (four tiles) and its factorisation, waves 1 - 3 the rest
+        if (wave == 0) {
+            const int n0 = o + 32;
+            const v4d a00 = cq_tile(Mx, Mx, n0, n0, o, o + 32, lane), a01 = cq_tile(Mx, Mx, n0, n0 + 16, o, o + 32, lane),
+                      a10 = cq_tile(Mx, Mx, n0 + 16, n0, o, o + 32, lane), a11 = cq_tile(Mx, Mx, n0 + 16, n0 + 16, o, o + 32, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = l4 + 4 * r;
+                L.M[(n0 + i) * CQ_LD + n0 + l15] -= a00[r];
+                L.M[(n0 + i) * CQ_LD + n0 + 16 + l15] -= a01[r];
+                L.M[(n0 + 16 + i) * CQ_LD + n0 + l15] -= a10[r];
+                L.M[(n0 + 16 + i) * CQ_LD + n0 + 16 + l15] -= a11[r];
+            }
+            cq_wave_sync_lds();
+            cq_lu_diag(L, n0, r2t, tid);
+        } else {
+            cq_tiles_rest(ntc, o + 32, false, wave, lane, [&](int i0, int j0) { return cq_tile(Mx, Mx, i0, j0, o, o + 32, lane); },
+                          [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
+        }
+        __syncthreads();
     }
     __syncthreads();
 }
@@ -497,7 +549,8 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
 // (the body returns true -- uniformly -- when the panel is refused; cqr_lu_kernel publishes the verdict)
 __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double* Vw, int ldv, const int* status)
 {
-    const CqLds L = cq_lds(sm);
+    CqLds L = cq_lds(sm);
+    L.dinv = ws + CQ_X3;
     const int tid = threadIdx.x;
     if (status[0]) return true;                               // the first Cholesky failed
     CQ_STAMP(8);
@@ -592,6 +645,18 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     }
 }
 
+// the diagonal 32 x 32 blocks of an inverse into their slots (X(i, j) at M[j + 1][i], i <= j) from the blocks the LU kernel left in the
+// workspace: per block U'11^-1 (row-major) then L11^-1;  lower = true: the inverse wanted is (L1^T)^-1, whose block is (L11^-1)^T
+__device__ __forceinline__ void cq_diag_slots(const CqLds& L, const double* dinv, int w, int tid, bool lower)
+{
+    for (int e = tid; e < (w >> 5) * 1024; e += CQ_T) {
+        const int blk = e >> 10, i = (e >> 5) & 31, j = e & 31, o = 32 * blk;          // element (i, j) of the block, i <= j kept
+        if (i > j) continue;
+        const double v = lower ? dinv[blk * 2048 + 1024 + j * 32 + i] : dinv[blk * 2048 + i * 32 + j];
+        L.M[(o + j + 1) * CQ_LD + o + i] = v;
+    }
+}
+
 // What follows the LU, on TWO workgroups side by side (four independent pieces were 120 us in a row on one):
 //   workgroup 0: U'^-1 -> UI (the operand of the V pass), then R = S R2 R1
 //   workgroup 1: U = U' R2^-1, the inverse of L1^T, T = -U S L1^-T
@@ -604,10 +669,11 @@ __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const
     if (status[0]) return;
     if (tid < w) L.sv[tid] = ws[CQ_SV + tid];
     if (blockIdx.x == 0) {
-        // ---- U'^-1 -> UI
+        // ---- U'^-1 -> UI (its diagonal blocks: left by the LU's matrix-core diagonal steps in the workspace)
         cq_load_upper(L, ws + CQ_LU, w, tid);
+        cq_diag_slots(L, ws + CQ_X3, w, tid, false);
         __syncthreads();
-        cq_upper_inv(L, w, 0, 0, tid);
+        cq_upper_inv(L, w, 1, 0, tid);
         cq_inv_out(L, ws + CQ_UI, w, tid);
         __syncthreads();
         // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
@@ -625,8 +691,9 @@ __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const
         // ---- L1^-T: the inverse of the unit upper-triangular L1^T stays below the diagonal of L.M
         // (L1^T)(j, i) = L1(i, j): row i of LU read along j
         cq_elems(w, tid, [&](int i, int j) { return ws[CQ_LU + i * CQ_W + j]; }, [&](int i, int j, double v) { if (j < w && i >= j) L.M[j * CQ_LD + i] = (i == j) ? 1.0 : v; });
+        cq_diag_slots(L, ws + CQ_X3, w, tid, true);
         __syncthreads();
-        cq_upper_inv(L, w, 0, 0, tid);
+        cq_upper_inv(L, w, 1, 0, tid);
         // ---- T = -U S L1^-T: U (X2) -> the upper triangle of L.M, S folded into U's columns
         cq_sync_global();
         cq_load_upper(L, ws + CQ_X2, w, tid);

@@ -31,6 +31,7 @@
 #include "qr_device.h"
 #include "qr_common.h"
 #include "qr_leaf_math.h"
+#include "qr_factor32.h"
 
 #define PF_THREADS 256            /* four waves, one per SIMD */
 #define PF_ROWS 256               /* rows per workgroup */
@@ -1110,28 +1111,16 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
         PF_STAMP_S(17);
         // R1 = chol(G1) and R1^-1 on one wave (the identity columns ride on the wave's upper half)
         if (wave == 0) {
-            double gg[PW];
-#pragma unroll
-            for (int i = 0; i < PW; ++i) gg[i] = (lane < PW) ? L.Gs[rc][i] : (i == rc ? 1.0 : 0.0);
+            // (round 5: on the matrix cores, micro-blocked by 4 -- qr_factor32.h; the register recurrence CholAugStep took 8 us here)
             int e2 = 0;                                        // even power-of-two scaling, as in cholq3_kernel
             {
-                const double d = readlane_f64(gg[0], 0);
+                const double d = L.Gs[0][0];
                 if (d > 0.0 && d < 1.7e308) { (void) frexp(d, &e2); e2 &= ~1; }
             }
             const double rs = ldexp(1.0, e2 / 2), wsc = ldexp(1.0, -(e2 / 2));
-            if (lane < PW) {
-#pragma unroll
-                for (int i = 0; i < PW; ++i) gg[i] = (gg[i] * wsc) * wsc;
-            }
-            bool ok = true;
-            CholAugStep<0>::run(gg, lane, ok);
-            if (lane >= PW) {
-#pragma unroll
-                for (int k = 0; k < PW; ++k) L.Ws[rc][k] = (k >= rc) ? gg[k] * wsc : 0.0;       // row rc of R1^-1
-            } else {
-#pragma unroll
-                for (int k = 0; k < PW; ++k) L.R1s[k][rc] = (k <= rc) ? gg[k] * rs : 0.0;       // column rc of R1
-            }
+            const bool ok = chol32_mfma(lane, [&](int i, int j) { return (L.Gs[j][i] * wsc) * wsc; },
+                                        [&](int i, int j, double v) { L.R1s[i][j] = v * rs; },                     // R1(i, j)
+                                        [&](int i, int j, double v) { L.Ws[j][i] = v * wsc; });                    // R1^-1(j, i) = R1^-T(i, j)
             if (lane == 0 && !ok) L.gflags[0] = 0;
         }
         __syncthreads();
@@ -1154,39 +1143,39 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
         if (wave == 0) {
             const bool refused = L.gflags[0] == 0 || L.gflags[1] != 0;
             const bool first_order = L.gflags[2] == 0;
-            double gg[PW], b[PW];
-            if (lane < PW) {
-#pragma unroll
-                for (int r = 0; r < PW; ++r) b[r] = pf_ld(f.QT + rc * 32 + r);
+            bool ok = true;
+            {
+                // R2 -> R2s (column `lane` per lane): to first order when G2 = I + E with |E| <= 1e-9 (R2 = I + striu(E) + diag(E) / 2 up to
+                // terms of size 32 |E|^2), else the second Cholesky as a register recurrence (leaves of condition > ~1e4)
+                double gg[PW];
+                double dinv = 1.0;
 #pragma unroll
                 for (int i = 0; i < PW; ++i) gg[i] = L.Gs[rc][i];
-            } else {
+                if (!first_order) {
+                    Chol3Step<0>::run(gg, lane, ok, dinv);
+                } else {
 #pragma unroll
-                for (int r = 0; r < PW; ++r) { b[r] = (r == rc) ? 1.0 : 0.0; gg[r] = 0.0; }
-            }
-            bool ok = true;
-            double dinv = 1.0, sgn = 1.0;
-            if (!first_order) {
-                Chol3Step<0>::run(gg, lane, ok, dinv);
-            } else if (lane < PW) {
-#pragma unroll
-                for (int i = 0; i < PW; ++i) gg[i] = (i < rc) ? gg[i] : (i == rc ? 1.0 + 0.5 * (gg[i] - 1.0) : 0.0);
-                double d = 1.0;
-#pragma unroll
-                for (int i = 0; i < PW; ++i) d = (i == rc) ? gg[i] : d;
-                dinv = 1.0 / d;
-            }
-            if (ok && !refused) {
-                Hr3Lu<0>::run(b, gg, lane, sgn);
+                    for (int i = 0; i < PW; ++i) gg[i] = (i < rc) ? gg[i] : (i == rc ? 1.0 + 0.5 * (gg[i] - 1.0) : 0.0);
+                }
                 if (lane < PW) {
 #pragma unroll
-                    for (int k = 0; k < PW; ++k) { L.R2s[k][lane] = gg[k]; L.Bs[k][lane] = b[k]; }
-                    L.r2inv[lane] = dinv;
-                    L.Ss[lane] = sgn;
-                } else {                                   // Ls aliases Gs: this wave has G2 in registers since the start of the LU
-#pragma unroll
-                    for (int k = 0; k < PW; ++k) L.Ls[k][rc] = (k >= rc) ? b[k] : 0.0;           // Ls[i][j] = L1^-1(i, j)
+                    for (int k = 0; k < PW; ++k) L.R2s[k][lane] = gg[k];
+                    L.r2inv[lane] = dinv;                      // (read by the row solve of the general case only)
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (ok && !refused) {
+                // modified LU  Q_top - S R2 = L1 U'  with L1^-1 and U'^-1, all on the matrix cores (qr_factor32.h; round 4: a register
+                // recurrence here, 10 us, and two 16-step recurrences + 8 MFMAs on waves 1 and 2 behind it for U'^-1, 3.5 us).
+                // Ls aliases Gs: G2 is not needed any more
+                lu32_mfma(lane, [&](int i, int j) { return pf_ld(f.QT + j * 32 + i); }, [&](int i, int j) { return L.R2s[i][j]; },
+                          [&](int i, int j, double v) { L.Bs[i][j] = v; }, [&](int i, double v) { L.Ss[i] = v; },
+                          [&](int i, int j, double v) { L.Ls[i][j] = v; }, [&](int i, int j, double v) { L.Uinv[j][i] = v; });
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             } else if (lane == 0) L.gflags[3] = 1;
             PF_STAMP_S(22);
             pf_lds_signal(&L.gflags[5], seq);
@@ -1223,45 +1212,6 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
 #pragma unroll
                     for (int cc = 0; cc < PW; ++cc) L.Us[lane][cc] = (cc >= lane) ? u[cc] : 0.0;
                 }
-            }
-        } else if (wave <= 2) {
-            pf_lds_await(&L.gflags[5], seq);
-            const int o = (wave == 2) ? 16 : 0, j = lane & 15;
-            double x[16];
-            PfUpperInv16<15>::run(x, L.Bs, o, j);
-            if (lane < 16) {                               // Uinv aliases the Gram partials (unused in this workgroup)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) L.Uinv[o + i][o + lane] = (i <= lane) ? x[i] : 0.0;  // Uinv[k][c] = U'^-1(k, c)
-                if (wave == 2)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) L.Uinv[16 + i][lane] = 0.0;
-            }
-            if (wave == 2) {
-                pf_lds_signal(&L.gflags[6], seq);
-            } else {
-                pf_lds_await(&L.gflags[6], seq);
-                // X12 = -X11 (U'12 X22): two 16 x 16 x 16 products; the intermediate goes through LDS scratch
-                const int l15 = lane & 15, l4 = lane >> 4;
-                double* tmp = L.scr + 4 * 128;
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {           // P = U'12 X22:  P(i, c) = sum_k U'(i, 16 + k) X22(k, c)
-                    const int k = 4 * ks + l4;
-                    acc = pf_mfma(L.Bs[l15][16 + k], L.Uinv[16 + k][16 + l15], acc);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tmp[(l4 + 4 * r) * 16 + l15] = acc[r];            // P(i = l4 + 4 r, c = l15)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                acc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {           // X12(i, c) = -sum_k X11(i, k) P(k, c)
-                    const int k = 4 * ks + l4;
-                    acc = pf_mfma(-L.Uinv[l15][k], tmp[k * 16 + l15], acc);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) L.Uinv[l4 + 4 * r][16 + l15] = acc[r];
             }
         }
         __syncthreads();

@@ -24,6 +24,7 @@
 #include "qr_common.h"
 #include "qr_gemm_tile.h"
 #include "qr_leaf_math.h"
+#include "qr_factor32.h"
 
 #define PT 512            // threads per workgroup = rows per block
 #define PWAVES (PT / 64)
@@ -1107,32 +1108,20 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
     __syncthreads();
     STAMP(1);
     if (tid < 64) {
-        double g[PW];
-        const int j = lane & (PW - 1);
-#pragma unroll
-        for (int i = 0; i < PW; ++i) g[i] = (lane < PW) ? Gs[j][i] : (i == j ? 1.0 : 0.0);
-        // Bring G to O(1) by an even power of two first (exact): next to the underflow threshold the Gram half of the wave would
-        // round to multiples of 4.9e-324 while the identity half stays in the normal range, and R1 and "its" inverse would stop
+        // Bring G to O(1) by an even power of two first (exact): next to the underflow threshold the Gram part of the factorisation would
+        // round to multiples of 4.9e-324 while the identity part stays in the normal range, and R1 and "its" inverse would stop
         // being inverses of each other (a panel scaled by 1e-160 lost 8 digits).  G' = 4^-h G = R'^T R', R = 2^h R', R^-1 = 2^-h R'^-1.
         int e2 = 0;
         {
-            const double d = readlane_f64(g[0], 0);
+            const double d = Gs[0][0];
             if (d > 0.0 && d < 1.7e308) { (void) frexp(d, &e2); e2 &= ~1; }
         }
         const double rs = ldexp(1.0, e2 / 2), ws = ldexp(1.0, -(e2 / 2));       // 4^-h itself may not be representable (G ~ 1e-317)
-        if (lane < PW) {
-#pragma unroll
-            for (int i = 0; i < PW; ++i) g[i] = (g[i] * ws) * ws;
-        }
-        bool ok = true;
-        CholAugStep<0>::run(g, lane, ok);
-        if (lane >= PW) {
-#pragma unroll
-            for (int k = 0; k < PW; ++k) Ws[j][k] = (k >= j) ? g[k] * ws : 0.0;      // row j of R1^-1
-        } else if (b == 0 && ok) {
-#pragma unroll
-            for (int k = 0; k < PW; ++k) R1[j * PW + k] = (k <= j) ? g[k] * rs : 0.0;   // column j of R1
-        }
+        // (round 5: on the matrix cores, qr_factor32.h; the register recurrence CholAugStep took 7-8 us of every workgroup here)
+        const bool wr = b == 0;
+        const bool ok = chol32_mfma(lane, [&](int i, int j) { return (Gs[j][i] * ws) * ws; },
+                                    [&](int i, int j, double v) { if (wr) R1[j * PW + i] = v * rs; },             // R1 column-major
+                                    [&](int i, int j, double v) { Ws[j][i] = v * ws; });                           // Ws[j][k] = R1^-1(j, k)
         if (lane == 0) *okf = ok ? 1 : 0;
     }
     __syncthreads();
@@ -1236,29 +1225,17 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
 __global__ __launch_bounds__(64) void chol1_kernel(const double* __restrict__ G1, double* __restrict__ R1, double* __restrict__ Rinv,
                                                    int* __restrict__ guard)
 {
-    const int lane = threadIdx.x, j = lane & (PW - 1);
-    double g[PW];
-#pragma unroll
-    for (int i = 0; i < PW; ++i) g[i] = (lane < PW) ? G1[j * PW + i] : (i == j ? 1.0 : 0.0);     // G1(i, j); lanes >= 32: identity
+    const int lane = threadIdx.x;
     int e2 = 0;                                            // power-of-two scaling as in cholq3_kernel
     {
-        const double d = readlane_f64(g[0], 0);
+        const double d = G1[0];
         if (d > 0.0 && d < 1.7e308) { (void) frexp(d, &e2); e2 &= ~1; }
     }
     const double rs = ldexp(1.0, e2 / 2), ws = ldexp(1.0, -(e2 / 2));
-    if (lane < PW) {
-#pragma unroll
-        for (int i = 0; i < PW; ++i) g[i] = (g[i] * ws) * ws;
-    }
-    bool ok = true;
-    CholAugStep<0>::run(g, lane, ok);
-    if (lane >= PW) {
-#pragma unroll
-        for (int k = 0; k < PW; ++k) Rinv[k * PW + j] = (k >= j) ? g[k] * ws : 0.0;       // row j of R1^-1, stored column-major: (j, k)
-    } else if (ok) {
-#pragma unroll
-        for (int k = 0; k < PW; ++k) R1[j * PW + k] = (k <= j) ? g[k] * rs : 0.0;         // column j of R1
-    }
+    // (round 5: on the matrix cores, qr_factor32.h)
+    const bool ok = chol32_mfma(lane, [&](int i, int j) { return (G1[j * PW + i] * ws) * ws; },
+                                [&](int i, int j, double v) { R1[j * PW + i] = v * rs; },                         // R1(i, j), column-major
+                                [&](int i, int j, double v) { Rinv[i * PW + j] = v * ws; });                       // R1^-1(j, i) = R1^-T(i, j)
     if (lane == 0) *guard = ok ? 0 : 1;
 }
 
@@ -1445,12 +1422,8 @@ __device__ __forceinline__ void hr3_body(const double* __restrict__ G2s, int nsl
     // would put one more global round trip -- 2-4 us next to a running update GEMM -- in front of every other load
     const int gword = *guard;
     if (tid < 3) flags[tid] = 0;
-    double b[PW];
-    if (g == 0) {                                          // column rc of Q_top: 32 consecutive doubles, in flight under the sum
-        const v2d* col = reinterpret_cast<const v2d*>(Vw + (size_t) rc * ldv);
-#pragma unroll
-        for (int r2 = 0; r2 < PW / 2; ++r2) { const v2d v = col[r2]; b[2 * r2] = v[0]; b[2 * r2 + 1] = v[1]; }
-    }
+    // Q_top -> Us (free until U is formed), two consecutive entries of a column per thread, in flight under the sum of the slabs below
+    const v2d qtop = *reinterpret_cast<const v2d*>(Vw + (size_t) ((2 * tid) / PW) * ldv + (2 * tid) % PW);
     __syncthreads();
     {
         const v2d gsum = slab_sum2(G2s, nslab, tid);       // elements 2 tid, 2 tid + 1 of G2 (column-major, ld 32)
@@ -1462,76 +1435,75 @@ __device__ __forceinline__ void hr3_body(const double* __restrict__ G2s, int nsl
         if (!(fabs(d0) <= QRD_CHOL1_THR) || !(fabs(d1) <= QRD_CHOL1_THR)) flags[2] = 1;     // G2 - I too large for the first-order factor
         R1s[i][c] = (i <= c) ? R1[e] : 0.0;
         R1s[i + 1][c] = (i + 1 <= c) ? R1[e + 1] : 0.0;
+        Us[i][c] = qtop[0];
+        Us[i + 1][c] = qtop[1];
     }
     __syncthreads();
     STAMP(17);
     if (gword != 0) return;                                // pass 1 already refused
     if (flags[0]) { if (tid == 0) *guard = 1; return; }
+    const bool first_order = flags[2] == 0;
     if (g == 0) {
-        double gg[PW];
-#pragma unroll
-        for (int i = 0; i < PW; ++i) gg[i] = Gs[rc][i];
+        // Round 5: everything 32-step on this wave runs on the matrix cores (qr_factor32.h).  R2 = chol(G2) -- to first order when
+        // G2 = I + E with max|E| <= 1e-9 (after one CholeskyQR pass E ~ cond(leaf)^2 eps: R2 = I + striu(E) + diag(E)/2 up to terms of
+        // size n |E|^2 <= 3e-17, below the rounding of R2 itself), else chol32_mfma, which also leaves R2^-1 (in Gs) -- then the modified
+        // LU with L1^-1 and U'^-1 (lu32_mfma): rounds 2-4 ran three more 32-step recurrences on waves 0-2 behind the LU for U, L1^-1, U'^-1.
         bool ok = true;
-        double dinv = 1.0, sgn = 1.0;
-        if (flags[2]) {
-            Chol3Step<0>::run(gg, rc, ok, dinv);
-        } else {
-            // G2 = I + E with max|E| <= 1e-9 (the usual case: after one CholeskyQR pass E ~ cond(leaf)^2 eps): the Cholesky factor is
-            // R2 = I + striu(E) + diag(E)/2 up to terms of size n |E|^2 <= 3e-17 -- below the rounding of R2 itself.  Replaces the
-            // 32-step dependent recurrence (~5 us of this one-workgroup kernel, on every leaf's critical chain) by one pass.
+        if (first_order) {
+            double gg[PW];
 #pragma unroll
-            for (int i = 0; i < PW; ++i) gg[i] = (i < rc) ? gg[i] : (i == rc ? 1.0 + 0.5 * (gg[i] - 1.0) : 0.0);
-            double d = 1.0;
-#pragma unroll
-            for (int i = 0; i < PW; ++i) d = (i == rc) ? gg[i] : d;
-            dinv = 1.0 / d;
-        }
-        STAMP(18);
-        if (ok) {
-            Hr3Lu<0>::run(b, gg, rc, sgn);
+            for (int i = 0; i < PW; ++i) gg[i] = Gs[rc][i];
             if (lane < PW) {
 #pragma unroll
-                for (int k = 0; k < PW; ++k) { R2s[k][lane] = gg[k]; Bs[k][lane] = b[k]; }
-                r2inv[lane] = dinv;
-                Ss[lane] = sgn;
+                for (int i = 0; i < PW; ++i) R2s[i][lane] = (i < lane) ? gg[i] : (i == lane ? 1.0 + 0.5 * (gg[i] - 1.0) : 0.0);
             }
+        } else {
+            ok = chol32_mfma(lane, [&](int i, int j) { return Gs[j][i]; }, [&](int i, int j, double v) { R2s[i][j] = v; },
+                             [&](int i, int j, double v) { Gs[j][i] = v; });                       // Gs[k][c] <- R2^-1(k, c) = R2^-T(c, k)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(18);
+        if (ok) {
+            lu32_mfma(lane, [&](int i, int j) { return Us[i][j]; }, [&](int i, int j) { return R2s[i][j]; },
+                      [&](int i, int j, double v) { Bs[i][j] = v; }, [&](int i, double v) { Ss[i] = v; },
+                      [&](int i, int j, double v) { Ls[i][j] = v; },                               // L1^-1(i, j)
+                      [&](int i, int j, double v) {                                                // v = U'^-1(j, i): column-major outputs
+                          if (UINV) Uout[i * PW + j] = v;
+                          if (EP) epw[1 * PW * PW + i * PW + j] = v;
+                      });
         } else if (lane == 0) flags[1] = 1;
     }
     __syncthreads();
     STAMP(19);
     if (flags[1]) { if (tid == 0) *guard = 1; return; }
-    // wave 0: U = U' R2^-1 (row i in lane i); wave 1: L1^-1 (column j in lane j); the other six waves: R = S (R2 R1) and L1
+    // wave 0: U = U' R2^-1 on the matrix cores (R2^-1 = 2 I - R2 to first order, else from Gs) -> Us; the other waves: R = S (R2 R1) and L1
     // -> A, unit-lower L1 -> Vw, U' -> Uout
     if (g == 0) {
-        double u[PW];
+        const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-        for (int c = 0; c < PW; ++c) u[c] = (c >= rc) ? Bs[rc][c] : 0.0;
-        RowSolve<0>::run(u, R2s, r2inv);
-        if (lane < PW) {
+        for (int tile = 0; tile < 3; ++tile) {
+            const int ti = (tile == 2) ? 1 : 0, tc = (tile == 0) ? 0 : 1;
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < PW; ++c) Us[lane][c] = (c >= lane) ? u[c] : 0.0;
-        }
-    } else if (g == 1) {
-        double x[PW];
-        UnitLowerInv<0>::run(x, Bs, rc);
-        if (lane < PW) {
+            for (int ks = 0; ks < 8; ++ks) {
+                const int k = 4 * ks + l4, i = 16 * ti + l15, cc = 16 * tc + l15;
+                const double up = (k >= i) ? Bs[i][k] : 0.0;
+                const double ri = first_order ? ((k == cc) ? 2.0 - R2s[k][cc] : -R2s[k][cc]) : Gs[k][cc];
+                acc = f32_mma(up, (k <= cc) ? ri : 0.0, acc);
+            }
 #pragma unroll
-            for (int i = 0; i < PW; ++i) Ls[i][lane] = (i >= lane) ? x[i] : 0.0;       // Ls[i][j] = L1^-1(i, j)
-        }
-    } else if ((UINV || EP) && g == 2) {
-        double x[PW];
-        UpperInv<PW - 1>::run(x, Bs, rcp_newton(Bs[rc][rc]), rc);   // |U'(i, i)| >= R2(i, i) > 0
-        if (lane < PW) {
-#pragma unroll
-            for (int i = 0; i < PW; ++i) {
-                const double v = (i <= lane) ? x[i] : 0.0;                                     // column `lane` of U'^-1
-                if (UINV) Uout[lane * PW + i] = v;
-                if (EP) epw[1 * PW * PW + lane * PW + i] = v;                                    // column-major U'^-1
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ti + l4 + 4 * r, cc = 16 * tc + l15;
+                Us[i][cc] = (cc >= i) ? acc[r] : 0.0;
             }
         }
+        if (lane < 16)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Us[16 + r][lane] = 0.0;
     } else {
-        const int first = (UINV || EP) ? 192 : 128;
-        for (int el = tid - first; el < PW * PW; el += 64 * H3G - first) {
+        for (int el = tid - 64; el < PW * PW; el += 64 * H3G - 64) {
             const int i = el % PW, c = el / PW;
             if (c >= i) {
                 double acc = 0.0;

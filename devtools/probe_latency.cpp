@@ -22,6 +22,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     long long t0, t1;
     // 1. dependent fma chain
     t0 = tick();
+    PIN(x);
 #pragma unroll
     for (int i = 0; i < N; ++i) x = __builtin_fma(x, y, z);
     PIN(x);
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     // 2. dependent rsq chain
     double r = 1.5 + x * 1e-300;
     t0 = tick();
+    PIN(r);
 #pragma unroll
     for (int i = 0; i < N; ++i) r = __builtin_amdgcn_rsq(r) + 1.0;
     PIN(r);
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     // 3. dependent rcp chain
     double q = 1.5 + r * 1e-300;
     t0 = tick();
+    PIN(q);
 #pragma unroll
     for (int i = 0; i < N; ++i) q = __builtin_amdgcn_rcp(q) + 1.0;
     PIN(q);
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     // 4. readlane -> valu -> readlane chain
     double w = q;
     t0 = tick();
+    PIN(w);
 #pragma unroll
     for (int i = 0; i < N; ++i) w = rdl(w, (i * 7) & 63) * y + (double) lane;
     PIN(w);
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     // 5. dependent MFMA chain (accumulator dependence)
     v4d acc = (v4d){w, 0.0, 0.0, 0.0};
     t0 = tick();
+    { double pv = acc[0]; PIN(pv); acc[0] = pv; }
 #pragma unroll
     for (int i = 0; i < N; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(y, z, acc, 0, 0, 0);
     { double pv = acc[0]; PIN(pv); acc[0] = pv; }
@@ -62,6 +67,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     // 6. MFMA -> VALU -> MFMA (operand dependence through a VALU op)
     double a = acc[0] * 1e-300 + 1.0;
     t0 = tick();
+    PIN(a);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         v4d d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     // 7. independent MFMAs (4 accumulators)
     v4d b0 = acc, b1 = acc, b2 = acc, b3 = acc;
     t0 = tick();
+    { double pv = b0[0]; PIN(pv); b0[0] = pv; b1[0] = pv + 1.0; b2[0] = pv + 2.0; b3[0] = pv + 3.0; }
 #pragma unroll
     for (int i = 0; i < N / 4; ++i) {
         b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, z, b0, 0, 0, 0);
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
 #pragma unroll
     for (int k = 0; k < 8; ++k) c[k] = a + k;
     t0 = tick();
+    { double pv = c[0]; PIN(pv); c[0] = pv; }
 #pragma unroll
     for (int i = 0; i < N / 8; ++i)
 #pragma unroll
@@ -98,6 +106,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     // 9. cndmask chain (f64 select)
     double s = a;
     t0 = tick();
+    PIN(s);
 #pragma unroll
     for (int i = 0; i < N; ++i) s = (lane == (i & 63)) ? c[i & 7] : s;
     PIN(s);
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     __shared__ double sh[64];
     double u = s;
     t0 = tick();
+    PIN(u);
 #pragma unroll 16
     for (int i = 0; i < N; ++i) { sh[lane] = u; __builtin_amdgcn_s_waitcnt(0xc07f); u = sh[(lane + 1) & 63] + 1.0; }
     PIN(u);

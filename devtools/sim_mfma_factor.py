@@ -65,7 +65,19 @@ def chol4_inv(d):
     return M, ok
 
 
-def chol32_aug(G):
+def chol4_u(d):
+    w = np.array(d, dtype=float); u = np.zeros((4, 4))
+    for k in range(4):
+        inv = 1.0 / np.sqrt(w[k, k])
+        for j in range(k, 4):
+            u[k, j] = w[k, j] * inv
+        for i in range(k + 1, 4):
+            for j in range(i, 4):
+                w[i, j] -= u[k, i] * u[k, j]
+    return u
+
+
+def chol32_aug(G, udiag=False):
     """G 32 x 32 SPD -> R (upper, G = R^T R), X = R^-T (lower), ok.  One wave; tiles T00, T01, T11 and aug X00, X10, X11."""
     T = {(0, 0): tile_load(G, 0, 0), (0, 1): tile_load(G, 0, 16), (1, 1): tile_load(G, 16, 16)}
     I = np.eye(32)
@@ -82,12 +94,19 @@ def chol32_aug(G):
                 d[i, j] = readlane(dreg, 16 * i + 4 * r + j)
         M, okk = chol4_inv(d)
         ok = ok and okk
+        U4 = np.linalg.inv(M).T if False else None
         Amat = np.where((L15 < 4) & (L4 <= L15), M[np.minimum(L15, 3), L4], 0.0)
         S = {}
         for b in range(ti, 2):
             z = mfma(Amat, T[(ti, b)][r], zero)[0]
             col = 16 * b + L15; row = K + L4
             S[b] = np.where(col >= row, z, 0.0)
+            if udiag and b == ti:
+                # the pivot block of R from the uniform factorisation (exactly upper triangular, consistent with M = U4^-T)
+                U4 = chol4_u(d)
+                inblk = (col >= K) & (col < K + 4)
+                S[b] = np.where(inblk, U4[L4, np.clip(col - K, 0, 3)], S[b])
+                S[b] = np.where(col >= row, S[b], 0.0)
             Rout[row, col] = S[b]
         Y = {}
         for b in range(0, ti + 1):

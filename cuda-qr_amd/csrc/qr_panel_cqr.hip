@@ -107,97 +107,99 @@ __device__ __forceinline__ CqLds cq_lds(double* sm)
 }
 constexpr size_t CQ_LDS_BYTES = sizeof(double) * (CQ_LD * CQ_LD + 2 * 32 * 33 + CQ_W + CQ_T / 64) + 64;
 
-// one 16 x 16 tile of a product on the matrix cores: sum over k0 <= k < k1 (multiples of 4) of a(i0 + p, k) b(k, j0 + q).
-// Accumulator register r of a lane: row i0 + (lane >> 4) + 4 r, column j0 + (lane & 15)
-template <class FA, class FB>
-__device__ __forceinline__ v4d cq_tile(FA a, FB b, int i0, int j0, int k0, int k1, int lane)
+// ---- 16 x 16 tiles of the block steps' products, all contracting over one 32-column block (8 matrix-core steps per tile) -------------
+// Two lessons shaped this (round 5, stamps in profiles/r05_cq_stamps.txt): (1) as a chain of  ds_read, ds_read, wait, MFMA  a tile cost
+// ~190 cycles per step where the MFMA takes 64: the 16 operand values of a tile are requested together, and the NEXT tile's before this
+// tile's eight MFMAs; (2) these kernels run every instruction ONCE: unrolled over a dozen tiles per wave the LU kernel was 41 000
+// instructions (~250 KB against a 64 KB instruction cache) and ran at the speed of instruction fetch -- the tile lists are walked by ROLLED
+// loops (two tiles per trip: the operand sets ping-pong), and the diagonal-block routine is inlined once per kernel.
+struct CqOps { double a[8], b[8]; v4d c; };
+template <bool SUB, class FA, class FB, class FC>
+__device__ __forceinline__ void cq_ops_load(CqOps& o, FA a, FB b, FC c, int i0, int j0, int k0, int l15, int l4)
+{
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { o.a[s] = a(i0 + l15, k0 + 4 * s + l4); o.b[s] = b(k0 + 4 * s + l4, j0 + l15); }
+    if (SUB)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.c[r] = c(i0 + l4 + 4 * r, j0 + l15);
+}
+template <bool SUB, class FS>
+__device__ __forceinline__ void cq_ops_mma_store(const CqOps& o, FS store, int i0, int j0, int l15, int l4)
+{
+    v4d acc = SUB ? o.c : (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[s], o.b[s], acc, 0, 0, SUB ? 1 : 0);      // SUB: acc - a b
+#pragma unroll
+    for (int r = 0; r < 4; ++r) store(i0 + l4 + 4 * r, j0 + l15, acc[r]);
+}
+// Tile lists: mode 0 = all tiles of a grid with ntc tile columns (row-major), 1 = the tiles on and above the tile diagonal of an
+// ntc x ntc grid, 2 / 3 = modes 0 / 1 of an ntc x ntc grid WITHOUT its leading 2 x 2 tiles.  Walked with scalar increments.
+__device__ __forceinline__ int cq_tile_count(int nt, int ntc, int mode)
+{
+    return mode == 0 ? nt : (mode == 1 ? ntc * (ntc + 1) / 2 : (mode == 2 ? ntc * ntc - 4 : ntc * (ntc + 1) / 2 - 3));
+}
+struct CqTileIt {
+    int tr, tc, ntc, mode;
+    __device__ __forceinline__ int row_first(int r) const { return mode == 0 ? 0 : (mode == 1 ? r : (mode == 2 ? (r < 2 ? 2 : 0) : (r < 2 ? 2 : r))); }
+    __device__ __forceinline__ void norm() { while (tc >= ntc && tr < 64) { ++tr; tc = row_first(tr); } }     // (rows 0, 1 of modes 2 / 3 are empty when ntc == 2)
+    __device__ __forceinline__ void init(int ntc_, int mode_, int skip) { ntc = ntc_; mode = mode_; tr = 0; tc = row_first(0); norm(); step(skip); }
+    __device__ __forceinline__ void step(int k) { for (int q = 0; q < k; ++q) { ++tc; norm(); } }
+};
+// tiles n = first, first + stride, ... of the list at (r0, c0): out(i, j) = [c(i, j) -] sum_k a(i, k) b(k, j), k = k0 .. k0 + 31, each
+// tile stored as soon as it is complete -- the outputs must not overlap the operands of tiles this wave (or a concurrently running one)
+// still has to compute.  Rolled loop, two tiles per trip.
+template <bool SUB, class FA, class FB, class FC, class FS>
+__device__ __forceinline__ void cq_tiles_walk(int nt, int ntc, int mode, int r0, int c0, int k0, int first, int stride, int lane, FA a, FB b, FC c, FS store)
+{
+    const int l15 = lane & 15, l4 = lane >> 4, total = cq_tile_count(nt, ntc, mode);
+    if (first >= total) return;
+    CqOps o0, o1;
+    CqTileIt it;
+    it.init(ntc, mode, first);
+    int n = first, i0 = r0 + 16 * it.tr, j0 = c0 + 16 * it.tc;
+    cq_ops_load<SUB>(o0, a, b, c, i0, j0, k0, l15, l4);
+#pragma nounroll
+    for (;;) {
+        int i1 = 0, j1 = 0;
+        const bool more1 = n + stride < total;
+        if (more1) { it.step(stride); i1 = r0 + 16 * it.tr; j1 = c0 + 16 * it.tc; cq_ops_load<SUB>(o1, a, b, c, i1, j1, k0, l15, l4); }
+        cq_ops_mma_store<SUB>(o0, store, i0, j0, l15, l4);
+        if (!more1) break;
+        n += stride;
+        const bool more0 = n + stride < total;
+        if (more0) { it.step(stride); i0 = r0 + 16 * it.tr; j0 = c0 + 16 * it.tc; cq_ops_load<SUB>(o0, a, b, c, i0, j0, k0, l15, l4); }
+        cq_ops_mma_store<SUB>(o1, store, i1, j1, l15, l4);
+        if (!more0) break;
+        n += stride;
+    }
+}
+// In-place solves of a block step: two tiles that share an operand and whose outputs overlap each other's inputs are computed together
+// and stored afterwards, by ONE wave -- no workgroup barrier between compute and store.
+//   COLS: out(r0 .. r0+31, jc .. jc+15) = a(r0 .. r0+31, k) x b(k, jc ..)   (the two row tiles of a column: R12 = R11^-T G12, U'12 = L11^-1 W12)
+//  !COLS: out(ir .. ir+15, c0 .. c0+31) = a(ir .., k) x b(k, c0 .. c0+31)    (the two column tiles of a row: L21 = W21 U'11^-1)
+template <bool COLS, class FA, class FB, class FS>
+__device__ __forceinline__ void cq_tile_pair(int r0, int c0, int k0, int lane, FA a, FB b, FS store)
 {
     const int l15 = lane & 15, l4 = lane >> 4;
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k = k0; k < k1; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(i0 + l15, k + l4), b(k + l4, j0 + l15), acc, 0, 0, 0);
-    return acc;
-}
-
-// A list of 16 x 16 tiles dealt to the four waves; tile tl of a grid with ntc tile columns.  compute(i0, j0) -> accumulator,
-// store(i, j, value).  With `barrier` the stores wait until every wave has computed its tiles (in-place products whose operands
-// overlap the tiles written).  At most CQ_MAXT tiles per wave.
-constexpr int CQ_MAXT = 9;
-template <class FC, class FS>
-__device__ __forceinline__ void cq_tiles(int nt, int ntc, int r0, int c0, bool upper_only, bool barrier, int tid, FC compute, FS store)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    v4d acc[CQ_MAXT];
+    double x[8], y0[8], y1[8];
 #pragma unroll
-    for (int q = 0; q < CQ_MAXT; ++q) {
-        const int tl = wave + 4 * q, tr = tl / ntc, tc = tl - tr * ntc;
-        if (tl < nt && (!upper_only || tc >= tr)) acc[q] = compute(r0 + 16 * tr, c0 + 16 * tc);
+    for (int s = 0; s < 8; ++s) {
+        const int k = k0 + 4 * s + l4;
+        if (COLS) { x[s] = b(k, c0 + l15); y0[s] = a(r0 + l15, k); y1[s] = a(r0 + 16 + l15, k); }
+        else { x[s] = a(r0 + l15, k); y0[s] = b(k, c0 + l15); y1[s] = b(k, c0 + 16 + l15); }
     }
-    if (barrier) __syncthreads();
+    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
 #pragma unroll
-    for (int q = 0; q < CQ_MAXT; ++q) {
-        const int tl = wave + 4 * q, tr = tl / ntc, tc = tl - tr * ntc;
-        if (tl < nt && (!upper_only || tc >= tr))
-#pragma unroll
-            for (int r = 0; r < 4; ++r) store(r0 + 16 * tr + l4 + 4 * r, c0 + 16 * tc + l15, acc[q][r]);
+    for (int s = 0; s < 8; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(COLS ? y0[s] : x[s], COLS ? x[s] : y0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(COLS ? y1[s] : x[s], COLS ? x[s] : y1[s], acc1, 0, 0, 0);
     }
-    __syncthreads();
-}
-
-// Trailing tiles of a block step dealt to waves 1 .. 3 while wave 0 factors the next diagonal block: the (tr, tc) grid of ntc x ntc
-// 16 x 16 tiles at (r0, r0), WITHOUT the four tiles of its leading 32 x 32 block (wave 0 has updated those itself); upper_only: tiles
-// on and above the tile diagonal.  compute(i0, j0) -> accumulator, store(i, j, value).  At most 11 tiles per wave (ntc <= 6).
-template <class FC, class FS>
-__device__ __forceinline__ void cq_tiles_rest(int ntc, int r0, bool upper_only, int wave, int lane, FC compute, FS store)
-{
-    constexpr int MAXT = 11;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    v4d acc[MAXT];
-    // (enumeration: tl over the full grid, the leading block's tiles and -- upper_only -- the lower tiles skipped; the counter of kept
-    // tiles is dealt round-robin to the three waves)
-    int kept = 0, mine = 0;
-    for (int tl = 0; tl < ntc * ntc; ++tl) {
-        const int tr = tl / ntc, tc = tl - tr * ntc;
-        if ((tr < 2 && tc < 2) || (upper_only && tc < tr)) continue;
-        if (kept % 3 == wave - 1) {
 #pragma unroll
-            for (int q = 0; q < MAXT; ++q)
-                if (q == mine) acc[q] = compute(r0 + 16 * tr, r0 + 16 * tc);
-            ++mine;
-        }
-        ++kept;
+    for (int r = 0; r < 4; ++r) {
+        store(r0 + l4 + 4 * r, c0 + l15, acc0[r]);
+        if (COLS) store(r0 + 16 + l4 + 4 * r, c0 + l15, acc1[r]);
+        else store(r0 + l4 + 4 * r, c0 + 16 + l15, acc1[r]);
     }
-    kept = 0; mine = 0;
-    for (int tl = 0; tl < ntc * ntc; ++tl) {
-        const int tr = tl / ntc, tc = tl - tr * ntc;
-        if ((tr < 2 && tc < 2) || (upper_only && tc < tr)) continue;
-        if (kept % 3 == wave - 1) {
-#pragma unroll
-            for (int q = 0; q < MAXT; ++q)
-                if (q == mine)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) store(r0 + 16 * tr + l4 + 4 * r, r0 + 16 * tc + l15, acc[q][r]);
-            ++mine;
-        }
-        ++kept;
-    }
-}
-
-// Blocked right-looking Cholesky of the symmetric matrix whose upper triangle is in L.M: R (upper) in place.  Per block of 32 columns:
-// the diagonal block on wave 0 on the matrix cores (chol32_mfma: R11 in place, R11^-T -> sb1 and, as the inverse's diagonal block
-// R11^-1, into the slots strictly below the diagonal: X(c, i) at M[i + 1][c]), then R12 = R11^-T G12 and G22 -= R12^T R12 on the matrix
-// cores.  Round 5, look-ahead inside the workgroup: wave 0 updates only the NEXT diagonal block and factors it while waves 1 - 3
-// update the rest of G22, so a block step costs max(diagonal block, trailing update) instead of their sum.
-// Returns false on a non-positive pivot (uniform).
-__device__ __forceinline__ void cq_chol_diag(const CqLds& L, int o, int tid)
-{
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));                            // keeps the unrolled steps' lane constants inside the caller's iteration
-    double* const Mo = L.M + o * CQ_LD + o;
-    const bool ok = chol32_mfma(lane, [&](int i, int j) { return (j >= i) ? Mo[i * CQ_LD + j] : Mo[j * CQ_LD + i]; },
-                                [&](int i, int j, double v) { if (j >= i) Mo[i * CQ_LD + j] = v; },
-                                [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; if (j <= i) Mo[(i + 1) * CQ_LD + j] = v; });
-    if (!ok) L.flag[0] = 0;
 }
 __device__ __forceinline__ void cq_wave_sync_lds()
 {
@@ -205,40 +207,45 @@ __device__ __forceinline__ void cq_wave_sync_lds()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// Blocked right-looking Cholesky of the symmetric matrix whose upper triangle is in L.M: R (upper) in place.  Per block of 32 columns:
+// the diagonal block on wave 0 on the matrix cores (chol32_mfma: R11 in place, R11^-T -> sb1 and, as the inverse's diagonal block
+// R11^-1, into the slots strictly below the diagonal: X(c, i) at M[i + 1][c]), then R12 = R11^-T G12 and G22 -= R12^T R12 on the matrix
+// cores.  Look-ahead inside the workgroup (round 5): wave 0 updates only the NEXT diagonal block and factors it while waves 1 - 3 finish
+// the previous step's update of the rest of G22, so a block step costs max(diagonal block, trailing update) instead of their sum.
+// Returns false on a non-positive pivot (uniform).
 __device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
     auto Mt = [&](int i, int k) { return L.M[k * CQ_LD + i]; };
+    auto St = [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; };
     if (tid == 0) L.flag[0] = 1;
     __syncthreads();
-    if (wave == 0) cq_chol_diag(L, 0, tid);
-    __syncthreads();
-    for (int o = 0; o + 32 < w; o += 32) {
-        const int rest = w - o - 32, ntc = rest >> 4;
-        auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
-        cq_tiles(2 * ntc, ntc, o, o + 32, false, true, tid,
-                 [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, lane); },
-                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
+#pragma nounroll
+    for (int o = 0; o < w; o += 32) {
+        // wave 0: the diagonal block o (its three tiles were updated by this wave at the end of the previous trip);
+        // waves 1 - 3: the rest of the previous step's trailing update
         if (wave == 0) {
-            // the next diagonal block's three upper tiles, then its factorisation (sb1 is free: the block row is solved)
-            const int n0 = o + 32;
-            const v4d a00 = cq_tile(Mt, Mx, n0, n0, o, o + 32, lane), a01 = cq_tile(Mt, Mx, n0, n0 + 16, o, o + 32, lane),
-                      a11 = cq_tile(Mt, Mx, n0 + 16, n0 + 16, o, o + 32, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = l4 + 4 * r;
-                L.M[(n0 + i) * CQ_LD + n0 + l15] -= a00[r];
-                L.M[(n0 + i) * CQ_LD + n0 + 16 + l15] -= a01[r];
-                L.M[(n0 + 16 + i) * CQ_LD + n0 + 16 + l15] -= a11[r];
-            }
-            cq_wave_sync_lds();
-            cq_chol_diag(L, n0, tid);
-        } else {
-            cq_tiles_rest(ntc, o + 32, true, wave, lane, [&](int i0, int j0) { return cq_tile(Mt, Mx, i0, j0, o, o + 32, lane); },
-                          [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                       // keeps the unrolled steps' lane constants inside this trip
+            double* const Mo = L.M + o * CQ_LD + o;
+            const bool ok = chol32_mfma(ln, [&](int i, int j) { return (j >= i) ? Mo[i * CQ_LD + j] : Mo[j * CQ_LD + i]; },
+                                        [&](int i, int j, double v) { if (j >= i) Mo[i * CQ_LD + j] = v; },
+                                        [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; if (j <= i) Mo[(i + 1) * CQ_LD + j] = v; });
+            if (!ok) L.flag[0] = 0;
+        } else if (o > 0) {
+            cq_tiles_walk<true>(0, (w - o) >> 4, 3, o, o, o - 32, wave - 1, 3, lane, Mt, Mx, Mx, St);
         }
         __syncthreads();
+        const int rest = w - o - 32, ntc = rest >> 4;
+        if (rest <= 0) break;
+        // R12 = R11^-T G12 in place: a wave takes whole columns of tiles
+        auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
+        for (int tcol = wave; tcol < ntc; tcol += 4) cq_tile_pair<true>(o, o + 32 + 16 * tcol, o, lane, Li, Mx, St);
+        __syncthreads();
+        // wave 0: the next diagonal block's three upper tiles now (it factors that block at the top of the next trip)
+        if (wave == 0) { cq_tiles_walk<true>(3, 2, 1, o + 32, o + 32, o, 0, 1, lane, Mt, Mx, Mx, St); cq_wave_sync_lds(); }
     }
     return L.flag[0] != 0;
 }
@@ -248,35 +255,39 @@ __device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
 // (lu32_mfma: L11 \ U'11 in place, S, L11^-1 -> sb1, U'11^-1 -> sb2, and both into the workspace: they are the diagonal blocks of the
 // inverses cqr_post_kernel builds), then U'12 = L11^-1 (W12 - S R2_12), L21 = W21 U'11^-1, W22 -= L21 U'12 on the matrix cores --
 // with the same look-ahead as the Cholesky: wave 0 updates and factors the next diagonal block while waves 1 - 3 update the rest.
-__device__ __forceinline__ void cq_lu_r2(int o, const double* R2g, int tid, v4d (&R2t)[3])
-{
-    const double* const R2o = R2g + o * CQ_W + o;
-    lu32_load_r2(tid & 63, [&](int i, int j) { return (j >= i) ? R2o[i * CQ_W + j] : 0.0; }, R2t);
-}
-__device__ __forceinline__ void cq_lu_diag(const CqLds& L, int o, const v4d (&R2t)[3], int tid)
-{
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));
-    double* const Mo = L.M + o * CQ_LD + o;
-    double* const dinv = L.dinv ? L.dinv + (o >> 5) * 2048 : nullptr;
-    lu32_mfma_r2(lane, [&](int i, int j) { return Mo[i * CQ_LD + j]; }, R2t,
-                 [&](int i, int j, double v) { Mo[i * CQ_LD + j] = v; }, [&](int i, double v) { L.sv[o + i] = v; },
-                 [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; if (dinv) dinv[1024 + i * 32 + j] = v; },          // L11^-1(i, j)
-                 [&](int i, int j, double v) { L.sb2[j * 33 + i] = v; if (dinv) dinv[j * 32 + i] = v; });                // U'11^-1(j, i)
-}
 __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const double* R2g, int tid)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
+    auto St = [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; };
     v4d r2t[3];                                                // wave 0: R2's diagonal block of the block it factors next, requested a phase early
-    if (wave == 0) { cq_lu_r2(0, R2g, tid, r2t); cq_lu_diag(L, 0, r2t, tid); }
-    __syncthreads();
-    for (int o = 0; o + 32 < w; o += 32) {
+    if (wave == 0) {
+        lu32_load_r2(lane, [&](int i, int j) { return (j >= i) ? R2g[i * CQ_W + j] : 0.0; }, r2t);
+    }
+    CQ_STAMP_L(24);
+#pragma nounroll
+    for (int o = 0; o < w; o += 32) {
+        if (wave == 0) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            double* const Mo = L.M + o * CQ_LD + o;
+            double* const dinv = L.dinv ? L.dinv + (o >> 5) * 2048 : nullptr;
+            lu32_mfma_r2(ln, [&](int i, int j) { return Mo[i * CQ_LD + j]; }, r2t,
+                         [&](int i, int j, double v) { Mo[i * CQ_LD + j] = v; }, [&](int i, double v) { L.sv[o + i] = v; },
+                         [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; if (dinv) dinv[1024 + i * 32 + j] = v; },          // L11^-1(i, j)
+                         [&](int i, int j, double v) { L.sb2[j * 33 + i] = v; if (dinv) dinv[j * 32 + i] = v; });                // U'11^-1(j, i)
+            if (o + 32 < w) {
+                const double* const R2n = R2g + (o + 32) * CQ_W + o + 32;
+                lu32_load_r2(lane, [&](int i, int j) { return (j >= i) ? R2n[i * CQ_W + j] : 0.0; }, r2t);      // lands under the next phases
+            }
+        } else if (o > 0) {
+            cq_tiles_walk<true>(0, (w - o) >> 4, 2, o, o, o - 32, wave - 1, 3, lane, Mx, Mx, Mx, St);
+        }
+        __syncthreads();
+        if (o == 0) CQ_STAMP_L(25);
         const int rest = w - o - 32, ntc = rest >> 4;
-        if (wave == 0) cq_lu_r2(o + 32, R2g, tid, r2t);
-        // U'12 = L11^-1 (W12 - S R2_12): operands and result share W12 -> stores behind a barrier
-        auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
-        {   // W12 -= S R2_12 first, the R2 values of a thread requested together (element e: row o + (e >> 7), column o + 32 + (e & 127))
+        if (rest <= 0) break;
+        {   // W12 -= S R2_12, the R2 values of a thread requested together (element e: row o + (e >> 7), column o + 32 + (e & 127))
             double r2[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -290,34 +301,17 @@ __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const doubl
             }
             __syncthreads();
         }
-        cq_tiles(2 * ntc, ntc, o, o + 32, false, true, tid,
-                 [&](int i0, int j0) { return cq_tile(Li, Mx, i0, j0, o, o + 32, lane); },
-                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
-        // L21 = W21 U'11^-1 (the barrier of the call above also published sb2)
+        // U'12 = L11^-1 W12 (whole tile columns per wave) and L21 = W21 U'11^-1 (whole tile rows per wave), both in place; they touch
+        // disjoint parts of the matrix, so no barrier between them
+        auto Li = [&](int i, int k) { return L.sb1[(i - o) * 33 + (k - o)]; };
         auto Ui = [&](int k, int j) { return L.sb2[(k - o) * 33 + (j - o)]; };
-        cq_tiles(ntc * 2, 2, o + 32, o, false, true, tid,
-                 [&](int i0, int j0) { return cq_tile(Mx, Ui, i0, j0, o, o + 32, lane); },
-                 [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; });
-        // W22 -= L21 U'12: wave 0 the next diagonal block (four tiles) and its factorisation, waves 1 - 3 the rest
-        if (wave == 0) {
-            const int n0 = o + 32;
-            const v4d a00 = cq_tile(Mx, Mx, n0, n0, o, o + 32, lane), a01 = cq_tile(Mx, Mx, n0, n0 + 16, o, o + 32, lane),
-                      a10 = cq_tile(Mx, Mx, n0 + 16, n0, o, o + 32, lane), a11 = cq_tile(Mx, Mx, n0 + 16, n0 + 16, o, o + 32, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = l4 + 4 * r;
-                L.M[(n0 + i) * CQ_LD + n0 + l15] -= a00[r];
-                L.M[(n0 + i) * CQ_LD + n0 + 16 + l15] -= a01[r];
-                L.M[(n0 + 16 + i) * CQ_LD + n0 + l15] -= a10[r];
-                L.M[(n0 + 16 + i) * CQ_LD + n0 + 16 + l15] -= a11[r];
-            }
-            cq_wave_sync_lds();
-            cq_lu_diag(L, n0, r2t, tid);
-        } else {
-            cq_tiles_rest(ntc, o + 32, false, wave, lane, [&](int i0, int j0) { return cq_tile(Mx, Mx, i0, j0, o, o + 32, lane); },
-                          [&](int i, int j, double v) { L.M[i * CQ_LD + j] -= v; });
-        }
+        for (int t = wave; t < ntc; t += 4) cq_tile_pair<true>(o, o + 32 + 16 * t, o, lane, Li, Mx, St);
+        for (int t = wave; t < ntc; t += 4) cq_tile_pair<false>(o + 32 + 16 * t, o, o, lane, Mx, Ui, St);
         __syncthreads();
+        if (o == 0) CQ_STAMP_L(26);
+        // wave 0: the next diagonal block (four tiles) now; it factors that block at the top of the next trip
+        if (wave == 0) { cq_tiles_walk<true>(4, 2, 0, o + 32, o + 32, o, 0, 1, lane, Mx, Mx, Mx, St); cq_wave_sync_lds(); }
+        if (o == 0) CQ_STAMP_L(27);
     }
     __syncthreads();
 }
@@ -551,6 +545,9 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
 {
     CqLds L = cq_lds(sm);
     L.dinv = ws + CQ_X3;
+#ifdef CQ_STAMPS
+    L.wsdbg = ws;
+#endif
     const int tid = threadIdx.x;
     if (status[0]) return true;                               // the first Cholesky failed
     CQ_STAMP(8);

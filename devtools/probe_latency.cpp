@@ -122,6 +122,21 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc, double 
     PIN(u);
     t1 = tick();
     if (lane == 0) cyc[9] = t1 - t0;
+    // 11. the shader clock itself: s_memtime ticks per 100 MHz wall-clock tick over a long dependent chain (one wave on an idle chip)
+    {
+        double f = u;
+        const long long w0 = wall_clock64();
+        t0 = tick();
+        PIN(f);
+        for (int rep = 0; rep < 200; ++rep)
+#pragma unroll
+            for (int i = 0; i < N; ++i) f = __builtin_fma(f, y, z);
+        PIN(f);
+        t1 = tick();
+        const long long w1 = wall_clock64();
+        if (lane == 0) { cyc[10] = t1 - t0; cyc[11] = w1 - w0; }
+        u += f;
+    }
     double tot = x + r + q + w + acc[0] + a + b0[0] + b1[1] + b2[2] + b3[3] + s + u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) tot += c[k];
@@ -138,5 +153,7 @@ int main()
                              "dependent MFMA f64 16x16x4 (accumulator)", "MFMA -> VALU -> MFMA operand", "independent MFMA (4 accumulators)",
                              "independent fma (8 chains): issue", "dependent f64 select (2 cndmask)", "LDS write -> wait -> read -> wait + add"};
     for (int i = 0; i < 10; ++i) printf("%-48s %8.1f cycles per iteration (s_memtime/readcyclecounter units)\n", names[i], (double) h[i] / (i == 6 ? N : (i == 7 ? N : N)));
+    printf("s_memtime ticks %lld over %lld wall ticks (100 MHz): s_memtime runs at %.1f MHz; dependent fma = %.2f s_memtime ticks = %.2f ns\n", h[10], h[11],
+           100.0 * (double) h[10] / (double) h[11], (double) h[10] / (200.0 * N), 10.0 * (double) h[11] / (200.0 * N));
     return 0;
 }

@@ -119,7 +119,17 @@ __global__ __launch_bounds__(512, 4) void gemm_nn_w8_kernel(int M, int N, int K,
     double* Bs = smem + 2 * ASZ;            // [2][BN][LDKF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (TAG == 1 && gridDim.y <= 8 && (gridDim.x & 7) == 0) {
+        // Tall updates with a handful of column tiles (the tall-skinny factorisation: 128 x 128 of V against 1 - 4 column tiles of W): as
+        // launched, the column tiles of one row block are gridDim.x workgroups apart -- different XCDs, or the same one long after the
+        // block's tile of V has left its L2 -- and V came from HBM once per column tile (rocprofv3: x1.4 the algorithmic bytes).
+        // Workgroups are dealt round-robin to the 8 XCDs: XCD x takes the row blocks r = x (mod 8) and walks their column tiles back to back.
+        const int id = blockIdx.x + gridDim.x * blockIdx.y, x8 = id & 7, q = id >> 3;
+        by = q % (int) gridDim.y;
+        bx = 8 * (q / (int) gridDim.y) + x8;
+    }
+    const int i0 = bx * BM, j0 = by * BN;
     const int l15 = lane & 15, l4 = lane >> 4;
     const double inv_alpha = 1.0 / alpha;
     v4d acc[TJ][TI];
@@ -183,11 +193,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
     double* Bs = smem + 2 * BM * LDKF;        // [2][BN][LDKF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    int by = blockIdx.y, bz = blockIdx.z;
+    if (gridDim.x == 1 && gridDim.y > 1 && gridDim.y <= 8 && gridDim.z >= 8) {
+        // One row of output tiles against a long K split into slices (the tall-skinny update's V^T A2): the column tiles of a K slice all read
+        // the same slice of A, but round-robin dealing puts them on different XCDs.  Slices z < 8 floor(gz / 8) are regrouped so that XCD x
+        // takes the slices z = x (mod 8) and walks their column tiles back to back (the slice of A comes from HBM once, not gridDim.y times).
+        const int id = blockIdx.y + gridDim.y * blockIdx.z, zfull = (int) (gridDim.z & ~7u);
+        if (id < (int) gridDim.y * zfull) {
+            const int x8 = id & 7, q = id >> 3;
+            by = q % (int) gridDim.y;
+            bz = 8 * (q / (int) gridDim.y) + x8;
+        }
+    }
+    const int i0 = blockIdx.x * BM, j0 = by * BN;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = bz * kchunk;
     const int kend = min(K, kbeg + kchunk);
-    C += (size_t) blockIdx.z * slab_stride;
+    C += (size_t) bz * slab_stride;
 
     v4d acc[TJ][TI];
 #pragma unroll

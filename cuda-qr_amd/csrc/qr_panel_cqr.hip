@@ -255,14 +255,20 @@ __device__ __forceinline__ bool cq_chol_blocked(const CqLds& L, int w, int tid)
 // (lu32_mfma: L11 \ U'11 in place, S, L11^-1 -> sb1, U'11^-1 -> sb2, and both into the workspace: they are the diagonal blocks of the
 // inverses cqr_post_kernel builds), then U'12 = L11^-1 (W12 - S R2_12), L21 = W21 U'11^-1, W22 -= L21 U'12 on the matrix cores --
 // with the same look-ahead as the Cholesky: wave 0 updates and factors the next diagonal block while waves 1 - 3 update the rest.
-__device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const double* R2g, int tid)
+// R2g: R2 row-major (ld CQ_W) -- or, first_order, the Gram matrix G2 = I + E itself (both triangles, as cqr_gram_reduce_kernel leaves it), of
+// which R2 = I + striu(E) + diag(E) / 2 is read off on the fly: the launch then needs no R2 of its own in global memory before the LU
+__device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const double* R2g, bool first_order, int tid)
 {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    auto r2_at = [&](const double* blk, int i, int j) {        // element (i, j) of a DIAGONAL block
+        const double g = blk[i * CQ_W + j];
+        return (j > i) ? g : (j == i ? (first_order ? 1.0 + 0.5 * (g - 1.0) : g) : 0.0);
+    };
     auto Mx = [&](int i, int j) { return L.M[i * CQ_LD + j]; };
     auto St = [&](int i, int j, double v) { L.M[i * CQ_LD + j] = v; };
     v4d r2t[3];                                                // wave 0: R2's diagonal block of the block it factors next, requested a phase early
     if (wave == 0) {
-        lu32_load_r2(lane, [&](int i, int j) { return (j >= i) ? R2g[i * CQ_W + j] : 0.0; }, r2t);
+        lu32_load_r2(lane, [&](int i, int j) { return r2_at(R2g, i, j); }, r2t);
     }
     CQ_STAMP_L(24);
 #pragma nounroll
@@ -271,20 +277,27 @@ __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const doubl
             int ln = lane;
             asm volatile("" : "+v"(ln));
             double* const Mo = L.M + o * CQ_LD + o;
-            double* const dinv = L.dinv ? L.dinv + (o >> 5) * 2048 : nullptr;
             lu32_mfma_r2(ln, [&](int i, int j) { return Mo[i * CQ_LD + j]; }, r2t,
                          [&](int i, int j, double v) { Mo[i * CQ_LD + j] = v; }, [&](int i, double v) { L.sv[o + i] = v; },
-                         [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; if (dinv) dinv[1024 + i * 32 + j] = v; },          // L11^-1(i, j)
-                         [&](int i, int j, double v) { L.sb2[j * 33 + i] = v; if (dinv) dinv[j * 32 + i] = v; });                // U'11^-1(j, i)
+                         [&](int i, int j, double v) { L.sb1[i * 33 + j] = v; },          // L11^-1(i, j)
+                         [&](int i, int j, double v) { L.sb2[j * 33 + i] = v; });         // U'11^-1(j, i)
             if (o + 32 < w) {
                 const double* const R2n = R2g + (o + 32) * CQ_W + o + 32;
-                lu32_load_r2(lane, [&](int i, int j) { return (j >= i) ? R2n[i * CQ_W + j] : 0.0; }, r2t);      // lands under the next phases
+                lu32_load_r2(lane, [&](int i, int j) { return r2_at(R2n, i, j); }, r2t);      // lands under the next phases
             }
         } else if (o > 0) {
             cq_tiles_walk<true>(0, (w - o) >> 4, 2, o, o, o - 32, wave - 1, 3, lane, Mx, Mx, Mx, St);
         }
         __syncthreads();
         if (o == 0) CQ_STAMP_L(25);
+        if (L.dinv) {                                          // the block's inverses for cqr_post_kernel: U'11^-1 then L11^-1, row-major (stores only)
+            double* const dinv = L.dinv + (o >> 5) * 2048;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + u * CQ_T, i = (e >> 5) & 31, j = e & 31;
+                dinv[e] = (e < 1024) ? L.sb2[i * 33 + j] : L.sb1[i * 33 + j];
+            }
+        }
         const int rest = w - o - 32, ntc = rest >> 4;
         if (rest <= 0) break;
         {   // W12 -= S R2_12, the R2 values of a thread requested together (element e: row o + (e >> 7), column o + 32 + (e & 127))
@@ -441,6 +454,8 @@ __device__ __forceinline__ void cq_inv_out(const CqLds& L, double* X, int w, int
 // diagonal of L.M, where the inverses leave their result: B(k, j) at M[j + 1][k]); d = NULL: no scaling.  A wave owns two tile ROWS
 // (tr and 7 - tr: nine tiles on and above the diagonal each at w = 128): the A fragment of a k-step is shared by the row's tiles and
 // their accumulators interleave on the matrix core.  f(i, j, value) for every element on and above the tile diagonal.
+// (Round 5: a rolled k loop with a run-time tile row -- a third of the code -- was measured and is SLOWER: cqr_post_kernel 55 -> 92 us;
+// the unrolled form below stays.)
 template <int TR, bool FULL, class F>
 __device__ __forceinline__ void cq_product_row(const CqLds& L, const double* d, int nt, int l15, int l4, F f)
 {
@@ -551,6 +566,14 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
     const int tid = threadIdx.x;
     if (status[0]) return true;                               // the first Cholesky failed
     CQ_STAMP(8);
+    // Q_top (w x w, the first rows of Q) is requested now -- 64 values per thread, consecutive lanes = consecutive rows of a column -- and
+    // goes into L.M once G2 has been dealt with: one global round trip instead of two in a row
+    double qt[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+        const int e = tid + u * CQ_T, j = e >> 7, i = e & (CQ_W - 1);
+        qt[u] = Vw[(i < w ? i : w - 1) + (size_t) ldv * (j < w ? j : w - 1)];
+    }
     // ---- G2 -> L.M (upper); its distance from I decides between the first-order factor, the Cholesky and the refusal
     double dmax = 0.0;
     cq_elems(w, tid, [&](int i, int j) { return ws[CQ_G2 + j + CQ_W * i]; }, [&](int i, int j, double g) {
@@ -575,7 +598,8 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
         const bool ok = cq_chol_blocked(L, w, tid);
         if (!ok) return true;
     }
-    // R2 -> global (the LU and two products read it from there); R2^-1 -> X1 (first order: 2 I - R2)
+    // R2 -> global (cqr_post_kernel's products read it from there; this launch's LU too unless R2 is first order: it then reads G2
+    // and nothing waits for these stores); R2^-1 -> X1 (first order: 2 I - R2)
 #pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
@@ -588,37 +612,24 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
         __syncthreads();
         cq_upper_inv(L, w, 1, 0, tid);
         cq_inv_out(L, ws + CQ_X1, w, tid);
-    }
-    cq_sync_global();
+        cq_sync_global();
+    } else __syncthreads();
     CQ_STAMP(9);
     // ---- W = Q_top -> L.M (whole), blocked modified LU
-    // (consecutive lanes: consecutive rows of a column)
-    cq_elems(w, tid, [&](int j, int i) { return Vw[(i < w ? i : w - 1) + (size_t) ldv * j]; }, [&](int j, int i, double v) { if (i < w) L.M[i * CQ_LD + j] = v; });
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+        const int e = tid + u * CQ_T, j = e >> 7, i = e & (CQ_W - 1);
+        if (i < w && j < w) L.M[i * CQ_LD + j] = qt[u];
+    }
     __syncthreads();
-    cq_lu_blocked(L, w, ws + CQ_R2, tid);
+    cq_lu_blocked(L, w, first_order ? ws + CQ_G2 : ws + CQ_R2, first_order, tid);
     CQ_STAMP(10);
-    // L1 \ U' and S out; Q_top - S R2 back into Vw (the last pass multiplies it by U'^-1 like every other row: it becomes L1)
+    // L1 \ U' and S out.  (Rounds 4 wrote Q_top - S R2 back into the Q buffer here so that the last pass would turn it into L1: dead
+    // work -- cqr_top_kernel overwrites the top block of A and Vw behind that pass anyway.)
 #pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
         if (j < w) cq_st(ws + CQ_LU + i * CQ_W + j, L.M[i * CQ_LD + j]);
-    }
-    {   // (W in L.M has been overwritten: Q_top is read again, with R2, both requested 16 elements ahead)
-        const int n = w * CQ_W;
-        for (int base = tid; base < n; base += 16 * CQ_T) {
-            double qv[16], rv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = base + u * CQ_T, ee = e < n ? e : tid, j = ee >> 7, i = ee & (CQ_W - 1), ic = i < w ? i : w - 1;
-                qv[u] = Vw[ic + (size_t) ldv * j];
-                rv[u] = ws[CQ_R2 + ic * CQ_W + j];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = base + u * CQ_T, j = e >> 7, i = e & (CQ_W - 1);
-                if (e < n && i < w && j >= i) Vw[i + (size_t) ldv * j] = qv[u] - L.sv[i] * rv[u];
-            }
-        }
     }
     if (tid < w) cq_st(ws + CQ_SV + tid, L.sv[tid]);
     CQ_STAMP(11);

@@ -125,9 +125,12 @@ typedef struct qr_knobs {
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
     int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
-    int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: 128-column panels of at least this many rows at full width (0 = never).  Measured
-                                                             * (devtools/r4_cqr.sh, whole factorisations): 131072 x 256 1.69 against 1.44 ms, 262144 x 512 6.06 against 6.61, 524288 x 256 3.77
-                                                             * against 5.04, 2^20 x 128 2.51 against 5.67 */
+    int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: 128-column panels of at least this many rows at full width (0 = never).  Round 4:
+                                                             * 196608 (its one-workgroup kernels cost 274 us per panel); round 5 (181 us, profiles/r05_cqr_crossover.txt): everything
+                                                             * the one-launch panel cannot take (> 8192 rows) on single-stream plans -- 32768 x 256 0.73 against 0.82 ms,
+                                                             * 65536 x 256 0.93 against 0.99, 131072 x 256 1.28 against 1.35; below 8192 rows the one-launch panel wins (4096 x 512
+                                                             * 1.04 against 1.20), and on the CU-masked panel stream of a look-ahead plan the leaf chain does (16384 x 2048 8.0
+                                                             * against 8.7): there the round-4 threshold stays */
     int fused_gram;                                         /* the panel's Gram blocks V_prev^T V_l inside the one-launch panel (else one launch after it): constant 0 */
 } qr_knobs;
 static qr_knobs g_knobs;
@@ -150,7 +153,7 @@ static void knobs_init(void)
     k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
     k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
     k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
-    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 196608);
+    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
 }
 
 static const qr_knobs* knobs(void)
@@ -250,6 +253,14 @@ const char* qr_strerror(int status)
 }
 
 static int imin(int a, int b) { return a < b ? a : b; }
+
+/* rows from which a 128-column panel of this plan takes the full-width route (knob comment above) */
+#define QR_CQR_MIN_ROWS_LOOKAHEAD 196608
+static int plan_cqr_min_rows(const qr_plan* p)
+{
+    const int r = knobs()->cqr_min_rows;
+    return (p->lookahead && r > 0 && r < QR_CQR_MIN_ROWS_LOOKAHEAD) ? QR_CQR_MIN_ROWS_LOOKAHEAD : r;
+}
 
 /* ---------------------------------------------------------------------------------------------- */
 /* tsqr_local: the local factorisation of a multi-GPU TSQR plan.  Every choice that shapes the EXCHANGE (block size, look-ahead) must
@@ -410,7 +421,7 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         rc = qrd_malloc((void**) &p->slabs_ep, sizeof(double) * p->slab_ep_cap);
     }
     if (!rc && p->panel_tsqr == 3 && knobs()->fused_panel) {
-        if (knobs()->cqr_min_rows > 0 && m >= knobs()->cqr_min_rows) {
+        if (knobs()->cqr_min_rows > 0 && m >= plan_cqr_min_rows(p)) {
             rc = qrd_malloc((void**) &p->cq_ws, sizeof(double) * qrd_panel_cqr_ws_doubles());
             if (!rc) rc = qrd_malloc((void**) &p->cq_status, 4 * sizeof(int));
             if (!rc) rc = qrd_memset(p->stream, p->cq_status, 0, 4 * sizeof(int));
@@ -766,7 +777,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         /* the whole half in ONE launch (qr_panel_fused.hip: every leaf, its in-panel product and update; leaf T blocks, tau, V and
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
         int cqr_done = 0;
-        if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= kn->cqr_min_rows && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
+        if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= plan_cqr_min_rows(p) && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
             const int rc = panel_cqr_half(p, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
                                           p->Vw + (size_t) c0 * ldv + c0, ldv, p->VT + (size_t) c0 * ldv + c0);
             if (rc < 0) return rc;

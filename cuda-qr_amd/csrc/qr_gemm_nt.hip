@@ -64,7 +64,9 @@
 // IL = 1: the K loop with its issue order spelled out -- one LDS read or tile load behind every other MFMA, the barrier in the middle of
 // the last step's MFMAs with the next tile's first fragment reads behind it (see gemm_kloop_il in qr_gemm_tile.h for the measurement that
 // led there); IL = 0: fragment reads one step ahead in groups of three, the four tile loads at the top of the tile
-template <bool NEG, int STAMP, int IL = 0>
+// CEIL (measurement only, results wrong): 1 = the C tile is neither loaded nor stored, 2 = nor are the operand tiles loaded (K loop on
+// whatever the LDS holds): what the K loop alone / the matrix pipe alone deliver in the same launch mix (profiles/r05_nt_ceiling.txt)
+template <bool NEG, int STAMP, int IL = 0, int CEIL = 0>
 __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, const double* __restrict__ A, int lda,
                                                          const double* __restrict__ Bt, int ldbt,
                                                          double* __restrict__ C, int ldc, int gx, int gy, int gm,
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
     const double* gb = Bt + (size_t) wave * ldbt + j0 + 2 * lane;
     const size_t a8 = (size_t) 8 * lda, b8 = (size_t) 8 * ldbt;
     auto issue = [&](int kt, int stage) {
+        if (CEIL == 2) return;
         const double* pa = ga + (size_t) kt * NT_BK * lda;
         const double* pb = gb + (size_t) kt * NT_BK * ldbt;
         double* sa = smem + stage * NT_STAGE + wave * 128;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const v2d v = *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
+                const v2d v = CEIL ? (v2d){1.0, 2.0} : *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
                 acc[a][2 * c][r] = v[0];
                 acc[a][2 * c + 1][r] = v[1];
             }
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
             acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][b >> 1][b & 1], fb[set][a], acc[a][b], 0, 0, NEG ? 1 : 0);
         };
         auto ld = [&](int kt_, int stage, int q) {      // tile load q of 4 (see issue())
+            if (CEIL == 2) return;
             const double* pa = ga + (size_t) kt_ * NT_BK * lda;
             const double* pb = gb + (size_t) kt_ * NT_BK * ldbt;
             double* sa = smem + stage * NT_STAGE + wave * 128;
@@ -237,8 +241,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]};
+            for (int r = 0; r < 4; ++r) {
+                if (CEIL) { if (acc[a][2 * c][r] == 0.12345678) *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]}; }
+                else *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]};
+            }
     if (STAMP && tid == 0) {
         const unsigned long long t3 = __builtin_amdgcn_s_memtime();
         // 6 values per workgroup: the four stamps, where it ran (HW_ID | XCC_ID << 32) and its dispatch order
@@ -248,6 +254,178 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
         s[0] = t0; s[1] = t1; s[2] = t2; s[3] = t3; s[4] = (unsigned long long) hw | ((unsigned long long) (xcc & 0xf) << 32); s[5] = blockIdx.x;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 5, the variant the round-4 review asked for: FOUR independent 4-wave workgroups per compute unit instead of two 8-wave ones.
+// Same wave tile (64 x 32, 8 accumulators), same fragment maps, same occupancy (4 waves per SIMD); the workgroup tile is 128 x 64 and
+// the k-tile 8 deep in THREE LDS stages of 12 KB (36 KB per workgroup), tiles requested two ahead and the barrier waiting only for the
+// stage about to be read (s_waitcnt vmcnt(3)).  What it is after: a workgroup spends ~15 % of its time loading and storing its C tile,
+// and with two workgroups per CU the matrix pipe runs on half its waves 42 % of the time (stamps of round 3); four workgroups with
+// half-size tiles de-phase four ways.  What it costs: every tile of V serves 64 columns instead of 128 (x1.5 operand bytes L2 -> LDS).
+// Measured (profiles/r05_nt_ceiling.txt): 60.8 against 59.0 TFLOP/s isolated, 51.2 against 49.8 in situ at 16384^2 (117.6 against 118.5 ms):
+// the default since round 5; MI355XQR_NT4=0 restores the 8-wave kernel, =2 is a 3-per-CU form with 16-deep k-tiles (no gain).
+// ------------------------------------------------------------------------------------------------
+template <bool NEG, int CEIL, int BK4, int NS>
+__global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M, int N, int K, const double* __restrict__ A, int lda,
+                                                          const double* __restrict__ Bt, int ldbt,
+                                                          double* __restrict__ C, int ldc, int gx, int gy, int gm)
+{
+    // BK4 = 8, NS = 3: 36 KB of LDS, four workgroups per CU, tiles two ahead;  BK4 = 16, NS = 2: 48 KB, three per CU, tiles one ahead
+    constexpr int STAGE = BK4 * 128 + BK4 * 64;           // doubles per stage: A image [BK4][128] + B image [BK4][64]
+    constexpr int NLD = 3 * BK4 / 8;                       // tile-load instructions per wave and stage
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int tx, ty;
+    tile_of_block(blockIdx.x, gx, gy, gm, tx, ty);
+    const int i0 = tx * 128, j0 = ty * 64;
+    // tile loader, instructions of 1 KiB: k-rows wave, wave + 4, .. of the A image; k-row pairs (2 wave, 2 wave + 1), (2 wave + 8, ..) of
+    // the B image (32 lanes per 512-byte row)
+    const double* ga = A + (size_t) wave * lda + i0 + 2 * lane;
+    const double* gb = Bt + (size_t) (2 * wave + (lane >> 5)) * ldbt + j0 + 2 * (lane & 31);
+    auto issue = [&](int kt, int stage) {
+        if (CEIL == 2) return;
+        const double* pa = ga + (size_t) kt * BK4 * lda;
+        const double* pb = gb + (size_t) kt * BK4 * ldbt;
+        double* sa = smem + stage * STAGE;
+#pragma unroll
+        for (int q = 0; q < BK4 / 4; ++q)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + (size_t) (4 * q) * lda), LDS_PTR(sa + (wave + 4 * q) * 128), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < BK4 / 8; ++q)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + (size_t) (8 * q) * ldbt), LDS_PTR(sa + BK4 * 128 + (wave + 4 * q) * 128), 16, 0, 0);
+    };
+    const int nk = K / BK4;
+    issue(0, 0);
+    if (NS == 3 && nk > 1) issue(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    v4d acc[2][4];
+    double* cp[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        cp[a] = C + (size_t) (j0 + 32 * wj + 2 * l15 + a) * ldc + i0 + 64 * wi + 2 * l4;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const v2d v = CEIL ? (v2d){1.0, 2.0} : *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
+                acc[a][2 * c][r] = v[0];
+                acc[a][2 * c + 1][r] = v[1];
+            }
+    }
+    __syncthreads();                                   // vmcnt(0): the stages requested so far and the C tile have landed
+    const int aoff = 64 * wi + 2 * l15 + l4 * 128, boff = BK4 * 128 + 32 * wj + 2 * l15 + l4 * 64;
+    constexpr int NKS = BK4 / 4;
+    v2d fa[NKS][2], fb[NKS];
+    if constexpr (BK4 == 8 && NS == 3) {
+        // issue order spelled out as in gemm_nt_kernel<.., IL = 1>: one LDS read or tile load behind every other MFMA, the barrier in the
+        // middle of the stage's second step with the next stage's first fragment reads behind it
+        auto rd = [&](int set, const double* st_, int ks, int which) {
+            if (which == 0) fa[set][0] = *reinterpret_cast<const v2d*>(st_ + ks * 4 * 128 + aoff);
+            else if (which == 1) fb[set] = *reinterpret_cast<const v2d*>(st_ + ks * 4 * 64 + boff);
+            else fa[set][1] = *reinterpret_cast<const v2d*>(st_ + ks * 4 * 128 + aoff + 32);
+        };
+        auto mm = [&](int set, int j) {
+            const int a = j >> 2, b = j & 3;
+            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][b >> 1][b & 1], fb[set][a], acc[a][b], 0, 0, NEG ? 1 : 0);
+        };
+        auto ld = [&](int kt_, int q) {
+            if (CEIL == 2) return;
+            const double* pa = ga + (size_t) kt_ * BK4 * lda;
+            const double* pb = gb + (size_t) kt_ * BK4 * ldbt;
+            double* sa = smem + (kt_ % 3) * STAGE;
+            if (q == 0) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa), LDS_PTR(sa + wave * 128), 16, 0, 0);
+            else if (q == 1) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + (size_t) 4 * lda), LDS_PTR(sa + (wave + 4) * 128), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb), LDS_PTR(sa + BK4 * 128 + wave * 128), 16, 0, 0);
+        };
+#define N4_SB __builtin_amdgcn_sched_barrier(0)
+        rd(0, smem, 0, 0); rd(0, smem, 0, 1); rd(0, smem, 0, 2);
+        N4_SB;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const double* st = smem + (kt % 3) * STAGE;
+            const double* stn = smem + ((kt + 1) % 3) * STAGE;
+            const bool more = kt + 2 < nk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {               // step 0 (set 0): the reads of step 1 and the loads of the tile two ahead behind its MFMAs
+                mm(0, j);
+                if (j == 0) rd(1, st, 1, 0); else if (j == 2) rd(1, st, 1, 1); else if (j == 4) rd(1, st, 1, 2);
+                else if (more && j == 1) ld(kt + 2, 0); else if (more && j == 3) ld(kt + 2, 1); else if (more && j == 5) ld(kt + 2, 2);
+                N4_SB;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mm(1, j); N4_SB; }     // step 1 (set 1), first half
+            if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            N4_SB;
+#pragma unroll
+            for (int j = 4; j < 8; ++j) {                        // second half, over the next stage's first fragment reads (set 0 is free)
+                mm(1, j);
+                if (j < 7) rd(0, stn, 0, j - 4);
+                N4_SB;
+            }
+        }
+        {   // last tile
+            const double* st = smem + ((nk - 1) % 3) * STAGE;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { mm(0, j); if (j == 0) rd(1, st, 1, 0); else if (j == 2) rd(1, st, 1, 1); else if (j == 4) rd(1, st, 1, 2); N4_SB; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mm(1, j);
+        }
+#undef N4_SB
+    } else
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt % NS;
+        if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+        const double* st = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            fa[ks][0] = *reinterpret_cast<const v2d*>(st + ks * 4 * 128 + aoff);
+            fa[ks][1] = *reinterpret_cast<const v2d*>(st + ks * 4 * 128 + aoff + 32);
+            fb[ks] = *reinterpret_cast<const v2d*>(st + ks * 4 * 64 + boff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                acc[a][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][0][0], fb[ks][a], acc[a][0], 0, 0, NEG ? 1 : 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][0][1], fb[ks][a], acc[a][1], 0, 0, NEG ? 1 : 0);
+                acc[a][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][1][0], fb[ks][a], acc[a][2], 0, 0, NEG ? 1 : 0);
+                acc[a][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks][1][1], fb[ks][a], acc[a][3], 0, 0, NEG ? 1 : 0);
+            }
+        if (NS == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (CEIL) { if (acc[a][2 * c][r] == 0.12345678) *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]}; }
+                else *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]};
+            }
+}
+
+static int nt4(void)
+{
+    static const int v = [] { const char* e = getenv("MI355XQR_NT4"); return e ? atoi(e) : 1; }();   // round 5: default
+    return v;
+}
+
+static int nt_ceil(void)
+{
+    static const int v = [] { const char* e = getenv("MI355XQR_NT_CEIL"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 
 static int nt_gm(void)
 {
@@ -273,6 +451,14 @@ int qrd_gemm2_init(void)
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 0, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 1, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 2, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 0, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 192 * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 1, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 192 * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 2, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 192 * 8);
     return rc;
 }
 
@@ -293,6 +479,24 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
     static const int solo = 0;
     const size_t shm = solo ? (size_t) 100 * 1024 : 2 * NT_STAGE * sizeof(double);
     hipStream_t s = (hipStream_t) stream;
+    if (!stamps && sign < 0 && nt4() && K >= 32) {
+        // MI355XQR_NT4 = 1: four workgroups per CU (k-tiles of 8, three stages); 2: three per CU (k-tiles of 16, two stages)
+        const int gy4 = N / 64;
+        const dim3 g(gx * gy4), b(256);
+#define NT4_LAUNCH(CE, BK, NS) hipLaunchKernelGGL((gemm_nt4_kernel<true, CE, BK, NS>), g, b, NS * (BK * 192) * sizeof(double), s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy4, gm)
+        if (nt4() == 2) { if (nt_ceil() == 1) NT4_LAUNCH(1, 16, 2); else if (nt_ceil() == 2) NT4_LAUNCH(2, 16, 2); else NT4_LAUNCH(0, 16, 2); }
+        else { if (nt_ceil() == 1) NT4_LAUNCH(1, 8, 3); else if (nt_ceil() == 2) NT4_LAUNCH(2, 8, 3); else NT4_LAUNCH(0, 8, 3); }
+#undef NT4_LAUNCH
+        return (int) hipGetLastError();
+    }
+    if (!stamps && sign < 0 && nt_ceil() == 1) {
+        hipLaunchKernelGGL((gemm_nt_kernel<true, 0, 1, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
+        return (int) hipGetLastError();
+    }
+    if (!stamps && sign < 0 && nt_ceil() == 2) {
+        hipLaunchKernelGGL((gemm_nt_kernel<true, 0, 1, 2>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
+        return (int) hipGetLastError();
+    }
     if (stamps)
         hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
     else if (sign < 0 && nt_il())

@@ -54,6 +54,7 @@ int qrd_gemm_nn_batch(void* stream, int M, int N, int K, double alpha, const dou
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,
               double* Tt, int build_diag, double* X, int ldx);
 int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols);
+int qrd_transpose(void* stream, int rows, int cols, const double* S, int lds, double* D, int ldd);   /* D (cols x rows) = S^T */
 int qrd_extract_v(void* stream, const double* P, int ld, int mk, int w, double* V, int ldv);
 int qrd_extract_r(void* stream, const double* A, int lda, int m, int n, double* R, int ldr, int rrows);
 int qrd_extract_r_block(void* stream, const double* A, int lda, int k, int w, double* R, int ldr, int rrows);

@@ -131,6 +131,7 @@ typedef struct qr_knobs {
                                                              * 65536 x 256 0.93 against 0.99, 131072 x 256 1.28 against 1.35; below 8192 rows the one-launch panel wins (4096 x 512
                                                              * 1.04 against 1.20), and on the CU-masked panel stream of a look-ahead plan the leaf chain does (16384 x 2048 8.0
                                                              * against 8.7): there the round-4 threshold stays */
+    int tall_nt;                                            /* MI355XQR_TALL_NT: the update of a tall block through gemm_nt (W transposed first) */
     int fused_gram;                                         /* the panel's Gram blocks V_prev^T V_l inside the one-launch panel (else one launch after it): constant 0 */
 } qr_knobs;
 static qr_knobs g_knobs;
@@ -154,6 +155,7 @@ static void knobs_init(void)
     k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
     k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
     k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
+    k->tall_nt = env_int("MI355XQR_TALL_NT", 1) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -885,6 +887,14 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
         CHECK(qrd_gemm_tn(stream, kw, nc, mk, 1.0, V, ldv, A2, lda, 0.0, Ybuf, kw, slabs, p->slab_cap, NULL, 0));
         if (t_wait) CHECK(qrd_stream_wait_event(stream, t_wait));
         CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
+    }
+    /* Round 5: the update of a tall block through the trailing-update kernel of the square case (qr_gemm_nt.hip: four workgroups per CU,
+     * operands HBM -> LDS directly, tiles dealt to the XCDs so that the column tiles of a row block share V in one L2): it wants W
+     * transposed (nc x kw, row-fast), one more tiny launch.  MI355XQR_TALL_NT=0: the 8-wave NN kernel as before. */
+    if (knobs()->tall_nt && Ybuf && mk >= 16384 && kw >= 32 && kw % 16 == 0 && nc >= 128 && nc % 128 == 0 && mk % 128 == 0 &&
+        qrd_gemm_nt_ok(mk, nc, kw, V, ldv, Ybuf, nc, A2, lda)) {
+        CHECK(qrd_transpose(stream, kw, nc, Wbuf, kw, Ybuf, nc));          /* Ybuf (free by now) <- W^T */
+        return qrd_gemm_nt(stream, mk, nc, kw, -1, V, ldv, Ybuf, nc, A2, lda, -1, NULL);
     }
     /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
      * it hands anything it cannot take (ragged, unaligned) to the generic path itself */

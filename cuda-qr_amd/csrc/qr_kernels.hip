@@ -598,6 +598,13 @@ __global__ void transpose_kernel(int n, const double* __restrict__ S, int lds, d
     if (e < n * n) { const int p = e % n, c = e / n; D[(size_t) p * ldd + c] = S[(size_t) c * lds + p]; }
 }
 
+// D (cols x rows, ldd) = S (rows x cols, lds)^T: the small W of a tall update into the row-fast form gemm_nt wants
+__global__ void transpose_rect_kernel(int rows, int cols, const double* __restrict__ S, int lds, double* __restrict__ D, int ldd)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < rows * cols) { const int i = e % rows, j = e / rows; D[(size_t) i * ldd + j] = S[(size_t) j * lds + i]; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
@@ -1197,6 +1204,13 @@ int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const dou
         return (int) hipGetLastError();
     }
     return 0;
+}
+
+int qrd_transpose(void* stream, int rows, int cols, const double* S, int lds, double* D, int ldd)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned) (((size_t) rows * cols + 255) / 256)), dim3(256), 0, (hipStream_t) stream, rows, cols, S, lds, D, ldd);
+    return (int) hipGetLastError();
 }
 
 int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols)

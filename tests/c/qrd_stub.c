@@ -236,6 +236,12 @@ int qrd_host_word_alloc(unsigned** host, unsigned** dev)
     return 0;
 }
 int qrd_host_word_free(unsigned* host) { free(host); return 0; }
+int qrd_transpose(void* s, int rows, int cols, const double* S, int lds, double* D, int ldd)
+{
+    (void) s;
+    chk("transpose S", S, lds, rows, cols); chk("transpose D", D, ldd, cols, rows);
+    return 0;
+}
 int qrd_panel_cqr_init(void) { return 0; }
 int qrd_panel_cqr_ok(int mk, int w) { return w >= 32 && w <= 128 && w % 32 == 0 && mk >= 2 * w; }
 double* qrd_panel_cqr_g1(double* ws) { return ws; }

@@ -176,7 +176,8 @@ def main():
         m_local, n, nb = 16384, 16384, args.nb or 256
         desc = f"C3: 16384x16384 square fp64 QR on 1 MI355X, nb={nb}"
     elif wl == "c4":
-        m_local, n, nb = 262144 // world, 256, args.nb or 64      # 4 block columns of 64: more of the stacked QR runs under the local one
+        m_local, n, nb = 262144 // world, 256, args.nb or 128     # round 5: shards of 131072 / 65536 rows take the full-width panel route at nb 128
+                                                                  # (rank step 1.59 / 1.18 ms against 1.80 / 1.30 at nb 64, profiles/r05_tsqr_rank_step_latency.txt)
         desc = f"C4: tall-skinny 262144x256 fp64 TSQR, row-block sharded over {world} GPU(s)"
     elif wl == "c5":
         m_local, n, nb = 2097152 // world, 512, args.nb or 128
@@ -335,6 +336,46 @@ def main():
                               "and the stacked (world*n) x n matrix (redundant on every rank, latency-bound) is factored "
                               "left-looking while the local QR continues"}
 
+    # ---- N > 1: BOTH exchange schedules, three drained factorisations each, every rank's own numbers (qr_tsqr_set_schedule is collective:
+    # all ranks switch between the same two calls).  The first real multi-GPU run must explain itself: what an all-gather of n*nb doubles per
+    # rank costs beside a chip-filling local update, on THIS node, is not known before it.
+    by_schedule = None
+    if world > 1 and be.transport == "rccl":
+        try:
+            by_schedule = {}
+            chosen = "pipelined" if be.tp.is_pipelined() else "one_collective"
+            for name, mode in (("pipelined", 1), ("one_collective", 0)):
+                try:
+                    be.tp.set_schedule(mode)
+                except Exception as e:                 # the shape cannot run the pipelined form
+                    by_schedule[name] = {"error": repr(e)}
+                    continue
+                for i in range(4):
+                    be.fill(bufs[i % nbuf], m_local, n, rank * m_local, m_total, seeds[i % nbuf])
+                barrier()
+                ts.factor(bufs[0]); ts.sync()           # the schedule's first call pays RCCL's set-up for its message sizes
+                barrier()
+                t1 = time.perf_counter()
+                for i in range(1, 4):
+                    ts.factor(bufs[i % nbuf])
+                    ts.sync()
+                mine = {"rank": rank, "step_ms": (time.perf_counter() - t1) / 3 * 1e3}
+                gs2 = be.tp.gather_stats() if mode == 1 else None
+                if gs2:
+                    mine.update({"gather_ms": gs2["gather_ms"], "gather_max_ms": gs2["gather_max_ms"], "call_ms": gs2["call_ms"]})
+                allr = [None] * world
+                dist.all_gather_object(allr, mine)
+                by_schedule[name] = {"per_rank": allr, "step_ms_max": max(r["step_ms"] for r in allr)}
+            be.tp.set_schedule(2)
+            by_schedule["chosen_in_timed_region"] = chosen
+            by_schedule["reserve_cus"] = os.environ.get("MI355XQR_TSQR_RESERVE_CUS", "0")
+            by_schedule["note"] = ("drained latency of one factorisation per schedule and rank; gather_ms = sum over the block columns of [stacked stream "
+                                   "past its wait for the local panel -> ncclAllGather done] from events on the stacked stream.  MI355XQR_TSQR_RESERVE_CUS=c "
+                                   "masks the local stream to all but c compute units (RCCL's kernels then never queue behind the update); "
+                                   "MI355XQR_TSQR_PIPE=0|1 pins the schedule")
+        except Exception as e:
+            by_schedule = {"error": repr(e)}
+
     # ---- N > 1, fixed-size configs (C4 / C5): the SAME matrix on ONE GPU, measured by rank 0 in this run (the other ranks wait at
     # the next barrier) -- the strong-scaling denominator next to the N-GPU numbers above
     same_1gpu = None
@@ -379,17 +420,18 @@ def main():
     # ITS algorithmic bytes, and `traffic` itself only when that file was made for this block size; otherwise null.
     traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
     except Exception:
         tj = None
     gen = 2
-    kname = "gemm_nt_kernel<true, 0, 1> (trailing update A2 -= V*Wt^T, W kept transposed, direct-to-LDS tiles, v_mfma_f64_16x16x4_f64)"
+    kname = ("gemm_nt4_kernel<true, 0, 8, 3> (trailing update A2 -= V*Wt^T, W kept transposed; four 4-wave workgroups per CU on 128 x 64 tiles, "
+             "direct-to-LDS k-tiles of 8 in three stages, v_mfma_f64_16x16x4_f64; MI355XQR_NT4=0: the 8-wave gemm_nt_kernel<true, 0, 1>)")
     if wl in ("c2", "c3") and upd["launches"]:
         ach = upd["flops"] / (upd["ms"] * 1e-3) / 1e12
         if tj and wl == "c3" and nb == tj.get("nb") and gen == 2 and "gemm_nt_kernel" in tj:
-            e = tj["gemm_nt_kernel"]
+            e = tj["gemm_nt_kernel"]                    # (key kept from round 3: the entry is the update kernel of the pass, now gemm_nt4_kernel)
             traffic = e["hbm_bytes_per_launch"]
-            traffic_src = {"file": "profiles/r03_pmc_traffic.json", "git_head_of_pass": tj.get("git_head"),
+            traffic_src = {"file": "profiles/r05_pmc_traffic.json", "git_head_of_pass": tj.get("git_head"),
                            "launch_mix": tj.get("config"),
                            "algorithmic_bytes_per_launch_same_mix": e["algorithmic_bytes_per_launch"],
                            "ratio_traffic_to_algorithmic": e["ratio"],
@@ -415,7 +457,8 @@ def main():
                 # chip, as the contract asks): what the kernel itself leaves on the table, apart from the schedule's CU partition
                 "cus": cus_u,
                 "frac_of_cus_used": (ach / (FP64_MATRIX_PEAK_TFLOPS * cus_u / float(qr.device_info()["compute_units"] or 256))) if cus_u else None,
-                "rocprof_pmc": "profiles/r03_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel)",
+                "rocprof_pmc": "profiles/r05_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel, whole chip: rocprofv3 --pmc crashes on CU-masked streams on this pool)",
+                "ceiling": "profiles/r05_nt_ceiling.txt (same launch mix with the C traffic / the operand loads compiled out: 58.9 / 61.4 TFLOP/s in situ bound any K = 256 kernel on 224 CUs)",
                 "measured_probe": measured,
                 "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],
                 "profiled_steps_in_timed_region": len(range(0, K, stride)),
@@ -437,24 +480,24 @@ def main():
         ptraffic, psrc = None, None
         try:
             # round 4: a 262144-row, 128-column panel takes the full-width route (qr_panel_cqr.hip): PMC passes over one such panel
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_panel_hbm.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_panel_hbm.json")))
             if m_local == pj["mk"] and nb == pj["w"]:
                 ptraffic = pj["hbm_bytes_per_panel"]
-                psrc = {"file": "profiles/r04_pmc_panel_hbm.json", "covers": pj["covers"], "method": pj["method"] + "; replayed from the committed file"}
+                psrc = {"file": "profiles/r05_pmc_panel_hbm.json", "covers": pj["covers"], "method": pj["method"] + "; replayed from the committed file"}
         except Exception:
             pass
         # whole-factorisation HBM bytes of this shape (every dispatch: leaf kernels, in-panel products and updates, outer updates),
         # PMC passes of devtools/scripts_r4_pmc.sh -- replayed, not measured in this run
         whole = None
         try:
-            wj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_tsqr_total_traffic.json")))
+            wj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_tsqr_total_traffic.json")))
             if m_local == wj["m"] and n == wj["n"]:
-                whole = {"file": "profiles/r04_pmc_tsqr_total_traffic.json", "hbm_bytes_per_factorisation": wj["hbm_bytes_per_factorisation"],
+                whole = {"file": "profiles/r05_pmc_tsqr_total_traffic.json", "hbm_bytes_per_factorisation": wj["hbm_bytes_per_factorisation"],
                          "algorithmic_bytes_16mn": wj["algorithmic_bytes_16mn"], "ratio": wj["ratio"],
                          "achieved_GBps_whole_step": wj["hbm_bytes_per_factorisation"] / (dt / K) / 1e9}
         except Exception:
             pass
-        roof = None if not pan["launches"] else {"bound": "hbm", "kernel": "panel factorisation: panels of >= 196608 rows x 128 columns at full width (qr_panel_cqr.hip: cqr_gram / cqr_chol / cqr_stream<Q,G2> / cqr_lu / cqr_stream<V> kernels), others by the leaf chain (gram32 / chol1 / cholq4_tall / hr3 / final3 + in-panel gemm_tn_dual / leaf_update_gram, Gram + T merge)",
+        roof = None if not pan["launches"] else {"bound": "hbm", "kernel": "panel factorisation: 128-column panels of > 8192 rows at full width (qr_panel_cqr.hip: cqr_gram / cqr_chol / cqr_stream<Q,G2> / cqr_lu / cqr_post / cqr_stream<V> kernels; round 4: from 196608 rows), up to 8192 rows in one launch (panel_fused_kernel), others by the leaf chain",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": ptraffic, "traffic_source": psrc, "traffic_whole_factorisation": whole,
                 "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),
@@ -462,9 +505,15 @@ def main():
                 "algorithmic_bytes_per_launch": pan["bytes"] / max(pan["launches"], 1),
                 "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); a full-width panel moves 3.15x that in three passes "
                         "(G1; Q + G2; V to two destinations) at 1.8 TB/s overall -- its passes cost memory time plus matrix-core time, and two "
-                        "one-workgroup factor kernels (0.33 ms) sit between them (DESIGN.md section 3.1c)",
+                        "one-workgroup factor kernels (0.18 ms in round 5, 0.27 in round 4) sit between them (DESIGN.md section 3)",
                 "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None,
                 "measured_probe": measured}
+
+    # which panel routes the timed plan took, and whether a device-side guard fired (include/mi355x_qr.h: qr_plan_route_stats)
+    try:
+        panel_routes = be.plan.route_stats()
+    except Exception:
+        panel_routes = None
 
     # ---- N = 1 only: the one-GPU leg of the multi-GPU (TSQR, weak scaling) series, so that the N > 1 lines of this
     # bench (262144 x 512 per GPU) have their own denominator next to the C3 headline
@@ -492,8 +541,8 @@ def main():
         # -- the launches, streams and events of a real rank, which also factors the full stacked matrix redundantly, minus the network
         try:
             c5 = T.rank_step_latency(qr, 262144, 512, 8, 128)
-            c4 = T.rank_step_latency(qr, 65536, 256, 4, 64)
-            c4_2 = T.rank_step_latency(qr, 131072, 256, 2, 64)
+            c4 = T.rank_step_latency(qr, 65536, 256, 4, 128)
+            c4_2 = T.rank_step_latency(qr, 131072, 256, 2, 128)
 
             def whole_ms(m, ncol, nbw, reps_=2):
                 # the strong-scaling denominator: the WHOLE matrix of the multi-GPU config factored on this one GPU
@@ -515,7 +564,7 @@ def main():
                 return best
 
             NET_MS = 0.1                  # ASSUMPTION, never measured: what the n/nb small all-gathers of a step cost on xGMI
-            c5_whole, c4_whole = whole_ms(2097152, 512, 128), whole_ms(262144, 256, 64)
+            c5_whole, c4_whole = whole_ms(2097152, 512, 128), whole_ms(262144, 256, 128)
             tsqr_model = {"c5_rank_of_8": c5, "c4_rank_of_4": c4, "c4_rank_of_2": c4_2,
                           "stacked_step_alone_4096x512_ms": T.stacked_step_ms(qr, 8, 512, 128),
                           "assumed_network_ms_per_step": NET_MS,
@@ -553,9 +602,11 @@ def main():
             "frac_of_fp64_matrix_peak": value / 1e3 / (FP64_MATRIX_PEAK_TFLOPS * world),
             "accuracy": acc,
             "roofline": roof,
+            "panel_routes": panel_routes,
             "weak_scaling_base_1gpu": weak_base,
             "tsqr_model_1gpu": tsqr_model,
             "tsqr_step_split": tsqr_split,
+            "tsqr_exchange_by_schedule": by_schedule,
             "same_problem_1gpu": same_1gpu,
             "rccl": ({"nranks_seen_by_rccl": rccl_ranks, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                       "transport": be.transport, "fallback_reason": be.fallback_reason,

@@ -87,6 +87,7 @@ _sig("qr_tsqr_local_dev", C.c_int, _vp, _vp, C.c_int)
 _sig("qr_tsqr_exchange_buffers", C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp))
 _sig("qr_tsqr_stacked_dev", C.c_int, _vp, _vp)
 _sig("qr_tsqr_is_pipelined", C.c_int, _vp)
+_sig("qr_tsqr_set_schedule", C.c_int, _vp, C.c_int)
 _sig("qr_tsqr_gather_stats", C.c_int, _vp, C.POINTER(C.c_double))
 _sig("qr_tsqr_factor_virtual_dev", C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp))
 _sig("qr_tsqr_factor_selfgather_dev", C.c_int, _vp, _vp, C.c_int, _vp)
@@ -503,6 +504,10 @@ class TsqrPlan:
 
     def factor_selfgather(self, dA, lda, dR):
         check(lib.qr_tsqr_factor_selfgather_dev(self.h, _dptr(dA), lda, _dptr(dR)), "qr_tsqr_factor_selfgather_dev")
+
+    def set_schedule(self, mode):
+        """0 = one collective, 1 = panel-pipelined, 2 = the library's rule; every rank must make the same call"""
+        check(lib.qr_tsqr_set_schedule(self.h, int(mode)), "qr_tsqr_set_schedule")
 
     def is_pipelined(self):
         return bool(lib.qr_tsqr_is_pipelined(self.h))

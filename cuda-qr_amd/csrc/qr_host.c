@@ -309,7 +309,17 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
      * tall-skinny problems are all panel, so they keep the whole chip on one stream set. */
     /* (a multi-rank TSQR's local plan takes a normal-priority stream: the stacked plan's high-priority stream, which carries the exchange
      * and the short stacked panels everyone is waiting for, goes first whenever both have work queued) */
-    int rc = qrd_stream_create(&p->s_main, !tsqr_local);
+    /* MI355XQR_TSQR_RESERVE_CUS=c (multi-rank local plans only; default 0 = off): the local factorisation's stream is masked to all but c
+     * compute units, so that RCCL's kernels -- a handful of workgroups -- never wait for a slot behind a chip-filling update.  Stream priority
+     * alone orders the QUEUES, it does not free a compute unit.  c = 8 is one CU of every XCD (a mask bit is CU i/8 of XCC i%8). */
+    int rc = 0;
+    {
+        const int reserve = tsqr_local ? env_int("MI355XQR_TSQR_RESERVE_CUS", 0) : 0;
+        int cus = 256;
+        qrd_device_info(NULL, 0, &cus, NULL, NULL);
+        if (reserve > 0 && reserve < cus) rc = qrd_stream_create_cumask(&p->s_main, reserve, cus - reserve);
+        else rc = qrd_stream_create(&p->s_main, !tsqr_local);
+    }
     p->stream = p->s_main;
     p->pair_cur = -1;
     if (!rc && p->lookahead) {
@@ -1766,6 +1776,7 @@ struct qr_tsqr_plan {
     /* what the exchange costs on THIS node is not known before the first multi-rank run: the gathers are timed (qr_tsqr_gather_stats),
      * and with MI355XQR_TSQR_PIPE unset the ranks decide TOGETHER, once, whether to keep the pipelined form (tsqr_decide) */
     int pipe_auto, pipe_calls, pipe_fell_back, stats_valid;
+    int pipe_able, pipe_env_on, pipe_env_auto;   /* the plan can run the pipelined form at all / what the environment asked for (qr_tsqr_set_schedule) */
     double *dstat;                  /* 2 + 2 * nranks doubles: this rank's {gather sum, step} ms, then every rank's */
 };
 #define QR_TSQR_DECIDE_CALL 2       /* the decision is taken before this pipelined call (0-based): call 0 pays RCCL's lazy set-up, call 1 is warm */
@@ -1798,7 +1809,11 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
         /* panel-pipelined exchange: MI355XQR_TSQR_PIPE=0 keeps the one-collective form */
         const int pnb = rc ? 0 : t->p->nb;
         t->pipe_auto = getenv("MI355XQR_TSQR_PIPE") == NULL || strcmp(getenv("MI355XQR_TSQR_PIPE"), "auto") == 0;
-        if (!rc && (t->pipe_auto || env_int("MI355XQR_TSQR_PIPE", 1) != 0) && !t->p->lookahead && !t->p2->lookahead && pnb == t->p2->nb && n % pnb == 0 &&
+        t->pipe_env_auto = t->pipe_auto;
+        t->pipe_env_on = t->pipe_auto || env_int("MI355XQR_TSQR_PIPE", 1) != 0;
+        /* (the pipelined form's buffers and events exist whenever the shape allows it, whatever the environment says: qr_tsqr_set_schedule can
+         * switch between the two forms) */
+        if (!rc && !t->p->lookahead && !t->p2->lookahead && pnb == t->p2->nb && n % pnb == 0 &&
             n / pnb >= 2 && n / pnb + 1 <= QR_TSQR_MAXPAN) {
             t->npan = n / pnb;
             for (int k = 0; k <= t->npan; ++k) t->pan_k[k] = k * pnb;
@@ -1822,7 +1837,8 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
             if (!rc) rc = qrd_event_create(&t->ev_t1);
             if (!rc) rc = qrd_malloc((void**) &t->dstat, sizeof(double) * (size_t) (2 + 2 * nranks));
             if (!rc) rc = qrd_stream_sync(t->p2->s_main);
-            t->pipe_ok = !rc;
+            t->pipe_able = !rc;
+            t->pipe_ok = t->pipe_able && t->pipe_env_on;
         }
     }
     if (rc) { qr_tsqr_plan_destroy(t); return rc; }
@@ -2117,8 +2133,14 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
 int qr_tsqr_factor_selfgather_dev(qr_tsqr_plan* t, double* dA, int lda, double* dR)
 {
     if (!t || !dA || !dR || lda < t->m_local || t->nranks < 2) return QR_E_ARG;
-    if (t->pipe_ok && t->pipe_auto && t->pipe_calls == QR_TSQR_DECIDE_CALL) CHECK(tsqr_decide(t, 1));
-    if (t->pipe_ok) return tsqr_factor_pipelined(t, dA, lda, dR, 1);
+    /* (a diagnostic path: it neither takes part in the ranks' joint decision nor counts towards its call index -- a rank that made an
+     * extra self-gather call used to reach the decision collective one call before the others) */
+    if (t->pipe_ok) {
+        const int calls = t->pipe_calls;
+        const int rc = tsqr_factor_pipelined(t, dA, lda, dR, 1);
+        t->pipe_calls = calls;
+        return rc;
+    }
     CHECK(qr_tsqr_local_dev(t, dA, lda));
     for (int q = 0; q < t->nranks; ++q)
         CHECK(qrd_d2d(t->p->s_main, t->dRall + (size_t) q * t->n * t->n, t->dRp, sizeof(double) * (size_t) t->n * t->n));
@@ -2127,6 +2149,22 @@ int qr_tsqr_factor_selfgather_dev(qr_tsqr_plan* t, double* dA, int lda, double* 
 
 /* 1 when qr_tsqr_factor_dev runs the panel-pipelined form for this plan */
 int qr_tsqr_is_pipelined(qr_tsqr_plan* t) { return t && t->pipe_ok && t->nranks > 1; }
+
+/* Exchange schedule, set by the caller instead of by the timing rule: 0 = one collective after the local factorisation, 1 = panel-pipelined
+ * (QR_E_ARG when the plan's shape cannot run it), 2 = back to the library's choice (MI355XQR_TSQR_PIPE / the joint decision).  Every rank of
+ * the communicator must make the same call between the same two factorisations (the schedules issue different collectives); the plan's
+ * streams are drained first. */
+int qr_tsqr_set_schedule(qr_tsqr_plan* t, int mode)
+{
+    if (!t || mode < 0 || mode > 2) return QR_E_ARG;
+    if (t->nranks < 2) return 0;
+    CHECK(qr_tsqr_sync(t));
+    if (mode == 1 && !t->pipe_able) return QR_E_ARG;
+    if (mode == 2) { t->pipe_ok = t->pipe_able && t->pipe_env_on; t->pipe_auto = t->pipe_env_auto; t->pipe_calls = 0; t->pipe_fell_back = 0; }
+    else { t->pipe_ok = mode; t->pipe_auto = 0; }
+    t->stats_valid = 0;
+    return 0;
+}
 
 /* steps 1-3 with the RCCL exchange in between; asynchronous (qr_tsqr_sync before dR is read on another stream) */
 int qr_tsqr_factor_dev(qr_tsqr_plan* t, double* dA, int lda, double* dR)

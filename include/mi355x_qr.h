@@ -147,6 +147,10 @@ int qr_tsqr_stacked_dev(qr_tsqr_plan* tp, double* dR);
  * qr_tsqr_factor_selfgather_dev: one rank's complete step with its own factor copied into every rank slot: the launches, streams and
  * events of a real rank minus the network (latency measurements on one GPU). */
 int qr_tsqr_is_pipelined(qr_tsqr_plan* tp);
+/* The schedule chosen by the caller instead: mode 0 = one collective after the local factorisation, 1 = panel-pipelined (QR_E_ARG when the
+ * plan's shape cannot run it), 2 = back to the library's rule.  COLLECTIVE in the sense that every rank must make the same call between the
+ * same two factorisations (the two forms issue different collectives); drains the plan.  bench.py --gpus N uses it to time both forms. */
+int qr_tsqr_set_schedule(qr_tsqr_plan* tp, int mode);
 /* The exchange of the last pipelined qr_tsqr_factor_dev, from events on the stacked plan's stream (drains the plan's streams):
  * out5[0] = sum over the block columns of [stacked stream past its wait for the local panel -> gather done] in ms, out5[1] = the longest
  * of them, out5[2] = the whole call, out5[3] = 1 pipelined / 0 one collective, out5[4] = 1 when the ranks fell back together.

@@ -1,7 +1,7 @@
 """Single-rank RCCL round trip through the library's OWN loader (qr_comm.hip: dlopen librccl, ncclGetUniqueId, ncclCommInitRank,
 ncclAllGather on a plan's stream) in a process that has torch -- and torch's bundled HIP runtime and RCCL -- loaded, as bench.py has.
 What a one-GPU box can check of the multi-GPU transport: library resolution, symbol binding, the bootstrap, a collective kernel on the
-library's stream.   python devtools/tools_rccl_1rank.py"""
+library's stream.   python tests/rccl_single_rank_roundtrip.py"""
 import os as _os, sys as _sys
 _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

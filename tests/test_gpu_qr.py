@@ -734,6 +734,48 @@ def test_tsqr_selfgather_back_to_back_and_unpipelined_agree(qr, oracle):
     assert rel(oracle.sign_normalise(np.load(path)), outs[0]) < 1e-13
 
 
+def test_tsqr_set_schedule_switches_between_the_two_exchange_forms_in_one_plan(qr, oracle):
+    """qr_tsqr_set_schedule: one plan runs the panel-pipelined and the one-collective exchange (what bench.py --gpus N uses to print both
+    schedules per rank).  Both give the same R; the gather statistics belong to the pipelined form only; mode 2 re-arms the library's rule;
+    the diagnostic self-gather never takes part in the decision (three calls after mode 2 leave the plan pipelined)."""
+    m_local, n, P = 32768, 256, 4
+    tp = qr.TsqrPlan(m_local, n, P, 1, 128, comm="external")
+    dA, dR = zeros(m_local, n), zeros(n, n)
+    tp.local.fill_uniform(dA, m_local, m_local, n, seed=91)
+    tp.sync()
+    A0 = host(dA)
+    ref = oracle.sign_normalise(np.linalg.qr(A0, mode="r")) * np.sqrt(P)
+    got = {}
+    for mode in (1, 0, 1, 2):
+        tp.set_schedule(mode)
+        assert tp.is_pipelined() == (mode != 0)
+        dA.copy_(torch.from_numpy(np.ascontiguousarray(A0.T)).cuda())
+        torch.cuda.synchronize()
+        for _ in range(3 if mode == 2 else 1):
+            tp.factor_selfgather(dA, m_local, dR)
+            tp.sync()
+            if mode == 2:
+                dA.copy_(torch.from_numpy(np.ascontiguousarray(A0.T)).cuda()); torch.cuda.synchronize()
+        got[mode] = oracle.sign_normalise(host(dR))
+        assert rel(got[mode], ref) < 1e-13
+        gs = tp.gather_stats()
+        if mode == 0:
+            assert not gs["pipelined"]
+        else:
+            assert gs["pipelined"] and gs["gather_ms"] > 0 and not gs["fell_back"]
+    assert tp.is_pipelined()
+    assert rel(got[0], got[1]) < 1e-13
+    with pytest.raises(Exception):
+        tp.set_schedule(3)
+    tp.close()
+    small = qr.TsqrPlan(4096, 64, 2, 0, 64, comm="external")       # one block column: the pipelined form does not exist for this shape
+    assert not small.is_pipelined()
+    with pytest.raises(Exception):
+        small.set_schedule(1)
+    small.set_schedule(0)
+    small.close()
+
+
 def test_tsqr_exchange_buffers_as_torch_views(qr, oracle):
     """The fallback transport of bench.py (torch.distributed gathers the R factors when the library cannot create its own RCCL
     communicator) works directly on the plan's device buffers through zero-copy torch views: the send view must show this rank's R

@@ -186,7 +186,7 @@ def test_rccl_single_rank_round_trip_through_the_librarys_loader():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "devtools", "tools_rccl_1rank.py")], capture_output=True, text=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_single_rank_roundtrip.py")], capture_output=True, text=True,
                          timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

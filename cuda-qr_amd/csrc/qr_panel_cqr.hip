@@ -48,7 +48,7 @@ constexpr int CQ_X3 = 11 * CQ_W * CQ_W;
 constexpr int CQ_SV = 12 * CQ_W * CQ_W;   // S (CQ_W doubles)
 constexpr int CQ_ST = 12 * CQ_W * CQ_W + CQ_W;   // 64 phase stamps of the one-workgroup kernels (CQ_STAMPS builds)
 constexpr int CQ_SL = CQ_ST + 64;                  // Gram partials of the streaming passes: 256 workgroups x 36 tiles x 256 doubles (19 MB)
-constexpr int CQ_WS = CQ_SL + 257 * 36 * 256;          // (+ 1: the ragged tail of the direct pass 2 goes through the old kernel)
+constexpr int CQ_WS = CQ_SL + 256 * 36 * 256;
 
 // Workspace traffic of the one-workgroup kernels: plain stores and loads.  Every workspace matrix is written ONCE per launch and read
 // only after cq_sync_global() (so no line of it can be in this compute unit's cache before it is written); agent-scope atomic stores
@@ -743,6 +743,11 @@ constexpr int CS_NWG_GRAM = 256;                               // workgroups (= 
 constexpr size_t CS_LDS_BYTES = sizeof(double) * (CS_XC + 4 * 16 * CS_QLD);
 constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass
 __device__ __forceinline__ int cs_blk(int kb, int jb) { return (jb * (jb + 1) / 2 + kb) * 256; }
+// the 144 (tile jt, k-step ks) pairs of a 16-row block's product in order: chain jt (4 (jt + 1) MFMAs) starts at n = 2 jt (jt + 1)
+__host__ __device__ constexpr int cs_n_jt(int n) { int jt = 0; while (2 * (jt + 1) * (jt + 2) <= n) ++jt; return jt; }
+__host__ __device__ constexpr int cs_n_ks(int n) { return n - 2 * cs_n_jt(n) * (cs_n_jt(n) + 1); }
+struct cs_true { static constexpr bool value = true; };
+struct cs_false { static constexpr bool value = false; };
 
 // tile row TR of the Gram matrix of the workgroup's 64 x w block in LDS: tiles (TR, TR .. 7), 16 k-steps of 4 rows; the B operands of a
 // k-step are read together, unconditionally (the block's LDS rows are 130 doubles whatever w), then the matrix-core instructions
@@ -840,30 +845,58 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
         const int tile = 4 * blk + wave;
         // the next block's rows are requested before this block's matrix-core work: with GRAM into q itself once the block has gone to
         // LDS / through the product (the Gram instructions cover the latency, and a second buffer would cost the second wave per SIMD)
-        if (!GRAM) load(qn, tile + 4 * gridDim.x);            // (a tile beyond the end loads nothing: predicate in load)
         const int row = 16 * tile + l15;
         const bool rin = row < mk;
         if (MULT) {
             // (one column tile at a time: with the k-step outermost -- eight interleaved accumulator chains -- the stores came in one burst
-            // at the end and the pass was 10 % slower; tiles in pairs (jt, 7 - jt), two chains: 271 against 240 us)
+            // at the end and the pass was 10 % slower; tiles in pairs (jt, 7 - jt), two chains: 271 against 240 us.)
+            // Round 5: the vector-memory instructions are dealt out BETWEEN the matrix-core instructions, in a pinned order: the stores
+            // of tile jt - 1 one per MFMA from the third MFMA of tile jt on (its results are then two MFMAs old: no wait states to pad),
+            // and -- the pass without a Gram phase -- the next block's loads one per four MFMAs.  In a burst they fill the CU's
+            // vector-memory queue, the wave waits AT the instruction and the MFMAs behind it wait too (in-order issue).
+            const int tn = tile + 4 * gridDim.x, rown = 16 * tn + l15;
+            const double* spn = src + (rown < mk ? rown : mk - 1);
+            auto store_reg = [&](const v4d& acc, int jt, int r) {
+                const int colj = 16 * jt + l4 + 4 * r;
+                if (rin) {
+                    dst[row + (size_t) colj * ldd] = acc[r];
+                    if (DST2) dst2[row + (size_t) colj * ldd2] = acc[r];
+                }
+                if (GRAM) Qt[l15 * CS_QLD + colj] = rin ? acc[r] : 0.0;
+            };
+            // The X operand of MFMA n (n counts the 144 (tile, k-step) pairs in order) is read from LDS four MFMAs ahead into a ring of eight
+            // registers: with the order pinned MFMA by MFMA the compiler cannot hoist the read itself, and a read in front of its own MFMA
+            // costs the LDS latency per instruction.  fullw: 128 columns, no test around an instruction.
+            auto product = [&](auto fullw) {
+                constexpr bool FW = decltype(fullw)::value;
+                auto xop = [&](int n) { return Xc[cs_blk(cs_n_ks(n) >> 2, cs_n_jt(n)) + (4 * (cs_n_ks(n) & 3) + l4) * 16 + l15]; };
+                double xr[8];
 #pragma unroll
-            for (int jt = 0; jt < 8; ++jt) {
-                if (jt < nct) {
+                for (int n = 0; n < 4; ++n) xr[n] = xop(n);
+                v4d accp = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int jt = 0; jt < 8; ++jt) {
                     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int ks = 0; ks < 4 * (jt + 1); ++ks)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xc[cs_blk(ks >> 2, jt) + (4 * (ks & 3) + l4) * 16 + l15], q[ks], acc, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int colj = 16 * jt + l4 + 4 * r;
-                        if (rin) {
-                            dst[row + (size_t) colj * ldd] = acc[r];
-                            if (DST2) dst2[row + (size_t) colj * ldd2] = acc[r];
+                    for (int ks = 0; ks < 4 * (jt + 1); ++ks) {
+                        const int n = 2 * jt * (jt + 1) + ks;
+                        if (n + 4 < 144) xr[(n + 4) & 7] = xop(n + 4);
+                        if (FW || jt < nct) {
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[n & 7], q[ks], acc, 0, 0, 0);
+                            if (jt > 0 && ks >= 2 && ks < 6) store_reg(accp, jt - 1, ks - 2);
                         }
-                        if (GRAM) Qt[l15 * CS_QLD + colj] = rin ? acc[r] : 0.0;
+                        if (!GRAM && (ks & 3) == 3 && jt * (jt + 1) / 2 + (ks >> 2) < 32) {
+                            const int i = jt * (jt + 1) / 2 + (ks >> 2);
+                            qn[i] = spn[(size_t) (4 * i + l4 < w ? 4 * i + l4 : 0) * lds_];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (FW || jt < nct) accp = acc;
                 }
-            }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_reg(accp, nct - 1, r);
+            };
+            if (nct == 8) product(cs_true{}); else product(cs_false{});
         } else if (GRAM) {
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks)
@@ -914,443 +947,6 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, con
     cqr_stream_body<false, true, false>(sm, nullptr, w, mk, src, lds_, nullptr, 0, nullptr, 0, slabs, nullptr);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Round 5: the streaming passes at w = 128 WITHOUT the LDS transposition and its two barriers per block (6.2 us per 64-row block
-// where the 144 matrix-core instructions of a wave account for 3.8).  A Gram matrix sums over ROWS, and the four rows an MFMA step
-// contracts over may be any four: a lane loads its own column (l15) at two consecutive rows per 16-byte load, and the register it gets
-// IS both the A operand (transposed strip) and the B operand of the step -- no exchange between lanes, no LDS, no barrier.
-// All 36 accumulator tiles of the upper triangle in one wave are 288 registers: the compiler shuffles them between the two register
-// files at every step (913 v_accvgpr moves and 118 scratch accesses around 144 MFMAs).  So the waves work in PAIRS on the same rows:
-// both load them (the second load hits in the CU's L1), each keeps 18 of the 36 tiles (144 accumulator registers).
-// Rows are dealt to the 512 wave pairs of the launch in groups of 16 (one 128-byte line per column and group), three groups in flight.
-// ---------------------------------------------------------------------------------------------------------------------------------
-typedef double v2d __attribute__((ext_vector_type(2)));
-constexpr int CD_TILES = 36, CD_HALF = 18;
-constexpr size_t CD_LDS_BYTES = sizeof(double) * CD_TILES * 256;                  // the sum over the two pairs of a workgroup
-
-// The long-lived accumulators are pinned to the accumulation registers by hand: with the builtin the compiler keeps a value that is
-// live around a loop in the vector file and copies all 144 registers into the accumulation file at the top of every trip and back at
-// the bottom (288 v_accvgpr moves per 216 MFMAs, the read-back behind the last MFMA's full latency).  Inline asm hides the
-// instruction from the hazard recogniser: consecutive MFMAs below never touch the same accumulator (18 apart), operands come straight
-// from loads (s_waitcnt is inserted from the operand lists), and cd_acc_fence() puts the wait states the ISA asks for between the
-// matrix cores and the vector ALU on either side of a run.
-__device__ __forceinline__ void cd_mfma(v4d& acc, double a, double b)
-{
-    asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void cd_acc_fence(v4d (&g)[CD_HALF])
-{
-    asm volatile("s_nop 15\n\ts_nop 15"
-                 : "+a"(g[0]), "+a"(g[1]), "+a"(g[2]), "+a"(g[3]), "+a"(g[4]), "+a"(g[5]), "+a"(g[6]), "+a"(g[7]), "+a"(g[8]), "+a"(g[9]),
-                   "+a"(g[10]), "+a"(g[11]), "+a"(g[12]), "+a"(g[13]), "+a"(g[14]), "+a"(g[15]), "+a"(g[16]), "+a"(g[17]));
-}
-// x[2 cg + h][e]: column 16 cg + l15, row 16 grp + 8 h + 2 l4 + e  ->  MFMA step u = 2 h + e contracts over rows {8 h + e + 2 l4'}.
-// Tile t = cj (cj + 1) / 2 + ci (ci <= cj) belongs to the wave of parity t & 1, accumulator t >> 1.
-template <int PAR, bool PINNED>
-__device__ __forceinline__ void cd_gram_steps(v4d (&g)[CD_HALF], const v2d (&x)[16])
-{
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        int t = 0;
-#pragma unroll
-        for (int cj = 0; cj < 8; ++cj)
-#pragma unroll
-            for (int ci = 0; ci <= cj; ++ci, ++t)
-                if ((t & 1) == PAR) {
-                    if (PINNED) cd_mfma(g[t >> 1], x[2 * ci + (u >> 1)][u & 1], x[2 * cj + (u >> 1)][u & 1]);
-                    else g[t >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2 * ci + (u >> 1)][u & 1], x[2 * cj + (u >> 1)][u & 1], g[t >> 1], 0, 0, 0);
-                }
-    }
-}
-// pair 1's tiles added to pair 0's through LDS, waves 0 and 1 write the workgroup's slab (the layout cqr_gram_reduce_kernel reads)
-__device__ __forceinline__ void cd_reduce_out(v4d (&g)[CD_HALF], double* sm, double* out, int wave, int lane)
-{
-    const int par = wave & 1;
-    if (wave >= 2)
-#pragma unroll
-        for (int k = 0; k < CD_HALF; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm[(2 * k + par) * 256 + r * 64 + lane] = g[k][r];
-    __syncthreads();
-    if (wave < 2)
-#pragma unroll
-        for (int k = 0; k < CD_HALF; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[(2 * k + par) * 256 + r * 64 + lane] = g[k][r] + sm[(2 * k + par) * 256 + r * 64 + lane];
-}
-
-// EXP (lab builds of the kernel, MI355XQR_CD_EXP): 1 = the matrix-core instructions replaced by one add per loaded value, 2 = no loads
-// inside the loop (the first three groups over and over)
-template <int PAR, int EXP>
-__device__ __forceinline__ void cd_gram_body(double* sm, int mk, const double* __restrict__ src, int lds_, double* slabs)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
-    v4d g[CD_HALF];
-#pragma unroll
-    for (int t = 0; t < CD_HALF; ++t) g[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int ngrp = mk >> 4, stride = 2 * gridDim.x, pair = 2 * blockIdx.x + (wave >> 1);
-    v2d a[16], b[16], c[16];
-    // the ragged tail first (mk not a multiple of 16): one pair, rows beyond the panel read as zero, through the builtin
-    if ((mk & 15) && pair == ngrp % stride) {
-        const int r0 = 16 * ngrp;
-#pragma unroll
-        for (int cg = 0; cg < 8; ++cg)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int row = r0 + 8 * h + 2 * l4 + e;
-                    a[2 * cg + h][e] = row < mk ? src[(size_t) (16 * cg + l15) * lds_ + row] : 0.0;
-                }
-        cd_gram_steps<PAR, false>(g, a);
-    }
-    cd_acc_fence(g);
-    const double* base = src + (size_t) l15 * lds_ + 2 * l4;
-    // unconditional loads of a clamped group: a branch around a load makes the compiler's wait counts pessimistic at the join
-    const double* base_rows = src + l15 + (size_t) l4 * lds_;        // (lab: lane = row, four columns of 128 bytes per load)
-    auto load = [&](v2d (&x)[16], int grp) {
-        if ((EXP == 3 || EXP == 5) && PAR == 1) return;          // (lab: one wave of the pair loads)
-        if (EXP == 4 || EXP == 5) {
-            const double* p = base_rows + 16 * (size_t) (grp < ngrp ? grp : ngrp - 1);
-#pragma unroll
-            for (int ks = 0; ks < 32; ++ks) x[ks >> 1][ks & 1] = p[(size_t) (4 * ks) * lds_];
-            return;
-        }
-        const double* p = base + 16 * (size_t) (grp < ngrp ? grp : ngrp - 1);
-#pragma unroll
-        for (int cg = 0; cg < 8; ++cg) {
-            x[2 * cg] = *reinterpret_cast<const v2d*>(p + (size_t) (16 * cg) * lds_);
-            x[2 * cg + 1] = *reinterpret_cast<const v2d*>(p + (size_t) (16 * cg) * lds_ + 8);
-        }
-    };
-    // every pair has `full` groups or one more: the bulk in a counted loop of three groups per trip, the rest behind it
-    const int full = ngrp / stride, mine = full + (pair < ngrp - full * stride ? 1 : 0), ntrip = mine / 3;
-    int grp = pair;
-    if (ngrp > 0) { load(a, grp); load(b, grp + stride); }
-    double sink = 0.0;
-    auto steps = [&](const v2d (&x)[16]) {
-        if (EXP == 1 || EXP >= 3) {
-            if ((EXP == 3 || EXP == 5) && PAR == 1) return;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sink += x[i][0] + x[i][1];
-        } else cd_gram_steps<PAR, true>(g, x);
-    };
-    if (EXP == 2 && ngrp > 0) load(c, grp + 2 * stride);
-    for (int it = 0; it < ntrip; ++it) {
-        if (EXP != 2) load(c, grp + 2 * stride);
-        steps(a);
-        if (EXP != 2) load(a, grp + 3 * stride);
-        steps(b);
-        if (EXP != 2) load(b, grp + 4 * stride);
-        steps(c);
-        grp += 3 * stride;
-    }
-    if (EXP == 1 || EXP >= 3) g[0][0] += sink;
-    const int left = mine - 3 * ntrip;                        // 0 .. 2
-    if (left > 0) cd_gram_steps<PAR, true>(g, a);
-    if (left > 1) cd_gram_steps<PAR, true>(g, b);
-    cd_acc_fence(g);
-    cd_reduce_out(g, sm, slabs + (size_t) blockIdx.x * CD_TILES * 256, wave, lane);
-}
-
-// The pair WITHOUT the duplicated loads (lab table, profiles/r05_cqr_direct_passes.txt: loads alone take 120 us when both waves of a
-// pair load every column -- the second wave's loads miss in L1 more often than not -- and 58 us when each row is loaded once): a wave
-// loads the four column groups of ITS half, hands them to its partner through LDS (lane-linear 16-byte writes and reads: conflict-free)
-// and takes the partner's half.  One LDS-only barrier per group; the exchange runs one group ahead of the matrix cores (the partner's
-// half of group j + 1 lands under the MFMAs of group j) and the global loads four groups ahead.
-// mid(i), i = 0 .. 7: called after every ninth matrix-core instruction -- the caller issues ONE global load there.  A burst of loads at
-// the head of the group fills the CU's vector-memory queue, the wave then waits AT the load instruction, and in-order issue keeps the
-// MFMAs behind it waiting too: memory time and matrix-core time add up although every s_waitcnt is satisfied long before it is reached
-template <int PAR, bool PINNED, class FM>
-__device__ __forceinline__ void cd_gram_steps2(v4d (&g)[CD_HALF], const v2d (&own)[8], const v2d (&oth)[8], FM mid)
-{
-    int n = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        int t = 0;
-#pragma unroll
-        for (int cj = 0; cj < 8; ++cj)
-#pragma unroll
-            for (int ci = 0; ci <= cj; ++ci, ++t)
-                if ((t & 1) == PAR) {
-                    const double xa = ((ci >> 2) == PAR) ? own[2 * (ci & 3) + (u >> 1)][u & 1] : oth[2 * (ci & 3) + (u >> 1)][u & 1];
-                    const double xb = ((cj >> 2) == PAR) ? own[2 * (cj & 3) + (u >> 1)][u & 1] : oth[2 * (cj & 3) + (u >> 1)][u & 1];
-                    if (PINNED) cd_mfma(g[t >> 1], xa, xb);
-                    else g[t >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, g[t >> 1], 0, 0, 0);
-                    if (n % 9 == 4) mid(n / 9);
-                    ++n;
-                }
-    }
-}
-template <int PAR>
-__device__ __forceinline__ void cd_gram_xchg_body(double* sm, int mk, const double* __restrict__ src, int lds_, double* slabs)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
-    v4d g[CD_HALF];
-#pragma unroll
-    for (int t = 0; t < CD_HALF; ++t) g[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int ngrp = mk >> 4, stride = 2 * gridDim.x, pw = wave >> 1, pair = 2 * blockIdx.x + pw;
-    v2d O0[8], O1[8], O2[8], O3[8], P0[8], P1[8];
-    // the ragged tail first (mk not a multiple of 16): one pair, both waves read all of it, rows beyond the panel as zero, the builtin
-    if ((mk & 15) && pair == ngrp % stride) {
-        const int r0 = 16 * ngrp;
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int row = r0 + 8 * h + 2 * l4 + e;
-                        const double v = row < mk ? src[(size_t) (64 * (half ? 1 - PAR : PAR) + 16 * i + l15) * lds_ + row] : 0.0;
-                        if (half) P0[2 * i + h][e] = v; else O0[2 * i + h][e] = v;
-                    }
-        cd_gram_steps2<PAR, false>(g, O0, P0, [](int) {});
-    }
-    cd_acc_fence(g);
-    const double* base = src + (size_t) (64 * PAR + l15) * lds_ + 2 * l4;
-    auto load = [&](v2d (&o)[8], int grp) {                   // (unconditional, clamped: see cd_gram_body)
-        const double* p = base + 16 * (size_t) (grp < ngrp ? grp : ngrp - 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[2 * i] = *reinterpret_cast<const v2d*>(p + (size_t) (16 * i) * lds_);
-            o[2 * i + 1] = *reinterpret_cast<const v2d*>(p + (size_t) (16 * i) * lds_ + 8);
-        }
-    };
-    v2d* ex = reinterpret_cast<v2d*>(sm);                     // [buffer 2][pair 2][wave of the pair 2][8][64 lanes]
-    auto put = [&](const v2d (&o)[8], int buf) {
-        v2d* e = ex + (((buf * 2 + pw) * 2 + PAR) * 8) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[64 * i] = o[i];
-    };
-    auto get = [&](v2d (&q)[8], int buf) {
-        const v2d* e = ex + (((buf * 2 + pw) * 2 + (1 - PAR)) * 8) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = e[64 * i];
-    };
-    const int full = ngrp / stride, rest = ngrp - full * stride;
-    const int mine = full + (pair < rest ? 1 : 0), nstep = full + (2 * (int) blockIdx.x < rest ? 1 : 0);        // the workgroup's steps: its first pair's
-    int grp = pair;
-    if (ngrp > 0) {
-        load(O0, grp); load(O1, grp + stride); load(O2, grp + 2 * stride);
-        put(O0, 0);
-        cs_lds_barrier();
-        get(P0, 0);
-    }
-    // group j: operands (Oc, Pc) complete in registers; its successor's own half On goes to the partner, Oc is reloaded with group j + 4
-    // (Of: the buffer of group j - 1, free since that group's MFMAs: it takes group j + 3, one load per nine MFMAs)
-    auto step = [&](int j, v2d (&Oc)[8], v2d (&Pc)[8], v2d (&On)[8], v2d (&Pn)[8], v2d (&Of)[8]) {
-        put(On, (j + 1) & 1);
-        cs_lds_barrier();
-        get(Pn, (j + 1) & 1);
-        const int gl = grp + 3 * stride;
-        const double* p = base + 16 * (size_t) (gl < ngrp ? gl : ngrp - 1);
-        if (j < mine)
-            cd_gram_steps2<PAR, true>(g, Oc, Pc, [&](int i) { Of[i] = *reinterpret_cast<const v2d*>(p + (size_t) (16 * (i >> 1)) * lds_ + 8 * (i & 1)); });
-        else
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Of[i] = *reinterpret_cast<const v2d*>(p + (size_t) (16 * (i >> 1)) * lds_ + 8 * (i & 1));
-        grp += stride;
-    };
-    for (int j = 0; j < nstep; j += 4) {
-        step(j, O0, P0, O1, P1, O3);
-        if (j + 1 >= nstep) break;
-        step(j + 1, O1, P1, O2, P0, O0);
-        if (j + 2 >= nstep) break;
-        step(j + 2, O2, P0, O3, P1, O1);
-        if (j + 3 >= nstep) break;
-        step(j + 3, O3, P1, O0, P0, O2);
-    }
-    cd_acc_fence(g);
-    __syncthreads();                                          // the exchange buffers become the reduction's
-    cd_reduce_out(g, sm, slabs + (size_t) blockIdx.x * CD_TILES * 256, wave, lane);
-}
-__global__ __launch_bounds__(CS_THREADS) void cqr_gram_xchg_kernel(int mk, const double* __restrict__ src, int lds_, double* slabs)
-{
-    extern __shared__ double sm[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cd_gram_xchg_body<1>(sm, mk, src, lds_, slabs);
-    else cd_gram_xchg_body<0>(sm, mk, src, lds_, slabs);
-}
-
-// G1 = A^T A, w = 128, src 16-byte aligned with an even leading dimension (the launcher checks)
-__global__ __launch_bounds__(CS_THREADS) void cqr_gram_direct_kernel(int mk, const double* __restrict__ src, int lds_, double* slabs)
-{
-    extern __shared__ double sm[];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cd_gram_body<1, 0>(sm, mk, src, lds_, slabs);
-    else cd_gram_body<0, 0>(sm, mk, src, lds_, slabs);
-}
-// (lab) clk[2 EXP], clk[2 EXP + 1]: shader-clock and 100 MHz ticks of workgroup 0's first wave across the kernel body
-template <int EXP>
-__global__ __launch_bounds__(CS_THREADS) void cqr_gram_direct_lab_kernel(int mk, const double* __restrict__ src, int lds_, double* slabs,
-                                                                         unsigned long long* clk)
-{
-    extern __shared__ double sm[];
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cd_gram_body<1, EXP>(sm, mk, src, lds_, slabs);
-    else cd_gram_body<0, EXP>(sm, mk, src, lds_, slabs);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[2 * EXP] = __builtin_amdgcn_s_memtime() - c0; clk[2 * EXP + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Pass 2 in the same spirit: Q = A R1^-1 -> dst, G2 = Q^T Q, w = 128.  The product is taken UNtransposed, D(row, col) = sum_k
-// src(row, k) X(k, col): the operand registers are the ones the old pass loads (lane l15 = a row of the group, l4 = a column of the
-// k-step), X comes from the same compact LDS image (now as operand B), and with the group's rows dealt to l15 as rho(i) = 4 (i & 3) +
-// (i >> 2) accumulator register r of lane (l15, l4) is Q(row 4 l4 + r, column l15): four CONSECUTIVE rows per lane (two 16-byte
-// stores) and -- the point -- register r of a tile is, as it stands, both operands of the Gram step over the rows {4 l4' + r}.
-// No transposition.  A pair of waves shares a 16-row group: wave 0 of the pair computes column tiles {2, 6, 7}, wave 1 {0, 1, 3, 4, 5}
-// (18 units of four MFMAs each), they swap tiles through LDS (lane-linear: conflict-free, one LDS-only barrier per group, two
-// buffers), and each accumulates 18 of the 36 Gram tiles: 144 matrix-core instructions per wave and group, as before, without the
-// 2.4 us per block the transposition and its barriers cost.
-// ---------------------------------------------------------------------------------------------------------------------------------
-constexpr bool cd_in_a(int c) { return c == 2 || c == 6 || c == 7; }
-// which wave of the pair accumulates Gram tile (ci <= cj): tiles inside one wave's column set stay there; of the 15 mixed ones wave 1
-// takes (0,2), (1,2), (2,3) -- it then needs only D2 from its partner -- and wave 0 the other twelve
-constexpr int cd_owner(int ci, int cj)
-{
-    return (cd_in_a(ci) && cd_in_a(cj)) ? 0 : ((!cd_in_a(ci) && !cd_in_a(cj)) ? 1 : (((ci == 2 || cj == 2) && ci <= 3 && cj <= 3) ? 1 : 0));
-}
-constexpr size_t CD_QG_LDS_BYTES = sizeof(double) * (CS_XC + 2 * 2 * 8 * 256);   // X, and two exchange buffers of eight tiles per pair
-
-template <int PAR>
-__device__ __forceinline__ void cd_qgram_body(double* sm, const double* __restrict__ X, int mk, const double* __restrict__ src, int lds_,
-                                              double* __restrict__ dst, int ldd, double* slabs)
-{
-    double* Xc = sm;
-    double* Dx = sm + CS_XC;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
-    for (int e = tid; e < CQ_W * CQ_W; e += CS_THREADS) {
-        const int k = e >> 7, j = e & (CQ_W - 1);
-        if (j >= (k & ~15)) Xc[cs_blk(k >> 4, j >> 4) + (k & 15) * 16 + (j & 15)] = X[k * CQ_W + j];
-    }
-    __syncthreads();
-    v4d g[CD_HALF];
-#pragma unroll
-    for (int t = 0; t < CD_HALF; ++t) g[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    cd_acc_fence(g);
-    constexpr int NKS = PAR ? 24 : 32;                        // wave 1's widest tile is 5: columns < 96
-    const int ngrp = mk >> 4, stride = 2 * gridDim.x, pw = wave >> 1, pair = 2 * blockIdx.x + pw;
-    const int full = ngrp / stride, rest = ngrp - full * stride;
-    const int mine = full + (pair < rest ? 1 : 0), nstep = full + (2 * (int) blockIdx.x < rest ? 1 : 0);       // steps of the workgroup: its first pair's
-    const int rho = 4 * (l15 & 3) + (l15 >> 2);
-    const double* lbase = src + rho + (size_t) l4 * lds_;
-    auto load = [&](double (&x)[NKS], int grp) {
-        const double* p = lbase + 16 * (size_t) (grp < ngrp ? grp : ngrp - 1);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) x[ks] = p[(size_t) (4 * ks) * lds_];
-    };
-    double* sbase = dst + (size_t) l15 * ldd + 4 * l4;
-    const double* xop = Xc + l4 * 16 + l15;
-    // one group: the product of this wave's column tiles, Q stored, the tiles the partner needs into the exchange buffer
-    v4d D[8];
-    auto product = [&](const double (&x)[NKS], int grp, double* dx) {
-#pragma unroll
-        for (int jt = 0; jt < 8; ++jt) {
-            if (cd_in_a(jt) != (PAR == 0)) continue;
-            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4 * (jt + 1); ++ks)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks], xop[cs_blk(ks >> 2, jt) + 64 * (ks & 3)], acc, 0, 0, 0);
-            D[jt] = acc;
-            double* q = sbase + (size_t) (16 * jt) * ldd + 16 * (size_t) grp;
-            *reinterpret_cast<v2d*>(q) = (v2d){acc[0], acc[1]};
-            *reinterpret_cast<v2d*>(q + 2) = (v2d){acc[2], acc[3]};
-            if (PAR == 1 || jt == 2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dx[jt * 256 + r * 64 + lane] = acc[r];
-        }
-    };
-    auto gram = [&](const double* dx) {
-#pragma unroll
-        for (int jt = 0; jt < 8; ++jt)
-            if (cd_in_a(jt) != (PAR == 0) && (PAR == 0 || jt == 2))
-#pragma unroll
-                for (int r = 0; r < 4; ++r) D[jt][r] = dx[jt * 256 + r * 64 + lane];
-        // (this wave's own tiles reach the vector file through v_accvgpr_read: the wait states between a VALU write and a matrix-core
-        // read of the same register are ours to provide -- without them the first MFMA of the run read a stale operand)
-        if (PAR == 0) asm volatile("s_nop 7" : "+v"(D[2]), "+v"(D[6]), "+v"(D[7]));
-        else asm volatile("s_nop 7" : "+v"(D[0]), "+v"(D[1]), "+v"(D[3]), "+v"(D[4]), "+v"(D[5]));
-        // tiles of this wave's own columns first: the partner's tiles are still on their way from LDS
-#pragma unroll
-        for (int mixed = 0; mixed < 2; ++mixed)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int k = 0;
-#pragma unroll
-                for (int cj = 0; cj < 8; ++cj)
-#pragma unroll
-                    for (int ci = 0; ci <= cj; ++ci)
-                        if (cd_owner(ci, cj) == PAR) {
-                            const bool own = (cd_in_a(ci) == (PAR == 0)) && (cd_in_a(cj) == (PAR == 0));
-                            if (own != (mixed == 1)) cd_mfma(g[k], D[ci][r], D[cj][r]);
-                            ++k;
-                        }
-            }
-    };
-    double qa[NKS], qb[NKS];
-    if (ngrp > 0) { load(qa, pair); load(qb, pair + stride); }
-    int grp = pair;
-    for (int i = 0; i < nstep; i += 2) {
-        // even step: qa, exchange buffer 0
-        double* dx0 = Dx + (0 * 2 + pw) * 8 * 256;
-        if (i < mine) product(qa, grp, dx0);
-        load(qa, grp + 2 * stride);
-        cs_lds_barrier();
-        if (i < mine) gram(dx0);
-        grp += stride;
-        if (i + 1 >= nstep) break;
-        double* dx1 = Dx + (1 * 2 + pw) * 8 * 256;
-        if (i + 1 < mine) product(qb, grp, dx1);
-        load(qb, grp + 2 * stride);
-        cs_lds_barrier();
-        if (i + 1 < mine) gram(dx1);
-        grp += stride;
-    }
-    cd_acc_fence(g);
-    // pair 1's tiles added to pair 0's through LDS (over X and the exchange buffers), waves 0 and 1 write the workgroup's slab
-    __syncthreads();
-    double* out = slabs + (size_t) blockIdx.x * CD_TILES * 256;
-    {
-        int k = 0;
-#pragma unroll
-        for (int cj = 0; cj < 8; ++cj)
-#pragma unroll
-            for (int ci = 0; ci <= cj; ++ci)
-                if (cd_owner(ci, cj) == PAR) {
-                    if (wave >= 2)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sm[(cj * (cj + 1) / 2 + ci) * 256 + r * 64 + lane] = g[k][r];
-                    ++k;
-                }
-    }
-    __syncthreads();
-    if (wave < 2) {
-        int k = 0;
-#pragma unroll
-        for (int cj = 0; cj < 8; ++cj)
-#pragma unroll
-            for (int ci = 0; ci <= cj; ++ci)
-                if (cd_owner(ci, cj) == PAR) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int o = (cj * (cj + 1) / 2 + ci) * 256 + r * 64 + lane;
-                        out[o] = g[k][r] + sm[o];
-                    }
-                    ++k;
-                }
-    }
-}
-
-// the full 16-row groups of the panel (the launcher sends a ragged tail through cqr_stream_kernel); dst 16-byte aligned, ldd even
-__global__ __launch_bounds__(CS_THREADS) void cqr_qgram_direct_kernel(const double* __restrict__ X, int mk, const double* __restrict__ src, int lds_,
-                                                                      double* __restrict__ dst, int ldd, double* slabs, const int* status)
-{
-    extern __shared__ double sm[];
-    if (status && status[0]) return;                          // refused by the first Cholesky: nothing is written
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) cd_qgram_body<1>(sm, X, mk, src, lds_, dst, ldd, slabs);
-    else cd_qgram_body<0>(sm, X, mk, src, lds_, dst, ldd, slabs);
-}
-
 // G (column-major ld CQ_W, both triangles) = sum over the workgroup partials, in slab order.  Tile t = (ti <= tj), accumulator
 // register r of lane l: element (16 ti + (l >> 4) + 4 r, 16 tj + (l & 15)).  Grid: (tiles, 8 chunks of 32 elements).
 __global__ __launch_bounds__(256) void cqr_gram_reduce_kernel(const double* __restrict__ slabs, int nslab, double* G)
@@ -1392,11 +988,6 @@ __global__ __launch_bounds__(256) void cqr_top_kernel(const double* ws, int w, d
 }
 }   // namespace
 
-// MI355XQR_CQR_DIRECT: bit 0 = pass 1, bit 1 = pass 2 through the transposition-free kernels (w = 128, aligned operands); 0 = the
-// LDS-transposing kernels everywhere (A/B measurements)
-static int cd_direct_mode = 1, cd_exp = 0;
-static bool cd_aligned(const double* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 1) == 0; }
-
 extern "C" {
 
 size_t qrd_panel_cqr_ws_doubles(void) { return (size_t) CQ_WS; }
@@ -1410,19 +1001,6 @@ int qrd_panel_cqr_init(void)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_xchg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_qgram_direct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_QG_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_direct_lab_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_direct_lab_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_direct_lab_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_direct_lab_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_direct_lab_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_direct_lab_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CD_LDS_BYTES);
-    const char* d = getenv("MI355XQR_CQR_DIRECT");
-    if (d && *d) cd_direct_mode = atoi(d);
-    d = getenv("MI355XQR_CD_EXP");
-    if (d && *d) cd_exp = atoi(d);
     return (int) e;
 }
 
@@ -1443,46 +1021,12 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
     hipError_t e = hipMemsetAsync(status, 0, sizeof(int), s);
     if (e != hipSuccess) return (int) e;
     const int grid = cs_grid(mk), ggrid = cs_grid(mk, CS_NWG_GRAM), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
-    // the transposition-free passes: 128 columns, 16-byte aligned columns, and at least one 16-row group per wave pair to be worth it
-    const int ngrp = mk >> 4, dgrid = ngrp / 2 < CS_NWG ? (ngrp / 2 > 0 ? ngrp / 2 : 1) : CS_NWG;
-    const bool d1 = (cd_direct_mode & 1) && w == CQ_W && ngrp >= 2 && cd_aligned(A, lda);
-    const bool d2 = (cd_direct_mode & 2) && w == CQ_W && ngrp >= 2 && cd_aligned(Qb, ldq);
-    if (d1 && (cd_exp & 8)) {                                 // (lab) the table of profiles/r05_cqr_direct_passes.txt in one run
-        unsigned long long* clk = reinterpret_cast<unsigned long long*>(ws + CQ_SL + (size_t) 256 * 36 * 256);       // (the spare slab)
-        hipLaunchKernelGGL(cqr_gram_direct_lab_kernel<0>, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL, clk);
-        hipLaunchKernelGGL(cqr_gram_direct_lab_kernel<1>, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL, clk);
-        hipLaunchKernelGGL(cqr_gram_direct_lab_kernel<2>, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL, clk);
-        hipLaunchKernelGGL(cqr_gram_direct_lab_kernel<3>, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL, clk);
-        hipLaunchKernelGGL(cqr_gram_direct_lab_kernel<4>, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL, clk);
-        hipLaunchKernelGGL(cqr_gram_direct_lab_kernel<5>, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL, clk);
-    }
-    if (d1 && !(cd_direct_mode & 4)) {
-        hipLaunchKernelGGL(cqr_gram_xchg_kernel, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL);
-        hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, dgrid, ws + CQ_G1);
-    } else if (d1) {
-        hipLaunchKernelGGL(cqr_gram_direct_kernel, dim3(dgrid), dim3(CS_THREADS), CD_LDS_BYTES, s, mk, (const double*) A, lda, ws + CQ_SL);
-        hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, dgrid, ws + CQ_G1);
-    } else {
-        hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL);
-        hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
-    }
+    hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL);
+    hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
     hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
-    if (d2) {
-        hipLaunchKernelGGL(cqr_qgram_direct_kernel, dim3(dgrid), dim3(CS_THREADS), CD_QG_LDS_BYTES, s, ws + CQ_R1I, mk, (const double*) A, lda, Qb, ldq,
-                           ws + CQ_SL, (const int*) status);
-        int nslab = dgrid;
-        if (mk & 15) {                                        // the rows behind the last full group: the old kernel, one workgroup, its own slab
-            hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(1), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk & 15,
-                               (const double*) A + 16 * (size_t) ngrp, lda, Qb + 16 * (size_t) ngrp, ldq, (double*) nullptr, 0,
-                               ws + CQ_SL + (size_t) dgrid * 36 * 256, status);
-            ++nslab;
-        }
-        hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, nslab, ws + CQ_G2);
-    } else {
-        hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Qb, ldq,
-                           (double*) nullptr, 0, ws + CQ_SL, status);
-        hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
-    }
+    hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Qb, ldq,
+                       (double*) nullptr, 0, ws + CQ_SL, status);
+    hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
     hipLaunchKernelGGL(cqr_post_kernel, dim3(2), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
     hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Qb, ldq, Vw, ldv, A, lda,

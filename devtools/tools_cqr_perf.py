@@ -27,9 +27,3 @@ for pad in pads:
         dt = time.perf_counter() - t0
         if rep: best = min(best, dt)
     print("mk %d w %d lda %d: %.1f us  (rc %d status %s)" % (mk, w, lda, best * 1e6, rc, status.cpu().numpy()[:1]), flush=True)
-if _os.environ.get("MI355XQR_CD_EXP"):
-    off = 12 * 128 * 128 + 128 + 64 + 256 * 36 * 256          # CQ_SL + the 256 slabs (qr_panel_cqr.hip): the lab kernels' clock words
-    clk = ws[off: off + 12].view(torch.int64).cpu().numpy()
-    for e, name in enumerate(("pair loads every column + MFMA", "loads only, both waves load every column", "MFMA only", "loads only, one wave of the pair",
-                              "loads only, lane = row pattern, both waves", "loads only, lane = row pattern, one wave")):
-        if clk[2 * e + 1] > 0: print("lab %d (%s): %.1f us, shader clock %.2f GHz" % (e, name, clk[2 * e + 1] / 100.0, clk[2 * e] / clk[2 * e + 1] * 0.1))

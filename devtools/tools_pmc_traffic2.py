@@ -32,7 +32,8 @@ out = {
    "FETCH_SIZE_KiB": find(F, "stream_copy_kernel")[1], "true_read_KiB": 1048576, "WRITE_SIZE_KiB": find(Wr, "stream_copy_kernel")[1], "true_write_KiB": 1048576},
   "diff_norm_kernel (8 B/lane, 2 GiB read)": {"FETCH_SIZE_KiB": find(F, "diff_norm_kernel")[1], "true_read_KiB": 2097152},
   "rule": "FETCH_SIZE reports 1/2 of coalesced reads on gfx950 (x2 correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE is exact"},
- "gemm_nt_kernel": entry("gemm_nt_kernel", nn_alg),
+ "gemm_nt_kernel": entry("gemm_nt4_kernel" if any(k.startswith("gemm_nt4_kernel") for k in F) else "gemm_nt_kernel", nn_alg),
+ "gemm_nt_kernel_name": next((k for k in F if k.startswith("gemm_nt4_kernel") or k.startswith("gemm_nt_kernel")), None),
  "gemm_tn_kernel<4,4,true,1>": entry("gemm_tn_kernel<4, 4, true, 1>", tn_alg),
 }
 try:

@@ -29,8 +29,6 @@ int qrd_gemm2_init(void);
 int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc);
 int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt,
                 double* C, int ldc, int gm, unsigned long long* stamps);
-int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
-                   int ldv, double* scratch);
 size_t qrd_panel_ws_size(int m);
 int qrd_panel_tsqr_init(void);
 int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv,
@@ -152,7 +150,6 @@ int qrd_probe_mfma_f64(double* out3);
 int qrd_probe_copy(double* gbps);
 
 #define QRD_LEAFW 32
-#define QRD_LEAF_SCRATCH (2 * (256 * QRD_LEAFW + QRD_LEAFW) + QRD_LEAFW * QRD_LEAFW)
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,6 @@
  * dominates and 64 CUs are faster.  A mask bit i is compute unit i/8 of XCC i%8 (profiles/r02_probe_cumask.txt): a contiguous
  * range of 32 bits = 4 CUs of every XCD, so both streams stay balanced over the XCDs; a 48 / 208 split was measured 15 % slower. */
 #define QR_DEFAULT_SPLIT_BIG "32"
-#define QR_DEFAULT_PANEL 3
 struct qr_plan {
     int m, n, nb, ib, ldv, ldt;
     int use_graph;              /* 1: qr_geqrf_dev is captured into a hipGraph once per argument set and replayed */
@@ -72,11 +71,10 @@ struct qr_plan {
     double *Vw2[2], *VT2[2], *T2[2];
     int vt_formed[2];           /* VT2[e] = Vw2[e] * T2[e] of the panel NOW in set e exists (cleared when a panel is factored into the set,
                                  * set where the V*T product is issued): a slice of the wide update that needs it forms it on demand */
-    double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *leaf_scratch, *panel_ws;
+    double *W, *Wn, *Tt, *G, *X, *slabs, *slabs_u, *panel_ws;
     double* slabs_ep;           /* split-K slabs of the leaf's early product: written while the reconstruction still reads p->slabs */
     size_t slab_ep_cap;
-    int panel_tsqr;             /* 0: one launch per column; 1: intra-GPU TSQR + Householder reconstruction; 2: by height;
-                                 * 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
+    int panel_tsqr;             /* 1: Householder-TSQR leaf alone (MI355XQR_PANEL=tsqr); 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
     double* chol_ws;
     double* cq_ws; int* cq_status;   /* small-factor workspace and guard words of the full-width tall panel (qr_panel_cqr.hip); NULL: not used */
     unsigned *cq_hword, *cq_hword_dev;   /* host word (mapped into the device) that receives a tall panel's verdict as soon as it exists */
@@ -89,7 +87,6 @@ struct qr_plan {
     double* pf_ws;              /* exchange workspace of the one-launch panel (qr_panel_fused.hip); NULL: not used */
     unsigned pf_epoch;          /* its epoch counter: the workspace's epoch words never exceed it */
     int* pf_status;             /* device: [0] leaves that took the Householder route inside a one-launch panel, [1] a wait timed out */
-    int tsqr_min_rows;
     size_t slab_cap, w_cap;
     /* profiling */
     int prof_on, prof_mask, prof_count, prof_cap, prof_open, prof_paused;
@@ -418,14 +415,11 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
     if (!rc) rc = qrd_malloc((void**) &p->G, sizeof(double) * (size_t) nb * nb);
     if (!rc) rc = qrd_malloc((void**) &p->X, sizeof(double) * (size_t) nb * nb);
     if (!rc) rc = qrd_malloc((void**) &p->slabs, sizeof(double) * p->slab_cap);
-    if (!rc) rc = qrd_malloc((void**) &p->leaf_scratch, sizeof(double) * QRD_LEAF_SCRATCH);
     {
         const char* pa = getenv("MI355XQR_PANEL");
-        p->panel_tsqr = !pa ? QR_DEFAULT_PANEL : (strcmp(pa, "col") == 0 ? 0 : (strcmp(pa, "tsqr") == 0 ? 1 : (strcmp(pa, "cholqr") == 0 ? 3 : 2)));
-        const char* tm = getenv("MI355XQR_TSQR_MIN_ROWS");
-        p->tsqr_min_rows = tm ? atoi(tm) : 100000;
+        p->panel_tsqr = (pa && strcmp(pa, "tsqr") == 0) ? 1 : 3;
     }
-    if (!rc && p->panel_tsqr) rc = qrd_malloc((void**) &p->panel_ws, sizeof(double) * qrd_panel_ws_size(m));
+    if (!rc) rc = qrd_malloc((void**) &p->panel_ws, sizeof(double) * qrd_panel_ws_size(m));
     if (!rc && p->panel_tsqr == 3) rc = qrd_malloc((void**) &p->chol_ws, sizeof(double) * QRD_CHOLQR_WS);
     if (!rc && p->panel_tsqr == 3 && knobs()->early_product) {
         /* 32 x (nb - 32) outputs per K slice, up to 128 slices */
@@ -479,7 +473,7 @@ int qr_plan_destroy(qr_plan* p)
         if (p->prof_ev && p->prof_ev[i]) qrd_event_destroy(p->prof_ev[i]);
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
-    qrd_free(p->slabs); qrd_free(p->leaf_scratch); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
+    qrd_free(p->slabs); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
     qrd_free(p->pf_ws); qrd_free(p->pf_status); qrd_free(p->cq_ws); qrd_free(p->cq_status);
     qrd_host_word_free(p->cq_hword);
     if (p->s_main) qrd_stream_destroy(p->s_main);
@@ -772,7 +766,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
      * QR_FUSE_NN_MIN_ROWS: leaf heights the fused launch is used for (tall leaves only -- it saves a pass over
      * the next leaf, 262144 x 512: 7.15 -> 7.08 ms; on the short leaves of square problems its 128 matrix-core instructions per
      * wave sit on 10-14 compute units and the launch takes 18 us where gemm_nn + gram32 take 14: 8192^2 32.4 -> 33.0 ms);
-     * MI355XQR_FUSE_NN_GY: column pairs side by side on tall leaves (1 = every workgroup walks all columns, V read once) */
+     * on tall leaves every workgroup walks all columns (V read once) */
     const int fuse_nn = kn->fuse_nn, fuse_nn_min = QR_FUSE_NN_MIN_ROWS, fuse_nn_max = 0, fuse_nn_gy_tall = 1;
     for (int h = 0; h < nhalf; ++h) {
         const int c0 = h * QR_HALF, wh = imin(QR_HALF, wout - c0), cend = c0 + wh;
@@ -809,9 +803,8 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
             double* P = Ak + (size_t) c * lda + c;
             double* Vl = p->Vw + (size_t) c * ldv + c;
             double* Tl = p->T + (size_t) c * ldt + c;
-            /* leaf algorithm (MI355XQR_PANEL = cholqr [default] | tsqr | col | auto): CholeskyQR2 + Householder reconstruction
-             * (4 short launches) guarded by the Householder TSQR leaf (4-6 launches, no-ops unless the guard trips); tsqr = the
-             * Householder TSQR leaf alone; col = one launch per column (34 launches, ~25 passes over the leaf) */
+            /* leaf algorithm (MI355XQR_PANEL = cholqr [default] | tsqr): CholeskyQR2 + Householder reconstruction (4 short launches)
+             * guarded by the Householder TSQR leaf (4-6 launches, no-ops unless the guard trips); tsqr = the Householder TSQR leaf alone */
             const int nrest = cend - (c + w), nprev = gram_done ? c - c0 : 0;
             double* Arest = P + (size_t) w * lda;
             int fused = 0;
@@ -824,10 +817,8 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
             } else if (p->panel_tsqr == 3)
                 CHECK(qrd_panel_cholqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m, p->chol_ws,
                                        p->slabs, p->slab_cap, gram_nslab));
-            else if (p->panel_tsqr == 1 || (p->panel_tsqr == 2 && mkl >= p->tsqr_min_rows))
-                CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
             else
-                CHECK(qrd_leaf_panel(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->leaf_scratch));
+                CHECK(qrd_panel_tsqr(p->stream, P, lda, mkl, w, dtau + k + c, Tl, ldt, Vl, ldv, p->panel_ws, p->m));
             if (!fused && gram_done && w == 32 && nrest + nprev > 0) {
                 /* Wn, not W: with look-ahead the wide update on stream_u owns p->W while this panel runs */
                 const int rc = qrd_gemm_tn_dual(p->stream, nrest, nprev, mkl, Vl, ldv, Arest, lda, p->Vw + (size_t) c0 * ldv + c, ldv, Tl, ldt,

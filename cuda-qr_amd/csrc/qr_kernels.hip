@@ -2,10 +2,7 @@
 // plus the extern "C" launchers the C host layer (qr_host.c) calls.  No vendor BLAS/solver calls.
 //
 // What replaces what in the reference (brian-kelley/CUDA-QR):
-//   leaf_step_kernel      <- panelHouseholderKernel (qr.cu:60-333) / qr.c:109-235: Householder vector,
-//                            ||x||_2, reflector apply inside the panel.  Here: rows live one-per-thread
-//                            in registers, all loads coalesced down columns, norms + all v^T a dot
-//                            products come from ONE fused wave-shuffle reduction per column.
+//   (the panel: qr_panel_fused.hip / qr_panel_cqr.hip / qr_panel_tsqr.hip <- panelHouseholderKernel, qr.cu:60-333 / qr.c:109-235)
 //   gemm_tn / gemm_nn     <- trailingUpdateKernel (qr.cu:335-465) / qr.c:255-293: the compact-WY update
 //                            W = (V T)^T A2 ; A2 -= V W as two dense contractions on
 //                            v_mfma_f64_16x16x4_f64 tiles staged through LDS.
@@ -398,157 +395,6 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(int M, int N, int nsla
         *o = (beta != 0.0) ? beta * (*o) + v : v;
     }
 }
-
-// ------------------------------------------------------------------------------------------------
-// Leaf panel factorisation: one launch per column (the kernel boundary is the grid-wide
-// dependency of Householder QR: ~1.5 us, cheaper than an in-kernel grid barrier on 8 XCDs).
-// Launch j (j = -1 .. w-1), every global round trip issued up front so the launch costs ONE load
-// latency + ONE store latency:
-//   0. every thread issues the loads of its row of the panel (registers, one row per thread:
-//      each access is 64 consecutive doubles of one column -> coalesced);
-//   1. every block sums the per-block partial dot products left by launch j-1
-//        d[c] = sum_{i>j} P(i,j) P(i,c)   (c==j: ||x||^2 tail, c>j: x^T a_c, c<j: v_c^T x)
-//      in a fixed order (bitwise identical in all blocks, deterministic run to run);
-//   2. forms beta, tau, 1/u (LAPACK dlarfg convention; tau = 0 when the tail is exactly zero -- the
-//      reference divides by norm = 0 there and produces NaN, qr.c:152) and s_c = v^T a_c; block 0
-//      records tau_j and Z(0:j, j) = V(:,0:j)^T v_j (the Gram column leaf_t_kernel turns into T);
-//   3. scales its row of v, applies the reflector to its row of the remaining columns, stores,
-//      and accumulates the dot products of column j+1;
-//   4. transposing wave butterfly (32 shuffles for 32 sums) + LDS across waves -> part_out[block][c].
-// ------------------------------------------------------------------------------------------------
-// J is a template parameter (-1 .. 31): with the column index known at compile time the row update is
-// straight-line code on exactly the live columns (no per-column predicate masks: the runtime-j version
-// of this kernel executed ~3000 instructions per wave, most of them selects and SGPR spill traffic, and
-// took 12 us; this one is a few hundred).
-template <int J>
-__global__ __launch_bounds__(256) void leaf_step_kernel(double* __restrict__ P, int ld, int mk, int w, int rpt,
-                                                        const double* __restrict__ part_in, int nblk_in,
-                                                        const double* __restrict__ row_in,
-                                                        double* __restrict__ part_out,
-                                                        double* __restrict__ row_out,
-                                                        double* __restrict__ tau, double* __restrict__ Z,
-                                                        double* __restrict__ Vw, int ldv)
-{
-    __shared__ double s_red[8][LEAFW];
-    __shared__ double s_s[LEAFW];
-    __shared__ double s_scal[3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int JN = J + 1;
-
-    // 0. row loads first: independent of everything below.  Columns >= w read as zero and stay zero.
-    double x[LEAFW];
-    int i = blockIdx.x * rpt * 256 + tid;
-    {
-        const double* src = P + min(i, mk - 1);
-#pragma unroll
-        for (int c = 0; c < LEAFW; ++c) x[c] = (c < w) ? src[(size_t) c * ld] : 0.0;   // c < w is wave-uniform
-    }
-
-    double tj = 0.0, beta = 0.0, inv_u = 0.0;
-    if (J >= 0) {
-        {
-            const int c = tid & 31, part = tid >> 5;
-            double sum = 0.0;
-            for (int g0 = part; g0 < nblk_in; g0 += 64) {
-                double pv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)           // unconditional (clamped) loads: one round trip for all 8
-                    pv[u] = part_in[min(g0 + 8 * u, nblk_in - 1) * LEAFW + c];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) sum += (g0 + 8 * u < nblk_in) ? pv[u] : 0.0;
-            }
-            s_red[part][c] = sum;
-        }
-        const double alpha = row_in[J >= 0 ? J : 0];
-        const double rowc = row_in[tid & (LEAFW - 1)];
-        __syncthreads();
-        if (tid < LEAFW) {
-            double d = 0.0;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) d += s_red[p][tid];
-            const double sigma = __shfl(d, J >= 0 ? J : 0);
-            double t, b, iu;
-            if (sigma == 0.0) { t = 0.0; b = alpha; iu = 0.0; }
-            else {
-                const double nrm = sqrt(alpha * alpha + sigma);
-                b = -copysign(nrm, alpha);
-                t = (b - alpha) / b;
-                iu = 1.0 / (alpha - b);
-            }
-            const double sc = (tid < w) ? rowc + d * iu : 0.0;
-            s_s[tid] = sc;
-            if (tid == 0) { s_scal[0] = t; s_scal[1] = b; s_scal[2] = iu; }
-            if (blockIdx.x == 0) {
-                if (tid < J) Z[J * LEAFW + tid] = sc;
-                else if (tid == J) tau[J] = t;
-            }
-        }
-        __syncthreads();
-        tj = s_scal[0]; beta = s_scal[1]; inv_u = s_scal[2];
-    }
-
-    double acc[LEAFW];
-#pragma unroll
-    for (int c = 0; c < LEAFW; ++c) acc[c] = 0.0;
-
-    for (int r = 0; r < rpt; ++r) {
-        if (r > 0) {
-            i = (blockIdx.x * rpt + r) * 256 + tid;
-            const double* src = P + min(i, mk - 1);
-#pragma unroll
-            for (int c = 0; c < LEAFW; ++c) x[c] = (c < w) ? src[(size_t) c * ld] : 0.0;
-        }
-        const bool live = (i < mk);
-        if (J >= 0) {
-            constexpr int JJ = J >= 0 ? J : 0;
-            const bool below = live && (i > J), diag = live && (i == J);
-            // compute phase (every load consumed here, before the first store: vmcnt counts stores too)
-            const double vi = below ? x[JJ] * inv_u : (diag ? 1.0 : 0.0);       // component i of v_J
-            const double coef = tj * vi;                                        // 0 above the diagonal
-            x[JJ] = below ? vi : (diag ? beta : x[JJ]);
-#pragma unroll
-            for (int c = JJ + 1; c < LEAFW; ++c) x[c] -= coef * s_s[c];
-            // store phase
-            if (live) {
-                Vw[(size_t) JJ * ldv + i] = vi;
-                if (i >= J) {
-#pragma unroll
-                    for (int c = JJ; c < LEAFW; ++c)
-                        if (c < w) P[(size_t) c * ld + i] = x[c];
-                }
-            }
-        }
-        if (JN < LEAFW) {
-            constexpr int JC = JN < LEAFW ? JN : 0;
-            if (JN < w) {
-                if (live && i == JN) {
-#pragma unroll
-                    for (int c = 0; c < LEAFW; ++c) if (c < w) row_out[c] = x[c];
-                }
-                const double xn = (live && i > JN) ? x[JC] : 0.0;
-#pragma unroll
-                for (int c = 0; c < LEAFW; ++c) acc[c] += xn * x[c];
-            }
-        }
-    }
-    if (JN < LEAFW && JN < w) {
-        const double v = wave_reduce32(acc, lane);
-        if ((lane & 1) == 0) s_red[wave][lane >> 1] = v;
-        __syncthreads();
-        if (tid < LEAFW)
-            part_out[blockIdx.x * LEAFW + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-    }
-}
-
-typedef void (*leaf_step_fn)(double*, int, int, int, int, const double*, int, const double*, double*, double*,
-                             double*, double*, double*, int);
-template <int... Js>
-static const leaf_step_fn* leaf_step_table_impl(std::integer_sequence<int, Js...>)
-{
-    static const leaf_step_fn table[] = {leaf_step_kernel<Js - 1>...};
-    return table;
-}
-static const leaf_step_fn* leaf_step_table() { return leaf_step_table_impl(std::make_integer_sequence<int, LEAFW + 1>{}); }
 
 // ------------------------------------------------------------------------------------------------
 // Compact-WY T, the counterpart of the reference's W accumulation (qr.c:170-213):
@@ -1120,29 +966,6 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
         rc = (int) hipGetLastError();
     }
     return rc;
-}
-
-// One leaf: factor the mk x w panel at P (ld) in place; tau[0..w), leaf T (w x w at T, ldt), explicit V into Vw.
-// scratch: QRD_LEAF_SCRATCH doubles.
-int qrd_leaf_panel(void* stream, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw,
-                   int ldv, double* scratch)
-{
-    hipStream_t s = (hipStream_t) stream;
-    if (w < 1 || w > LEAFW || mk < w) return -4;
-    int rpt = (mk + 256 * 256 - 1) / (256 * 256);
-    if (rpt < 1) rpt = 1;
-    const int nblk = (mk + 256 * rpt - 1) / (256 * rpt);
-    double* part[2] = {scratch, scratch + 256 * LEAFW + LEAFW};
-    double* rowb[2] = {part[0] + 256 * LEAFW, part[1] + 256 * LEAFW};
-    double* Z = scratch + 2 * (256 * LEAFW + LEAFW);
-    const leaf_step_fn* table = leaf_step_table();
-    for (int j = -1; j < w; ++j) {
-        const int in = (j + 2) & 1, out = (j + 1) & 1;
-        hipLaunchKernelGGL(table[j + 1], dim3(nblk), dim3(256), 0, s, P, ld, mk, w, rpt, part[in], nblk,
-                           rowb[in], part[out], rowb[out], tau, Z, Vw, ldv);
-    }
-    hipLaunchKernelGGL(leaf_t_kernel, dim3(1), dim3(64), 0, s, w, w, Z, LEAFW, tau, T, ldt);
-    return (int) hipGetLastError();
 }
 
 int qrd_gemm_nn_batch(void* stream, int M, int N, int K, double alpha, const double* A, int lda, size_t sA,

@@ -880,8 +880,9 @@ static int gram32(hipStream_t s, const double* A, int ld, int mk, double* G, dou
 // =========================================================================================================
 // Second-generation CholeskyQR2 leaf: the same mathematics in 4 launches instead of 7 (plus the guard launches).
 //   gram32_kernel          G1 slabs (at most CQ2_MAXSLAB of them, so that a consumer can sum them itself)
-//   cholq2_kernel          every workgroup: G1 = sum of slabs, R1 = chol(G1) (one wave), its 512 rows of Q = A R1^-1 -> Vw,
-//                          AND its share of G2 = Q^T Q on the MFMA pipe (rows staged through LDS 256 at a time) -> slab2[b]
+//   cholq3_kernel          (short leaves) every workgroup: G1 = sum of slabs, R1 = chol(G1) (one wave), its rows of Q = A R1^-1 -> Vw,
+//                          AND its share of G2 = Q^T Q on the MFMA pipe (rows staged through LDS) -> slab2[b];
+//   chol1 + cholq4_tall    (tall leaves) the same with the Cholesky in a launch of its own and a streaming pass behind it
 //   hr3_kernel             one workgroup: G2 = sum of slab2 (or a pre-reduced G2), guard, R2 = chol(G2), then the modified LU
 //                          of the reconstruction run directly on Q_top:  with U' = U R2,
 //                              LU(Q_top - S R2) = L1 U'     (same L1, same S as LU(Q_top R2^-1 - S) = L1 U: R2 is upper
@@ -918,7 +919,7 @@ __device__ __forceinline__ v2d slab_sum2(const double* __restrict__ slabs, int n
 #ifdef QRD_STAMPS
 __device__ long long qrd_dbg_stamps[64];
 // stamps stay in scalar registers until the kernel's last line (a store per stamp in the middle of the unrolled recurrences
-// cost cholq2_kernel 3.5 KB of scratch per thread)
+// cost 3.5 KB of scratch per thread)
 #define STAMP_DECL long long qst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k) qst_[(k) & 7] = (long long) __builtin_amdgcn_s_memrealtime()
 #define STAMP_FLUSH(base, n) do { if (threadIdx.x == 0 && blockIdx.x == 0) for (int q_ = 0; q_ < (n); ++q_) qrd_dbg_stamps[(base) + q_] = qst_[q_]; } while (0)
@@ -931,139 +932,8 @@ __device__ long long qrd_dbg_stamps[64];
 #define CQ2_MAXSLAB 32
 #define CQ2_LDS_DOUBLES(HALF) (PW * ((HALF) + 2) + 2 * PW * (PW + 1) + PW + 8)
 
-// NT rows per workgroup (one per thread), staged HALF at a time for the Gram.  <512, 256>: short leaves (few, fat workgroups);
-// <256, 128>: tall leaves -- 50 KB of LDS and one wave per SIMD, so three workgroups share a compute unit and hide each
-// other's serial phases (the one-wave Cholesky, the barriers), which is what a bandwidth-bound pass over 64 MB needs.
-// RB row blocks of NT rows per workgroup, one after the other (tall leaves, RB = 2): all their loads are in flight from the start,
-// the slab sum and the one-wave Cholesky are paid once per workgroup instead of once per block, and the partial Gram of
-// both blocks leaves as ONE slab -- the kernel streamed at 1.9 TB/s with RB = 1 (two rounds of 1024 workgroups, each 6.6 us of
-// Cholesky with no load in flight).
-template <bool FULL, int NT, int HALF, int RB = 1>
-__global__ __launch_bounds__(NT) void cholq2_kernel(const double* __restrict__ P, int ld, int mk, int w,
-                                                    const double* __restrict__ gslabs, int nslab, double* __restrict__ R1,
-                                                    double* __restrict__ Vw, int ldv, double* __restrict__ slab2,
-                                                    int* __restrict__ guard)
-{
-    extern __shared__ __attribute__((aligned(16))) double cq_smem[];
-    double* Qs = cq_smem;                                                    // [PW][(HALF + 2)]; later 8 partial Grams [8][PW*PW]
-    double (*Gs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * (HALF + 2));
-    double (*Rs)[PW + 1] = reinterpret_cast<double (*)[PW + 1]>(cq_smem + PW * (HALF + 2) + PW * (PW + 1));
-    double* rinv = cq_smem + PW * (HALF + 2) + 2 * PW * (PW + 1);
-    int* okf = reinterpret_cast<int*>(rinv + PW);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-    double a[RB][PW];
-    STAMP_DECL;
-    STAMP(0);
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const double* p = P + min((b * RB + rb) * NT + tid, mk - 1);
-#pragma unroll
-        for (int c = 0; c < PW; ++c) a[rb][c] = (FULL || c < w) ? p[(size_t) c * ld] : 0.0;  // in flight under the Gram sum
-    }
-    // G1 = sum of the slabs (fixed order; every workgroup forms the same bits).  Stored column-major, ld PW.
-    for (int t2 = tid; t2 < PW * PW / 2; t2 += NT) {
-        const v2d gsum = slab_sum2(gslabs, nslab, t2);                        // elements 2 t2, 2 t2 + 1
-        const int e = 2 * t2;
-        Gs[e / PW][e % PW] = gsum[0];                                         // Gs[j][i] = G(i, j)
-        Gs[e / PW][e % PW + 1] = gsum[1];
-    }
-    __syncthreads();
-    STAMP(1);
-    if (tid < 64) {
-        // chol_wave reads G(i, j) as G[j * PW + i]: hand it the padded image row by row
-        double g[PW];
-        const int j = lane & (PW - 1);
-#pragma unroll
-        for (int i = 0; i < PW; ++i) g[i] = (i < w && j < w) ? Gs[j][i] : (i == j ? 1.0 : 0.0);
-        bool ok = true;
-        CholStep<0>::run(g, j, ok);
-        if (lane < PW) {
-#pragma unroll
-            for (int k = 0; k < PW; ++k) Rs[k][lane] = (k <= lane) ? g[k] : 0.0;
-        }
-        if (lane == 0) *okf = ok ? 1 : 0;
-    }
-    __syncthreads();
-    STAMP(2);
-    if (tid < PW) rinv[tid] = 1.0 / Rs[tid][tid];
-    const bool ok = *okf != 0;
-    if (b == 0) {
-        if (tid == 0) *guard = ok ? 0 : 1;
-        if (ok && tid < PW) {
-#pragma unroll
-            for (int k = 0; k < PW; ++k) R1[tid * PW + k] = Rs[k][tid];          // column tid
-        }
-    }
-    if (!ok) return;                                                          // workgroup-uniform
-    __syncthreads();
-    const int l15 = lane & 15, l4 = lane >> 4;
-    v4d acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-    const int r = (b * RB + rb) * NT + tid;
-    double q[PW];
-#pragma unroll
-    for (int k = 0; k < PW; ++k) {                                              // q R1 = a, column by column
-        q[k] = a[rb][k] * rinv[k];
-#pragma unroll
-        for (int c = k + 1; c < PW; ++c) a[rb][c] -= q[k] * Rs[k][c];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    const bool live = r < mk;
-    STAMP(3);
-    if (live) {
-#pragma unroll
-        for (int c = 0; c < PW; ++c)
-            if (FULL || c < w) Vw[(size_t) c * ldv + r] = q[c];
-    }
-    STAMP(4);
-    // ---- this workgroup's share of G2 = Q^T Q: rows staged 256 at a time as a [column][row] image (ld 258: the 16 columns a
-    // half-wave reads are 16 B apart in the bank row -> conflict-free ds_read_b64), wave v takes rows [32v, 32v+32) of the half
-#pragma unroll
-    for (int h = 0; h < NT / HALF; ++h) {
-        if (tid / HALF == h) {
-#pragma unroll
-            for (int c = 0; c < PW; ++c) Qs[c * (HALF + 2) + (tid & (HALF - 1))] = live ? q[c] : 0.0;
-        }
-        __syncthreads();
-        const double* base = Qs + 32 * wave + l4;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const double f0 = base[l15 * (HALF + 2) + 4 * ks], f1 = base[(16 + l15) * (HALF + 2) + 4 * ks];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    }   // rb
-    // D reg rr of lane (l4, l15) of tile (ti, tj) = G(16 ti + l4 + 4 rr, 16 tj + l15); partial of this wave -> LDS (over Qs)
-    double* red = Qs + wave * PW * PW;
-    STAMP(5);
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) red[(16 * tj + l15) * PW + 16 * ti + l4 + 4 * rr] = acc[ti][tj][rr];
-    __syncthreads();
-    for (int e = tid; e < PW * PW; e += NT) {
-        double s = 0.0;
-#pragma unroll
-        for (int v = 0; v < NT / 64; ++v) s += Qs[v * PW * PW + e];
-        slab2[(size_t) b * PW * PW + e] = s;
-    }
-    STAMP(6);
-    STAMP_FLUSH(0, 7);
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// Third-generation leaf: the two row solves (q = a R1^-1 in cholq2_kernel, v = q U'^-1 in final3_kernel) were 7 us each and
+// Third-generation leaf: the two row solves (q = a R1^-1 and v = q U'^-1 as per-thread triangular solves) were 7 us each and
 // bound by LDS bandwidth -- every thread reads all 528 entries of the triangle as broadcast reads, 8 waves x 496 x 512 B per
 // workgroup.  Here they are products with the explicit inverses on the matrix cores, the row operands going from global memory
 // straight into the MFMA operand layout (no LDS):
@@ -1163,7 +1033,7 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
         }
     }
     STAMP(4);
-    // ---- this workgroup's share of G2 = Q^T Q, as in cholq2_kernel: rows staged HALF at a time as a [column][row] image
+    // ---- this workgroup's share of G2 = Q^T Q: rows staged HALF at a time as a [column][row] image
     v4d acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1215,7 +1085,7 @@ __global__ __launch_bounds__(NT) void cholq3_kernel(const double* __restrict__ P
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Tall leaves, streaming form (round 2, end): cholq2_kernel spends 7.8 us of every workgroup in a one-wave Cholesky with nothing
+// Tall leaves, streaming form (round 2, end): a kernel that factors G1 itself spends 7.8 us of every workgroup in a one-wave Cholesky with nothing
 // in flight, solves q R1 = a on the vector ALUs with R1 broadcast from LDS, and stages Q through LDS for G2.  Here the Cholesky
 // (with R1^-1, CholAugStep) runs ONCE in a one-wave kernel, and the pass over the leaf is pure streaming on the matrix cores:
 // rows on the MFMA row index, each wave's 64 rows as four interleaved 16-row tiles (physical row 4 p + t: every global access is 32
@@ -1882,9 +1752,8 @@ __global__ __launch_bounds__(PT) void final4_coop_kernel(const double* __restric
 // runs on one wave with no cross-wave reduction instead of eight mostly-idle ones
 static int nt_for(int rows) { return rows <= 64 ? 64 : (rows <= 128 ? 128 : (rows <= 256 ? 256 : 512)); }
 
-// MI355XQR_LEAF_WAVES=8: 512-thread workgroups (two waves per SIMD) for the 512- and 1024-row blocks; default 4: the same
-// rows on 256 threads, one wave per SIMD -- per Householder step a SIMD then runs ONE transposing wave reduction instead
-// of two and the cross-wave sum has 4 partials instead of 8
+// 512- and 1024-row blocks on 256 threads, one wave per SIMD (not 512 threads, two per SIMD): per Householder step a SIMD then
+// runs ONE transposing wave reduction instead of two and the cross-wave sum has 4 partials instead of 8
 static int leaf_waves(void)
 {
     static const int v = 4;
@@ -2032,15 +1901,14 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
         if (fits) {
             t.L = Lv; t.top_off = off; t.top_rows = cur_rows;
             // participants: the launch is a no-op nearly always, and what a no-op costs is dispatching its workgroups (140 KB of LDS
-            // each) -- 64 are gone in ~5 us; on the guard route they walk their blocks grid-stride (MI355XQR_TALL_COOP_G to change)
+            // each) -- 64 are gone in ~5 us; on the guard route they walk their blocks grid-stride
             static const int gcap = 64;
             int G = qrd_stream_cus(stream);
             if (G > gcap) G = gcap;
             if (G > t.nblk0) G = t.nblk0;
             if (G < 1) G = 1;
             const int fblocks = (mk + PT - 1) / PT;
-            // MI355XQR_TALL_COOP_FUSE=0: final3 always as its own launch (measured equal within noise at 65536 / 131072 rows:
-            // 1.04 / 1.46 ms against 1.03 / 1.43 fused)
+            // (final3 as its own launch measured equal within noise at 65536 / 131072 rows: 1.04 / 1.46 ms against 1.03 / 1.43 fused)
             static const int fuse_tall = 1;
             if (fuse_tall && fblocks <= qrd_stream_cus(stream))
                 hipLaunchKernelGGL(final3_coop_tall_kernel, dim3(fblocks > G ? fblocks : G), dim3(PT), ep_shm, s, final3_u, t, G, mk, w, Vloc1, Vup,
@@ -2110,12 +1978,6 @@ int qrd_panel_tsqr(void* stream, double* P, int ld, int mk, int w, double* tau, 
 // cws: QRD_CHOLQR_WS doubles (G1, G2, R1, M, guard word).
 // MI355XQR_LEAF=2 selects the second-generation launch sequence (4 launches, row solves on
 // the vector ALUs), default 3 (4 launches, row solves as matrix-core products with explicit triangular inverses; short leaves)
-static int leaf_gen(void)
-{
-    static const int v = [] { const char* e = getenv("MI355XQR_LEAF"); int v_ = e ? atoi(e) : 3; if (v_ < 2 || v_ > 3) v_ = 3; return v_; }();
-    return v;
-}
-
 #ifdef QRD_STAMPS
 int qrd_dbg_read_stamps(long long* out)
 {
@@ -2125,12 +1987,7 @@ int qrd_dbg_read_stamps(long long* out)
 
 int qrd_panel_tsqr_init(void)
 {
-    int rc = (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 512, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
-    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
-    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq2_kernel<true, 256, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int) (CQ2_LDS_DOUBLES(128) * sizeof(double)));
+    int rc = 0;
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq3_kernel<512, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int) (CQ2_LDS_DOUBLES(256) * sizeof(double)));
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(cholq4_tall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2222,11 +2079,13 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
                     ((reinterpret_cast<uintptr_t>(Vw) & 15) == 0) && (ldv % 2 == 0);
     int rc;
     // third generation (matrix-core row solves) for short leaves only: on tall leaves, which stream 67 MB per pass, its operand
-    // loads (4 columns x 128 B per instruction instead of 1 x 512 B) cost more than the solves did (262144 x 512: 7.9 vs 7.6 ms)
-    const int gen = (leaf_gen() == 3 && nblk > CQ2_MAXSLAB) ? 2 : leaf_gen();
-    if (gen >= 2 && al && slab_cap >= (size_t) (CQ2_MAXSLAB + 2 * nblk) * PW * PW) {
+    // loads (4 columns x 128 B per instruction instead of 1 x 512 B) cost more than the solves did (262144 x 512: 7.9 vs 7.6 ms).
+    // A tall leaf the streaming form cannot take (rows not a multiple of 4, fewer than 32 columns) goes to the Householder route.
+    const int gen = nblk > CQ2_MAXSLAB ? 2 : 3;
+    const bool tall_ok = (mk & 3) == 0 && w == PW;
+    if (al && (gen == 3 || tall_ok) && slab_cap >= (size_t) (CQ2_MAXSLAB + 2 * nblk) * PW * PW) {
         double* slab2 = slabs + (size_t) CQ2_MAXSLAB * PW * PW;
-        int nblk2 = nblk;                                   // workgroups of cholq2_kernel = slabs of G2
+        int nblk2 = nblk;                                   // workgroups of the Q pass = slabs of G2
         if (nblk <= CQ2_MAXSLAB) {
             // short leaf (square problems): at most CQ2_MAXSLAB Gram slabs of >= 128 rows, summed by their consumers
             static const int gslab_max = CQ2_MAXSLAB;
@@ -2239,46 +2098,28 @@ static int panel_cholqr_impl(void* stream, double* P, int ld, int mk, int w, dou
             // square factorisation): the kernel is bound by its 128 matrix-core instructions per wave -- at two waves per SIMD 7.4 us
             // of its 25 -- and half-size workgroups put them on twice the compute units
             static const int half_wg = 1;
-            if (gen == 3 && half_wg && (mk + 255) / 256 <= CQ2_MAXSLAB) {
+            if (half_wg && (mk + 255) / 256 <= CQ2_MAXSLAB) {
                 nblk2 = (mk + 255) / 256;
                 hipLaunchKernelGGL((cholq3_kernel<256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk,
                                    slabs, nslab, R1, Vw, ldv, slab2, guard);
-            } else if (gen == 3)
+            } else
                 hipLaunchKernelGGL((cholq3_kernel<512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk,
-                                   slabs, nslab, R1, Vw, ldv, slab2, guard);
-            else
-                hipLaunchKernelGGL((cholq2_kernel<true, 512, 256>), dim3(nblk), dim3(512), CQ2_LDS_DOUBLES(256) * sizeof(double), s, P, ld, mk, w,
                                    slabs, nslab, R1, Vw, ldv, slab2, guard);
         } else {
             // tall leaf: the Gram pass needs hundreds of workgroups to reach HBM bandwidth, so its slabs go through a reduce launch;
-            // 256-row workgroups, three to a compute unit
-            // two row blocks per workgroup where that still leaves >= 1.5 workgroups per compute unit (262144 rows: 7.58 -> 7.31 ms
-            // for the 512-column shard; 65536 rows: 2 % slower, half the chip would idle)
-            static const int rb_env = 0;
-            const bool rb2 = rb_env == 2 || (rb_env != 1 && (mk + 511) / 512 >= 384);
-            nblk2 = rb2 ? (mk + 511) / 512 : (mk + 255) / 256;
+            // then the streaming form: one-wave Cholesky (R1, R1^-1 -> Mm, which hr3 overwrites later) and the matrix-core pass
+            static const int gq_max = 512;
+            int gq = (mk + PT - 1) / PT;
+            if (gq > gq_max) gq = gq_max;
+            nblk2 = gq;
             if (gram_nslab > 0 && (size_t) gram_nslab * PW * PW <= slab_cap - (size_t) nblk2 * PW * PW)
                 rc = qrd_slab_reduce(s, PW, PW, gram_nslab, slabs, PW, (size_t) PW * PW, G1, PW);   // partial Grams left by the previous leaf's update
             else
                 rc = gram32(s, P, ld, mk, G1, slabs, slab_cap - (size_t) nblk2 * PW * PW);      // the tail of the buffer holds slab2
             if (rc) return rc;
             slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
-            static const int tall_q = 4;
-            if (tall_q == 4 && (mk & 3) == 0 && w == PW) {
-                // streaming form: one-wave Cholesky (R1, R1^-1 -> Mm, which hr3 overwrites later), then the matrix-core pass
-                static const int gq_max = 512;
-                int gq = (mk + PT - 1) / PT;
-                if (gq > gq_max) gq = gq_max;
-                nblk2 = gq;
-                slab2 = slabs + (slab_cap - (size_t) nblk2 * PW * PW);
-                hipLaunchKernelGGL(chol1_kernel, dim3(1), dim3(64), 0, s, G1, R1, Mm, guard);
-                hipLaunchKernelGGL(cholq4_tall_kernel, dim3(gq), dim3(PT), 8 * PW * PW * sizeof(double), s, P, ld, mk, Mm, Vw, ldv, slab2, guard);
-            } else if (rb2)
-                hipLaunchKernelGGL((cholq2_kernel<true, 256, 128, 2>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
-                                   G1, 1, R1, Vw, ldv, slab2, guard);
-            else
-                hipLaunchKernelGGL((cholq2_kernel<true, 256, 128>), dim3(nblk2), dim3(256), CQ2_LDS_DOUBLES(128) * sizeof(double), s, P, ld, mk, w,
-                                   G1, 1, R1, Vw, ldv, slab2, guard);
+            hipLaunchKernelGGL(chol1_kernel, dim3(1), dim3(64), 0, s, G1, R1, Mm, guard);
+            hipLaunchKernelGGL(cholq4_tall_kernel, dim3(gq), dim3(PT), 8 * PW * PW * sizeof(double), s, P, ld, mk, Mm, Vw, ldv, slab2, guard);
         }
         const double* g2src = slab2;
         int g2n = nblk2;

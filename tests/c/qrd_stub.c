@@ -183,8 +183,6 @@ int qrd_gemm_nt(void* s, int M, int N, int K, int sign, const double* A, int lda
 { (void) s; (void) sign; (void) gm; (void) st; chk("gemm_nt A", A, lda, M, K); chk("gemm_nt Bt", Bt, ldbt, N, K); chk("gemm_nt C", C, ldc, M, N); return 0; }
 static void leaf_chk(const char* w, double* P, int ld, int mk, int wd, double* tau, double* T, int ldt, double* Vw, int ldv)
 { chk(w, P, ld, mk, wd); chk(w, tau, wd, wd, 1); chk(w, T, ldt, wd, wd); chk(w, Vw, ldv, mk, wd); }
-int qrd_leaf_panel(void* s, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* scratch)
-{ (void) s; leaf_chk("leaf_panel", P, ld, mk, w, tau, T, ldt, Vw, ldv); chkb("leaf scratch", scratch, sizeof(double) * QRD_LEAF_SCRATCH); return 0; }
 size_t qrd_panel_ws_size(int m) { return (size_t) 80 * (size_t) (m > 0 ? m : 1) + 65536; }
 int qrd_panel_tsqr(void* s, double* P, int ld, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int mcap)
 { (void) s; leaf_chk("panel_tsqr", P, ld, mk, w, tau, T, ldt, Vw, ldv); chkb("panel ws", ws, sizeof(double) * qrd_panel_ws_size(mcap)); return 0; }

@@ -89,7 +89,6 @@ np.save(sys.argv[1], O.sign_normalise(F))
     (512, {"MI355XQR_LOOKAHEAD": "1"}),                                               # ... with look-ahead (W_a / W_b pieces, ev_half)
     (512, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_NEXT": "update"}),
     (512, {"MI355XQR_LOOKAHEAD": "0"}),
-    (128, {"MI355XQR_LEAF": "2"}),                                                    # second-generation CholeskyQR2 leaf (row solves on the vector ALUs)
     (128, {"MI355XQR_EP": "0"}),                                                      # in-panel product as a launch of its own (no early product)
     (256, {"MI355XQR_FUSED_MIN_ROWS": "0"}),                                          # round 4: every outer panel in ONE launch (qr_panel_fused.hip)
     (128, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "0"}),     # ... single-stream schedule

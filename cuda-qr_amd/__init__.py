@@ -136,9 +136,7 @@ _sig("qrd_gemm_tn_update_wide", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_dou
      _vp, C.c_int, _vp, C.c_size_t)
 _sig("qrd_gemm_tn_dual", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
      _vp, C.c_size_t)
-_sig("qrd_leaf_panel", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp)
 _sig("qrd_larft", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
-LEAF_SCRATCH = 2 * (256 * 32 + 32) + 32 * 32
 _sig("qrd_panel_ws_size", C.c_size_t, C.c_int)
 _sig("qrd_panel_tsqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
 _sig("qrd_panel_cholqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, C.c_int)

@@ -135,42 +135,6 @@ def test_gemm_tn_fused_Tt(q, w, N, K):
     assert np.abs(host(dC) - ref).max() < 1e-12 * np.sqrt(K) * max(1.0, np.abs(ref).max())
 
 
-LEAF_SHAPES = [(32, 32), (64, 32), (256, 32), (1000, 32), (4096, 16), (16384, 32), (70000, 32), (300, 7), (5, 5),
-               (2, 1), (200000, 24)]
-
-
-@pytest.mark.parametrize("mk,w", LEAF_SHAPES)
-def test_leaf_panel(q, oracle, mk, w):
-    """Householder panel kernel vs unblocked numpy geqr2 (LAPACK convention): R, v tails, tau, T, explicit V."""
-    rng = np.random.default_rng(mk + w)
-    P = rng.random((mk, w))
-    ld, ldv, ldt = mk + 6, mk + 2, w + 3
-    buf = np.full((ld, w), 7.0); buf[:mk] = P
-    dP = dev(buf)
-    dtau, dT, dV = zeros(w, 1), zeros(ldt, w), dev(np.full((ldv, w), np.nan))
-    scratch = torch.zeros(q.LEAF_SCRATCH, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    q.check(q.lib.qrd_leaf_panel(None, dP.data_ptr(), ld, mk, w, dtau.data_ptr(), dT.data_ptr(), ldt,
-                                 dV.data_ptr(), ldv, scratch.data_ptr()))
-    _sync(q)
-    F, tau = oracle.np_geqr2(P)
-    out = host(dP)
-    assert np.array_equal(out[mk:], buf[mk:])                                   # padding rows untouched
-    scale = np.abs(F).max()
-    assert np.abs(out[:mk] - F).max() < 2e-13 * scale * np.sqrt(mk), "R / reflector tails"
-    assert np.abs(host(dtau)[:, 0] - tau).max() < 1e-13
-    V = oracle.np_unit_lower(F)
-    assert np.abs(host(dV)[:mk] - V).max() < 2e-13 * np.sqrt(mk)
-    T = oracle.np_larft(V, tau)
-    assert np.abs(host(dT)[:w] - T).max() < 1e-12
-    # the factorisation property itself: (I - V T V^T)^T P = [R; 0]
-    Vd, Td = host(dV)[:mk], host(dT)[:w]
-    QtP = P - Vd @ (Td.T @ (Vd.T @ P))
-    assert np.abs(np.triu(QtP[:w]) - np.triu(out[:w])).max() < 1e-12 * np.sqrt(mk)
-    assert np.abs(np.tril(QtP[:w], -1)).max(initial=0.0) < 1e-12 * np.sqrt(mk)
-    assert np.abs(QtP[w:]).max(initial=0.0) < 1e-12 * np.sqrt(mk)
-
-
 TSQR_SHAPES = [(32, 32), (33, 32), (512, 32), (513, 32), (1000, 32), (4096, 32), (8192, 32), (8193, 32), (16384, 32),
                (70000, 32), (200000, 32), (262144, 16), (300, 7), (5, 5), (2, 1), (600, 1), (5000, 24), (20000, 8)]
 
@@ -347,16 +311,16 @@ def test_panel_cholqr2_moderate_condition_stays_accurate(q, oracle):
 
 
 def test_leaf_panel_zero_column_gives_tau_zero(q):
-    """Deviation from the reference stated in include/mi355x_qr.h: zero tail -> tau = 0 (reference: NaN)."""
+    """Deviation from the reference stated in include/mi355x_qr.h: zero tail -> tau = 0 (reference: NaN).  The Householder leaf."""
     mk, w = 300, 8
     P = np.random.default_rng(1).random((mk, w))
     P[:, 3] = 0.0
     P[4:, 5] = 0.0
     dP, dtau, dT, dV = dev(P), zeros(w, 1), zeros(w, w), zeros(mk, w)
-    scratch = torch.zeros(q.LEAF_SCRATCH, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(int(q.lib.qrd_panel_ws_size(mk)), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
-    q.check(q.lib.qrd_leaf_panel(None, dP.data_ptr(), mk, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(),
-                                 mk, scratch.data_ptr()))
+    q.check(q.lib.qrd_panel_tsqr(None, dP.data_ptr(), mk, mk, w, dtau.data_ptr(), dT.data_ptr(), w, dV.data_ptr(),
+                                 mk, ws.data_ptr(), mk))
     _sync(q)
     out, tau = host(dP), host(dtau)[:, 0]
     assert np.isfinite(out).all() and np.isfinite(tau).all()

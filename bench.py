@@ -340,7 +340,7 @@ def main():
     # all ranks switch between the same two calls).  The first real multi-GPU run must explain itself: what an all-gather of n*nb doubles per
     # rank costs beside a chip-filling local update, on THIS node, is not known before it.
     by_schedule = None
-    if world > 1 and be.transport == "rccl":
+    if world > 1 and be.transport == "rccl" and os.environ.get("BENCH_SCHEDULE_AB", "1") != "0":
         try:
             by_schedule = {}
             chosen = "pipelined" if be.tp.is_pipelined() else "one_collective"

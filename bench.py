@@ -415,8 +415,8 @@ def main():
         except Exception:
             measured = None
     # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 counter passes cannot share a process with the
-    # timed region, and crash on CU-masked streams on this pool).  The committed round-3 PMC pass (profiles/r03_pmc_traffic.json,
-    # devtools/scripts_r3_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
+    # timed region, and crash on CU-masked streams on this pool).  The committed round-5 PMC pass (profiles/r05_pmc_traffic.json,
+    # devtools/scripts_r5_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
     # ITS algorithmic bytes, and `traffic` itself only when that file was made for this block size; otherwise null.
     traffic, traffic_src = None, None
     try:
@@ -436,7 +436,10 @@ def main():
                            "algorithmic_bytes_per_launch_same_mix": e["algorithmic_bytes_per_launch"],
                            "ratio_traffic_to_algorithmic": e["ratio"],
                            "method": "2*FETCH_SIZE + WRITE_SIZE per dispatch (gfx950 correction, MI355X_MICROARCH.md HBM section), "
-                                     "separate rocprofv3 --pmc passes; replayed from the committed file, not measured in this run"}
+                                     "separate rocprofv3 --pmc passes; replayed from the committed file, not measured in this run",
+                           "note": "x1.55: the write-allocated C tiles push the operand tiles of the 128 x 64 tiling (3.75 MB per XCD at a time) out of the 4 MB L2 "
+                                   "and they are fetched again -- from the 256 MB Infinity Cache, which FETCH_SIZE (L2 misses) cannot tell from HBM; with "
+                                   "non-temporal C accesses the refetches go away (-40 %) and nothing gets faster (profiles/r05_nt_ceiling.txt)"}
         cus_u = None
         try:
             cus_u = int(be.plan.update_cus())

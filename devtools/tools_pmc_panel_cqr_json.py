@@ -12,11 +12,12 @@ def avg(path):
 F, W = avg(sys.argv[1]), avg(sys.argv[2])
 mk, w = 262144, 128
 kern, tot = {}, 0.0
+npanel = max(float(n) for name, (n, f) in F.items() if "cqr_chol_kernel" in name)     # one Cholesky launch per panel
 for name in F:
     if "cqr_" not in name: continue
     short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
     n, f = F[name]; wn, wr = W.get(name, (n, 0.0))
-    per_panel = n / 6.0                          # tools_cqr_perf.py: six panels; the reduce kernel runs twice per panel
+    per_panel = n / npanel                       # (the reduce kernel runs twice per panel)
     rd, wt = 2.0 * f * 1024 * per_panel, wr * 1024 * per_panel
     kern[short] = {"read_MB": round(rd / 1e6, 1), "write_MB": round(wt / 1e6, 1), "launches_per_panel": per_panel}
     tot += rd + wt

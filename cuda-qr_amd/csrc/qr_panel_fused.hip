@@ -848,24 +848,6 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         }
         pf_publish(flags, 16 * g, er + 1);                    // (an empty publish when G1 is derived: the epoch count stays uniform)
         PF_STAMP(1);
-        // ---- (the factor workgroup sums G1 and runs the Cholesky.)  The PREVIOUS leaf's update of everything beyond this leaf's
-        // columns happens here, off the critical chain: this leaf only needed its own 32 columns (done at the end of the previous
-        // pass).  V of the previous leaf comes back from Vw (this lane's own rows); this leaf's a is parked in its LDS image meanwhile
-        if (c > 0 && f.nrest > 0) {
-            const int cp_ = c - 32;
-            const bool actp = r4 >= cp_ && r4 < mk;
-            pf_load_rows(ar, Vw, ldv, cp_, r4c, l4);
-            if (!actp) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) ar[t][ks] = 0.0;
-            }
-            pf_update_groups(ar, P.ws + PF_OFF_X4 + (size_t) (((cp_ >> 5) & 1)) * 32 * PF_ZCOLS, A, lda, cp_, 1, (wh - cp_ - 32) / 32, false,
-                             r4, r4c, actp, l15, l4);
-            pf_image_read(L.img, ar, wave, l15, l4);
-        }
-        PF_STAMP(2);
         pf_wait(flags, 0, ef + 1, &L.gflags[4]);
         PF_STAMP(3);
         { pf_m33 m1[1] = {L.Ws}; pf_m33_in<1>(m1, f.F1); }    // R1^-1
@@ -885,6 +867,27 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         pf_gram_publish(L.part, f.X2 + (size_t) g * 1024);
         pf_publish(flags, 16 * g, er + 2);
         PF_STAMP(4);
+        // ---- (the factor workgroup: G2, modified LU, triangular inverses -- ~17 us.)  The PREVIOUS leaf's update of everything beyond
+        // this leaf's columns happens HERE (round 5; until then it sat in front of the wait for R1^-1, which the matrix-core Cholesky now
+        // publishes 2.4 us into the leaf: the 9-24 us of this update had become part of the critical chain).  This leaf only needed its
+        // own 32 columns (done at the end of the previous pass); the product below needs the rest.  V of the previous leaf comes back
+        // from Vw (this lane's own rows); this leaf's q is parked in its LDS image meanwhile
+        if (c > 0 && f.nrest > 0) {
+            const int cp_ = c - 32;
+            const bool actp = r4 >= cp_ && r4 < mk;
+            pf_load_rows(ar, Vw, ldv, cp_, r4c, l4);
+            if (!actp) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) ar[t][ks] = 0.0;
+            }
+            pf_update_groups(ar, P.ws + PF_OFF_X4 + (size_t) (((cp_ >> 5) & 1)) * 32 * PF_ZCOLS, A, lda, cp_, 1, (wh - cp_ - 32) / 32, false,
+                             r4, r4c, actp, l15, l4);
+            pf_image_read(L.img, ar, wave, l15, l4);
+            __syncthreads();                                  // the product's waves read rows other waves have just updated
+        }
+        PF_STAMP(2);
         // ---- (the factor workgroup: G2, modified LU, triangular inverses.)  Meanwhile  Z = Q^T [A_rest | V_prev]  for this workgroup's
         // rows, 16-column tiles dealt to the waves.  A tile's 256 rows go by in four chunks of 64; the rows of the next chunk (or of
         // the next tile) are requested before the 32 matrix-core instructions of the current one, and a tile is published as soon as

@@ -340,10 +340,21 @@ def main():
     # all ranks switch between the same two calls).  The first real multi-GPU run must explain itself: what an all-gather of n*nb doubles per
     # rank costs beside a chip-filling local update, on THIS node, is not known before it.
     by_schedule = None
-    if world > 1 and be.transport == "rccl" and os.environ.get("BENCH_SCHEDULE_AB", "1") != "0":
+    if world > 1 and os.environ.get("BENCH_SCHEDULE_AB", "1") != "0":
         try:
             by_schedule = {}
+            real = be.transport == "rccl"
             chosen = "pipelined" if be.tp.is_pipelined() else "one_collective"
+
+            def one_step(buf):
+                # bring-up transports (R factors through torch.distributed): the same two schedules with this rank's own factor copied
+                # into every slot -- the launches, streams and events of a real rank, so the fields exist before the first RCCL run
+                if real:
+                    ts.factor(buf)
+                else:
+                    be.tp.factor_selfgather(buf, m_local, be.R)
+                ts.sync()
+
             for name, mode in (("pipelined", 1), ("one_collective", 0)):
                 try:
                     be.tp.set_schedule(mode)
@@ -353,12 +364,11 @@ def main():
                 for i in range(4):
                     be.fill(bufs[i % nbuf], m_local, n, rank * m_local, m_total, seeds[i % nbuf])
                 barrier()
-                ts.factor(bufs[0]); ts.sync()           # the schedule's first call pays RCCL's set-up for its message sizes
+                one_step(bufs[0])                       # the schedule's first call pays RCCL's set-up for its message sizes
                 barrier()
                 t1 = time.perf_counter()
                 for i in range(1, 4):
-                    ts.factor(bufs[i % nbuf])
-                    ts.sync()
+                    one_step(bufs[i % nbuf])
                 mine = {"rank": rank, "step_ms": (time.perf_counter() - t1) / 3 * 1e3}
                 gs2 = be.tp.gather_stats() if mode == 1 else None
                 if gs2:
@@ -367,7 +377,8 @@ def main():
                 dist.all_gather_object(allr, mine)
                 by_schedule[name] = {"per_rank": allr, "step_ms_max": max(r["step_ms"] for r in allr)}
             be.tp.set_schedule(2)
-            by_schedule["chosen_in_timed_region"] = chosen
+            by_schedule["chosen_in_timed_region"] = chosen if real else "one_collective (transport %s: the factors travel through torch.distributed)" % be.transport
+            by_schedule["source"] = "ncclAllGather (RCCL)" if real else "self-gather: device copies in place of the collective (transport %s)" % be.transport
             by_schedule["reserve_cus"] = os.environ.get("MI355XQR_TSQR_RESERVE_CUS", "0")
             by_schedule["note"] = ("drained latency of one factorisation per schedule and rank; gather_ms = sum over the block columns of [stacked stream "
                                    "past its wait for the local panel -> ncclAllGather done] from events on the stacked stream.  MI355XQR_TSQR_RESERVE_CUS=c "

@@ -170,6 +170,14 @@ def test_bench_bringup_two_ranks_on_one_gpu_through_the_c_abi_plan(tmp_path):
     print("tsqr_step_split:", {k: sp[k] for k in ("gather_ms", "gather_max_ms", "gather_call_ms", "fell_back_to_one_collective", "gather_source")})
     assert sp["gather_ms"] > 0 and sp["gather_call_ms"] > sp["gather_max_ms"] > 0 and sp["fell_back_to_one_collective"] is False
     assert "self-gather" in sp["gather_source"]
+    # both exchange schedules, every rank's own numbers (here in the self-gather form; over RCCL the same fields from the collectives)
+    ab = line["tsqr_exchange_by_schedule"]
+    print("tsqr_exchange_by_schedule:", json.dumps({k: ab[k] for k in ("pipelined", "one_collective", "chosen_in_timed_region", "source")})[:1500])
+    assert "error" not in ab, ab
+    for name in ("pipelined", "one_collective"):
+        pr = ab[name]["per_rank"]
+        assert sorted(r["rank"] for r in pr) == [0, 1] and all(r["step_ms"] > 0 for r in pr)
+    assert all(r["gather_ms"] > 0 and r["call_ms"] > r["gather_max_ms"] > 0 for r in ab["pipelined"]["per_rank"])
     one = line["same_problem_1gpu"]           # the same 262144 x 256 matrix on rank 0's GPU alone: the strong-scaling denominator
     assert one["ms"] > 0 and one["speedup_latency"] > 0 and one["speedup_throughput"] > 0
 

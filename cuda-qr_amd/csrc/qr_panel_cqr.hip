@@ -583,6 +583,7 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
             dmax = (d == d) ? fmax(dmax, d) : 1e300;
         }
     });
+    CQ_STAMP(28);
     for (int o = 32; o > 0; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
     if ((tid & 63) == 0) L.red[tid >> 6] = dmax;
     __syncthreads();
@@ -598,6 +599,7 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
         const bool ok = cq_chol_blocked(L, w, tid);
         if (!ok) return true;
     }
+    CQ_STAMP(29);
     // R2 -> global (cqr_post_kernel's products read it from there; this launch's LU too unless R2 is first order: it then reads G2
     // and nothing waits for these stores); R2^-1 -> X1 (first order: 2 I - R2)
 #pragma unroll 8
@@ -608,6 +610,7 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
         cq_st(ws + CQ_R2 + i * CQ_W + j, r);
         if (first_order) cq_st(ws + CQ_X1 + i * CQ_W + j, (j > i) ? -r : (j == i ? 2.0 - r : 0.0));
     }
+    CQ_STAMP(30);
     if (!first_order) {
         __syncthreads();
         cq_upper_inv(L, w, 1, 0, tid);
@@ -669,6 +672,46 @@ __device__ __forceinline__ void cq_diag_slots(const CqLds& L, const double* dinv
 //   workgroup 0: U'^-1 -> UI (the operand of the V pass), then R = S R2 R1
 //   workgroup 1: U = U' R2^-1, the inverse of L1^T, T = -U S L1^-T
 // Operands from the workspace (written by cqr_lu_kernel / cqr_chol_kernel: an earlier launch); S from ws + CQ_SV.
+// (round 5, later: only U'^-1 stands between the LU and the last pass -- it is a launch of its own, cqr_ui_kernel, and the two other
+// pieces ride in the last pass's launch as its first two workgroups, cqr_vpass_kernel: 56 us of one-workgroup work off the chain)
+__device__ __forceinline__ void cq_post_ui(const CqLds& L, double* ws, int w, int tid)
+{
+    // ---- U'^-1 -> UI (its diagonal blocks: left by the LU's matrix-core diagonal steps in the workspace)
+    cq_load_upper(L, ws + CQ_LU, w, tid);
+    cq_diag_slots(L, ws + CQ_X3, w, tid, false);
+    __syncthreads();
+    cq_upper_inv(L, w, 1, 0, tid);
+    cq_inv_out(L, ws + CQ_UI, w, tid);
+}
+__device__ __forceinline__ void cq_post_r(const CqLds& L, double* ws, int w, int tid)
+{
+    // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
+    cq_load_upper(L, ws + CQ_R2, w, tid);
+    cq_load_lowerT(L, ws + CQ_R1, w, tid);
+    __syncthreads();
+    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_RR + i * CQ_W + j, (j >= i) ? L.sv[i] * v : 0.0); });
+}
+__device__ __forceinline__ void cq_post_t(const CqLds& L, double* ws, int w, int tid)
+{
+    // ---- U = U' R2^-1 -> X2 (U' above the diagonal, R2^-1 transposed below it)
+    cq_load_upper(L, ws + CQ_LU, w, tid);
+    cq_load_lowerT(L, ws + CQ_X1, w, tid);
+    __syncthreads();
+    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_X2 + i * CQ_W + j, (j >= i) ? v : 0.0); });
+    __syncthreads();
+    // ---- L1^-T: the inverse of the unit upper-triangular L1^T stays below the diagonal of L.M
+    // (L1^T)(j, i) = L1(i, j): row i of LU read along j
+    cq_elems(w, tid, [&](int i, int j) { return ws[CQ_LU + i * CQ_W + j]; }, [&](int i, int j, double v) { if (j < w && i >= j) L.M[j * CQ_LD + i] = (i == j) ? 1.0 : v; });
+    cq_diag_slots(L, ws + CQ_X3, w, tid, true);
+    __syncthreads();
+    cq_upper_inv(L, w, 1, 0, tid);
+    // ---- T = -U S L1^-T: U (X2) -> the upper triangle of L.M, S folded into U's columns
+    cq_sync_global();
+    cq_load_upper(L, ws + CQ_X2, w, tid);
+    __syncthreads();
+    cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
+}
+// all three pieces in one launch (two workgroups): the stage-by-stage entry points of devtools/tools_cqr_debug.py
 __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const int* status)
 {
     extern __shared__ double sm[];
@@ -677,37 +720,17 @@ __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const
     if (status[0]) return;
     if (tid < w) L.sv[tid] = ws[CQ_SV + tid];
     if (blockIdx.x == 0) {
-        // ---- U'^-1 -> UI (its diagonal blocks: left by the LU's matrix-core diagonal steps in the workspace)
-        cq_load_upper(L, ws + CQ_LU, w, tid);
-        cq_diag_slots(L, ws + CQ_X3, w, tid, false);
+        cq_post_ui(L, ws, w, tid);
         __syncthreads();
-        cq_upper_inv(L, w, 1, 0, tid);
-        cq_inv_out(L, ws + CQ_UI, w, tid);
-        __syncthreads();
-        // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
-        cq_load_upper(L, ws + CQ_R2, w, tid);
-        cq_load_lowerT(L, ws + CQ_R1, w, tid);
-        __syncthreads();
-        cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_RR + i * CQ_W + j, (j >= i) ? L.sv[i] * v : 0.0); });
-    } else {
-        // ---- U = U' R2^-1 -> X2 (U' above the diagonal, R2^-1 transposed below it)
-        cq_load_upper(L, ws + CQ_LU, w, tid);
-        cq_load_lowerT(L, ws + CQ_X1, w, tid);
-        __syncthreads();
-        cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_X2 + i * CQ_W + j, (j >= i) ? v : 0.0); });
-        __syncthreads();
-        // ---- L1^-T: the inverse of the unit upper-triangular L1^T stays below the diagonal of L.M
-        // (L1^T)(j, i) = L1(i, j): row i of LU read along j
-        cq_elems(w, tid, [&](int i, int j) { return ws[CQ_LU + i * CQ_W + j]; }, [&](int i, int j, double v) { if (j < w && i >= j) L.M[j * CQ_LD + i] = (i == j) ? 1.0 : v; });
-        cq_diag_slots(L, ws + CQ_X3, w, tid, true);
-        __syncthreads();
-        cq_upper_inv(L, w, 1, 0, tid);
-        // ---- T = -U S L1^-T: U (X2) -> the upper triangle of L.M, S folded into U's columns
-        cq_sync_global();
-        cq_load_upper(L, ws + CQ_X2, w, tid);
-        __syncthreads();
-        cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
-    }
+        cq_post_r(L, ws, w, tid);
+    } else cq_post_t(L, ws, w, tid);
+}
+__global__ __launch_bounds__(CQ_T) void cqr_ui_kernel(double* ws, int w, const int* status)
+{
+    extern __shared__ double sm[];
+    const CqLds L = cq_lds(sm);
+    if (status[0]) return;
+    cq_post_ui(L, ws, w, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -742,6 +765,7 @@ constexpr int CS_NWG = 256;                                    // workgroups of 
 constexpr int CS_NWG_GRAM = 256;                               // workgroups (= partials) of the Gram-only pass
 constexpr size_t CS_LDS_BYTES = sizeof(double) * (CS_XC + 4 * 16 * CS_QLD);
 constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass
+constexpr size_t CQ_VP_LDS_BYTES = CQ_LDS_BYTES > CS_LDS_BYTES ? CQ_LDS_BYTES : CS_LDS_BYTES;   // cqr_vpass_kernel: one-workgroup riders + the streaming workgroups
 __device__ __forceinline__ int cs_blk(int kb, int jb) { return (jb * (jb + 1) / 2 + kb) * 256; }
 // the 144 (tile jt, k-step ks) pairs of a 16-row block's product in order: chain jt (4 (jt + 1) MFMAs) starts at n = 2 jt (jt + 1)
 __host__ __device__ constexpr int cs_n_jt(int n) { int jt = 0; while (2 * (jt + 1) * (jt + 2) <= n) ++jt; return jt; }
@@ -808,7 +832,7 @@ __device__ __forceinline__ void cs_gram_rows(v4d (&g0)[8], v4d (&g1)[8], const d
 
 template <bool MULT, bool GRAM, bool DST2>
 __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __restrict__ X, int w, int mk, const double* src, int lds_, double* dst,
-                                                int ldd, double* dst2, int ldd2, double* slabs, const int* status)
+                                                int ldd, double* dst2, int ldd2, double* slabs, const int* status, const int bid, const int nbid)
 {
     if (MULT && status && status[0]) return;                  // refused (pass 2: by the first Cholesky): nothing is written
     double* Xc = sm;
@@ -839,10 +863,19 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) x[ks] = sp[(size_t) (4 * ks + l4 < w ? 4 * ks + l4 : 0) * lds_];
     };
-    int blk = blockIdx.x;
-    if (blk < nblk) load(q, 4 * blk + wave);
-    for (; blk < nblk; blk += gridDim.x) {
-        const int tile = 4 * blk + wave;
+    // Tile order: tile = 4 blk + wave, blocks strided over the workgroups (the four waves of a workgroup on one 64-row block: the Gram
+    // phase needs that, and the chip then reads ONE moving window of the panel).  The pass without a Gram phase has independent waves and
+    // deals its LAST, partial round out by tiles, wave-major (tile = base + wave nbid + bid): the round is then short by tiles, not by
+    // whole blocks -- which is what lets cqr_vpass_kernel give two of the 256 compute units to its riders (254 streaming workgroups:
+    // 16.13 rounds; by blocks 32 workgroups would run a 17th block, +6 %; by tiles +1.5 %)
+    const int tstride = 4 * nbid;
+    const int tend = GRAM ? 4 * nblk : ntile;                 // (GRAM: every wave of a workgroup makes the same number of trips: barriers inside)
+    const int nfull = GRAM ? 0x7fffffff / (tstride + 1) : ntile / tstride;
+    auto tile_at = [&](int k) { return k < nfull ? k * tstride + 4 * bid + wave : (k == nfull ? nfull * tstride + wave * nbid + bid : tend); };
+    int kround = 0, tile = tile_at(0);
+    if (tile < tend) load(q, tile);
+    for (int tnext; tile < tend; tile = tnext) {
+        tnext = tile_at(++kround);
         // the next block's rows are requested before this block's matrix-core work: with GRAM into q itself once the block has gone to
         // LDS / through the product (the Gram instructions cover the latency, and a second buffer would cost the second wave per SIMD)
         const int row = 16 * tile + l15;
@@ -854,7 +887,7 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
             // of tile jt - 1 one per MFMA from the third MFMA of tile jt on (its results are then two MFMAs old: no wait states to pad),
             // and -- the pass without a Gram phase -- the next block's loads one per four MFMAs.  In a burst they fill the CU's
             // vector-memory queue, the wave waits AT the instruction and the MFMAs behind it wait too (in-order issue).
-            const int tn = tile + 4 * gridDim.x, rown = 16 * tn + l15;
+            const int tn = tnext, rown = 16 * tn + l15;
             const double* spn = src + (rown < mk ? rown : mk - 1);
             auto store_reg = [&](const v4d& acc, int jt, int r) {
                 const int colj = 16 * jt + l4 + 4 * r;
@@ -904,7 +937,7 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
         }
         if (GRAM) {
             // the next block's rows: one load per k-step of the Gram instructions (32 k-steps per wave and block)
-            const int tn = tile + 4 * gridDim.x, rown = 16 * tn + l15;
+            const int tn = tnext, rown = 16 * tn + l15;
             const double* spn = src + (rown < mk ? rown : mk - 1);
             auto load1 = [&](int ks) { q[ks] = spn[(size_t) (4 * ks + l4 < w ? 4 * ks + l4 : 0) * lds_]; };
             cs_lds_barrier();
@@ -917,7 +950,7 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
             for (int ks = 0; ks < 32; ++ks) q[ks] = qn[ks];
     }
     if (GRAM) {
-        double* out = slabs + (size_t) blockIdx.x * 36 * 256;
+        double* out = slabs + (size_t) bid * 36 * 256;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int tr = half ? 7 - wave : wave;
@@ -935,7 +968,24 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
                                                                  int ldd, double* dst2, int ldd2, double* slabs, const int* status)
 {
     extern __shared__ double sm[];
-    cqr_stream_body<MULT, GRAM, DST2>(sm, X, w, mk, src, lds_, dst, ldd, dst2, ldd2, slabs, status);
+    cqr_stream_body<MULT, GRAM, DST2>(sm, X, w, mk, src, lds_, dst, ldd, dst2, ldd2, slabs, status, blockIdx.x, gridDim.x);
+}
+// The last pass (V = (Q - [S R2; 0]) U'^-1 -> Vw and A) with T and R riding along: workgroups 0 and 1 run cq_post_t / cq_post_r (one-workgroup
+// work that nothing in this launch waits for: cqr_top_kernel, behind it, reads T and R), the others stream.  LDS: the larger of the two.
+__global__ __launch_bounds__(CS_THREADS) void cqr_vpass_kernel(double* ws, int w, int mk, const double* src, int lds_, double* dst, int ldd, double* dst2,
+                                                                int ldd2, const int* status)
+{
+    extern __shared__ double sm[];
+    if (status[0]) return;
+    if (blockIdx.x < 2) {
+        const CqLds L = cq_lds(sm);
+        const int tid = threadIdx.x;
+        if (tid < w) L.sv[tid] = ws[CQ_SV + tid];
+        if (blockIdx.x == 0) cq_post_t(L, ws, w, tid);
+        else { __syncthreads(); cq_post_r(L, ws, w, tid); }
+        return;
+    }
+    cqr_stream_body<true, false, true>(sm, ws + CQ_UI, w, mk, src, lds_, dst, ldd, dst2, ldd2, nullptr, status, blockIdx.x - 2, gridDim.x - 2);
 }
 // The Gram-only pass, G1 = A^T A (33 KB of LDS).  Tried and no faster: two waves per SIMD (132 us against 128), four workgroups per CU
 // (191 = 191 before the scalar wave index), two LDS block buffers with one barrier per block and the transposition of block i + 1
@@ -944,7 +994,7 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
 __global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs)
 {
     extern __shared__ double sm[];
-    cqr_stream_body<false, true, false>(sm, nullptr, w, mk, src, lds_, nullptr, 0, nullptr, 0, slabs, nullptr);
+    cqr_stream_body<false, true, false>(sm, nullptr, w, mk, src, lds_, nullptr, 0, nullptr, 0, slabs, nullptr, blockIdx.x, gridDim.x);
 }
 
 // G (column-major ld CQ_W, both triangles) = sum over the workgroup partials, in slab order.  Tile t = (ti <= tj), accumulator
@@ -954,8 +1004,16 @@ __global__ __launch_bounds__(256) void cqr_gram_reduce_kernel(const double* __re
     __shared__ double part[8][33];
     const int t = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, el = tid & 31, grp = tid >> 5;
     const int e = chunk * 32 + el;
+    // fixed order per group; the (up to) 32 partials of a thread are requested together: one after the other, each add waited for its own
+    // load and the launch was 32 memory latencies long (11.7 us for 19 MB)
     double s = 0.0;
-    for (int q = grp; q < nslab; q += 8) s += slabs[(size_t) q * 36 * 256 + t * 256 + e];       // fixed order per group
+    for (int q0 = grp; q0 < nslab; q0 += 8 * 32) {
+        double x[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int q = q0 + 8 * u; x[u] = slabs[(size_t) (q < nslab ? q : grp) * 36 * 256 + t * 256 + e]; }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) if (q0 + 8 * u < nslab) s += x[u];
+    }
     part[grp][el] = s;
     __syncthreads();
     if (grp == 0) {
@@ -997,6 +1055,8 @@ int qrd_panel_cqr_init(void)
     hipError_t e = hipFuncSetAttribute((const void*) cqr_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_ui_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_GRAM);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
@@ -1028,9 +1088,10 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
                        (double*) nullptr, 0, ws + CQ_SL, status);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
-    hipLaunchKernelGGL(cqr_post_kernel, dim3(2), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
-    hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Qb, ldq, Vw, ldv, A, lda,
-                       (double*) nullptr, status);
+    hipLaunchKernelGGL(cqr_ui_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
+    const int vgrid = grid + 2 <= CS_NWG ? grid + 2 : CS_NWG;       // riders included: never more workgroups than compute units
+    hipLaunchKernelGGL(cqr_vpass_kernel, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, Vw, ldv, A, lda,
+                       (const int*) status);
     hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
     return (int) hipGetLastError();
 }

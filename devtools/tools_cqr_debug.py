@@ -68,6 +68,8 @@ if len(sys.argv) > 3:
     print('  inverse inside the Cholesky kernel: zero %.1f  diagonal blocks %.1f  level 1 %.1f  level 2 %.1f us' % tuple((int(st[b]) - int(st[a])) * 0.01 for a, b in ((2, 20), (20, 21), (21, 22), (22, 23))))
     t = lambda i: int(st[i]) * 0.01
     print('  LU kernel (us): diagonal block 0 %.1f | S R2 + U12 + L21 (all waves) %.1f | wave 0: next block update %.1f' % (t(25) - t(24), t(26) - t(25), t(27) - t(26)))
+    print('  LU kernel start (us): Q_top requested + G2 into LDS %.1f | distance from I, first-order factor %.1f | R2 and R2^-1 stores issued %.1f | to the barrier %.1f'
+          % (t(28) - t(8), t(29) - t(28), t(30) - t(29), t(9) - t(30)))
     for a, b in ((0, 5), (8, 12)):
         for i in range(a + 1, b):
             print("  %-16s %8.1f us" % (names.get(i, i), (int(st[i]) - int(st[i - 1])) * 0.01))

@@ -288,7 +288,10 @@ def test_panel_guard_route_all_heights(q, oracle, mk):
     P = np.random.default_rng(mk).random((mk, w))
     P[:, 17] = P[:, 4]
     out, tau, T, V, guard, _ = _cholqr_leaf(q, P)
-    assert guard == 1
+    # (a tall leaf whose height is not a multiple of 4 has no streaming CholeskyQR2 form since round 5: it takes the Householder route
+    # directly, without a refusal to record)
+    direct = mk > 32 * 512 and mk % 4 != 0
+    assert guard == (0 if direct else 1)
     assert np.isfinite(out).all() and np.isfinite(T).all() and np.isfinite(V).all() and np.isfinite(tau).all()
     QtP = P - V @ (T.T @ (V.T @ P))
     assert np.abs(np.tril(QtP, -1)).max() < 1e-11 * np.sqrt(mk)

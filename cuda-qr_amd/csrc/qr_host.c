@@ -308,10 +308,15 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
      * and the short stacked panels everyone is waiting for, goes first whenever both have work queued) */
     /* MI355XQR_TSQR_RESERVE_CUS=c (multi-rank local plans only; default 0 = off): the local factorisation's stream is masked to all but c
      * compute units, so that RCCL's kernels -- a handful of workgroups -- never wait for a slot behind a chip-filling update.  Stream priority
-     * alone orders the QUEUES, it does not free a compute unit.  c = 8 is one CU of every XCD (a mask bit is CU i/8 of XCC i%8). */
+     * alone orders the QUEUES, it does not free a compute unit.  c is rounded up to a multiple of 32 = one CU of every shader engine of
+     * every XCD (a mask bit is CU i/8 of XCC i%8, and CU j of an XCC sits in its shader engine j%4): the dispatcher deals the workgroups of a
+     * launch evenly over the shader engines whatever the mask says, so with 16 reserved (two engines of each XCD one CU short) the
+     * one-workgroup-per-CU passes of the full-width panel ran a second round on those engines and took twice as long
+     * (local QR of a 262144 x 512 shard 4.7 -> 7.0 ms; with 32: see profiles/NOTES.md). */
     int rc = 0;
     {
-        const int reserve = tsqr_local ? env_int("MI355XQR_TSQR_RESERVE_CUS", 0) : 0;
+        int reserve = tsqr_local ? env_int("MI355XQR_TSQR_RESERVE_CUS", 0) : 0;
+        if (reserve > 0) reserve = (reserve + 31) / 32 * 32;
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
         if (reserve > 0 && reserve < cus) rc = qrd_stream_create_cumask(&p->s_main, reserve, cus - reserve);

@@ -1080,7 +1080,11 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
     hipStream_t s = (hipStream_t) stream;
     hipError_t e = hipMemsetAsync(status, 0, sizeof(int), s);
     if (e != hipSuccess) return (int) e;
-    const int grid = cs_grid(mk), ggrid = cs_grid(mk, CS_NWG_GRAM), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
+    // one persistent workgroup per compute unit OF THIS STREAM (a CU-masked stream -- MI355XQR_TSQR_RESERVE_CUS, a panel partition -- would
+    // otherwise run the workgroups beyond its mask as a second round behind the first: twice the pass)
+    int cap = qrd_stream_cus(stream);
+    if (cap <= 0 || cap > CS_NWG) cap = CS_NWG;
+    const int grid = cs_grid(mk, cap), ggrid = cs_grid(mk, cap), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
     hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
     hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
@@ -1089,7 +1093,7 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
     hipLaunchKernelGGL(cqr_ui_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
-    const int vgrid = grid + 2 <= CS_NWG ? grid + 2 : CS_NWG;       // riders included: never more workgroups than compute units
+    const int vgrid = grid + 2 <= cap ? grid + 2 : cap;             // riders included: never more workgroups than compute units
     hipLaunchKernelGGL(cqr_vpass_kernel, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, Vw, ldv, A, lda,
                        (const int*) status);
     hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);

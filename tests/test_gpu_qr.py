@@ -776,6 +776,24 @@ def test_tsqr_set_schedule_switches_between_the_two_exchange_forms_in_one_plan(q
     small.close()
 
 
+def test_tsqr_reserve_cus_masks_the_local_stream_and_changes_nothing_else(qr, oracle):
+    """MI355XQR_TSQR_RESERVE_CUS=16 (child process: the knob is read at plan creation; rounded up to 32 = one CU per shader engine): the
+    local factorisation of a multi-rank plan runs on a stream masked to 224 compute units -- the full-width panel sizes its launches to
+    that -- and the result is LAPACK's."""
+    import subprocess, sys, os
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import cuda_qr_amd as q\n"
+            "tp = q.TsqrPlan(65536, 256, 4, 1, 128, comm='external')\n"
+            "A = torch.zeros((256, 65536), dtype=torch.float64, device='cuda'); R = torch.zeros((256, 256), dtype=torch.float64, device='cuda'); torch.cuda.synchronize()\n"
+            "tp.local.fill_uniform(A, 65536, 65536, 256, seed=7); tp.sync(); A0 = A.cpu().numpy().T.copy()\n"
+            "tp.factor_selfgather(A, 65536, R); tp.sync()\n"
+            "np.save(sys.argv[1], R.cpu().numpy().T); np.save(sys.argv[2], A0)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code, "/tmp/tsqr_reserve_R.npy", "/tmp/tsqr_reserve_A.npy"], check=True,
+                   env=dict(os.environ, MI355XQR_TSQR_RESERVE_CUS="16"), timeout=300)
+    R, A0 = np.load("/tmp/tsqr_reserve_R.npy"), np.load("/tmp/tsqr_reserve_A.npy")
+    ref = oracle.sign_normalise(np.linalg.qr(A0, mode="r")) * 2.0          # sqrt(P) with the rank's own factor in every slot
+    assert rel(oracle.sign_normalise(np.triu(R)), ref) < 1e-13
+
+
 def test_tsqr_exchange_buffers_as_torch_views(qr, oracle):
     """The fallback transport of bench.py (torch.distributed gathers the R factors when the library cannot create its own RCCL
     communicator) works directly on the plan's device buffers through zero-copy torch views: the send view must show this rank's R

@@ -451,6 +451,19 @@ def main():
                            "note": "x1.55: the write-allocated C tiles push the operand tiles of the 128 x 64 tiling (3.75 MB per XCD at a time) out of the 4 MB L2 "
                                    "and they are fetched again -- from the 256 MB Infinity Cache, which FETCH_SIZE (L2 misses) cannot tell from HBM; with "
                                    "non-temporal C accesses the refetches go away (-40 %) and nothing gets faster (profiles/r05_nt_ceiling.txt)"}
+        # the committed rocprofv3 --kernel-trace --stats summary of this bench command: the kernel's average duration there, next to the
+        # HIP-event figure of this run (an event bracket also holds two barrier packets and the dispatch latency: ~15 us per launch)
+        rocprof_ref = None
+        try:
+            import csv
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_bench_c3_kernel_stats.csv"))):
+                if wl == "c3" and row["Name"].startswith("void gemm_nt4_kernel<true, 0, 8, 3>"):
+                    ns = float(row["AverageNs"])
+                    rocprof_ref = {"file": "profiles/r05_bench_c3_kernel_stats.csv", "calls": int(row["Calls"]), "avg_launch_ms": ns * 1e-6,
+                                   "achieved_at_that_duration": (upd["flops"] / upd["launches"]) / (ns * 1e-9) / 1e12,
+                                   "note": "same command under rocprofv3 (committed); the launch mix per step is the one timed here"}
+        except Exception:
+            rocprof_ref = None
         cus_u = None
         try:
             cus_u = int(be.plan.update_cus())
@@ -474,6 +487,7 @@ def main():
                 "rocprof_pmc": "profiles/r05_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel, whole chip: rocprofv3 --pmc crashes on CU-masked streams on this pool)",
                 "ceiling": "profiles/r05_nt_ceiling.txt (same launch mix with the C traffic / the operand loads compiled out: 58.9 / 61.4 TFLOP/s in situ bound any K = 256 kernel on 224 CUs)",
                 "measured_probe": measured,
+                "rocprofv3_same_kernel": rocprof_ref,
                 "launches": upd["launches"], "avg_launch_ms": upd["ms"] / upd["launches"],
                 "profiled_steps_in_timed_region": len(range(0, K, stride)),
                 "algorithmic_flops_per_launch": upd["flops"] / upd["launches"],

@@ -129,6 +129,7 @@ int qrd_graph_destroy(void* exec);
 int qrd_stream_sync(void* s);
 int qrd_device_sync(void);
 int qrd_event_create(void** e);
+int qrd_event_create_timing(void** e);          /* timing brackets only: recorded without a system-scope fence */
 int qrd_event_create_notiming(void** e);
 int qrd_event_destroy(void* e);
 int qrd_event_record(void* e, void* s);

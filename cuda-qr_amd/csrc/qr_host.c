@@ -623,7 +623,7 @@ static int prof_begin_on(qr_plan* p, int cls, void* stream)
     }
     const int r = p->prof_count;
     for (int e = 0; e < 2; ++e)
-        if (!p->prof_ev[2 * r + e]) CHECK(qrd_event_create(&p->prof_ev[2 * r + e]));
+        if (!p->prof_ev[2 * r + e]) CHECK(qrd_event_create_timing(&p->prof_ev[2 * r + e]));
     p->prof_cls[r] = cls;
     p->prof_open = 1;
     p->prof_stream = stream;

@@ -110,6 +110,7 @@ int qrd_graph_launch(void* exec, void* s) { (void) s; return exec ? 0 : 1; }
 int qrd_graph_destroy(void* exec) { free(exec); return 0; }
 int qrd_event_create(void** e) { *e = calloc(1, 8); return *e ? 0 : 2; }
 int qrd_event_create_notiming(void** e) { return qrd_event_create(e); }
+int qrd_event_create_timing(void** e) { return qrd_event_create(e); }
 int qrd_event_destroy(void* e) { free(e); return 0; }
 /* a record stamps the event with a process-wide tick (0.01 "ms" apart, or QRD_STUB_GATHER_MS after a collective: the joint fall-back
  * decision of the pipelined exchange can be driven from a test), so that elapsed times are ordered like the records */

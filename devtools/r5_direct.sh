@@ -1,15 +1,14 @@
 #!/bin/bash
-# the transposition-free streaming passes (MI355XQR_CQR_DIRECT) against the LDS-transposing ones: parity tests, kernel times, whole shapes
+# the full-width tall panel: parity tests, kernel times of one 262144 x 128 panel under rocprofv3, whole shapes (the lab knob
+# MI355XQR_CQR_DIRECT this script once swept lived in commit b04e155 only: profiles/r05_cqr_direct_passes.txt)
 R=gpurun_out/r5_direct; rm -rf $R; mkdir -p $R
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout -k 10 600 python3 -m pytest tests/test_gpu_panel_cqr.py -x -q > $R/tests.txt 2>&1; echo "tests rc=$?"; tail -3 $R/tests.txt
 for d in 0; do
-  true
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/s$d -o tl -- python3 devtools/tools_cqr_perf.py 262144 128 0 > $R/log$d.txt 2>&1
   python3 - <<PY
 import csv, glob
 f = glob.glob("$R/s$d/*kernel_stats.csv")[0]
-print("MI355XQR_CQR_DIRECT=$d")
 for r in list(csv.DictReader(open(f)))[:12]:
     if 'cqr' in r['Name']: print(r['Name'][:90].ljust(90), r['Calls'].rjust(5), ('%.1f' % (float(r['AverageNs']) / 1e3)).rjust(8), 'us avg')
 PY

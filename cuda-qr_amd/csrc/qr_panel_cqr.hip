@@ -1093,7 +1093,7 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
     hipLaunchKernelGGL(cqr_ui_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
-    const int vgrid = grid + 2 <= cap ? grid + 2 : cap;             // riders included: never more workgroups than compute units
+    const int vgrid = grid + 2 <= cap ? grid + 2 : (cap >= 3 ? cap : 3);      // riders included: never more workgroups than compute units (and at least one streaming workgroup)
     hipLaunchKernelGGL(cqr_vpass_kernel, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, Vw, ldv, A, lda,
                        (const int*) status);
     hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);

@@ -1813,7 +1813,12 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
             n / pnb >= 2 && n / pnb + 1 <= QR_TSQR_MAXPAN) {
             t->npan = n / pnb;
             for (int k = 0; k <= t->npan; ++k) t->pan_k[k] = k * pnb;
-            if (pnb >= 128 && (pnb / 2) % t->p->ib == 0 && 1) {   /* halves of 32 columns lose (65536 x 256, nb 64: 0.39 against 0.32 ms exposed) */
+            /* the last block column in two halves -- what stays exposed after the local QR has ended is the stacked factorisation of the
+             * last block, and the first half's can run under the local second half -- while the stacked matrix is short (its panels go
+             * leaf by leaf); from 3072 stacked rows a stacked panel is ONE launch (qr_panel_fused.hip) and two of them with an update in
+             * between cost more than they hide (C5 rank, 4096 stacked rows: 0.83 -> 0.65 ms exposed without the split; C4 ranks, 1024 /
+             * 512 rows: 0.29 / 0.40 with it against 0.32 / 0.44).  Halves of 32 columns lose (65536 x 256, nb 64: 0.39 against 0.32) */
+            if (pnb >= 128 && (pnb / 2) % t->p->ib == 0 && t->sm < knobs()->fused_min_rows) {
                 t->pan_k[t->npan] = n - pnb / 2;
                 t->pan_k[++t->npan] = n;
             }

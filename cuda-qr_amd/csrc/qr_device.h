@@ -58,6 +58,7 @@ int qrd_extract_r(void* stream, const double* A, int lda, int m, int n, double* 
 int qrd_extract_r_block(void* stream, const double* A, int lda, int k, int w, double* R, int ldr, int rrows);
 int qrd_set_identity(void* stream, double* C, int ld, int rows, int cols, int row_off);
 int qrd_copy_block(void* stream, const double* S, int lds, double* D, int ldd, int rows, int cols);
+int qrd_copy_blocks(void* stream, const double* S, int lds, size_t sstride, double* D, int ldd, size_t dstride, int rows, int cols, int batch);
 int qrd_fill_uniform(void* stream, double* A, int ld, long long rows, int cols, long long row_off,
                      long long total_rows, unsigned long long seed);
 double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx);

@@ -1986,8 +1986,8 @@ static int tsqr_stacked_panel(qr_tsqr_plan* t, int pi)
     qr_plan* p2 = t->p2;
     const int n = t->n, P = t->nranks, sm = t->sm, nb = p2->nb, k = t->pan_k[pi], wout = t->pan_k[pi + 1] - k;
     void* s = p2->s_main;
-    for (int q = 0; q < P; ++q)      /* rank q's block column: n x wout, packed (stride n * wout) */
-        CHECK(qrd_copy_block(s, t->drecv + (size_t) q * n * wout, n, t->dS + (size_t) k * sm + (size_t) q * n, sm, n, wout));
+    /* rank q's block column: n x wout, packed (stride n * wout) -> rows q n .. of the stacked block column; one launch for all ranks */
+    CHECK(qrd_copy_blocks(s, t->drecv, n, (size_t) n * wout, t->dS + (size_t) k * sm, sm, (size_t) n, n, wout, P));
     for (int j = 0; j < pi; ++j) {      /* (I - V_j T_j V_j^T)^T on rows pan_k[j] .. of the new block column */
         const int kj = t->pan_k[j], wj = t->pan_k[j + 1] - kj;
         CHECK(apply_small_t(p2, s, t->Vst + (size_t) j * p2->ldv * nb, p2->ldv, t->Tst + (size_t) j * p2->ldt * nb, p2->ldt, sm - kj, wj,

@@ -494,6 +494,15 @@ __global__ void copy_block_kernel(const double* __restrict__ S, int lds, double*
     if (i < rows && c < cols) D[(size_t) c * ldd + i] = S[(size_t) c * lds + i];
 }
 
+// `batch` blocks in one launch: block q at S + q * sstride -> D + q * dstride (the P rank blocks of a stacked block column: P launches of
+// ~6 us each sat on the exposed tail of every multi-GPU step)
+__global__ void copy_blocks_kernel(const double* __restrict__ S, int lds, size_t sstride, double* __restrict__ D, int ldd, size_t dstride, int rows, int cols)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    const size_t q = blockIdx.z;
+    if (i < rows && c < cols) D[q * dstride + (size_t) c * ldd + i] = S[q * sstride + (size_t) c * lds + i];
+}
+
 // Counter-based uniform[0,1) generator: element (global row gi, column c) of a total_rows x cols
 // matrix depends only on (seed, c*total_rows + gi): shard-count independent, so 1/2/4/8-GPU
 // runs factor the same matrix.  splitmix64 finaliser; 53 random mantissa bits.
@@ -1079,6 +1088,14 @@ int qrd_copy_block(void* stream, const double* S, int lds, double* D, int ldd, i
     if (rows <= 0 || cols <= 0) return 0;
     hipLaunchKernelGGL(copy_block_kernel, dim3((rows + 255) / 256, cols), dim3(256), 0, (hipStream_t) stream, S, lds,
                        D, ldd, rows, cols);
+    return (int) hipGetLastError();
+}
+
+int qrd_copy_blocks(void* stream, const double* S, int lds, size_t sstride, double* D, int ldd, size_t dstride, int rows, int cols, int batch)
+{
+    if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3((rows + 255) / 256, cols, batch), dim3(256), 0, (hipStream_t) stream, S, lds, sstride, D, ldd, dstride,
+                       rows, cols);
     return (int) hipGetLastError();
 }
 

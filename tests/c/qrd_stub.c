@@ -305,6 +305,8 @@ int qrd_extract_r(void* s, const double* A, int lda, int m, int n, double* R, in
 int qrd_extract_r_block(void* s, const double* A, int lda, int k, int w, double* R, int ldr, int rr)
 { (void) s; chk("extract_r_block A", A + (size_t) k * lda, lda, k + w, w); chk("extract_r_block R", R, ldr, rr, w); return 0; }
 int qrd_set_identity(void* s, double* C, int ld, int r, int c, int ro) { (void) s; (void) ro; chk("set_identity", C, ld, r, c); return 0; }
+int qrd_copy_blocks(void* s, const double* S, int lds, size_t ss, double* D, int ldd, size_t ds, int r, int c, int batch)
+{ (void) s; for (int q = 0; q < batch; ++q) { chk("copy_blocks S", S + q * ss, lds, r, c); chk("copy_blocks D", D + q * ds, ldd, r, c); } return 0; }
 int qrd_copy_block(void* s, const double* S, int lds, double* D, int ldd, int r, int c) { (void) s; chk("copy_block S", S, lds, r, c); chk("copy_block D", D, ldd, r, c); return 0; }
 int qrd_fill_uniform(void* s, double* A, int ld, long long rows, int cols, long long ro, long long tr, unsigned long long seed)
 { (void) s; (void) ro; (void) tr; (void) seed; chk("fill", A, ld, (long) rows, cols); return 0; }

@@ -78,6 +78,12 @@ int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, 
  * the verdict exists -- two thirds into the panel, so the host can decide what comes next while the last pass is still running */
 int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
                     double* Qb, int ldq, unsigned* hflag, unsigned seq);
+/* parked form (park != 0): V written once, into A (top block: unit lower, zeros above); R stays in ws until qrd_panel_cqr_restore_r;
+ * qrd_panel_cqr_r_block: R (upper, zeros below) into a w x w block of its own */
+int qrd_panel_cqr_p(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                    double* Qb, int ldq, unsigned* hflag, unsigned seq, int park);
+int qrd_panel_cqr_restore_r(void* stream, double* A, int lda, int w, const double* ws);
+int qrd_panel_cqr_r_block(void* stream, const double* ws, int w, double* D, int ldd);
 double* qrd_panel_cqr_g1(double* ws);
 double* qrd_panel_cqr_g2(double* ws);
 int qrd_panel_cqr_stage1(void* stream, const double* A, int lda, int mk, int w, double* Vw, int ldv, double* ws, int* status);

@@ -77,6 +77,12 @@ struct qr_plan {
     int panel_tsqr;             /* 1: Householder-TSQR leaf alone (MI355XQR_PANEL=tsqr); 3: CholeskyQR2 + Householder reconstruction, guarded by (1) */
     double* chol_ws;
     double* cq_ws; int* cq_status;   /* small-factor workspace and guard words of the full-width tall panel (qr_panel_cqr.hip); NULL: not used */
+    /* "parked" full-width panels (round 5): on single-stream plans whose next update applies T to the small product (tall shapes) the panel's
+     * V is written once, into the caller's array -- top block included, as the unit lower triangle -- and the update reads it from there;
+     * R of the top block waits in the workspace and is put back right after that update (cq_unpark).  park_hint: set by the caller of
+     * factor_panel for ONE call (it knows what follows the panel); cq_parked: the panel in cq_park_top is in that state now */
+    int park_hint, cq_parked, cq_park_lda, cq_park_w;
+    double* cq_park_top;
     unsigned *cq_hword, *cq_hword_dev;   /* host word (mapped into the device) that receives a tall panel's verdict as soon as it exists */
     unsigned cq_seq;            /* sequence number of the last tall panel issued */
     int guard_latch;            /* 0: a refused tall panel is handed to the leaf chain (the host reads the verdict while the panel's last pass
@@ -129,6 +135,7 @@ typedef struct qr_knobs {
                                                              * 1.04 against 1.20), and on the CU-masked panel stream of a look-ahead plan the leaf chain does (16384 x 2048 8.0
                                                              * against 8.7): there the round-4 threshold stays */
     int tall_nt;                                            /* MI355XQR_TALL_NT: the update of a tall block through gemm_nt (W transposed first) */
+    int cqr_park;                                           /* MI355XQR_CQR_PARK: full-width panels of tall single-stream plans write V once (into A) */
     int fused_gram;                                         /* the panel's Gram blocks V_prev^T V_l inside the one-launch panel (else one launch after it): constant 0 */
 } qr_knobs;
 static qr_knobs g_knobs;
@@ -153,6 +160,7 @@ static void knobs_init(void)
     k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
     k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
     k->tall_nt = env_int("MI355XQR_TALL_NT", 1) != 0;
+    k->cqr_park = env_int("MI355XQR_CQR_PARK", 1) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -726,11 +734,11 @@ static int factor_panel(qr_plan* p, double* dA, int m, int lda, int k, int wout,
  * draining the stream as round 4 did: whatever comes next is queued ~0.2 ms before the stream needs it, the GPU never idles.  The host
  * thread does wait for that word; a caller that must not block inside qr_geqrf_dev sets the latch mode (qr_plan_set_guard_mode), in
  * which nothing is read here and a refusal is reported by qr_plan_sync. */
-static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, double* tauh, double* Th, int ldt, double* Vh, int ldv, double* Qh)
+static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, double* tauh, double* Th, int ldt, double* Vh, int ldv, double* Qh, int park)
 {
     const unsigned seq = (++p->cq_seq) & 0x3fffffffu;
     const int latch = p->guard_latch || !p->cq_hword;
-    CHECK(qrd_panel_cqr_q(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status, Qh, ldv, latch ? NULL : p->cq_hword_dev, seq));
+    CHECK(qrd_panel_cqr_p(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status, Qh, ldv, latch ? NULL : p->cq_hword_dev, seq, park));
     p->n_cqr += 1;
     p->cq_dirty = 1;
     if (latch) return 0;
@@ -756,8 +764,19 @@ static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, doub
     return st[0] != 0;
 }
 
+/* R of a parked panel back into the top block of the caller's array (after the updates that read V from there) */
+static int cq_unpark(qr_plan* p)
+{
+    if (!p->cq_parked) return 0;
+    p->cq_parked = 0;
+    return qrd_panel_cqr_restore_r(p->stream, p->cq_park_top, p->cq_park_lda, p->cq_park_w, p->cq_ws);
+}
+
 static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t, void* half_ready)
 {
+    const int park_hint = p->park_hint;
+    p->park_hint = 0;
+    CHECK(cq_unpark(p));                                      /* (never pending here: every caller that hints unparks behind its update) */
     const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt, nb = p->nb;
     double* Ak = dA + (size_t) k * lda + k;
     /* No per-panel zeroing of V's strictly upper part: column j of a panel only ever receives rows >= ib * floor(j / ib) (every
@@ -789,10 +808,12 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
         int cqr_done = 0;
         if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= plan_cqr_min_rows(p) && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
+            const int park = park_hint && kn->cqr_park && nhalf == 1 && !p->lookahead;
             const int rc = panel_cqr_half(p, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
-                                          p->Vw + (size_t) c0 * ldv + c0, ldv, p->VT + (size_t) c0 * ldv + c0);
+                                          p->Vw + (size_t) c0 * ldv + c0, ldv, p->VT + (size_t) c0 * ldv + c0, park);
             if (rc < 0) return rc;
             cqr_done = rc == 0;
+            if (cqr_done && park) { p->cq_parked = 1; p->cq_park_top = Ak; p->cq_park_lda = lda; p->cq_park_w = wh; }
         }
         const int fused_half = !cqr_done && p->pf_ws && !p->fused_off && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
                                qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);
@@ -941,7 +962,9 @@ static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int ld
         /* tall-skinny: forming V*T (mk x wout, 16 mk wout bytes, 2 mk wout^2 flops) would cost more than the few columns it is
          * applied to; apply T to the small product instead (262144 x 512: 1.1 GB less HBM traffic per factorisation) */
         CHECK(prof_begin_on(p, 3, stream));
-        CHECK(apply_small_t(p, stream, p->Vw2[e], ldv, p->T2[e], p->ldt, mk, wout, A2, lda, nc, Wbuf, Ybuf ? Ybuf : p->Ye2, slabs));
+        /* a parked panel (cq_parked): its V is the panel itself in the caller's array */
+        const double* Vp = p->cq_parked ? dA + (size_t) k * lda + k : p->Vw2[e];
+        CHECK(apply_small_t(p, stream, Vp, p->cq_parked ? lda : ldv, p->T2[e], p->ldt, mk, wout, A2, lda, nc, Wbuf, Ybuf ? Ybuf : p->Ye2, slabs));
         CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
         return 0;
     }
@@ -1101,9 +1124,13 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         for (int k = 0; k < n; k += nb) {
             const int wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
             CHECK(prof_begin(p, 2));
+            /* (what follows decides whether a full-width panel may park its R: only the update that applies T to the small product reads V
+             * through a pointer of its own) */
+            p->park_hint = nt > 0 && (size_t) nt * 8 <= (size_t) mk && p->Ye2 != NULL;
             CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0, NULL));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
             if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, NULL, p->slabs, 1, 1));
+            CHECK(cq_unpark(p));
         }
         return 0;
     }
@@ -1970,13 +1997,17 @@ static int tsqr_local_panel(qr_tsqr_plan* t, double* dA, int lda, int pi)
     const int m = t->m_local, n = t->n, k = t->pan_k[pi], wout = t->pan_k[pi + 1] - k, mk = m - k, nt = n - (k + wout);
     use_set(p, 0);
     CHECK(prof_begin(p, 2));
+    p->park_hint = nt > 0 && (size_t) nt * 8 <= (size_t) mk && p->Ye2 != NULL;
     CHECK(factor_panel(p, dA, m, lda, k, wout, t->dtau, nt > 0, NULL));
     CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
     /* block column k of R is final (its rows above the panel were finished by the earlier trailing updates): pack it */
     if (t->sent_pending[pi]) { CHECK(qrd_stream_wait_event(p->stream, t->ev_sent[pi])); t->sent_pending[pi] = 0; }
     CHECK(qrd_extract_r_block(p->stream, dA, lda, k, wout, t->dsend + (size_t) k * n, n, n));
+    /* (a parked panel's diagonal block of R is still in the panel workspace: the array holds V there until the update has run) */
+    if (p->cq_parked) CHECK(qrd_panel_cqr_r_block(p->stream, p->cq_ws, wout, t->dsend + (size_t) k * n + k, n));
     CHECK(qrd_event_record(t->ev_pan[pi], p->stream));
     if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, NULL, p->slabs, 1, 1));
+    CHECK(cq_unpark(p));
     return 0;
 }
 
@@ -2107,6 +2138,16 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
             tps[r]->npan != tps[0]->npan || tps[r]->p->nb != tps[0]->p->nb || lda < tps[r]->m_local)
             return QR_E_ARG;                 /* (shards of unequal height are fine: the schedule of the exchange does not depend on them) */
     const int n = tps[0]->n;
+    {
+        /* P ranks on ONE device are 2 P streams, each of which may hold a one-launch panel (up to 33 co-resident workgroups, a compute unit
+         * each): beyond the chip's compute units two such launches can each sit on part of the chip and wait for workgroups the other one
+         * keeps out -- until the hand-off times out (QR_E_STALL).  A real rank has the chip to itself (2 streams); here the launch chain is
+         * used instead once the streams could crowd each other. */
+        int cus = 256;
+        qrd_device_info(NULL, 0, &cus, NULL, NULL);
+        if (2 * P * 33 > cus)
+            for (int r = 0; r < P; ++r) { tps[r]->p->fused_off = 1; if (tps[r]->p2) tps[r]->p2->fused_off = 1; }
+    }
     for (int pi = 0; pi < tps[0]->npan; ++pi) {
         for (int r = 0; r < P; ++r) CHECK(tsqr_local_panel(tps[r], dA[r], lda, pi));
         for (int r = 0; r < P; ++r) {

@@ -972,6 +972,10 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
 }
 // The last pass (V = (Q - [S R2; 0]) U'^-1 -> Vw and A) with T and R riding along: workgroups 0 and 1 run cq_post_t / cq_post_r (one-workgroup
 // work that nothing in this launch waits for: cqr_top_kernel, behind it, reads T and R), the others stream.  LDS: the larger of the two.
+// DST2 = false: V goes to ONE destination -- the "parked" form (qrd_panel_cqr_p): the caller's array takes the whole of V, its top block
+// included (cqr_top_kernel<true>), the updates that follow read V from there, and R -- which stays in the workspace -- is put back
+// by cqr_restore_r_kernel afterwards: one 8 mk w byte write of the pass less.
+template <bool DST2>
 __global__ __launch_bounds__(CS_THREADS) void cqr_vpass_kernel(double* ws, int w, int mk, const double* src, int lds_, double* dst, int ldd, double* dst2,
                                                                 int ldd2, const int* status)
 {
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_vpass_kernel(double* ws, int w
         else { __syncthreads(); cq_post_r(L, ws, w, tid); }
         return;
     }
-    cqr_stream_body<true, false, true>(sm, ws + CQ_UI, w, mk, src, lds_, dst, ldd, dst2, ldd2, nullptr, status, blockIdx.x - 2, gridDim.x - 2);
+    cqr_stream_body<true, false, DST2>(sm, ws + CQ_UI, w, mk, src, lds_, dst, ldd, dst2, ldd2, nullptr, status, blockIdx.x - 2, gridDim.x - 2);
 }
 // The Gram-only pass, G1 = A^T A (33 KB of LDS).  Tried and no faster: two waves per SIMD (132 us against 128), four workgroups per CU
 // (191 = 191 before the scalar wave index), two LDS block buffers with one barrier per block and the transposition of block i + 1
@@ -1029,7 +1033,10 @@ __global__ __launch_bounds__(256) void cqr_gram_reduce_kernel(const double* __re
     }
 }
 
-// the top block after the last pass: A <- R on and above the diagonal, L1 below; Vw <- unit lower L1; T, tau
+// the top block after the last pass: A <- R on and above the diagonal, L1 below; Vw <- unit lower L1; T, tau.
+// PARK: A <- the unit lower L1 itself (zero above its diagonal: the whole of V now sits in A, ready to be a GEMM operand); Vw untouched;
+// R waits in the workspace for cqr_restore_r_kernel
+template <bool PARK>
 __global__ __launch_bounds__(256) void cqr_top_kernel(const double* ws, int w, double* A, int lda, double* Vw, int ldv, double* T, int ldt,
                                                        double* tau, const int* status)
 {
@@ -1037,11 +1044,24 @@ __global__ __launch_bounds__(256) void cqr_top_kernel(const double* ws, int w, d
     for (int e = threadIdx.x + blockIdx.x * blockDim.x; e < w * w; e += blockDim.x * gridDim.x) {
         const int j = e / w, i = e - j * w;                   // consecutive threads: consecutive rows of a column
         const double lu = ws[CQ_LU + i * CQ_W + j];
-        A[i + (size_t) lda * j] = (j >= i) ? ws[CQ_RR + i * CQ_W + j] : lu;
-        Vw[i + (size_t) ldv * j] = (j < i) ? lu : (j == i ? 1.0 : 0.0);
+        if (PARK) A[i + (size_t) lda * j] = (j < i) ? lu : (j == i ? 1.0 : 0.0);
+        else {
+            A[i + (size_t) lda * j] = (j >= i) ? ws[CQ_RR + i * CQ_W + j] : lu;
+            Vw[i + (size_t) ldv * j] = (j < i) ? lu : (j == i ? 1.0 : 0.0);
+        }
         const double tv = (j >= i) ? ws[CQ_TT + i * CQ_W + j] : 0.0;      // (tiles below the tile diagonal are never written)
         T[i + (size_t) ldt * j] = tv;
         if (i == j) tau[i] = tv;
+    }
+}
+// R (upper triangle, from the workspace) into a column-major w x w block: the top block of A after a parked panel's updates (lower part
+// kept: L1), or -- zero_below -- a block of its own (the multi-GPU step packs R before the update has run)
+__global__ __launch_bounds__(256) void cqr_restore_r_kernel(const double* ws, int w, double* D, int ldd, int zero_below)
+{
+    for (int e = threadIdx.x + blockIdx.x * blockDim.x; e < w * w; e += blockDim.x * gridDim.x) {
+        const int j = e / w, i = e - j * w;
+        if (j >= i) D[i + (size_t) ldd * j] = ws[CQ_RR + i * CQ_W + j];
+        else if (zero_below) D[i + (size_t) ldd * j] = 0.0;
     }
 }
 }   // namespace
@@ -1056,7 +1076,8 @@ int qrd_panel_cqr_init(void)
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_ui_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_GRAM);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_stream_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_BYTES);
@@ -1072,8 +1093,34 @@ static int cs_grid(int mk, int cap = CS_NWG) { const int g = (mk + 63) / 64; ret
 // The whole panel: six launches + two small reductions on `stream`.  status (device, 4 ints): [0] is zeroed here and is 1 afterwards when the
 // guard refused the panel -- A is then untouched, and so is Vw when Q has a buffer of its own (Qb: mk x w, ld ldq; NULL = Q lives in
 // Vw, whose contents are then garbage after a refusal); [1] counts refused panels (never reset here).  hflag / seq: see cqr_lu_kernel.
+static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                          double* Qb, int ldq, unsigned* hflag, unsigned seq, int park);
 int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
                     double* Qb, int ldq, unsigned* hflag, unsigned seq)
+{
+    return panel_cqr_impl(stream, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, Qb, ldq, hflag, seq, 0);
+}
+// park != 0 ("parked" form; Qb must be a buffer other than A): V is written ONCE, into A -- all of it, the top block as the unit lower
+// triangle with zeros above -- and Vw is not touched; R stays in the workspace until qrd_panel_cqr_restore_r puts it into the top block
+// (after the updates that use A's panel as V; before the next panel of this workspace).  qrd_panel_cqr_r_block: R as a block of its own.
+int qrd_panel_cqr_p(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                    double* Qb, int ldq, unsigned* hflag, unsigned seq, int park)
+{
+    if (park && (!Qb || Qb == A)) return -7;
+    return panel_cqr_impl(stream, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, Qb, ldq, hflag, seq, park);
+}
+int qrd_panel_cqr_restore_r(void* stream, double* A, int lda, int w, const double* ws)
+{
+    hipLaunchKernelGGL(cqr_restore_r_kernel, dim3((w * w + 255) / 256), dim3(256), 0, (hipStream_t) stream, ws, w, A, lda, 0);
+    return (int) hipGetLastError();
+}
+int qrd_panel_cqr_r_block(void* stream, const double* ws, int w, double* D, int ldd)
+{
+    hipLaunchKernelGGL(cqr_restore_r_kernel, dim3((w * w + 255) / 256), dim3(256), 0, (hipStream_t) stream, ws, w, D, ldd, 1);
+    return (int) hipGetLastError();
+}
+static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                          double* Qb, int ldq, unsigned* hflag, unsigned seq, int park)
 {
     if (!qrd_panel_cqr_ok(mk, w)) return -7;
     if (!Qb) { Qb = Vw; ldq = ldv; }
@@ -1094,9 +1141,15 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
     hipLaunchKernelGGL(cqr_ui_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
     const int vgrid = grid + 2 <= cap ? grid + 2 : (cap >= 3 ? cap : 3);      // riders included: never more workgroups than compute units (and at least one streaming workgroup)
-    hipLaunchKernelGGL(cqr_vpass_kernel, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, Vw, ldv, A, lda,
-                       (const int*) status);
-    hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+    if (park) {
+        hipLaunchKernelGGL(cqr_vpass_kernel<false>, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, A, lda,
+                           (double*) nullptr, 0, (const int*) status);
+        hipLaunchKernelGGL(cqr_top_kernel<true>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+    } else {
+        hipLaunchKernelGGL(cqr_vpass_kernel<true>, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, Vw, ldv, A, lda,
+                           (const int*) status);
+        hipLaunchKernelGGL(cqr_top_kernel<false>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+    }
     return (int) hipGetLastError();
 }
 
@@ -1124,7 +1177,7 @@ int qrd_panel_cqr_stage2(void* stream, double* A, int lda, int mk, int w, double
     hipLaunchKernelGGL(cqr_post_kernel, dim3(2), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
     hipLaunchKernelGGL((cqr_stream_kernel<true, false, true>), dim3(cs_grid(mk)), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_UI, w, mk, Vw, ldv, Vw, ldv, A, lda,
                        (double*) nullptr, status);
-    hipLaunchKernelGGL(cqr_top_kernel, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+    hipLaunchKernelGGL(cqr_top_kernel<false>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
     return (int) hipGetLastError();
 }
 

@@ -1119,6 +1119,8 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
 static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     const int nb = p->nb;
+    p->cq_parked = 0;             /* (a factorisation that ended in an error may have left a panel parked in ANOTHER array: never restore into that) */
+    p->park_hint = 0;
     if (!p->lookahead) {
         use_set(p, 0);
         for (int k = 0; k < n; k += nb) {
@@ -1996,6 +1998,7 @@ static int tsqr_local_panel(qr_tsqr_plan* t, double* dA, int lda, int pi)
     qr_plan* p = t->p;
     const int m = t->m_local, n = t->n, k = t->pan_k[pi], wout = t->pan_k[pi + 1] - k, mk = m - k, nt = n - (k + wout);
     use_set(p, 0);
+    if (pi == 0) p->cq_parked = 0;                            /* (see geqrf_issue_inner) */
     CHECK(prof_begin(p, 2));
     p->park_hint = nt > 0 && (size_t) nt * 8 <= (size_t) mk && p->Ye2 != NULL;
     CHECK(factor_panel(p, dA, m, lda, k, wout, t->dtau, nt > 0, NULL));

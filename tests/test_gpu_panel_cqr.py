@@ -170,6 +170,38 @@ def test_geqrf_takes_the_full_width_route_on_tall_shapes(qr, m, n, nb):
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
 
 
+def test_parked_panels_give_the_same_bits_as_v_written_twice(qr):
+    """Parked full-width panels (tall single-stream plans: V written once, into the caller's array, R of the top block restored from
+    the panel workspace behind the update) against MI355XQR_CQR_PARK=0 (child process: the knob is read once): the factored array, tau
+    and the thin Q must be IDENTICAL -- the update reads the same V values from another place, nothing else changes."""
+    import subprocess, sys, os
+    m, n, nb = 98304, 384, 128                     # two parked panels and a last one that is not (nothing follows it)
+    p = qr.Plan(m, n, nb, 32)
+    dA, dtau, dQ = zeros(m, n), zeros(n, 1), zeros(m, n)
+    p.fill_uniform(dA, m, m, n, seed=31)
+    p.sync()
+    A0 = host(dA)
+    p.geqrf(dA, m, n, m, dtau)
+    p.sync()
+    F, tau = host(dA), host(dtau)[:, 0]
+    assert p.route_stats()["tall_panels"] == 3 and p.route_stats()["tall_panels_refused"] == 0
+    p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+    p.sync()
+    Q = host(dQ)
+    p.close()
+    R = np.triu(F[:n])
+    assert np.linalg.norm(A0 - Q @ R) / np.linalg.norm(A0) < 1e-13 and np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import cuda_qr_amd as q\n"
+            "m, n = 98304, 384\n"
+            "p = q.Plan(m, n, 128, 32)\n"
+            "A = torch.zeros((n, m), dtype=torch.float64, device='cuda'); tau = torch.zeros((1, n), dtype=torch.float64, device='cuda'); torch.cuda.synchronize()\n"
+            "p.fill_uniform(A, m, m, n, seed=31); p.sync(); p.geqrf(A, m, n, m, tau); p.sync()\n"
+            "np.save(sys.argv[1], A.cpu().numpy().T); np.save(sys.argv[2], tau.cpu().numpy().ravel())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code, "/tmp/park_off_F.npy", "/tmp/park_off_tau.npy"], check=True,
+                   env=dict(os.environ, MI355XQR_CQR_PARK="0"), timeout=300)
+    assert np.array_equal(np.load("/tmp/park_off_F.npy"), F) and np.array_equal(np.load("/tmp/park_off_tau.npy"), tau)
+
+
 def _ill_conditioned(kind, m, n, seed):
     rng = np.random.default_rng(seed)
     A = rng.random((m, n))

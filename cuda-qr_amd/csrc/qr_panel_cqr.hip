@@ -91,6 +91,7 @@ struct CqLds {
     int* flag;            // [4]
     double* wsdbg;        // workspace (phase stamps of CQ_STAMPS builds)
     double* dinv;         // global: per 32-block, U'11^-1 (row-major 32 x 32) then L11^-1; NULL: not kept
+    double* dui;          // global: the last pass's mixed matrix, whose diagonal blocks are U'11^-1; NULL: not kept
 };
 __device__ __forceinline__ CqLds cq_lds(double* sm)
 {
@@ -103,6 +104,7 @@ __device__ __forceinline__ CqLds cq_lds(double* sm)
     L.flag = reinterpret_cast<int*>(L.red + CQ_T / 64);
     L.wsdbg = nullptr;
     L.dinv = nullptr;
+    L.dui = nullptr;
     return L;
 }
 constexpr size_t CQ_LDS_BYTES = sizeof(double) * (CQ_LD * CQ_LD + 2 * 32 * 33 + CQ_W + CQ_T / 64) + 64;
@@ -296,6 +298,7 @@ __device__ __forceinline__ void cq_lu_blocked(const CqLds& L, int w, const doubl
             for (int u = 0; u < 8; ++u) {
                 const int e = tid + u * CQ_T, i = (e >> 5) & 31, j = e & 31;
                 dinv[e] = (e < 1024) ? L.sb2[i * 33 + j] : L.sb1[i * 33 + j];
+                if (L.dui && e < 1024) L.dui[(o + i) * CQ_W + o + j] = (j < i) ? 0.0 : L.sb2[i * 33 + j];   // the last pass's diagonal block
             }
         }
         const int rest = w - o - 32, ntc = rest >> 4;
@@ -545,9 +548,15 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
         if (j < w) cq_st(ws + CQ_R1 + i * CQ_W + j, (j >= i) ? L.M[i * CQ_LD + j] : 0.0);
     }
     CQ_STAMP(2);
-    cq_upper_inv(L, w, 1, 0, tid);                             // (diagonal blocks: from the Cholesky's augmented columns)
-    CQ_STAMP(3);
-    cq_inv_out(L, ws + CQ_R1I, w, tid);
+    // what pass 2 multiplies by (cqr_stream_body: block back substitution): R1's off-diagonal 32 x 32 blocks and the inverses of its
+    // diagonal blocks, which the Cholesky's augmented columns left in the slots below the diagonal (X(i, j) at M[j + 1][i]) -- the
+    // full inverse (two more levels of products, 14 us + 4 us to write it) is not formed any more
+#pragma unroll 8
+    for (int e = tid; e < w * CQ_W; e += CQ_T) {
+        const int i = e >> 7, j = e & (CQ_W - 1);
+        if (j >= w) continue;
+        cq_st(ws + CQ_R1I + i * CQ_W + j, (j < i) ? 0.0 : (((i ^ j) & ~31) == 0 ? L.M[(j + 1) * CQ_LD + i] : L.M[i * CQ_LD + j]));
+    }
     CQ_STAMP(4);
 }
 
@@ -560,6 +569,7 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
 {
     CqLds L = cq_lds(sm);
     L.dinv = ws + CQ_X3;
+    L.dui = ws + CQ_UI;
 #ifdef CQ_STAMPS
     L.wsdbg = ws;
 #endif
@@ -632,7 +642,13 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
 #pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
-        if (j < w) cq_st(ws + CQ_LU + i * CQ_W + j, L.M[i * CQ_LD + j]);
+        if (j < w) {
+            const double v = L.M[i * CQ_LD + j];
+            cq_st(ws + CQ_LU + i * CQ_W + j, v);
+            // what the last pass multiplies by: U''s off-diagonal 32 x 32 blocks here, the inverses of its diagonal blocks from the
+            // blocked LU's diagonal steps -- nobody forms U'^-1 any more
+            if (((i ^ j) & ~31) != 0) cq_st(ws + CQ_UI + i * CQ_W + j, (j < i) ? 0.0 : v);
+        }
     }
     if (tid < w) cq_st(ws + CQ_SV + tid, L.sv[tid]);
     CQ_STAMP(11);
@@ -672,17 +688,8 @@ __device__ __forceinline__ void cq_diag_slots(const CqLds& L, const double* dinv
 //   workgroup 0: U'^-1 -> UI (the operand of the V pass), then R = S R2 R1
 //   workgroup 1: U = U' R2^-1, the inverse of L1^T, T = -U S L1^-T
 // Operands from the workspace (written by cqr_lu_kernel / cqr_chol_kernel: an earlier launch); S from ws + CQ_SV.
-// (round 5, later: only U'^-1 stands between the LU and the last pass -- it is a launch of its own, cqr_ui_kernel, and the two other
-// pieces ride in the last pass's launch as its first two workgroups, cqr_vpass_kernel: 56 us of one-workgroup work off the chain)
-__device__ __forceinline__ void cq_post_ui(const CqLds& L, double* ws, int w, int tid)
-{
-    // ---- U'^-1 -> UI (its diagonal blocks: left by the LU's matrix-core diagonal steps in the workspace)
-    cq_load_upper(L, ws + CQ_LU, w, tid);
-    cq_diag_slots(L, ws + CQ_X3, w, tid, false);
-    __syncthreads();
-    cq_upper_inv(L, w, 1, 0, tid);
-    cq_inv_out(L, ws + CQ_UI, w, tid);
-}
+// (round 5, later: NOTHING stands between the LU and the last pass any more -- that pass solves with U' block by block, cqr_stream_body --
+// and the two pieces below ride in its launch as its first two workgroups, cqr_vpass_kernel: 56 us of one-workgroup work off the chain)
 __device__ __forceinline__ void cq_post_r(const CqLds& L, double* ws, int w, int tid)
 {
     // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
@@ -711,7 +718,7 @@ __device__ __forceinline__ void cq_post_t(const CqLds& L, double* ws, int w, int
     __syncthreads();
     cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
 }
-// all three pieces in one launch (two workgroups): the stage-by-stage entry points of devtools/tools_cqr_debug.py
+// both pieces in one launch (two workgroups): the stage-by-stage entry points of devtools/tools_cqr_debug.py
 __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const int* status)
 {
     extern __shared__ double sm[];
@@ -719,18 +726,8 @@ __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const
     const int tid = threadIdx.x;
     if (status[0]) return;
     if (tid < w) L.sv[tid] = ws[CQ_SV + tid];
-    if (blockIdx.x == 0) {
-        cq_post_ui(L, ws, w, tid);
-        __syncthreads();
-        cq_post_r(L, ws, w, tid);
-    } else cq_post_t(L, ws, w, tid);
-}
-__global__ __launch_bounds__(CQ_T) void cqr_ui_kernel(double* ws, int w, const int* status)
-{
-    extern __shared__ double sm[];
-    const CqLds L = cq_lds(sm);
-    if (status[0]) return;
-    cq_post_ui(L, ws, w, threadIdx.x);
+    if (blockIdx.x == 0) { __syncthreads(); cq_post_r(L, ws, w, tid); }
+    else cq_post_t(L, ws, w, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -767,9 +764,21 @@ constexpr size_t CS_LDS_BYTES = sizeof(double) * (CS_XC + 4 * 16 * CS_QLD);
 constexpr size_t CS_LDS_GRAM = sizeof(double) * (4 * 16 * CS_QLD);      // the Gram-only pass
 constexpr size_t CQ_VP_LDS_BYTES = CQ_LDS_BYTES > CS_LDS_BYTES ? CQ_LDS_BYTES : CS_LDS_BYTES;   // cqr_vpass_kernel: one-workgroup riders + the streaming workgroups
 __device__ __forceinline__ int cs_blk(int kb, int jb) { return (jb * (jb + 1) / 2 + kb) * 256; }
-// the 144 (tile jt, k-step ks) pairs of a 16-row block's product in order: chain jt (4 (jt + 1) MFMAs) starts at n = 2 jt (jt + 1)
-__host__ __device__ constexpr int cs_n_jt(int n) { int jt = 0; while (2 * (jt + 1) * (jt + 2) <= n) ++jt; return jt; }
-__host__ __device__ constexpr int cs_n_ks(int n) { return n - 2 * cs_n_jt(n) * (cs_n_jt(n) + 1); }
+// the 144 X operands of a 16-row block's solve by 32-column blocks, in the order the MFMAs use them.  Block b (start cs_s_off(b)): for the
+// destination half h = 0, 1, every earlier 16-column tile it (0 .. 2 b - 1), sub-step r: X tile (it, 2 b + h), sub-step r -- 16 b operands
+// (half 0's chain first: it is complete, and no wait state is left to pad, when the diagonal block's products need it); then the
+// diagonal block's three tiles (2b, 2b), (2b, 2b+1), (2b+1, 2b+1), four sub-steps each.  cs_s_dec: tile row | tile column << 4 | r << 8.
+__host__ __device__ constexpr int cs_s_off(int b) { return 8 * b * (b - 1) + 12 * b; }
+__host__ __device__ constexpr int cs_s_dec(int n)
+{
+    int b = 0;
+    while (b < 3 && n >= cs_s_off(b + 1)) ++b;
+    const int m = n - cs_s_off(b);
+    if (m < 16 * b) return ((m % (8 * b)) >> 2) | ((2 * b + m / (8 * b)) << 4) | ((m & 3) << 8);
+    const int d = m - 16 * b;
+    return d < 4 ? ((2 * b) | ((2 * b) << 4) | (d << 8)) : (d < 8 ? ((2 * b) | ((2 * b + 1) << 4) | ((d - 4) << 8)) : ((2 * b + 1) | ((2 * b + 1) << 4) | ((d - 8) << 8)));
+}
+template <int I> struct cs_int { static constexpr int value = I; };
 struct cs_true { static constexpr bool value = true; };
 struct cs_false { static constexpr bool value = false; };
 
@@ -889,7 +898,7 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
             // vector-memory queue, the wave waits AT the instruction and the MFMAs behind it wait too (in-order issue).
             const int tn = tnext, rown = 16 * tn + l15;
             const double* spn = src + (rown < mk ? rown : mk - 1);
-            auto store_reg = [&](const v4d& acc, int jt, int r) {
+            auto store_reg = [&](const v4d& acc, int jt, int r) __attribute__((always_inline)) {
                 const int colj = 16 * jt + l4 + 4 * r;
                 if (rin) {
                     dst[row + (size_t) colj * ldd] = acc[r];
@@ -897,37 +906,79 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
                 }
                 if (GRAM) Qt[l15 * CS_QLD + colj] = rin ? acc[r] : 0.0;
             };
-            // The X operand of MFMA n (n counts the 144 (tile, k-step) pairs in order) is read from LDS four MFMAs ahead into a ring of eight
-            // registers: with the order pinned MFMA by MFMA the compiler cannot hoist the read itself, and a read in front of its own MFMA
-            // costs the LDS latency per instruction.  fullw: 128 columns, no test around an instruction.
+            // The multiplication by the inverse of the upper-triangular factor (R1 in pass 2, U' in pass 3) as a BLOCK back substitution
+            // over 32-column blocks (end of round 5): X holds the factor's off-diagonal 32 x 32 blocks and the INVERSES of its diagonal
+            // blocks -- which the matrix-core diagonal steps of the Cholesky / the LU leave behind anyway -- so that nobody has to form the
+            // full inverse between the factorisation and this pass (cqr_ui_kernel, 30 us, and 18 us of cqr_chol_kernel were exactly that):
+            //     T_b = q_b - sum_{i < b} V_i X_ib   (accumulators initialised with the block's source registers: the accumulator layout of
+            //                                         the transposed product IS the operand layout, register r of tile t <-> q[4 t + r])
+            //     V_b = T_b X_bb
+            // 16 b + 12 MFMAs for block b: 144 per 16 rows, as for the product with the explicit inverse.  The X operand of MFMA n (n counts
+            // them in order, cs_s_dec) is read from LDS four MFMAs ahead into a ring of eight registers: with the order pinned MFMA by MFMA
+            // the compiler cannot hoist the read itself, and a read in front of its own MFMA costs the LDS latency per instruction.
+            // fullw: 128 columns, no test around an instruction.
             auto product = [&](auto fullw) {
                 constexpr bool FW = decltype(fullw)::value;
-                auto xop = [&](int n) { return Xc[cs_blk(cs_n_ks(n) >> 2, cs_n_jt(n)) + (4 * (cs_n_ks(n) & 3) + l4) * 16 + l15]; };
+                auto xop = [&](int n) __attribute__((always_inline)) { return Xc[cs_blk(cs_s_dec(n) & 15, (cs_s_dec(n) >> 4) & 15) + (4 * (cs_s_dec(n) >> 8) + l4) * 16 + l15]; };
                 double xr[8];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) xr[n] = xop(n);
-                v4d accp = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int jt = 0; jt < 8; ++jt) {
-                    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int ks = 0; ks < 4 * (jt + 1); ++ks) {
-                        const int n = 2 * jt * (jt + 1) + ks;
-                        if (n + 4 < 144) xr[(n + 4) & 7] = xop(n + 4);
-                        if (FW || jt < nct) {
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[n & 7], q[ks], acc, 0, 0, 0);
-                            if (jt > 0 && ks >= 2 && ks < 6) store_reg(accp, jt - 1, ks - 2);
-                        }
-                        if (!GRAM && (ks & 3) == 3 && jt * (jt + 1) / 2 + (ks >> 2) < 32) {
-                            const int i = jt * (jt + 1) / 2 + (ks >> 2);
-                            qn[i] = spn[(size_t) (4 * i + l4 < w ? 4 * i + l4 : 0) * lds_];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                v4d V[8];
+                // behind MFMA n: one store of the previous block's two tiles (MFMAs 2 .. 9 of a block); in the pass without a Gram phase
+                // one load of the next 16 rows per four MFMAs.  (n is spelled out from the loop indices: as a running counter it stayed a
+                // run-time value, and every array it indexes -- the ring, V, q -- went to scratch: 1.2 ms per pass)
+                auto behind = [&](int b, int n, bool on) __attribute__((always_inline)) {      // (not inlined, it takes n at run time and every array it captures lives in scratch)
+                    const int m = n - cs_s_off(b);
+                    if (on && b > 0 && m >= 2 && m < 10) store_reg(V[2 * (b - 1) + ((m - 2) >> 2)], 2 * (b - 1) + ((m - 2) >> 2), (m - 2) & 3);
+                    if (!GRAM && (n & 3) == 3 && (n >> 2) < 32) {
+                        const int i = n >> 2;
+                        qn[i] = spn[(size_t) (4 * i + l4 < w ? 4 * i + l4 : 0) * lds_];
                     }
-                    if (FW || jt < nct) accp = acc;
-                }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // (one instantiation per block, b a compile-time constant: as a loop over b the compiler kept the loop -- dynamic register
+                // indexing, the operand table decoded with scalar instructions at run time, every array in scratch: 1.2 ms per pass)
+                auto block = [&](auto bc) __attribute__((always_inline)) {
+                    constexpr int b = decltype(bc)::value;
+                    const bool on = FW || 2 * b < nct;
+                    v4d T0, T1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) store_reg(accp, nct - 1, r);
+                    for (int r = 0; r < 4; ++r) { T0[r] = q[8 * b + r]; T1[r] = q[8 * b + 4 + r]; }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int it = 0; it < 2 * b; ++it)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int n = cs_s_off(b) + 8 * b * h + 4 * it + r;
+                                if (n + 4 < 144) xr[(n + 4) & 7] = xop(n + 4);
+                                if (on) {
+                                    if (h) T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[n & 7], V[it][r], T1, 0, 0, 1);      // T - x v
+                                    else T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[n & 7], V[it][r], T0, 0, 0, 1);
+                                }
+                                behind(b, n, on);
+                            }
+                    v4d o0 = (v4d){0.0, 0.0, 0.0, 0.0}, o1 = o0;
+#pragma unroll
+                    for (int d = 0; d < 12; ++d) {
+                        const int n = cs_s_off(b) + 16 * b + d;
+                        if (n + 4 < 144) xr[(n + 4) & 7] = xop(n + 4);
+                        if (on) {
+                            if (d < 4) o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[n & 7], T0[d], o0, 0, 0, 0);
+                            else if (d < 8) o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[n & 7], T0[d - 4], o1, 0, 0, 0);
+                            else o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[n & 7], T1[d - 8], o1, 0, 0, 0);
+                        }
+                        behind(b, n, on);
+                    }
+                    if (on) { V[2 * b] = o0; V[2 * b + 1] = o1; }
+                    // the last active block's two tiles go out at once (the others ride in the next block).  (Indexed by b, not by nct: a
+                    // run-time index into V sends the whole array to scratch)
+                    if (b == 3 ? on : (!FW && on && 2 * (b + 1) == nct)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { store_reg(o0, 2 * b, r); store_reg(o1, 2 * b + 1, r); }
+                    }
+                };
+                block(cs_int<0>{}); block(cs_int<1>{}); block(cs_int<2>{}); block(cs_int<3>{});
             };
             if (nct == 8) product(cs_true{}); else product(cs_false{});
         } else if (GRAM) {
@@ -1075,7 +1126,6 @@ int qrd_panel_cqr_init(void)
     hipError_t e = hipFuncSetAttribute((const void*) cqr_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_ui_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_GRAM);
@@ -1139,7 +1189,6 @@ static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, doubl
                        (double*) nullptr, 0, ws + CQ_SL, status);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
-    hipLaunchKernelGGL(cqr_ui_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
     const int vgrid = grid + 2 <= cap ? grid + 2 : (cap >= 3 ? cap : 3);      // riders included: never more workgroups than compute units (and at least one streaming workgroup)
     if (park) {
         hipLaunchKernelGGL(cqr_vpass_kernel<false>, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, A, lda,

@@ -28,6 +28,13 @@ def mat(idx, colmajor=False):
     a = ws.cpu().numpy()[idx * 128 * 128:(idx + 1) * 128 * 128].reshape(128, 128)
     return (a.T if colmajor else a)[:w, :w].copy()
 def err(a, b): return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+def mixed(M):
+    """what the streaming passes multiply by since the end of round 5: the upper-triangular factor's off-diagonal 32 x 32 blocks and the
+    INVERSES of its diagonal blocks (block back substitution instead of a product with the full inverse)"""
+    X = np.triu(M).copy()
+    for o in range(0, M.shape[0], 32):
+        X[o:o + 32, o:o + 32] = np.linalg.inv(np.triu(M[o:o + 32, o:o + 32]))
+    return X
 g1, g2 = L.qrd_panel_cqr_g1(ws.data_ptr()), L.qrd_panel_cqr_g2(ws.data_ptr())
 print("tn", L.qrd_gemm_tn(None, w, w, mk, 1.0, dA.data_ptr(), mk, dA.data_ptr(), mk, 0.0, g1, 128, slabs.data_ptr(), cap, None, 0))
 G1 = P.T @ P
@@ -36,7 +43,7 @@ print("stage1", L.qrd_panel_cqr_stage1(None, dA.data_ptr(), mk, mk, w, dV.data_p
 L.qrd_device_sync()
 print("status", status.cpu().numpy())
 R1 = np.linalg.cholesky(G1).T
-print("R1 err", err(mat(2), R1), " R1inv err", err(mat(3), np.linalg.inv(R1)))
+print("R1 err", err(mat(2), R1), " R1 blocks / diagonal-block inverses err", err(mat(3), mixed(R1)))
 Q = host(dV)
 Qref = P @ np.linalg.inv(mat(2))
 print("Q err", err(Q, Qref), " |QtQ - I|", np.abs(Q.T @ Q - np.eye(w)).max())
@@ -51,7 +58,7 @@ print("R2 err", err(mat(5), R2))
 LU, S = mat(6), ws.cpu().numpy()[12 * 128 * 128:12 * 128 * 128 + w]
 L1, Up = np.tril(LU, -1) + np.eye(w), np.triu(LU)
 print("LU err", err(L1 @ Up, Q[:w] - S[:, None] * mat(5)))
-print("Uinv err", err(mat(4), np.linalg.inv(Up)))
+print("U' blocks / diagonal-block inverses err", err(mat(4), mixed(Up)))
 print("R err", err(np.triu(mat(9)), S[:, None] * mat(5) @ mat(2)))
 U = Up @ np.linalg.inv(mat(5))
 print("T err", err(np.triu(mat(10)), -U @ np.diag(S) @ np.linalg.inv(L1).T))
@@ -63,7 +70,7 @@ QtP = P - V @ (T.T @ (V.T @ P))
 print("below-diagonal of Q^T P", np.abs(np.tril(QtP, -1)).max(), " R match", err(np.triu(QtP[:w]), np.triu(out[:w])))
 if len(sys.argv) > 3:
     st = ws.cpu().numpy()[12 * 128 * 128 + 128:12 * 128 * 128 + 128 + 64].view(np.uint64)
-    names = {1: "chol", 2: "R1 out", 3: "inverse", 4: "inverse out", 9: "G2 -> R2, R2^-1", 10: "W load + LU", 11: "LU out", 12: "U product",
+    names = {1: "chol", 2: "R1 out", 3: "(unused)", 4: "blocks + diagonal inverses out", 9: "G2 -> R2, R2^-1", 10: "W load + LU", 11: "LU out", 12: "U product",
              13: "U' inverse", 14: "L1^-T inverse", 15: "T product", 16: "R product"}
     print('  inverse inside the Cholesky kernel: zero %.1f  diagonal blocks %.1f  level 1 %.1f  level 2 %.1f us' % tuple((int(st[b]) - int(st[a])) * 0.01 for a, b in ((2, 20), (20, 21), (21, 22), (22, 23))))
     t = lambda i: int(st[i]) * 0.01

@@ -1127,8 +1127,8 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
             const int wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
             CHECK(prof_begin(p, 2));
             /* (what follows decides whether a full-width panel may park its R: only the update that applies T to the small product reads V
-             * through a pointer of its own) */
-            p->park_hint = nt > 0 && (size_t) nt * 8 <= (size_t) mk && p->Ye2 != NULL;
+             * through a pointer of its own -- and behind the last panel nothing reads V at all: R goes back at once) */
+            p->park_hint = nt == 0 || ((size_t) nt * 8 <= (size_t) mk && p->Ye2 != NULL);
             CHECK(factor_panel(p, dA, m, lda, k, wout, dtau, nt > 0, NULL));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
             if (nt > 0) CHECK(update_cols(p, p->stream, 0, dA, lda, k, mk, wout, k + wout, nt, p->W, NULL, p->slabs, 1, 1));
@@ -2000,7 +2000,7 @@ static int tsqr_local_panel(qr_tsqr_plan* t, double* dA, int lda, int pi)
     use_set(p, 0);
     if (pi == 0) p->cq_parked = 0;                            /* (see geqrf_issue_inner) */
     CHECK(prof_begin(p, 2));
-    p->park_hint = nt > 0 && (size_t) nt * 8 <= (size_t) mk && p->Ye2 != NULL;
+    p->park_hint = nt == 0 || ((size_t) nt * 8 <= (size_t) mk && p->Ye2 != NULL);
     CHECK(factor_panel(p, dA, m, lda, k, wout, t->dtau, nt > 0, NULL));
     CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 16.0 * mk * wout));
     /* block column k of R is final (its rows above the panel were finished by the earlier trailing updates): pack it */

@@ -525,15 +525,16 @@ def main():
                          "achieved_GBps_whole_step": wj["hbm_bytes_per_factorisation"] / (dt / K) / 1e9}
         except Exception:
             pass
-        roof = None if not pan["launches"] else {"bound": "hbm", "kernel": "panel factorisation: 128-column panels of > 8192 rows at full width (qr_panel_cqr.hip: cqr_gram / cqr_chol / cqr_stream<Q,G2> / cqr_lu / cqr_post / cqr_stream<V> kernels; round 4: from 196608 rows), up to 8192 rows in one launch (panel_fused_kernel), others by the leaf chain",
+        roof = None if not pan["launches"] else {"bound": "hbm", "kernel": "panel factorisation: 128-column panels of > 8192 rows at full width (qr_panel_cqr.hip: cqr_gram / cqr_chol / cqr_stream<Q,G2> / cqr_lu / cqr_vpass kernels; round 4: from 196608 rows), up to 8192 rows in one launch (panel_fused_kernel), others by the leaf chain",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": ptraffic, "traffic_source": psrc, "traffic_whole_factorisation": whole,
                 "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),
                 "profiled_steps_in_timed_region": len(range(0, K, stride)),
                 "algorithmic_bytes_per_launch": pan["bytes"] / max(pan["launches"], 1),
-                "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); a full-width panel moves 3.15x that in three passes "
-                        "(G1; Q + G2; V to two destinations) at 1.8 TB/s overall -- its passes cost memory time plus matrix-core time, and two "
-                        "one-workgroup factor kernels (0.18 ms in round 5, 0.27 in round 4) sit between them (DESIGN.md section 3)",
+                "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); a full-width panel moves 2.5x that in three passes "
+                        "(G1; Q + G2; V -- to one destination when the panel is parked, two otherwise) -- its passes cost memory time plus "
+                        "matrix-core time, and two one-workgroup factor kernels (0.12 ms in round 5, 0.27 in round 4) sit between them "
+                        "(DESIGN.md section 3)",
                 "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None,
                 "measured_probe": measured}
 

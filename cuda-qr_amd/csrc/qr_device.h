@@ -82,7 +82,7 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
  * qrd_panel_cqr_r_block: R (upper, zeros below) into a w x w block of its own */
 int qrd_panel_cqr_p(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
                     double* Qb, int ldq, unsigned* hflag, unsigned seq, int park);
-int qrd_panel_cqr_restore_r(void* stream, double* A, int lda, int w, const double* ws);
+int qrd_panel_cqr_restore_r(void* stream, double* A, int lda, int w, const double* ws, const int* status);   /* status[0] != 0 (refused panel): A stays untouched */
 int qrd_panel_cqr_r_block(void* stream, const double* ws, int w, double* D, int ldd);
 double* qrd_panel_cqr_g1(double* ws);
 double* qrd_panel_cqr_g2(double* ws);

@@ -769,7 +769,7 @@ static int cq_unpark(qr_plan* p)
 {
     if (!p->cq_parked) return 0;
     p->cq_parked = 0;
-    return qrd_panel_cqr_restore_r(p->stream, p->cq_park_top, p->cq_park_lda, p->cq_park_w, p->cq_ws);
+    return qrd_panel_cqr_restore_r(p->stream, p->cq_park_top, p->cq_park_lda, p->cq_park_w, p->cq_ws, p->cq_status);
 }
 
 static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int wout, double* dtau, int want_t, void* half_ready)

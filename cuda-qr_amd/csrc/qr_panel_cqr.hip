@@ -1107,8 +1107,10 @@ __global__ __launch_bounds__(256) void cqr_top_kernel(const double* ws, int w, d
 }
 // R (upper triangle, from the workspace) into a column-major w x w block: the top block of A after a parked panel's updates (lower part
 // kept: L1), or -- zero_below -- a block of its own (the multi-GPU step packs R before the update has run)
-__global__ __launch_bounds__(256) void cqr_restore_r_kernel(const double* ws, int w, double* D, int ldd, int zero_below)
+// (status: the panel's refusal word -- a refused panel left the array untouched, and so does this launch; NULL: not consulted)
+__global__ __launch_bounds__(256) void cqr_restore_r_kernel(const double* ws, int w, double* D, int ldd, int zero_below, const int* status)
 {
+    if (status && status[0]) return;
     for (int e = threadIdx.x + blockIdx.x * blockDim.x; e < w * w; e += blockDim.x * gridDim.x) {
         const int j = e / w, i = e - j * w;
         if (j >= i) D[i + (size_t) ldd * j] = ws[CQ_RR + i * CQ_W + j];
@@ -1159,14 +1161,14 @@ int qrd_panel_cqr_p(void* stream, double* A, int lda, int mk, int w, double* tau
     if (park && (!Qb || Qb == A)) return -7;
     return panel_cqr_impl(stream, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, Qb, ldq, hflag, seq, park);
 }
-int qrd_panel_cqr_restore_r(void* stream, double* A, int lda, int w, const double* ws)
+int qrd_panel_cqr_restore_r(void* stream, double* A, int lda, int w, const double* ws, const int* status)
 {
-    hipLaunchKernelGGL(cqr_restore_r_kernel, dim3((w * w + 255) / 256), dim3(256), 0, (hipStream_t) stream, ws, w, A, lda, 0);
+    hipLaunchKernelGGL(cqr_restore_r_kernel, dim3((w * w + 255) / 256), dim3(256), 0, (hipStream_t) stream, ws, w, A, lda, 0, status);
     return (int) hipGetLastError();
 }
 int qrd_panel_cqr_r_block(void* stream, const double* ws, int w, double* D, int ldd)
 {
-    hipLaunchKernelGGL(cqr_restore_r_kernel, dim3((w * w + 255) / 256), dim3(256), 0, (hipStream_t) stream, ws, w, D, ldd, 1);
+    hipLaunchKernelGGL(cqr_restore_r_kernel, dim3((w * w + 255) / 256), dim3(256), 0, (hipStream_t) stream, ws, w, D, ldd, 1, (const int*) nullptr);
     return (int) hipGetLastError();
 }
 static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,

@@ -229,8 +229,8 @@ int qrd_panel_cqr_p(void* s, double* A, int lda, int mk, int w, double* tau, dou
     if (park && (!Qb || Qb == A)) return -7;
     return qrd_panel_cqr_q(s, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, Qb, ldq, hflag, seq);
 }
-int qrd_panel_cqr_restore_r(void* s, double* A, int lda, int w, const double* ws)
-{ (void) s; chk("cqr restore A", A, lda, w, w); chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); return 0; }
+int qrd_panel_cqr_restore_r(void* s, double* A, int lda, int w, const double* ws, const int* status)
+{ (void) s; (void) status; chk("cqr restore A", A, lda, w, w); chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); return 0; }
 int qrd_panel_cqr_r_block(void* s, const double* ws, int w, double* D, int ldd)
 { (void) s; chk("cqr r block", D, ldd, w, w); chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); return 0; }
 int qrd_panel_cqr(void* s, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status)

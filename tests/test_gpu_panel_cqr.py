@@ -254,6 +254,29 @@ def test_geqrf_with_refused_tall_panels_is_householder_grade(qr, kind):
         assert abs(R[jd, jd]) < 1e-10 * np.abs(np.diag(R)[:jd]).max()
 
 
+def test_latch_mode_leaves_a_refused_parked_panel_untouched(qr):
+    """latch mode, one 128-column panel (the last panel parks: V once, R restored from the workspace behind it): when the device-side
+    guard refuses it, every launch of the panel -- the restore included -- returns at once and the array is bit for bit what it was"""
+    m, n, nb = 32768, 128, 128
+    p = qr.Plan(m, n, nb, 32)
+    p.set_guard_mode(True)
+    dtau = zeros(n, 1)
+    good = np.random.default_rng(5).standard_normal((m, n))
+    dG = dev(good)
+    p.geqrf(dG, m, n, m, dtau)              # leaves an R of its own in the panel workspace
+    p.sync()
+    assert p.route_stats()["tall_panels"] >= 1
+    A = np.random.default_rng(9).random((m, n))
+    A[:, 17] = A[:, 3]
+    dA = dev(A)
+    p.geqrf(dA, m, n, m, dtau)
+    with pytest.raises(qr.QRError, match="-106"):
+        p.sync()
+    back = host(dA)
+    p.close()
+    assert np.array_equal(back, A)
+
+
 def test_latch_mode_reports_a_refused_panel_at_sync_and_never_blocks(qr):
     """latch mode (qr_plan_set_guard_mode): qr_geqrf_dev is stream-ordered -- four tall factorisations are queued before the first has
     finished -- and a refusal comes back from qr_plan_sync as QR_E_REFUSED (-106), once"""

@@ -531,8 +531,8 @@ def main():
                 "launches": pan["launches"], "avg_launch_ms": pan["ms"] / max(pan["launches"], 1),
                 "profiled_steps_in_timed_region": len(range(0, K, stride)),
                 "algorithmic_bytes_per_launch": pan["bytes"] / max(pan["launches"], 1),
-                "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); a full-width panel moves 2.5x that in three passes "
-                        "(G1; Q + G2; V -- to one destination when the panel is parked, two otherwise) -- its passes cost memory time plus "
+                "note": "algorithmic bytes = 16*mk*nb per outer panel (read + write once); a full-width panel moves 2.6x that in three passes "
+                        "(G1; Q + G2; V -- to one destination when the panel is parked; 3.15x with two, the stand-alone panel of the PMC file) -- its passes cost memory time plus "
                         "matrix-core time, and two one-workgroup factor kernels (0.12 ms in round 5, 0.27 in round 4) sit between them "
                         "(DESIGN.md section 3)",
                 "update_nn_tflops": upd["flops"] / (upd["ms"] * 1e-3) / 1e12 if upd["ms"] else None,

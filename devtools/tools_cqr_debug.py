@@ -70,13 +70,10 @@ QtP = P - V @ (T.T @ (V.T @ P))
 print("below-diagonal of Q^T P", np.abs(np.tril(QtP, -1)).max(), " R match", err(np.triu(QtP[:w]), np.triu(out[:w])))
 if len(sys.argv) > 3:
     st = ws.cpu().numpy()[12 * 128 * 128 + 128:12 * 128 * 128 + 128 + 64].view(np.uint64)
-    names = {1: "chol", 2: "R1 out", 3: "(unused)", 4: "blocks + diagonal inverses out", 9: "G2 -> R2, R2^-1", 10: "W load + LU", 11: "LU out", 12: "U product",
-             13: "U' inverse", 14: "L1^-T inverse", 15: "T product", 16: "R product"}
-    print('  inverse inside the Cholesky kernel: zero %.1f  diagonal blocks %.1f  level 1 %.1f  level 2 %.1f us' % tuple((int(st[b]) - int(st[a])) * 0.01 for a, b in ((2, 20), (20, 21), (21, 22), (22, 23))))
+    names = {1: "chol", 2: "R1 out", 4: "blocks + diagonal inverses out", 9: "G2 -> R2, R2^-1", 10: "W load + LU", 11: "LU out"}
     t = lambda i: int(st[i]) * 0.01
     print('  LU kernel (us): diagonal block 0 %.1f | S R2 + U12 + L21 (all waves) %.1f | wave 0: next block update %.1f' % (t(25) - t(24), t(26) - t(25), t(27) - t(26)))
     print('  LU kernel start (us): Q_top requested + G2 into LDS %.1f | distance from I, first-order factor %.1f | R2 and R2^-1 stores issued %.1f | to the barrier %.1f'
           % (t(28) - t(8), t(29) - t(28), t(30) - t(29), t(9) - t(30)))
-    for a, b in ((0, 5), (8, 12)):
-        for i in range(a + 1, b):
-            print("  %-16s %8.1f us" % (names.get(i, i), (int(st[i]) - int(st[i - 1])) * 0.01))
+    for i, prev in ((1, 0), (2, 1), (4, 2), (9, 8), (10, 9), (11, 10)):     # (stamp 3 went with the inverse levels of the Cholesky kernel)
+        print("  %-32s %8.1f us" % (names[i], (int(st[i]) - int(st[prev])) * 0.01))

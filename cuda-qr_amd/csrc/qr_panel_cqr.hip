@@ -47,6 +47,7 @@ constexpr int CQ_TT = 10 * CQ_W * CQ_W;   // T row-major
 constexpr int CQ_X3 = 11 * CQ_W * CQ_W;
 constexpr int CQ_SV = 12 * CQ_W * CQ_W;   // S (CQ_W doubles)
 constexpr int CQ_ST = 12 * CQ_W * CQ_W + CQ_W;   // 64 phase stamps of the one-workgroup kernels (CQ_STAMPS builds)
+constexpr int CQ_FO = CQ_ST + 63;                  // 1.0: R2 of this panel is the first-order factor (its inverse is 2 I - R2: nobody stores it)
 constexpr int CQ_SL = CQ_ST + 64;                  // Gram partials of the streaming passes: 256 workgroups x 36 tiles x 256 doubles (19 MB)
 constexpr int CQ_WS = CQ_SL + 256 * 36 * 256;
 
@@ -611,15 +612,15 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
     }
     CQ_STAMP(29);
     // R2 -> global (cqr_post_kernel's products read it from there; this launch's LU too unless R2 is first order: it then reads G2
-    // and nothing waits for these stores); R2^-1 -> X1 (first order: 2 I - R2)
+    // and nothing waits for these stores); R2^-1 -> X1 (first order: it is 2 I - R2, which the T rider reads off R2 itself)
 #pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
         if (j >= w) continue;
         const double r = (j >= i) ? L.M[i * CQ_LD + j] : 0.0;
         cq_st(ws + CQ_R2 + i * CQ_W + j, r);
-        if (first_order) cq_st(ws + CQ_X1 + i * CQ_W + j, (j > i) ? -r : (j == i ? 2.0 - r : 0.0));
     }
+    if (tid == 0) cq_st(ws + CQ_FO, first_order ? 1.0 : 0.0);
     CQ_STAMP(30);
     if (!first_order) {
         __syncthreads();
@@ -702,7 +703,10 @@ __device__ __forceinline__ void cq_post_t(const CqLds& L, double* ws, int w, int
 {
     // ---- U = U' R2^-1 -> X2 (U' above the diagonal, R2^-1 transposed below it)
     cq_load_upper(L, ws + CQ_LU, w, tid);
-    cq_load_lowerT(L, ws + CQ_X1, w, tid);
+    if (ws[CQ_FO] != 0.0)                                     // first-order R2: R2^-1 = 2 I - R2
+        cq_elems(w, tid, [&](int k, int j) { return ws[CQ_R2 + k * CQ_W + j]; },
+                 [&](int k, int j, double v) { if (j < w && j >= k) L.M[(j + 1) * CQ_LD + k] = (j > k) ? -v : 2.0 - v; });
+    else cq_load_lowerT(L, ws + CQ_X1, w, tid);
     __syncthreads();
     cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_X2 + i * CQ_W + j, (j >= i) ? v : 0.0); });
     __syncthreads();

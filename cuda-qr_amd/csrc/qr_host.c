@@ -808,12 +808,13 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
         int cqr_done = 0;
         if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= plan_cqr_min_rows(p) && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
-            const int park = park_hint && kn->cqr_park && nhalf == 1 && !p->lookahead;
+            /* (2: the last panel -- V once, R in place at once, nothing parked) */
+            const int park = (park_hint && kn->cqr_park && nhalf == 1 && !p->lookahead) ? (want_t ? 1 : 2) : 0;
             const int rc = panel_cqr_half(p, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
                                           p->Vw + (size_t) c0 * ldv + c0, ldv, p->VT + (size_t) c0 * ldv + c0, park);
             if (rc < 0) return rc;
             cqr_done = rc == 0;
-            if (cqr_done && park) { p->cq_parked = 1; p->cq_park_top = Ak; p->cq_park_lda = lda; p->cq_park_w = wh; }
+            if (cqr_done && park == 1) { p->cq_parked = 1; p->cq_park_top = Ak; p->cq_park_lda = lda; p->cq_park_w = wh; }
         }
         const int fused_half = !cqr_done && p->pf_ws && !p->fused_off && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
                                qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);

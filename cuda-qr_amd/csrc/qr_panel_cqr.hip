@@ -1159,6 +1159,7 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
 // park != 0 ("parked" form; Qb must be a buffer other than A): V is written ONCE, into A -- all of it, the top block as the unit lower
 // triangle with zeros above -- and Vw is not touched; R stays in the workspace until qrd_panel_cqr_restore_r puts it into the top block
 // (after the updates that use A's panel as V; before the next panel of this workspace).  qrd_panel_cqr_r_block: R as a block of its own.
+// park == 2: V once, into A, and R into the top block at once (the last panel of a factorisation: no update reads V).
 int qrd_panel_cqr_p(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
                     double* Qb, int ldq, unsigned* hflag, unsigned seq, int park)
 {
@@ -1199,7 +1200,10 @@ static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, doubl
     if (park) {
         hipLaunchKernelGGL(cqr_vpass_kernel<false>, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, A, lda,
                            (double*) nullptr, 0, (const int*) status);
-        hipLaunchKernelGGL(cqr_top_kernel<true>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+        // park == 2: nobody reads V behind this panel -- the top block takes R at once (the ordinary top block; Vw gets its 128 x 128 corner
+        // and is otherwise stale), and there is nothing to restore
+        if (park == 2) hipLaunchKernelGGL(cqr_top_kernel<false>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+        else hipLaunchKernelGGL(cqr_top_kernel<true>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
     } else {
         hipLaunchKernelGGL(cqr_vpass_kernel<true>, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, Vw, ldv, A, lda,
                            (const int*) status);

@@ -691,16 +691,44 @@ __device__ __forceinline__ void cq_diag_slots(const CqLds& L, const double* dinv
 // Operands from the workspace (written by cqr_lu_kernel / cqr_chol_kernel: an earlier launch); S from ws + CQ_SV.
 // (round 5, later: NOTHING stands between the LU and the last pass any more -- that pass solves with U' block by block, cqr_stream_body --
 // and the two pieces below ride in its launch as its first two workgroups, cqr_vpass_kernel: 56 us of one-workgroup work off the chain)
-__device__ __forceinline__ void cq_post_r(const CqLds& L, double* ws, int w, int tid)
+// Where the riders put the panel's top block (end of round 5: cqr_top_kernel, a launch of its own behind the last pass, did this from the
+// workspace; the streaming workgroups of the pass then leave the first w rows alone).  mode 0: nowhere (cqr_top_kernel follows);
+// 1: A <- R on and above the diagonal, L1 below, Vw <- the unit lower L1; 2 (parked): A <- the unit lower L1, zeros above.  T, tau always.
+struct CqTop { double* A; int lda; double* Vw; int ldv; double* T; int ldt; double* tau; int mode; };
+
+__device__ __forceinline__ void cq_post_r(const CqLds& L, double* ws, int w, int tid, const CqTop& top)
 {
+    if (top.mode) {
+        // L1 (from the LU kernel's L1 \ U') into the top block: consecutive threads, consecutive rows of a column
+        for (int e = tid; e < w * w; e += CQ_T) {
+            const int j = e / w, i = e - j * w;
+            const double lu = ws[CQ_LU + i * CQ_W + j], unit = (j < i) ? lu : (j == i ? 1.0 : 0.0);
+            if (top.mode == 2) top.A[i + (size_t) top.lda * j] = unit;
+            else {
+                if (j < i) top.A[i + (size_t) top.lda * j] = lu;
+                top.Vw[i + (size_t) top.ldv * j] = unit;
+            }
+        }
+    }
     // ---- R = S R2 R1: R2 -> upper triangle, R1 -> below the diagonal
     cq_load_upper(L, ws + CQ_R2, w, tid);
     cq_load_lowerT(L, ws + CQ_R1, w, tid);
     __syncthreads();
-    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_RR + i * CQ_W + j, (j >= i) ? L.sv[i] * v : 0.0); });
+    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) {
+        const double r = (j >= i) ? L.sv[i] * v : 0.0;
+        cq_st(ws + CQ_RR + i * CQ_W + j, r);
+        if (top.mode == 1 && j >= i) top.A[i + (size_t) top.lda * j] = r;
+    });
 }
-__device__ __forceinline__ void cq_post_t(const CqLds& L, double* ws, int w, int tid)
+__device__ __forceinline__ void cq_post_t(const CqLds& L, double* ws, int w, int tid, const CqTop& top)
 {
+    if (top.mode) {
+        // (the product below stores the tiles on and above the tile diagonal; the others are zero)
+        for (int e = tid; e < w * w; e += CQ_T) {
+            const int j = e / w, i = e - j * w;
+            if ((i >> 4) > (j >> 4)) top.T[i + (size_t) top.ldt * j] = 0.0;
+        }
+    }
     // ---- U = U' R2^-1 -> X2 (U' above the diagonal, R2^-1 transposed below it)
     cq_load_upper(L, ws + CQ_LU, w, tid);
     if (ws[CQ_FO] != 0.0)                                     // first-order R2: R2^-1 = 2 I - R2
@@ -720,7 +748,14 @@ __device__ __forceinline__ void cq_post_t(const CqLds& L, double* ws, int w, int
     cq_sync_global();
     cq_load_upper(L, ws + CQ_X2, w, tid);
     __syncthreads();
-    cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_TT + i * CQ_W + j, (j >= i) ? -v : 0.0); });
+    cq_upper_product(L, L.sv, w, tid, [&](int i, int j, double v) {
+        const double tv = (j >= i) ? -v : 0.0;
+        cq_st(ws + CQ_TT + i * CQ_W + j, tv);
+        if (top.mode) {
+            top.T[i + (size_t) top.ldt * j] = tv;
+            if (i == j) top.tau[i] = tv;
+        }
+    });
 }
 // both pieces in one launch (two workgroups): the stage-by-stage entry points of devtools/tools_cqr_debug.py
 __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const int* status)
@@ -730,8 +765,9 @@ __global__ __launch_bounds__(CQ_T) void cqr_post_kernel(double* ws, int w, const
     const int tid = threadIdx.x;
     if (status[0]) return;
     if (tid < w) L.sv[tid] = ws[CQ_SV + tid];
-    if (blockIdx.x == 0) { __syncthreads(); cq_post_r(L, ws, w, tid); }
-    else cq_post_t(L, ws, w, tid);
+    const CqTop none{};
+    if (blockIdx.x == 0) { __syncthreads(); cq_post_r(L, ws, w, tid, none); }
+    else cq_post_t(L, ws, w, tid, none);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -845,7 +881,7 @@ __device__ __forceinline__ void cs_gram_rows(v4d (&g0)[8], v4d (&g1)[8], const d
 
 template <bool MULT, bool GRAM, bool DST2>
 __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __restrict__ X, int w, int mk, const double* src, int lds_, double* dst,
-                                                int ldd, double* dst2, int ldd2, double* slabs, const int* status, const int bid, const int nbid)
+                                                int ldd, double* dst2, int ldd2, double* slabs, const int* status, const int bid, const int nbid, const int skip = 0)
 {
     if (MULT && status && status[0]) return;                  // refused (pass 2: by the first Cholesky): nothing is written
     double* Xc = sm;
@@ -904,7 +940,7 @@ __device__ __forceinline__ void cqr_stream_body(double* sm, const double* __rest
             const double* spn = src + (rown < mk ? rown : mk - 1);
             auto store_reg = [&](const v4d& acc, int jt, int r) __attribute__((always_inline)) {
                 const int colj = 16 * jt + l4 + 4 * r;
-                if (rin) {
+                if (rin && row >= skip) {                      // (skip: the first rows belong to the riders of cqr_vpass_kernel)
                     dst[row + (size_t) colj * ldd] = acc[r];
                     if (DST2) dst2[row + (size_t) colj * ldd2] = acc[r];
                 }
@@ -1032,7 +1068,7 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_stream_kernel(const double* __
 // by cqr_restore_r_kernel afterwards: one 8 mk w byte write of the pass less.
 template <bool DST2>
 __global__ __launch_bounds__(CS_THREADS) void cqr_vpass_kernel(double* ws, int w, int mk, const double* src, int lds_, double* dst, int ldd, double* dst2,
-                                                                int ldd2, const int* status)
+                                                                int ldd2, const int* status, const CqTop top)
 {
     extern __shared__ double sm[];
     if (status[0]) return;
@@ -1040,11 +1076,11 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_vpass_kernel(double* ws, int w
         const CqLds L = cq_lds(sm);
         const int tid = threadIdx.x;
         if (tid < w) L.sv[tid] = ws[CQ_SV + tid];
-        if (blockIdx.x == 0) cq_post_t(L, ws, w, tid);
-        else { __syncthreads(); cq_post_r(L, ws, w, tid); }
+        if (blockIdx.x == 0) cq_post_t(L, ws, w, tid, top);
+        else { __syncthreads(); cq_post_r(L, ws, w, tid, top); }
         return;
     }
-    cqr_stream_body<true, false, DST2>(sm, ws + CQ_UI, w, mk, src, lds_, dst, ldd, dst2, ldd2, nullptr, status, blockIdx.x - 2, gridDim.x - 2);
+    cqr_stream_body<true, false, DST2>(sm, ws + CQ_UI, w, mk, src, lds_, dst, ldd, dst2, ldd2, nullptr, status, blockIdx.x - 2, gridDim.x - 2, top.mode ? w : 0);
 }
 // The Gram-only pass, G1 = A^T A (33 KB of LDS).  Tried and no faster: two waves per SIMD (132 us against 128), four workgroups per CU
 // (191 = 191 before the scalar wave index), two LDS block buffers with one barrier per block and the transposition of block i + 1
@@ -1197,17 +1233,17 @@ static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, doubl
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
     const int vgrid = grid + 2 <= cap ? grid + 2 : (cap >= 3 ? cap : 3);      // riders included: never more workgroups than compute units (and at least one streaming workgroup)
+    // the riders of the last pass also place the top block, T and tau (cqr_top_kernel: stage-by-stage entry points only)
     if (park) {
+        // park == 1: A <- the unit lower L1, R parked in the workspace; park == 2: nobody reads V behind this panel -- R into the top block
+        // at once (Vw gets its w x w corner and is otherwise stale), nothing to restore
+        const CqTop top{A, lda, Vw, ldv, T, ldt, tau, park == 2 ? 1 : 2};
         hipLaunchKernelGGL(cqr_vpass_kernel<false>, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, A, lda,
-                           (double*) nullptr, 0, (const int*) status);
-        // park == 2: nobody reads V behind this panel -- the top block takes R at once (the ordinary top block; Vw gets its 128 x 128 corner
-        // and is otherwise stale), and there is nothing to restore
-        if (park == 2) hipLaunchKernelGGL(cqr_top_kernel<false>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
-        else hipLaunchKernelGGL(cqr_top_kernel<true>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+                           (double*) nullptr, 0, (const int*) status, top);
     } else {
+        const CqTop top{A, lda, Vw, ldv, T, ldt, tau, 1};
         hipLaunchKernelGGL(cqr_vpass_kernel<true>, dim3(vgrid), dim3(CS_THREADS), CQ_VP_LDS_BYTES, s, ws, w, mk, (const double*) Qb, ldq, Vw, ldv, A, lda,
-                           (const int*) status);
-        hipLaunchKernelGGL(cqr_top_kernel<false>, dim3((w * w + 255) / 256), dim3(256), 0, s, ws, w, A, lda, Vw, ldv, T, ldt, tau, status);
+                           (const int*) status, top);
     }
     return (int) hipGetLastError();
 }

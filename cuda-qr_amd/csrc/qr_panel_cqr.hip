@@ -1086,9 +1086,11 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_vpass_kernel(double* ws, int w
 // (191 = 191 before the scalar wave index), two LDS block buffers with one barrier per block and the transposition of block i + 1
 // behind the matrix-core instructions of block i (143-145 us: memory time plus matrix-core time again, although the ISA has the waits
 // for the prefetched block behind the MFMAs)
-__global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs)
+// (status: the panel's refusal word starts at zero -- cleared here, by the panel's first launch, instead of by a memset node in front of it)
+__global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs, int* status)
 {
     extern __shared__ double sm[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0;
     cqr_stream_body<false, true, false>(sm, nullptr, w, mk, src, lds_, nullptr, 0, nullptr, 0, slabs, nullptr, blockIdx.x, gridDim.x);
 }
 
@@ -1218,14 +1220,12 @@ static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, doubl
     if (!qrd_panel_cqr_ok(mk, w)) return -7;
     if (!Qb) { Qb = Vw; ldq = ldv; }
     hipStream_t s = (hipStream_t) stream;
-    hipError_t e = hipMemsetAsync(status, 0, sizeof(int), s);
-    if (e != hipSuccess) return (int) e;
     // one persistent workgroup per compute unit OF THIS STREAM (a CU-masked stream -- MI355XQR_TSQR_RESERVE_CUS, a panel partition -- would
     // otherwise run the workgroups beyond its mask as a second round behind the first: twice the pass)
     int cap = qrd_stream_cus(stream);
     if (cap <= 0 || cap > CS_NWG) cap = CS_NWG;
     const int grid = cs_grid(mk, cap), ggrid = cs_grid(mk, cap), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
-    hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL);
+    hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL, status);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
     hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
     hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Qb, ldq,

@@ -7,8 +7,12 @@ import numpy as np, torch
 import cuda_qr_amd as qr
 from gpu_util import dev, host, zeros
 worst = 0.0
-for (m, n, nb, kind) in [(200003, 128, 128, 0), (262147, 384, 128, 0), (300000, 256, 128, 1), (196608, 128, 128, 0), (196607, 128, 128, 0),
-                         (250001, 130, 128, 0), (230000, 200, 128, 2), (400000, 128, 128, 3)]:
+SHAPES = [(200003, 128, 128, 0), (262147, 384, 128, 0), (300000, 256, 128, 1), (196608, 128, 128, 0), (196607, 128, 128, 0),
+          (250001, 130, 128, 0), (230000, 200, 128, 2), (400000, 128, 128, 3)]
+if len(_sys.argv) > 1 and _sys.argv[1] == "more":     # the heights the route took over in round 5 (from 8193 rows), ragged widths, every kind
+    SHAPES = [(8200, 128, 128, 0), (8321, 256, 128, 3), (9000, 384, 128, 1), (12345, 130, 128, 2), (20000, 512, 128, 0), (33000, 96, 128, 0),
+              (65536, 256, 128, 3), (70001, 200, 128, 2), (131072, 256, 128, 1), (16390, 640, 128, 3), (50000, 128, 128, 1), (99999, 257, 128, 0)]
+for (m, n, nb, kind) in SHAPES:
     rng = np.random.default_rng(m + n)
     A = rng.random((m, n))
     if kind == 1: A = A * np.logspace(0, -6, n)[None, :]                 # graded columns

@@ -13,12 +13,18 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355xqr.so")
+# CUDA_QR_AMD_LIB=lab (this binding's own switch, not a library knob): load libmi355xqr_lab.so -- the same sources built with -DQR_LAB
+# (`make -C cuda-qr_amd lab`), in which the measurement knobs are environment variables and the development entry points of the 32 x 32
+# factor core exist.  For devtools/ scripts and the tests that force a schedule branch on a small matrix; everything else (bench.py,
+# smoke(), the parity tests) runs the product library.
+LAB = os.environ.get("CUDA_QR_AMD_LIB", "") == "lab"
+LAB_LIB_PATH = os.path.join(HERE, "libmi355xqr_lab.so")
+LIB_PATH = LAB_LIB_PATH if LAB else os.path.join(HERE, "libmi355xqr.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mi355x_qr.h")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
-        f"{LIB_PATH} is missing: build it with `make -C {HERE}` (or python -c 'import __graft_entry__ as g; "
+        f"{LIB_PATH} is missing: build it with `make -C {HERE} all lab` (or python -c 'import __graft_entry__ as g; "
         "g.build()').  The HIP extension is mandatory; there is no CPU fallback.")
 
 # Load order matters when torch is used in the same process (every caller in this repo: device buffers are torch tensors): the torch

@@ -8,6 +8,15 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define LEAFW 32
 
+// Measurement knobs (settled A/Bs, ceiling experiments) are environment variables only in the LAB build (`make lab`: libmi355xqr_lab.so,
+// -DQR_LAB); in the product library they are the constants given here, so that no stray variable changes what a launch does.
+#ifdef QR_LAB
+#include <stdlib.h>
+#define QRD_LAB_ENV_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define QRD_LAB_ENV_INT(name, dflt) (dflt)
+#endif
+
 // ---- cross-lane moves on the VALU (no LDS traffic) -----------------------------------------------------
 // ds_bpermute-based shuffles go through the CU's single LDS pipeline; with 8 waves of a workgroup reducing 32
 // sums per Householder column that pipeline, not the SIMDs, set the pace (measured 3 us per column).  gfx950

@@ -414,17 +414,22 @@ __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M
             }
 }
 
+// Measurement knobs (lab build only, qr_common.h): MI355XQR_NT4 = 1 (default): four workgroups per CU; 2: three per CU, k-tiles of 16;
+// 0: the 8-wave kernel of round 3.  MI355XQR_NT_CEIL = 1 | 2: the ceiling experiment (profiles/r05_nt_ceiling.txt) -- C traffic / operand
+// loads compiled out, RESULTS WRONG: those instantiations do not exist in the product library.
 static int nt4(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_NT4"); return e ? atoi(e) : 1; }();   // round 5: default
+    static const int v = QRD_LAB_ENV_INT("MI355XQR_NT4", 1);
     return v;
 }
 
+#ifdef QR_LAB
 static int nt_ceil(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_NT_CEIL"); return e ? atoi(e) : 0; }();
+    static const int v = QRD_LAB_ENV_INT("MI355XQR_NT_CEIL", 0);
     return v;
 }
+#endif
 
 
 static int nt_gm(void)
@@ -436,7 +441,7 @@ static int nt_gm(void)
 // MI355XQR_NT_IL=0: the trailing update's K loop with grouped fragment reads (default 1: issue order spelled out, gemm_nt_kernel<.., 1>)
 static int nt_il(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_NT_IL"); return e ? atoi(e) : 1; }();
+    static const int v = QRD_LAB_ENV_INT("MI355XQR_NT_IL", 1);
     return v;
 }
 
@@ -451,14 +456,16 @@ int qrd_gemm2_init(void)
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 0, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
+#ifdef QR_LAB
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 0, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 1, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 2, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 0, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 192 * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 1, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 192 * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 2, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 192 * 8);
+#endif
     return rc;
 }
 
@@ -480,15 +487,20 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
     const size_t shm = solo ? (size_t) 100 * 1024 : 2 * NT_STAGE * sizeof(double);
     hipStream_t s = (hipStream_t) stream;
     if (!stamps && sign < 0 && nt4() && K >= 32) {
-        // MI355XQR_NT4 = 1: four workgroups per CU (k-tiles of 8, three stages); 2: three per CU (k-tiles of 16, two stages)
+        // four workgroups per CU (k-tiles of 8, three stages)
         const int gy4 = N / 64;
         const dim3 g(gx * gy4), b(256);
 #define NT4_LAUNCH(CE, BK, NS) hipLaunchKernelGGL((gemm_nt4_kernel<true, CE, BK, NS>), g, b, NS * (BK * 192) * sizeof(double), s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy4, gm)
+#ifdef QR_LAB
         if (nt4() == 2) { if (nt_ceil() == 1) NT4_LAUNCH(1, 16, 2); else if (nt_ceil() == 2) NT4_LAUNCH(2, 16, 2); else NT4_LAUNCH(0, 16, 2); }
         else { if (nt_ceil() == 1) NT4_LAUNCH(1, 8, 3); else if (nt_ceil() == 2) NT4_LAUNCH(2, 8, 3); else NT4_LAUNCH(0, 8, 3); }
+#else
+        NT4_LAUNCH(0, 8, 3);
+#endif
 #undef NT4_LAUNCH
         return (int) hipGetLastError();
     }
+#ifdef QR_LAB
     if (!stamps && sign < 0 && nt_ceil() == 1) {
         hipLaunchKernelGGL((gemm_nt_kernel<true, 0, 1, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
         return (int) hipGetLastError();
@@ -497,6 +509,7 @@ int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, in
         hipLaunchKernelGGL((gemm_nt_kernel<true, 0, 1, 2>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
         return (int) hipGetLastError();
     }
+#endif
     if (stamps)
         hipLaunchKernelGGL((gemm_nt_kernel<true, 1>), dim3(gx * gy), dim3(512), shm, s, M, N, K, A, lda, Bt, ldbt, C, ldc, gx, gy, gm, stamps);
     else if (sign < 0 && nt_il())

@@ -15,6 +15,7 @@
  */
 #define _POSIX_C_SOURCE 200809L      /* strtok_r, pthread under -std=c99 */
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -87,7 +88,8 @@ struct qr_plan {
     unsigned cq_seq;            /* sequence number of the last tall panel issued */
     int guard_latch;            /* 0: a refused tall panel is handed to the leaf chain (the host reads the verdict while the panel's last pass
                                  * runs); 1: nothing is read inside qr_geqrf_dev, a refusal is reported by qr_plan_sync (QR_E_REFUSED) */
-    int cq_dirty, pf_dirty;     /* tall / one-launch panels have been issued since the status words were last read */
+    int cq_dirty, pf_dirty;     /* tall panels in LATCH mode / one-launch panels have been issued since the status words were last read (a tall
+                                 * panel in poll mode has its verdict read at once: nothing is left pending) */
     int fused_off;              /* 1: never the one-launch panel (set by the host-pointer entry points after a stalled hand-off, QR_E_STALL) */
     long long n_cqr, n_cqr_refused, n_pf_leaf_fallback, n_pf_stall;   /* qr_plan_route_stats */
     double* pf_ws;              /* exchange workspace of the one-launch panel (qr_panel_fused.hip); NULL: not used */
@@ -147,20 +149,37 @@ static int env_int(const char* name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
+/* Two classes of environment variables.  The twelve PUBLIC ones (NB, IB, PANEL, GUARD, LOOKAHEAD, SPLIT,
+ * CQR_MIN_ROWS, FUSED_MIN_ROWS, TSQR_PIPE, TSQR_RESERVE_CUS, PLAN_CACHE, ROCTX) are read in every build.  The measurement knobs -- settled
+ * A/Bs and overrides of the schedule's own choices -- exist only in the LAB build (`make lab`: libmi355xqr_lab.so, -DQR_LAB), which the
+ * scripts under devtools/ and the schedule-variant tests load; in the product library they are the constants below and no stray
+ * variable can change what a factorisation does. */
+#ifdef QR_LAB
+#define lab_getenv(name) getenv(name)
+#else
+#define lab_getenv(name) ((const char*) NULL)
+#endif
+static int lab_env_int(const char* name, int dflt)
+{
+    const char* e = lab_getenv(name);
+    (void) name;
+    return e ? atoi(e) : dflt;
+}
+
 static void knobs_init(void)
 {
     qr_knobs* k = &g_knobs;
-    k->fuse_nn = env_int("MI355XQR_FUSE_NN", 1) != 0;
-    k->split_t = env_int("MI355XQR_SPLIT_T", 1) != 0;
-    k->early_next = env_int("MI355XQR_EARLY_NEXT", 1) != 0;
+    k->fuse_nn = lab_env_int("MI355XQR_FUSE_NN", 1) != 0;
+    k->split_t = lab_env_int("MI355XQR_SPLIT_T", 1) != 0;
+    k->early_next = lab_env_int("MI355XQR_EARLY_NEXT", 1) != 0;
     k->plan_cache = env_int("MI355XQR_PLAN_CACHE", 1) != 0;
-    k->early_product = env_int("MI355XQR_EP", 1) != 0;
-    k->fused_panel = env_int("MI355XQR_FUSED_PANEL", 1) != 0;
+    k->early_product = lab_env_int("MI355XQR_EP", 1) != 0;
+    k->fused_panel = lab_env_int("MI355XQR_FUSED_PANEL", 1) != 0;
     k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
     k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
     k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
-    k->tall_nt = env_int("MI355XQR_TALL_NT", 1) != 0;
-    k->cqr_park = env_int("MI355XQR_CQR_PARK", 1) != 0;
+    k->tall_nt = lab_env_int("MI355XQR_TALL_NT", 1) != 0;
+    k->cqr_park = lab_env_int("MI355XQR_CQR_PARK", 1) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -261,6 +280,15 @@ const char* qr_strerror(int status)
 
 static int imin(int a, int b) { return a < b ? a : b; }
 
+static inline void cpu_relax(void)
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+
 /* rows from which a 128-column panel of this plan takes the full-width route (knob comment above) */
 #define QR_CQR_MIN_ROWS_LOOKAHEAD 196608
 static int plan_cqr_min_rows(const qr_plan* p)
@@ -304,13 +332,13 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
     /* MI355XQR_GRAPH=1: the single-stream schedule captured once per argument set and replayed (no measured gain: the cost of a leaf is
      * the device-side kernel boundary, not the host launch).  Never with look-ahead: capturing the CU-masked two-stream schedule
      * crashes inside the runtime (round 3: segmentation fault in hipStreamEndCapture), so the knob is ignored there. */
-    const char* gr = getenv("MI355XQR_GRAPH");
+    const char* gr = lab_getenv("MI355XQR_GRAPH");
     p->use_graph = (gr ? atoi(gr) != 0 : 0) && !p->lookahead;
     /* MI355XQR_SPLIT = "c0:f0,c1:f1,...,ck": the panel chain runs on its own c_i compute units and the wide update
      * on the other 256-c_i while more than the fraction f_i of the columns is still to be factored (last entry: to
      * the end), so a leaf kernel never queues behind resident GEMM workgroups and the split follows the shrinking
-     * trailing matrix.  "0" = no partition (shared CUs, stream priority only).  MI355XQR_PANEL_CUS=c is the
-     * one-phase form.  Default: partition when there is a wide update worth overlapping with (n >= 2048);
+     * trailing matrix.  "0" = no partition (shared CUs, stream priority only); a single number c is the one-phase
+     * form.  Default: partition when there is a wide update worth overlapping with (n >= 2048);
      * tall-skinny problems are all panel, so they keep the whole chip on one stream set. */
     /* (a multi-rank TSQR's local plan takes a normal-priority stream: the stacked plan's high-priority stream, which carries the exchange
      * and the short stacked panels everyone is waiting for, goes first whenever both have work queued) */
@@ -334,10 +362,8 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
     p->pair_cur = -1;
     if (!rc && p->lookahead) {
         const char* sp = getenv("MI355XQR_SPLIT");
-        const char* pc = getenv("MI355XQR_PANEL_CUS");
         char spec[128];
         if (sp) snprintf(spec, sizeof spec, "%s", sp);
-        else if (pc) snprintf(spec, sizeof spec, "%s", pc);
         else snprintf(spec, sizeof spec, "%s", n >= 2048 ? ((m >= 10240 && n >= 10240) ? QR_DEFAULT_SPLIT_BIG : QR_DEFAULT_SPLIT) : "0");
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
@@ -377,14 +403,14 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         /* MI355XQR_NEXT=panel|update|auto: which stream applies panel s to the columns of panel s+1 (the look-ahead update
          * N(s)).  On the update stream it is a 60 us job for 190+ CUs instead of a 180 us one for the panel stream's few --
          * but while the update stream is busy back to back it would only delay W(s); auto (default) switches with the phase. */
-        const char* nx = getenv("MI355XQR_NEXT");
+        const char* nx = lab_getenv("MI355XQR_NEXT");
         p->next_on_update = !nx ? 2 : (strcmp(nx, "update") == 0 ? 1 : (strcmp(nx, "panel") == 0 ? 0 : 2));   /* 2 = by phase */
         if (!nx && p->npairs && qrd_stream_cus(p->s_pair[0][0]) <= 32) p->next_on_update = 1;
     }
     {
         /* MI355XQR_BALANCE = "Rp,Ru,tc0,tc1" (TFLOP/s on the panel CUs, on the update CUs; next-panel chain time
          * tc0 + tc1*mk/16384 ms at nb = 256); "0" = the panel stream takes no share of the wide update */
-        const char* b = getenv("MI355XQR_BALANCE");
+        const char* b = lab_getenv("MI355XQR_BALANCE");
         p->bal_rp = 14.0; p->bal_ru = 44.0; p->bal_tc0 = 1.1; p->bal_tc1 = 0.6;
         if (p->npairs) {            /* measured ~0.22 TFLOP/s per CU for the K = 256 update GEMMs on either side of the partition */
             int cus = 256;
@@ -512,7 +538,7 @@ static int plan_read_status(qr_plan* p)
         p->n_pf_leaf_fallback += st[0];
         if (st[1]) { p->n_pf_stall += 1; rc = QR_E_STALL; }
     }
-    if (p->cq_dirty && p->cq_status && p->guard_latch) {
+    if (p->cq_dirty && p->cq_status) {       /* (keyed on what was ISSUED, not on the current mode: qr_plan_set_guard_mode may have switched since) */
         int st[4] = {0, 0, 0, 0};
         CHECK(qrd_d2h(p->s_main, st, p->cq_status, sizeof st));
         CHECK(qrd_stream_sync(p->s_main));
@@ -538,11 +564,14 @@ int qr_plan_sync(qr_plan* p)
     return plan_read_status(p);
 }
 
+/* Drains the plan first: panels issued in the old mode have their status read (and reported: the return value is qr_plan_sync's) before
+ * the mode changes -- a refusal latched earlier is neither lost nor left to surface under the other mode's rules. */
 int qr_plan_set_guard_mode(qr_plan* p, int latch)
 {
     if (!p || (latch != 0 && latch != 1)) return QR_E_ARG;
+    const int rc = qr_plan_sync(p);
     p->guard_latch = latch;
-    return 0;
+    return rc;
 }
 
 int qr_plan_route_stats(qr_plan* p, long long* out4)
@@ -740,8 +769,7 @@ static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, doub
     const int latch = p->guard_latch || !p->cq_hword;
     CHECK(qrd_panel_cqr_p(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status, Qh, ldv, latch ? NULL : p->cq_hword_dev, seq, park));
     p->n_cqr += 1;
-    p->cq_dirty = 1;
-    if (latch) return 0;
+    if (latch) { p->cq_dirty = 1; return 0; }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (unsigned spins = 0;; ++spins) {
@@ -750,9 +778,12 @@ static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, doub
             if (v & 1u) p->n_cqr_refused += 1;
             return (int) (v & 1u);
         }
+        cpu_relax();                         /* the verdict is ~0.3 ms away: do not hammer the line the device is about to write */
         if ((spins & 1023u) == 1023u) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 5.0) break;
+            const double waited = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+            if (waited > 5.0) break;
+            if (waited > 0.002) sched_yield();       /* far beyond a panel's time (a queue full of other work in front): let the core go */
         }
     }
     /* the word never came (a fault in front of it?): drain the stream -- an error there is the caller's answer -- and read the device word */
@@ -1497,17 +1528,21 @@ int mmqr_status(double* mat, double** tau, int m, int n)
     if (!htau) { slot_release(sl); return QR_E_ALLOC; }
     const size_t bytes = sizeof(double) * (size_t) m * n;
     int rc = 0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    /* host-pointer entry points block anyway: their plans always POLL the guard's verdict (a refused tall panel goes to the leaf chain
+     * at once), whatever MI355XQR_GUARD says -- the latch mode is for callers of the device API that must not block */
+    const int latch0 = p->guard_latch;
+    p->guard_latch = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
         rc = qrd_h2d(p->stream, sl->dA, mat, bytes);
         if (!rc) rc = qr_geqrf_dev(p, sl->dA, m, n, m, sl->dtau);
-        /* the status words of the panel kernels, before the result replaces the caller's matrix: a stalled one-launch panel or (latch
-         * mode, MI355XQR_GUARD=latch) a refused tall panel is factored again from the host copy on the plain routes */
+        /* the status words of the panel kernels, before the result replaces the caller's matrix: after a stalled one-launch panel the
+         * matrix is factored again from the host copy with that route off */
         const int rs = qr_plan_sync(p);
         if (!rc) rc = rs;
         if (rc == QR_E_STALL && !p->fused_off) { p->fused_off = 1; continue; }
-        if (rc == QR_E_REFUSED && p->guard_latch) { p->guard_latch = 0; continue; }
         break;
     }
+    p->guard_latch = latch0;
     if (!rc) rc = qrd_d2h(p->stream, mat, sl->dA, bytes);
     if (!rc) rc = qrd_d2h(p->stream, htau, sl->dtau, sizeof(double) * n);
     if (!rc) rc = qrd_stream_sync(p->stream);
@@ -1730,34 +1765,54 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
     if (!rc) rc = qrd_malloc((void**) &dQ, abytes);
     if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * (size_t) n * nshards);
     if (!rc) rc = qrd_malloc((void**) &dR, sizeof(double) * (size_t) n * n);
-    if (!rc) rc = qrd_h2d(p->stream, dA, A, abytes);
-    if (!rc && nshards == 1) {
-        rc = qr_geqrf_dev(p, dA, m, n, m, dtau);
-        if (!rc) rc = qr_extract_r_dev(p, dA, m, n, m, dR, n, n);
-        if (!rc) rc = qr_applyq_dev(p, dA, m, n, m, dtau, dQ, n, m, 1);
-    } else if (!rc) {
+    if (!rc && nshards > 1) {
         rc = qr_plan_create(&p2, sm, n, nb, 0);
         if (!rc) rc = qrd_malloc((void**) &dS, sizeof(double) * (size_t) sm * n);
         if (!rc) rc = qrd_malloc((void**) &dQt, sizeof(double) * (size_t) sm * n);
         if (!rc) rc = qrd_malloc((void**) &dtau2, sizeof(double) * n);
-        for (int s = 0; s < nshards && !rc; ++s) {            /* step 1: independent local QRs */
-            const int r0 = s * ms, rows = imin(ms, m - r0);
-            rc = qr_geqrf_dev(p, dA + r0, rows, n, m, dtau + (size_t) s * n);
-            if (!rc) rc = qr_extract_r_dev(p, dA + r0, rows, n, m, dS + (size_t) s * n, n, sm);
+    }
+    /* a host-pointer entry point: its plans poll the guard's verdict (see mmqr_status), and the status words of the panel kernels are
+     * read (qr_plan_sync, both plans) BEFORE anything is copied back -- after a stalled one-launch panel everything is redone from the
+     * caller's matrix with that route off; any other status is the caller's answer, never a silent rc = 0 over garbage */
+    if (p) p->guard_latch = 0;
+    if (p2) p2->guard_latch = 0;
+    for (int attempt = 0; attempt < 2 && !rc; ++attempt) {
+        rc = qrd_h2d(p->stream, dA, A, abytes);
+        if (!rc && nshards == 1) {
+            rc = qr_geqrf_dev(p, dA, m, n, m, dtau);
+            if (!rc) rc = qr_extract_r_dev(p, dA, m, n, m, dR, n, n);
+            if (!rc) rc = qr_applyq_dev(p, dA, m, n, m, dtau, dQ, n, m, 1);
+        } else if (!rc) {
+            for (int s = 0; s < nshards && !rc; ++s) {            /* step 1: independent local QRs */
+                const int r0 = s * ms, rows = imin(ms, m - r0);
+                rc = qr_geqrf_dev(p, dA + r0, rows, n, m, dtau + (size_t) s * n);
+                if (!rc) rc = qr_extract_r_dev(p, dA + r0, rows, n, m, dS + (size_t) s * n, n, sm);
+            }
+            if (!rc) rc = qr_plan_sync(p);
+            /* step 2: QR of the stacked R factors (what every rank does after the all-gather) */
+            if (!rc) rc = qr_geqrf_dev(p2, dS, sm, n, sm, dtau2);
+            if (!rc) rc = qr_extract_r_dev(p2, dS, sm, n, sm, dR, n, n);
+            if (!rc) rc = qr_applyq_dev(p2, dS, sm, n, sm, dtau2, dQt, n, sm, 1);
+            if (!rc) rc = qr_plan_sync(p2);
+            /* step 3: Q_s = Q_local_s * [Qtree_s ; 0] */
+            if (!rc) rc = qrd_memset(p->stream, dQ, 0, abytes);
+            for (int s = 0; s < nshards && !rc; ++s) {
+                const int r0 = s * ms, rows = imin(ms, m - r0);
+                rc = qrd_copy_block(p->stream, dQt + (size_t) s * n, sm, dQ + r0, m, n, n);
+                if (!rc) rc = qr_applyq_dev(p, dA + r0, rows, n, m, dtau + (size_t) s * n, dQ + r0, n, m, 0);
+            }
         }
-        if (!rc) rc = qrd_stream_sync(p->stream);
-        /* step 2: QR of the stacked R factors (what every rank does after the all-gather) */
-        if (!rc) rc = qr_geqrf_dev(p2, dS, sm, n, sm, dtau2);
-        if (!rc) rc = qr_extract_r_dev(p2, dS, sm, n, sm, dR, n, n);
-        if (!rc) rc = qr_applyq_dev(p2, dS, sm, n, sm, dtau2, dQt, n, sm, 1);
-        if (!rc) rc = qrd_stream_sync(p2->stream);
-        /* step 3: Q_s = Q_local_s * [Qtree_s ; 0] */
-        if (!rc) rc = qrd_memset(p->stream, dQ, 0, abytes);
-        for (int s = 0; s < nshards && !rc; ++s) {
-            const int r0 = s * ms, rows = imin(ms, m - r0);
-            rc = qrd_copy_block(p->stream, dQt + (size_t) s * n, sm, dQ + r0, m, n, n);
-            if (!rc) rc = qr_applyq_dev(p, dA + r0, rows, n, m, dtau + (size_t) s * n, dQ + r0, n, m, 0);
+        {
+            const int rs = qr_plan_sync(p), rs2 = p2 ? qr_plan_sync(p2) : 0;
+            if (!rc) rc = rs ? rs : rs2;
         }
+        if (rc == QR_E_STALL && !p->fused_off) {
+            p->fused_off = 1;
+            if (p2) p2->fused_off = 1;
+            rc = 0;
+            continue;
+        }
+        break;
     }
     if (!rc) rc = qrd_d2h(p->stream, Q, dQ, abytes);
     if (!rc) rc = qrd_d2h(p->stream, R, dR, sizeof(double) * (size_t) n * n);
@@ -1773,7 +1828,10 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
  *   2. ONE ncclAllGather of the R factors on the plan's stream (RCCL over xGMI; latency-bound: n = 512 is 2 MiB per rank)
  *   3. redundant QR of the stacked (P n) x n matrix on every rank -> the final R (identical bits everywhere)
  *   4. (qr_tsqr_formq_dev) Q_p = Q_local_p [Qtree_p; 0]
- * Everything is stream-ordered: no host synchronisation inside a step.  The stacked factorisation runs on its own plan's streams
+ * Stream-ordered, with ONE exception: in the default guard mode the host thread waits for the verdict word of each full-width panel of
+ * the local factorisation (shards above 8192 rows: once per 128 columns, while that panel's last pass still runs -- the GPU does not
+ * idle, see panel_cqr_half); qr_plan_set_guard_mode(qr_tsqr_local_plan(tp), 1) removes that wait at the price of QR_E_REFUSED on
+ * ill-conditioned input.  No stream is ever drained inside a step.  The stacked factorisation runs on its own plan's streams
  * behind an event, and the next step's exchange waits for it through another, so in a sequence of independent factorisations the
  * stacked QR of step i runs under the local QR of step i+1 without the caller doing anything; qr_tsqr_sync() drains both.
  * No reference counterpart: the reference is single-device (qr.cu:711,737). */
@@ -1921,9 +1979,11 @@ int qr_tsqr_plan_destroy(qr_tsqr_plan* t)
 int qr_tsqr_sync(qr_tsqr_plan* t)
 {
     if (!t) return QR_E_ARG;
-    int rc = t->p ? qr_plan_sync(t->p) : 0;
-    if (!rc && t->p2) rc = qr_plan_sync(t->p2);
-    return rc;
+    /* BOTH plans, always: a soft status of the local plan (QR_E_REFUSED / QR_E_STALL) must not leave the stacked plan's streams -- and
+     * the collectives of the invalid step -- running, nor its status words unread, when the caller reacts by factoring again */
+    const int rc = t->p ? qr_plan_sync(t->p) : 0;
+    const int rc2 = t->p2 ? qr_plan_sync(t->p2) : 0;
+    return rc ? rc : rc2;
 }
 
 void* qr_tsqr_stream(qr_tsqr_plan* t) { return t && t->p ? t->p->s_main : NULL; }
@@ -2266,6 +2326,10 @@ static int mg_run(mg_ctx* c)
     double *dA = NULL, *dQ = NULL, *dR = NULL;
     int rc = qrd_set_device(c->dev);
     if (!rc) rc = qr_tsqr_plan_create_comm(&t, c->comm, c->ngpu, c->rank, rows, n, c->nb);
+    if (!rc) {                  /* host-pointer entry point: poll the guard (see mmqr_status); the final qr_tsqr_sync reports QR_E_STALL, if any */
+        t->p->guard_latch = 0;
+        if (t->p2) t->p2->guard_latch = 0;
+    }
     if (!rc) rc = qrd_malloc((void**) &dA, sizeof(double) * (size_t) rows * n);
     if (!rc) rc = qrd_malloc((void**) &dQ, sizeof(double) * (size_t) rows * n);
     if (!rc) rc = qrd_malloc((void**) &dR, sizeof(double) * nn);
@@ -2303,6 +2367,7 @@ int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, in
     int ndev = 0;
     if (qrd_device_count(&ndev) != 0 || ndev < 1) return QR_E_NODEVICE;
     if (ngpu > ndev) return QR_E_ARG;                       /* more shards than visible devices */
+    if (ngpu == 1) return qr_thin(A, m, n, Q, R, nb, 1);    /* no thread, no communicator; qr_thin's status handling (retry after a stall) */
     const int ms = (m + ngpu - 1) / ngpu;
     if (m - (ngpu - 1) * ms < n) return QR_E_ARG;           /* every shard needs at least n rows */
     int prev = 0;
@@ -2327,10 +2392,7 @@ int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, in
         c->r0 = d * ms; c->rows = imin(ms, m - d * ms);
         c->A = A; c->Q = Q; c->R = R; c->comm = comms[d]; c->bar = &bar; c->any_fail = &any_fail;
     }
-    if (ngpu == 1) {
-        mg_worker(&ctx[0]);                                 /* no thread, no communicator */
-        rc = ctx[0].rc;
-    } else {
+    {
         for (int d = 0; d < ngpu; ++d) {
             if (pthread_create(&th[d], NULL, mg_worker, &ctx[d])) break;
             ++started;

@@ -910,7 +910,7 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     // the wide product of the trailing update on 128 x 256 workgroup tiles (gemm_tn_wide_kernel: A2 read N / 256 times instead of
     // N / 128) -- measured in round 3: half the HBM traffic, the same rate (16384^2: 50.7 against 51.4 TFLOP/s in situ; the product
     // is bound on the matrix-core side, not by bytes), so the 128 x 128 kernel stays the default; MI355XQR_TN_WIDE=1 or tag 2 select it
-    static const int wide_ok = [] { const char* e = getenv("MI355XQR_TN_WIDE"); return e ? (int) (atoi(e) != 0) : 0; }();
+    static const int wide_ok = QRD_LAB_ENV_INT("MI355XQR_TN_WIDE", 0) != 0;
     const bool wide = (tag == 2 || (tag == 1 && wide_ok)) && ti == 4 && Tm == nullptr && alpha == 1.0 && beta == 0.0 && N % 256 == 0 && M >= 128 &&
                       K % BK == 0 && vec_ok(A, lda) && vec_ok(B, ldb) && slabs != nullptr;
     const int BM = 32 * ti, BN = wide ? 256 : 32 * tj;
@@ -929,7 +929,7 @@ static int gemm_tn_impl(void* stream, int M, int N, int K, double alpha, const d
     // K loop of the 128 x 128 products: MI355XQR_KPIPE=1 (default) issue order spelled out, one memory instruction behind every MFMA
     // (gemm_kloop_il); 0 = the plain double-buffered loop.  Isolated, 15872 x 256 x 16128: 65.8 -> 68.9 TFLOP/s; one workgroup per CU:
     // 58.4 -> 68.1.  In situ at 16384^2: 51.5 -> 54.3 TFLOP/s (profiles/r03_tn_issue_order.txt)
-    static const int kpipe = [] { const char* e = getenv("MI355XQR_KPIPE"); return e ? atoi(e) : 1; }();
+    static const int kpipe = QRD_LAB_ENV_INT("MI355XQR_KPIPE", 1);
     const int slots = (wide ? 1 : 2) * stream_cus(s);
     const double row_us = 2.0 * BM * BN / (wide ? 0.226e6 : 0.113e6);   // one K row of one tile on one workgroup slot (wide: the whole CU)
     const double red_rows = (double) per * 8.0 / 2.0e6 / row_us;   // reading one slab of the output at ~2 TB/s, in K rows
@@ -1263,7 +1263,9 @@ int qrd_host_word_alloc(unsigned** host, unsigned** dev)
 {
     void* h = nullptr;
     void* d = nullptr;
-    hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+    // coherent (fine-grained) on purpose: the device's store must become visible to the polling host thread while the stream still runs,
+    // whatever HIP_HOST_COHERENT says
+    hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
     if (e != hipSuccess) { if (h) hipHostFree(h); return (int) e; }
     *reinterpret_cast<volatile unsigned*>(h) = 0u;

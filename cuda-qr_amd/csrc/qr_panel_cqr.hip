@@ -656,8 +656,9 @@ __device__ __forceinline__ bool cq_lu_body(double* sm, double* ws, int w, double
     return false;
 }
 
-// status[0]: this panel was refused (the kernels behind this one return at once, A is untouched); status[1]: refused panels since the
-// host last cleared the word (sticky: the plan's latch mode reports it at qr_plan_sync); hflag (optional, host memory mapped into the
+// status[0]: this panel was refused (the kernels behind this one return at once, A is untouched); status[1]: panels refused in LATCH
+// mode (hflag == NULL) since the host last cleared the word (sticky: reported at qr_plan_sync; a refusal the polling host reads from
+// hflag is dealt with at once and must not surface again after a later switch of modes); hflag (optional, host memory mapped into the
 // device): 2 * seq + refused, written with system scope as soon as the verdict exists -- the host reads it while the panel's last pass
 // is still running, so its decision (the leaf chain, or nothing) is queued long before the stream gets there
 __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double* Vw, int ldv, int* status, unsigned* hflag, unsigned seq)
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(CQ_T) void cqr_lu_kernel(double* ws, int w, double*
     extern __shared__ double sm[];
     const bool refused = cq_lu_body(sm, ws, w, Vw, ldv, status);
     if (threadIdx.x == 0) {
-        if (refused) { status[0] = 1; status[1] += 1; }
+        if (refused) { status[0] = 1; if (!hflag) status[1] += 1; }
         if (hflag) {
             __threadfence_system();
             __hip_atomic_store(hflag, 2u * seq + (refused ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1818,7 +1818,7 @@ size_t qrd_panel_ws_size(int m)
 // MI355XQR_COOP=0: the guard route always as separate launches (default 1: one cooperative launch for short leaves)
 static int coop_enabled(void)
 {
-    static const int v = [] { const char* e = getenv("MI355XQR_COOP"); int v_ = (e && atoi(e) == 0) ? 0 : 1; return v_; }();
+    static const int v = QRD_LAB_ENV_INT("MI355XQR_COOP", 1) != 0;
     return v;
 }
 

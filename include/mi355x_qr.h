@@ -121,7 +121,9 @@ int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, in
  *   per matrix:  qr_tsqr_factor_dev(tp, dA_shard, lda, dR)      local QR -> ONE ncclAllGather of the n x n R factors ->
  *                                                               redundant QR of the stacked (nranks n) x n matrix -> dR (n x n, ld n)
  *                qr_tsqr_formq_dev(tp, dA_shard, lda, dQ, ldq)  optional: this rank's m_local x n rows of the thin Q
- * Stream-ordered, no host synchronisation inside a step; the stacked factorisation of one call overlaps the local factorisation
+ * Stream-ordered: no stream is drained inside a step; in the default guard mode (qr_plan_set_guard_mode below) the host thread waits
+ * once per full-width panel of a shard above 8192 rows for that panel's verdict word while its last pass still runs -- latch mode on
+ * qr_tsqr_local_plan(tp) removes even that.  The stacked factorisation of one call overlaps the local factorisation
  * of the next (independent matrices).  qr_tsqr_sync() before results are read on another stream.  librccl.so is dlopen()ed
  * on first use.  nranks = 1 needs no id (NULL) and no communicator.  qr_tsqr_plan_create_comm takes an ncclComm_t the caller
  * already owns (as void*; NULL = the caller exchanges the factors itself: qr_tsqr_local_dev, copy through
@@ -236,7 +238,9 @@ int qr_plan_sync(qr_plan* plan);
  *   latch = 1: qr_geqrf_dev never waits for the device (fully stream-ordered).  A refused panel makes the factorisation INVALID (the
  *              matrix is overwritten with garbage from that panel on); qr_plan_sync / qr_tsqr_sync return QR_E_REFUSED and the caller
  *              factors a fresh copy with latch = 0.  For pipelines that own their inputs and check a residual anyway.
- * MI355XQR_GUARD=latch selects latch = 1 for every plan of the process. */
+ * MI355XQR_GUARD=latch selects latch = 1 for every plan a caller of the DEVICE API creates; the host-pointer entry points (mmqr, explicitQR,
+ * qr_thin, qr_thin_mgpu) block anyway and always use latch = 0 on their own plans.
+ * The call drains the plan and returns qr_plan_sync's status: a refusal latched before the switch is reported here, not lost. */
 int qr_plan_set_guard_mode(qr_plan* plan, int latch);
 /* out4: full-width tall panels issued, of them refused, leaves of one-launch panels that took their Householder route, one-launch
  * panels whose hand-off stalled -- since the plan was created (refusals in latch mode and the last two are counted at qr_plan_sync) */

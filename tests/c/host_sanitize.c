@@ -11,6 +11,7 @@
 #include "../../include/mi355x_qr.h"
 
 long qrd_stub_launches(void);
+long qrd_stub_stalls(void);
 int qrd_stub_live_allocations(void);
 
 #define OK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #x, rc_, qr_strerror(rc_)); exit(1); } } while (0)
@@ -113,23 +114,71 @@ int main(void)
     factor_once(3000, 2100, 128, 3000, 2100, 1, 1);
     factor_once(2304, 2304, 512, 2304, 2304, 0, 0);
     factor_once(16384, 2048, 256, 8192, 2048, 0, 0);
-    setenv("MI355XQR_PANEL_CUS", "64", 1);
+    setenv("MI355XQR_SPLIT", "64", 1);
     setenv("MI355XQR_BALANCE", "14,44,0.05,0.05", 1);
     factor_once(6144, 4096, 256, 6144, 4096, 0, 1);
     factor_once(6144, 4096, 128, 6000, 3900, 0, 0);
     factor_once(5120, 5120, 512, 5120, 5120, 0, 0);
     setenv("MI355XQR_NEXT", "update", 1);
     factor_once(6144, 4096, 256, 6144, 4096, 0, 0);
-    unsetenv("MI355XQR_NEXT"); unsetenv("MI355XQR_PANEL_CUS"); unsetenv("MI355XQR_BALANCE");
+    unsetenv("MI355XQR_NEXT"); unsetenv("MI355XQR_SPLIT"); unsetenv("MI355XQR_BALANCE");
     setenv("MI355XQR_LOOKAHEAD", "0", 1);
     setenv("MI355XQR_GRAPH", "1", 1);
     factor_once(2000, 500, 128, 2000, 500, 0, 0);
     unsetenv("MI355XQR_GRAPH"); unsetenv("MI355XQR_LOOKAHEAD");
     setenv("MI355XQR_PANEL", "tsqr", 1);
     factor_once(9000, 200, 128, 9000, 200, 1, 0);
-    setenv("MI355XQR_PANEL", "col", 1);
-    factor_once(900, 200, 64, 900, 200, 0, 0);
     unsetenv("MI355XQR_PANEL");
+    /* 1b. guard modes of the full-width panel.  The stub's guard refuses heights with bit 12 set: of a 65536 x 256 problem, panel 0
+     *     (65536 rows) is accepted and panel 1 (65408) refused.  Poll mode hands the refused panel to the leaf chain (status 0); latch
+     *     mode reports QR_E_REFUSED at the sync, also when the mode is switched in between (the pending refusal must not be lost), and
+     *     a plan that has reported is clean again */
+    {
+        qr_plan* p = NULL;
+        double *dA = NULL, *dtau = NULL;
+        long long st[4];
+        const int m = 65536, n = 256;
+        OK(qr_plan_create(&p, m, n, 128, 0));
+        OK(qr_device_malloc((void**) &dA, sizeof(double) * (size_t) m * n));
+        OK(qr_device_malloc((void**) &dtau, sizeof(double) * n));
+        OK(qr_geqrf_dev(p, dA, m, n, m, dtau));                               /* poll (default) */
+        OK(qr_plan_sync(p));
+        OK(qr_plan_route_stats(p, st));
+        if (st[0] != 2 || st[1] != 1) { fprintf(stderr, "poll mode: %lld tall panels, %lld refused\n", st[0], st[1]); return 20; }
+        OK(qr_plan_set_guard_mode(p, 1));
+        OK(qr_geqrf_dev(p, dA, m, n, m, dtau));
+        if (qr_plan_sync(p) != QR_E_REFUSED) return 21;
+        OK(qr_plan_sync(p));                                                  /* reported once, then clean */
+        OK(qr_geqrf_dev(p, dA, m, n, m, dtau));
+        if (qr_plan_set_guard_mode(p, 0) != QR_E_REFUSED) return 22;          /* the switch drains and reports what was latched */
+        OK(qr_plan_sync(p));
+        OK(qr_geqrf_dev(p, dA, m, n, m, dtau));                               /* poll again */
+        OK(qr_plan_sync(p));
+        OK(qr_plan_route_stats(p, st));
+        if (st[0] != 8 || st[1] != 4) { fprintf(stderr, "after the mode switches: %lld tall panels, %lld refused\n", st[0], st[1]); return 23; }
+        OK(qr_device_free(dA)); OK(qr_device_free(dtau));
+        OK(qr_plan_destroy(p));
+    }
+    /* 1c. a stalled one-launch panel under the host-pointer entry points: mmqr_status and qr_thin must see QR_E_STALL at their plan
+     *     sync and factor again with the route off (status 0 for the caller), never return rc = 0 over the stalled result */
+    {
+        const int m = 4096, n = 256;
+        double* A = (double*) calloc((size_t) m * n, sizeof(double));
+        double* Q = (double*) calloc((size_t) m * n, sizeof(double));
+        double* R = (double*) calloc((size_t) n * n, sizeof(double));
+        double* tau = NULL;
+        const long s0 = qrd_stub_stalls();
+        setenv("QRD_STUB_STALL_ONCE", "1", 1);
+        OK(mmqr_status(A, &tau, m, n));
+        free(tau);
+        setenv("QRD_STUB_STALL_ONCE", "1", 1);
+        OK(qr_thin(A, m, n, Q, R, 0, 1));
+        setenv("QRD_STUB_STALL_ONCE", "1", 1);
+        OK(qr_thin(A, 2 * m, n / 2, Q, R, 0, 2));
+        if (qrd_stub_stalls() != s0 + 3) { fprintf(stderr, "stall injection: %ld of 3 fired\n", qrd_stub_stalls() - s0); return 24; }
+        OK(qr_release_cached_plans());
+        free(A); free(Q); free(R);
+    }
     /* argument errors */
     { qr_plan* p = NULL; if (qr_plan_create(&p, 10, 20, 0, 0) != QR_E_ARG || qr_plan_create(&p, 64, 64, 100, 32) != QR_E_ARG) return 2; }
 

@@ -13,6 +13,8 @@
 #include <string.h>
 #include "../../cuda-qr_amd/csrc/qr_device.h"
 
+static long g_stub_stalls = 0;      /* injected stalls of the one-launch panel (QRD_STUB_STALL_ONCE) */
+
 #define MAXA 4096
 static struct { char* p; size_t n; } g_alloc[MAXA];
 static int g_nalloc;
@@ -219,7 +221,7 @@ int qrd_panel_cqr_q(void* s, double* A, int lda, int mk, int w, double* tau, dou
     if (Qb) chk("panel_cqr Q", Qb, ldq, mk, w);
     chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); chkb("cqr status", status, 4 * sizeof(int));
     status[0] = 0;
-    if (mk & 4096) { status[0] = 1; status[1] += 1; }
+    if (mk & 4096) { status[0] = 1; if (!hflag) status[1] += 1; }
     if (hflag) __atomic_store_n(hflag, 2u * seq + (unsigned) status[0], __ATOMIC_RELEASE);
     return 0;
 }
@@ -288,8 +290,12 @@ int qrd_panel_fused(void* s, double* A, int lda, int mk, int wh, double* tau, do
     chkb("panel_fused ws", ws, sizeof(double) * qrd_panel_fused_ws_doubles());
     chkb("panel_fused status", status, 4 * sizeof(int));
     *epoch += 1024u;
+    /* QRD_STUB_STALL_ONCE=1 (host_sanitize.c): the next one-launch panel reports a timed-out hand-off, once -- the host-pointer entry
+     * points must notice (QR_E_STALL at their plan sync) and factor again with the route off */
+    if (getenv("QRD_STUB_STALL_ONCE")) { status[1] = 1; unsetenv("QRD_STUB_STALL_ONCE"); ++g_stub_stalls; }
     return 0;
 }
+long qrd_stub_stalls(void) { return g_stub_stalls; }
 int qrd_slab_reduce(void* s, int M, int N, int ns, const double* slabs, int lds, size_t stride, double* out, int ldo)
 { (void) s; chk("slab_reduce in", slabs, lds, M, N); (void) ns; (void) stride; chk("slab_reduce out", out, ldo, M, N); return 0; }
 int qrd_leaf_update_gram(void* s, int mk, int N, const double* V, int ldv, const double* W, double* C, int ldc, double* gs, size_t cap, int gy,

@@ -3,6 +3,7 @@ modified LU of the Householder reconstruction (W - S R2 = L1 U', signs as Househ
 factors.  One wave per matrix, through the development entry points qrd_dbg_chol32 / qrd_dbg_lu32; variant 0 is the register recurrence the
 routine replaces and must agree with it too."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -13,8 +14,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def L(qr):
-    qr.check(qr.lib.qrd_init(), "qrd_init")
-    lib = qr.lib
+    """The development entry points live in the LAB library only (make lab: libmi355xqr_lab.so = the product sources + qr_factor32_dbg.hip
+    with -DQR_LAB); the core they exercise, qr_factor32.h, is the one the product's panel kernels include."""
+    assert os.path.exists(qr.LAB_LIB_PATH), f"{qr.LAB_LIB_PATH} is missing: make -C cuda-qr_amd lab (__graft_entry__.build() does)"
+    lib = C.CDLL(qr.LAB_LIB_PATH)
+    qr.check(lib.qrd_init(), "qrd_init")
     lib.qrd_dbg_chol32.restype = C.c_int
     lib.qrd_dbg_chol32.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3
     lib.qrd_dbg_lu32.restype = C.c_int

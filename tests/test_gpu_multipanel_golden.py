@@ -60,6 +60,9 @@ def test_1184x640_dropin_mmqr_vs_reference_R(qr, oracle):
     assert rel(oracle.sign_normalise(F), _golden_R(g, n)) <= 1e-13
 
 
+_PUBLIC_KNOBS = {"MI355XQR_" + k for k in ("NB", "IB", "PANEL", "GUARD", "LOOKAHEAD", "SPLIT", "CQR_MIN_ROWS", "FUSED_MIN_ROWS", "TSQR_PIPE",
+                                            "TSQR_RESERVE_CUS", "PLAN_CACHE", "ROCTX")}
+
 _CHILD = r"""
 import sys, json, numpy as np, torch
 sys.path.insert(0, %r)
@@ -79,24 +82,24 @@ np.save(sys.argv[1], O.sign_normalise(F))
 @pytest.mark.parametrize("nb,env", [
     (128, {}),                                                                        # default schedule (this shape: single stream)
     (128, {"MI355XQR_LOOKAHEAD": "1"}),                                               # look-ahead on two streams, shared CUs
-    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0"}),   # CU-masked streams + panel-stream share
-    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0"}),
-    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_EARLY_NEXT": "0"}),   # look-ahead update never issued early
-    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0.05,0.05"}),     # early look-ahead update on some steps only
+    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64", "MI355XQR_BALANCE": "14,44,0,0"}),   # CU-masked streams + panel-stream share
+    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "32", "MI355XQR_BALANCE": "14,44,0,0"}),
+    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_EARLY_NEXT": "0"}),   # look-ahead update never issued early
+    (128, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64", "MI355XQR_BALANCE": "14,44,0.05,0.05"}),     # early look-ahead update on some steps only
     (128, {"MI355XQR_PANEL": "tsqr"}),                                                # Householder-TSQR leaf only
     (64, {"MI355XQR_LOOKAHEAD": "0"}),                                                # single-stream schedule
     (512, {}),                                                                        # two-level panels (K = 512 wide update)
     (512, {"MI355XQR_LOOKAHEAD": "1"}),                                               # ... with look-ahead (W_a / W_b pieces, ev_half)
-    (512, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_NEXT": "update"}),
+    (512, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_NEXT": "update"}),
     (512, {"MI355XQR_LOOKAHEAD": "0"}),
     (128, {"MI355XQR_EP": "0"}),                                                      # in-panel product as a launch of its own (no early product)
     (256, {"MI355XQR_FUSED_MIN_ROWS": "0"}),                                          # round 4: every outer panel in ONE launch (qr_panel_fused.hip)
     (128, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "0"}),     # ... single-stream schedule
-    (64, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "64", "MI355XQR_BALANCE": "14,44,0,0"}),   # ... on a 64-CU panel stream
+    (64, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64", "MI355XQR_BALANCE": "14,44,0,0"}),   # ... on a 64-CU panel stream
     (512, {"MI355XQR_FUSED_MIN_ROWS": "0", "MI355XQR_LOOKAHEAD": "0"}),               # ... two-level panels: each half one launch
     (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "64:0.5,U", "MI355XQR_BALANCE": "14,44,0,0"}),   # late phase: panel chain on an unmasked stream
-    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_TN_WIDE": "1"}),   # wide-tile TN product
-    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_PANEL_CUS": "32", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_KPIPE": "0", "MI355XQR_NT_IL": "0"}),   # plain K loops (round-2 issue order) in the update's two GEMMs
+    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "32", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_TN_WIDE": "1"}),   # wide-tile TN product
+    (256, {"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "32", "MI355XQR_BALANCE": "14,44,0,0", "MI355XQR_KPIPE": "0", "MI355XQR_NT_IL": "0"}),   # plain K loops (round-2 issue order) in the update's two GEMMs
 ])
 def test_2024_square_vs_reference_R_slices(qr, oracle, tmp_path, nb, env):
     """16 (nb = 128) / 8 / 32 outer panels: wide update, look-ahead, CU partition, balance_cols -- against slices of the
@@ -104,6 +107,10 @@ def test_2024_square_vs_reference_R_slices(qr, oracle, tmp_path, nb, env):
     columns, the diagonal, the row norms and the Frobenius norm)."""
     g = load_golden("ref_2024x2024_f64_64x8")
     out = str(tmp_path / "rn.npy")
+    # the twelve public knobs work in the product library; a case that forces a schedule branch with a measurement knob (the balance
+    # model, the look-ahead update's stream, settled kernel A/Bs) runs on the lab build of the same sources
+    if set(env) - _PUBLIC_KNOBS:
+        env = dict(env, CUDA_QR_AMD_LIB="lab")
     subprocess.run([sys.executable, "-c", _CHILD % ROOT, out, str(nb)], check=True, env=dict(os.environ, **env))
     Rn = np.load(out)
     n = 2024

@@ -172,7 +172,7 @@ def test_geqrf_takes_the_full_width_route_on_tall_shapes(qr, m, n, nb):
 
 def test_parked_panels_give_the_same_bits_as_v_written_twice(qr):
     """Parked full-width panels (tall single-stream plans: V written once, into the caller's array, R of the top block restored from
-    the panel workspace behind the update) against MI355XQR_CQR_PARK=0 (child process: the knob is read once): the factored array, tau
+    the panel workspace behind the update) against MI355XQR_CQR_PARK=0 (child process on the lab library: a measurement knob, read once): the factored array, tau
     and the thin Q must be IDENTICAL -- the update reads the same V values from another place, nothing else changes."""
     import subprocess, sys, os
     m, n, nb = 98304, 384, 128                     # two parked panels and a last one that is not (nothing follows it)
@@ -198,7 +198,7 @@ def test_parked_panels_give_the_same_bits_as_v_written_twice(qr):
             "p.fill_uniform(A, m, m, n, seed=31); p.sync(); p.geqrf(A, m, n, m, tau); p.sync()\n"
             "np.save(sys.argv[1], A.cpu().numpy().T); np.save(sys.argv[2], tau.cpu().numpy().ravel())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run([sys.executable, "-c", code, "/tmp/park_off_F.npy", "/tmp/park_off_tau.npy"], check=True,
-                   env=dict(os.environ, MI355XQR_CQR_PARK="0"), timeout=300)
+                   env=dict(os.environ, CUDA_QR_AMD_LIB="lab", MI355XQR_CQR_PARK="0"), timeout=300)      # a measurement knob: lab library
     assert np.array_equal(np.load("/tmp/park_off_F.npy"), F) and np.array_equal(np.load("/tmp/park_off_tau.npy"), tau)
 
 

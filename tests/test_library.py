@@ -176,3 +176,36 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
+
+
+PUBLIC_KNOBS = {"MI355XQR_" + k for k in ("NB", "IB", "PANEL", "GUARD", "LOOKAHEAD", "SPLIT", "CQR_MIN_ROWS", "FUSED_MIN_ROWS", "TSQR_PIPE",
+                                          "TSQR_RESERVE_CUS", "PLAN_CACHE", "ROCTX")}
+
+
+def _knob_strings(path):
+    import re
+    return set(re.findall(rb"MI355XQR_[A-Z0-9_]+", open(path, "rb").read()))
+
+
+def test_product_library_reads_only_the_public_knobs(qr):
+    """VERDICT r5 item 7 / ADVICE r5: the shipped library must not change what a factorisation does because of a stray measurement
+    variable (MI355XQR_NT_CEIL made it return wrong results).  The product build holds the names of the twelve documented knobs and no
+    others; the measurement knobs, the results-wrong ceiling variants and the development entry points exist in the lab build only."""
+    prod = {s.decode() for s in _knob_strings(os.path.join(os.path.dirname(qr.LIB_PATH), "libmi355xqr.so"))}
+    assert prod == PUBLIC_KNOBS, sorted(prod ^ PUBLIC_KNOBS)
+    syms = subprocess.run(["nm", "-D", os.path.join(os.path.dirname(qr.LIB_PATH), "libmi355xqr.so")], capture_output=True, text=True).stdout
+    assert "qrd_dbg_" not in syms and "gemm_nt4_kernelILb1ELi1E" not in syms and "gemm_nt4_kernelILb1ELi2E" not in syms
+    if os.path.exists(qr.LAB_LIB_PATH):
+        lab = {s.decode() for s in _knob_strings(qr.LAB_LIB_PATH)}
+        assert PUBLIC_KNOBS < lab and "MI355XQR_NT_CEIL" in lab
+        assert "qrd_dbg_lu32" in subprocess.run(["nm", "-D", qr.LAB_LIB_PATH], capture_output=True, text=True).stdout
+
+
+def test_integration_md_documents_exactly_the_public_knobs():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import re
+    txt = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = txt[txt.index("## 6."):]
+    sec = sec[:sec.index("\n## ", 5)] if "\n## " in sec[5:] else sec
+    table = {m for m in re.findall(r"^\| `(MI355XQR_[A-Z0-9_]+)`", sec, flags=re.M)}
+    assert table == PUBLIC_KNOBS, sorted(table ^ PUBLIC_KNOBS)

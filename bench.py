@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tsqr", "c4", "c5"])
     ap.add_argument("--nb", type=int, default=0)
     ap.add_argument("--ib", type=int, default=0)
+    ap.add_argument("--cond", type=float, default=0.0,
+                    help="ill-conditioned input: every 128-column panel gets condition ~COND (columns = the panel's first column + "
+                         "uniform noise / COND), so the device-side guard refuses every full-width panel -- prices the refusal "
+                         "(VERDICT r5 item 4); 0 = the plain uniform matrix")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run residual/orthogonality check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="792x384", help="m x n of the bounded multi-panel CPU-baseline sample")
@@ -203,8 +207,19 @@ def main():
     nbuf = min(K + W, max(1, int(160e9 // bytes_per)))
     bufs = [be.new_matrix(m_local, n) for _ in range(nbuf)]
     seeds = [12 + i for i in range(nbuf)]
+    def condition(A):
+        """--cond: columns c+1 .. c+127 of every 128-column panel <- the panel's first column + themselves / cond (A is the (n, m) torch
+        image of the column-major matrix: a row of the tensor is a column of the matrix).  The panel then has one direction of size
+        ~sqrt(m / 3) and 127 of size ~sqrt(m / 12) / cond: CholeskyQR2 at panel width cannot take it above cond ~ 1e7."""
+        if args.cond > 0.0:
+            torch.cuda.synchronize()
+            for c in range(0, n, 128):
+                A[c + 1:c + 128] = A[c:c + 1] + A[c + 1:c + 128] / args.cond
+            torch.cuda.synchronize()
+
     for A, s in zip(bufs, seeds):
         be.fill(A, m_local, n, rank * m_local, m_total, s)
+        condition(A)
     torch.cuda.synchronize()
 
     def barrier():
@@ -217,6 +232,7 @@ def main():
         A = bufs[i % nbuf]
         if i >= nbuf:                       # only when K+W exceeds the buffer pool: regenerate (stated in config)
             be.fill(A, m_local, n, rank * m_local, m_total, seeds[i % nbuf])
+            condition(A)
         return ts.factor(A)      # stream-ordered in C; independent factorisations: the small stacked QR of step i runs
                                  # under the local QR of step i+1 (everything is finished inside the timed bracket)
 
@@ -270,8 +286,15 @@ def main():
         be.plan.gemm("N", m_local, n, n, 1.0, Q, m_local, R, n, 0.0, QR, m_local)
         be.plan.gemm("T", n, n, m_local, 1.0, Q, m_local, Q, m_local, 0.0, G, n)
         be.plan.sync()
-        d, a = be.plan.diffnorm(QR, m_local, m_local, n, row_off=rank * m_local, total_rows=m_total,
-                                seed=seeds[last])
+        if args.cond > 0.0:                 # the input is not the generator's any more: rebuild it (same seed, same transformation)
+            cond_ref = be.new_matrix(m_local, n)
+            be.fill(cond_ref, m_local, n, rank * m_local, m_total, seeds[last])
+            condition(cond_ref)
+            d, a = be.plan.diffnorm(QR, m_local, m_local, n, dY=cond_ref, ldy=m_local)
+            del cond_ref
+        else:
+            d, a = be.plan.diffnorm(QR, m_local, m_local, n, row_off=rank * m_local, total_rows=m_total,
+                                    seed=seeds[last])
         sums = torch.tensor([d, a], dtype=torch.float64, device=coll_dev)
         if world > 1:
             dist.all_reduce(sums)
@@ -626,7 +649,10 @@ def main():
             "config": {"workload": desc, "m": m_total, "n": n, "m_per_gpu": m_local, "nb": nb,
                        "ib": args.ib or qr.get_block_size()[1],
                        "flops_per_step": flops(m_total, n), "input_buffers": nbuf,
-                       "input": "uniform[0,1) counter-hash generator, seed 12+i, resident in HBM",
+                       "input": ("uniform[0,1) counter-hash generator, seed 12+i, resident in HBM" if args.cond <= 0.0 else
+                                 "uniform[0,1) counter-hash generator, seed 12+i, then every 128-column panel made ill-conditioned (columns = the panel's "
+                                 "first column + noise / %g): the guard refuses every full-width panel; resident in HBM" % args.cond),
+                       "cond": args.cond or None,
                        "collective": "none" if world == 1 else (f"{n // nb} all_gathers of n*nb doubles per rank (panel-pipelined, RCCL)" if (backend == "nccl" and be.transport == "rccl" and be.tp.is_pipelined()) else f"1 all_gather of n*n doubles per rank ({'RCCL' if backend == 'nccl' else backend + ' via host, bring-up only'})")},
             "frac_of_fp64_matrix_peak": value / 1e3 / (FP64_MATRIX_PEAK_TFLOPS * world),
             "accuracy": acc,

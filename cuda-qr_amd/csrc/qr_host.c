@@ -58,6 +58,7 @@ struct qr_plan {
     double *Ye2;                /* raw V^T A2 of a wide update that applies T to the small product (tall-skinny plans) */
     double *Yn;                 /* raw V^T A_next of the look-ahead update */
     double bal_rp, bal_ru, bal_tc0, bal_tc1;   /* load-balance model (TFLOP/s, ms); bal_rp = 0: off */
+    double bal_tail_tc;         /* chain time where the next panel is ONE launch (see chain_ms); 0: the linear model everywhere */
     double bal_tc0_base, bal_tc1_base; int bal_auto;   /* bal_auto: no MI355XQR_BALANCE override -- rates follow the phase's partition */
     void* ev_half[2];           /* W_a(s): the wide update has finished the columns of panel s+1 that N(s) left out (its second half) */
     void* ev_next[2];           /* look-ahead update N(s) of the next panel's columns finished (when it runs on the update stream) */
@@ -121,6 +122,7 @@ static unsigned char g_dev_inited[QR_MAX_DEVICES];
 #define QR_FUSE_NN_MIN_ROWS 20000   /* the fused in-panel update + next leaf's Gram launch: tall leaves only */
 #define QR_TFOLD_MAX 128            /* T^T folded into the slab reduce up to this panel width */
 #define QR_EARLY_W1 4096            /* columns of the first slice of an early look-ahead step's wide update */
+#define QR_TAIL_TC_MS 0.0           /* chain_ms: flat chain time (ms per 256 columns) behind a one-launch panel; 0 = linear model only */
 
 typedef struct qr_knobs {
     int fuse_nn;                                            /* MI355XQR_FUSE_NN */
@@ -421,6 +423,10 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         if (b) {
             p->bal_rp = 0.0;
             sscanf(b, "%lf,%lf,%lf,%lf", &p->bal_rp, &p->bal_ru, &p->bal_tc0, &p->bal_tc1);
+        }
+        {
+            const char* tt = lab_getenv("MI355XQR_TAILTC");          /* lab: ms; "0" = off */
+            p->bal_tail_tc = tt ? atof(tt) : QR_TAIL_TC_MS;
         }
         p->bal_auto = (b == NULL) && p->npairs > 1;
         p->bal_tc0_base = p->bal_tc0; p->bal_tc1_base = p->bal_tc1;
@@ -1053,11 +1059,22 @@ static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int ld
 /* Columns of the wide update that the panel stream takes over after it has factored the next panel, so that both
  * streams finish step s together:  tc + F x / Rp = F (nwide - x) / Ru  with F = 4 mk nb flops per column, tc the
  * modelled time of the next panel chain, Rp / Ru the GEMM rates of the panel CUs / the update CUs. */
+/* modelled time (ms) of the chain the panel stream runs before it can take a share of / while the update stream runs W(s): the next
+ * panel (mk - wout rows) plus its look-ahead update.  Linear in the height where the panel is a launch chain on the masked stream;
+ * FLAT where the next panel is one launch (<= 8192 rows: qr_panel_fused.hip, 0.58-0.65 ms at 256 columns whatever the height, round 5
+ * gantt) -- the linear model, fitted to the leaf chain, said 1.4 ms there and declared the factorisation chain-bound nine steps early */
+static double chain_ms(const qr_plan* p, int mk, int wout)
+{
+    if (p->bal_tail_tc > 0.0 && p->pf_ws && !p->fused_off && mk - wout <= 8192 && mk - wout >= knobs()->fused_min_rows && wout <= QR_HALF)
+        return p->bal_tail_tc * (double) wout / 256.0;
+    return (p->bal_tc0 + p->bal_tc1 * (double) mk / 16384.0) * (double) wout / 256.0;
+}
+
 static int balance_cols(const qr_plan* p, int mk, int wout, int nwide)
 {
     if (!p->npairs || p->bal_rp <= 0.0 || nwide <= 0) return 0;
     const double F = 4.0 * mk * (double) wout * 1e-9;                  /* GFLOP per column */
-    const double tc = (p->bal_tc0 + p->bal_tc1 * (double) mk / 16384.0) * (double) wout / 256.0;   /* ms */
+    const double tc = chain_ms(p, mk, wout);                           /* ms */
     const double x = (F * nwide / p->bal_ru - tc) / (F * (1.0 / p->bal_rp + 1.0 / p->bal_ru));   /* rates in GFLOP/ms = TFLOP/s */
     int xi = (int) x;
     xi -= xi % 128;
@@ -1073,7 +1090,7 @@ static int update_bound(const qr_plan* p, int mk, int wout, int nwide)
 {
     if (!p->npairs || p->bal_ru <= 0.0 || nwide <= 0) return 0;
     const double F = 4.0 * mk * (double) wout * 1e-9;
-    const double tc = (p->bal_tc0 + p->bal_tc1 * (double) mk / 16384.0) * (double) wout / 256.0;
+    const double tc = chain_ms(p, mk, wout);
     return F * nwide / p->bal_ru > tc;
 }
 
@@ -1263,7 +1280,8 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
                 {
                     /* ... but W1(s) must be over well before P(s+1) is (N(s+1) waits for it): at most 0.7 of the panel's measured
                      * time 0.62 + 0.9 mk / 16384 ms (nb = 256) at the update stream's rate, and never more than early_w1 columns */
-                    const double pest = (0.62 + 0.9 * (double) mk1 / 16384.0) * (double) wnext / 256.0;            /* ms */
+                    const int one_launch = p->bal_tail_tc > 0.0 && p->pf_ws && !p->fused_off && mk1 <= 8192 && mk1 >= knobs()->fused_min_rows;
+                    const double pest = (one_launch ? 0.62 : 0.62 + 0.9 * (double) mk1 / 16384.0) * (double) wnext / 256.0;   /* ms */
                     const double fcol = 4.0 * mk * (double) wout * 1e-9;                                         /* GFLOP per column */
                     int cap = (int) (0.7 * pest * p->bal_ru / fcol);
                     cap -= cap % 128;

@@ -315,15 +315,66 @@ int qrd_larft(void* s, int nbp, int ib, const double* G, int ldg, const double* 
     if (Tt) chk("larft Tt", Tt, ldt, nbp, nbp);
     return 0;
 }
-int qrd_zero_block(void* s, double* A, int ld, int r, int c) { (void) s; chk("zero_block", A, ld, r, c); return 0; }
+/* The pure DATA MOVERS move data (still no arithmetic: the factorisations above them are no-ops on the values), so that a test can
+ * follow a tagged R factor through pack -> exchange -> stack -> extract (tests/test_tsqr_cplan_gloo.py: the C qr_tsqr_plan over gloo).
+ * Every copy_block is also logged (source, destination, shape): the stacking order of the gathered factors is read off the log. */
+#define STUB_COPYLOG 256
+static __thread struct { const double* S; double* D; int lds, ldd, r, c; } t_copylog[STUB_COPYLOG];
+static __thread long t_ncopy = 0;
+long qrd_stub_copy_count(void) { return t_ncopy; }
+int qrd_stub_copy_entry(long i, const double** S, double** D, int* lds, int* ldd, int* r, int* c)
+{
+    if (i < 0 || i >= t_ncopy || t_ncopy - i > STUB_COPYLOG) return 1;
+    *S = t_copylog[i % STUB_COPYLOG].S; *D = t_copylog[i % STUB_COPYLOG].D; *lds = t_copylog[i % STUB_COPYLOG].lds;
+    *ldd = t_copylog[i % STUB_COPYLOG].ldd; *r = t_copylog[i % STUB_COPYLOG].r; *c = t_copylog[i % STUB_COPYLOG].c;
+    return 0;
+}
+int qrd_zero_block(void* s, double* A, int ld, int r, int c)
+{
+    (void) s; chk("zero_block", A, ld, r, c);
+    for (int j = 0; j < c; ++j) memset(A + (size_t) j * ld, 0, sizeof(double) * (size_t) r);
+    return 0;
+}
 int qrd_extract_v(void* s, const double* P, int ld, int mk, int w, double* V, int ldv) { (void) s; chk("extract_v P", P, ld, mk, w); chk("extract_v V", V, ldv, mk, w); return 0; }
-int qrd_extract_r(void* s, const double* A, int lda, int m, int n, double* R, int ldr, int rr) { (void) s; chk("extract_r A", A, lda, m, n); chk("extract_r R", R, ldr, rr, n); return 0; }
+int qrd_extract_r(void* s, const double* A, int lda, int m, int n, double* R, int ldr, int rr)
+{
+    (void) s; chk("extract_r A", A, lda, m, n); chk("extract_r R", R, ldr, rr, n);
+    for (int c = 0; c < n; ++c)
+        for (int i = 0; i < rr; ++i) R[(size_t) c * ldr + i] = (i <= c && i < m) ? A[(size_t) c * lda + i] : 0.0;
+    return 0;
+}
 int qrd_extract_r_block(void* s, const double* A, int lda, int k, int w, double* R, int ldr, int rr)
-{ (void) s; chk("extract_r_block A", A + (size_t) k * lda, lda, k + w, w); chk("extract_r_block R", R, ldr, rr, w); return 0; }
-int qrd_set_identity(void* s, double* C, int ld, int r, int c, int ro) { (void) s; (void) ro; chk("set_identity", C, ld, r, c); return 0; }
+{
+    (void) s; chk("extract_r_block A", A + (size_t) k * lda, lda, k + w, w); chk("extract_r_block R", R, ldr, rr, w);
+    for (int j = 0; j < w; ++j)
+        for (int i = 0; i < rr; ++i) R[(size_t) j * ldr + i] = (i <= k + j) ? A[(size_t) (k + j) * lda + i] : 0.0;
+    return 0;
+}
+int qrd_set_identity(void* s, double* C, int ld, int r, int c, int ro)
+{
+    (void) s; chk("set_identity", C, ld, r, c);
+    for (int j = 0; j < c; ++j)
+        for (int i = 0; i < r; ++i) C[(size_t) j * ld + i] = (i + ro == j) ? 1.0 : 0.0;
+    return 0;
+}
 int qrd_copy_blocks(void* s, const double* S, int lds, size_t ss, double* D, int ldd, size_t ds, int r, int c, int batch)
-{ (void) s; for (int q = 0; q < batch; ++q) { chk("copy_blocks S", S + q * ss, lds, r, c); chk("copy_blocks D", D + q * ds, ldd, r, c); } return 0; }
-int qrd_copy_block(void* s, const double* S, int lds, double* D, int ldd, int r, int c) { (void) s; chk("copy_block S", S, lds, r, c); chk("copy_block D", D, ldd, r, c); return 0; }
+{
+    (void) s;
+    for (int q = 0; q < batch; ++q) {
+        chk("copy_blocks S", S + q * ss, lds, r, c); chk("copy_blocks D", D + q * ds, ldd, r, c);
+        for (int j = 0; j < c; ++j) memmove(D + q * ds + (size_t) j * ldd, S + q * ss + (size_t) j * lds, sizeof(double) * (size_t) r);
+    }
+    return 0;
+}
+int qrd_copy_block(void* s, const double* S, int lds, double* D, int ldd, int r, int c)
+{
+    (void) s; chk("copy_block S", S, lds, r, c); chk("copy_block D", D, ldd, r, c);
+    for (int j = 0; j < c; ++j) memmove(D + (size_t) j * ldd, S + (size_t) j * lds, sizeof(double) * (size_t) r);
+    t_copylog[t_ncopy % STUB_COPYLOG].S = S; t_copylog[t_ncopy % STUB_COPYLOG].D = D; t_copylog[t_ncopy % STUB_COPYLOG].lds = lds;
+    t_copylog[t_ncopy % STUB_COPYLOG].ldd = ldd; t_copylog[t_ncopy % STUB_COPYLOG].r = r; t_copylog[t_ncopy % STUB_COPYLOG].c = c;
+    ++t_ncopy;
+    return 0;
+}
 int qrd_fill_uniform(void* s, double* A, int ld, long long rows, int cols, long long ro, long long tr, unsigned long long seed)
 { (void) s; (void) ro; (void) tr; (void) seed; chk("fill", A, ld, (long) rows, cols); return 0; }
 double qrd_hash_uniform_host(unsigned long long seed, unsigned long long idx) { (void) seed; (void) idx; return 0.5; }

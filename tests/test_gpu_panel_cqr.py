@@ -319,3 +319,30 @@ def test_latch_mode_reports_a_refused_panel_at_sync_and_never_blocks(qr):
     Q = host(dQ)
     p.close()
     assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13 and np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+
+
+def test_bench_cond_input_refuses_every_tall_panel(qr):
+    """bench.py --workload tsqr --cond 1e9 (the price of a refusal): its input -- every 128-column panel = the panel's
+    first column + uniform noise / cond -- must make the device-side guard refuse EVERY full-width panel, and the leaf chain that takes
+    them over must still deliver a Householder-grade factorisation."""
+    m, n, nb, cond = 65536, 256, 128, 1e9
+    p = qr.Plan(m, n, nb, 32)
+    dA, dtau, dQ = zeros(m, n), zeros(n, 1), zeros(m, n)
+    p.fill_uniform(dA, m, m, n, seed=12)
+    p.sync()
+    for c in range(0, n, 128):                      # bench.py: condition()
+        dA[c + 1:c + 128] = dA[c:c + 1] + dA[c + 1:c + 128] / cond
+    torch.cuda.synchronize()
+    A = host(dA)
+    p.geqrf(dA, m, n, m, dtau)
+    p.sync()
+    st = p.route_stats()
+    assert st["tall_panels"] == 2 and st["tall_panels_refused"] == 2, st
+    R = np.triu(host(dA)[:n])
+    p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+    p.sync()
+    Q = host(dQ)
+    p.close()
+    assert np.isfinite(R).all() and np.isfinite(Q).all()
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12

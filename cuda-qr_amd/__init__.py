@@ -122,6 +122,7 @@ _sig("qr_plan_sync", C.c_int, _vp)
 _sig("qr_plan_stream", _vp, _vp)
 _sig("qr_plan_set_guard_mode", C.c_int, _vp, C.c_int)
 _sig("qr_plan_route_stats", C.c_int, _vp, C.POINTER(C.c_longlong))
+_sig("qr_plan_retry_stats", C.c_int, _vp, C.POINTER(C.c_longlong))
 _sig("qr_plan_info", C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("qr_plan_update_cus", C.c_int, _vp)
 _sig("qr_plan_set_profile", C.c_int, _vp, C.c_int)
@@ -407,7 +408,10 @@ class Plan:
     def route_stats(self):
         out = (C.c_longlong * 4)()
         check(lib.qr_plan_route_stats(self.h, out), "qr_plan_route_stats")
-        return {"tall_panels": out[0], "tall_panels_refused": out[1], "fused_leaf_fallbacks": out[2], "fused_stalls": out[3]}
+        rt = (C.c_longlong * 2)()
+        check(lib.qr_plan_retry_stats(self.h, rt), "qr_plan_retry_stats")
+        return {"tall_panels": out[0], "tall_panels_refused": out[1], "fused_leaf_fallbacks": out[2], "fused_stalls": out[3],
+                "tall_panels_retried": rt[0], "tall_panels_retry_accepted": rt[1]}
 
     @property
     def stream(self):

@@ -82,6 +82,9 @@ int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau
  * qrd_panel_cqr_r_block: R (upper, zeros below) into a w x w block of its own */
 int qrd_panel_cqr_p(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
                     double* Qb, int ldq, unsigned* hflag, unsigned seq, int park);
+/* the retry of a panel that call has just refused, preconditioned (shifted CholeskyQR3): same arguments, Qb a buffer of its own */
+int qrd_panel_cqr_retry(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                    double* Qb, int ldq, unsigned* hflag, unsigned seq, int park);
 int qrd_panel_cqr_restore_r(void* stream, double* A, int lda, int w, const double* ws, const int* status);   /* status[0] != 0 (refused panel): A stays untouched */
 int qrd_panel_cqr_r_block(void* stream, const double* ws, int w, double* D, int ldd);
 double* qrd_panel_cqr_g1(double* ws);
@@ -95,6 +98,9 @@ int qrd_panel_fused_init(void);
 int qrd_panel_fused_ok(void* stream, const double* A, int lda, int mk, int wh, const double* Vw, int ldv);
 int qrd_panel_fused(void* stream, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv,
                     double* G, int ldg, double* ws, unsigned* epoch, int* status);
+/* the same with the rows per row workgroup given (0 = the library's choice, 128, 256): kernel unit tests */
+int qrd_panel_fused_rows(void* stream, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv,
+                    double* G, int ldg, double* ws, unsigned* epoch, int* status, int want_rows);
 
 /* the reference's sliding-window schedule on the device (qr_legacy.hip): legacy-layout shim */
 size_t qrd_legacy_ws_size(int m, int PR, int PC);

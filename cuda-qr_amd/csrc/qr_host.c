@@ -68,6 +68,9 @@ struct qr_plan {
     void* t_wait;               /* see apply_small_t */
     void* ev_v[2];              /* V of panel set s complete (its T merge still running): the long-K product of N(s) may start */
     void* v_ready;              /* event factor_panel records before the T merge of a one-level panel (NULL: none) */
+    int defer_hint, t_deferred; /* defer_hint (set by the caller for ONE factor_panel call): behind a one-launch panel leave the Gram matrix and the
+                                 * T merge to the caller (deferred_t_merge, on the update stream: 224 compute units instead of the panel stream's 32);
+                                 * t_deferred: factor_panel did so */
     void* ev_wide[2];           /* wide update that read panel set s finished */
     double *Vw, *VT, *T;        /* current panel set (aliases of set[cur]) */
     double *Vw2[2], *VT2[2], *T2[2];
@@ -93,6 +96,7 @@ struct qr_plan {
                                  * panel in poll mode has its verdict read at once: nothing is left pending) */
     int fused_off;              /* 1: never the one-launch panel (set by the host-pointer entry points after a stalled hand-off, QR_E_STALL) */
     long long n_cqr, n_cqr_refused, n_pf_leaf_fallback, n_pf_stall;   /* qr_plan_route_stats */
+    long long n_cqr_retried, n_cqr_retry_ok;                          /* qr_plan_retry_stats: refused panels retried preconditioned / accepted then */
     double* pf_ws;              /* exchange workspace of the one-launch panel (qr_panel_fused.hip); NULL: not used */
     unsigned pf_epoch;          /* its epoch counter: the workspace's epoch words never exceed it */
     int* pf_status;             /* device: [0] leaves that took the Householder route inside a one-launch panel, [1] a wait timed out */
@@ -140,6 +144,8 @@ typedef struct qr_knobs {
                                                              * against 8.7): there the round-4 threshold stays */
     int tall_nt;                                            /* MI355XQR_TALL_NT: the update of a tall block through gemm_nt (W transposed first) */
     int cqr_park;                                           /* MI355XQR_CQR_PARK: full-width panels of tall single-stream plans write V once (into A) */
+    int cqr_retry;                                          /* MI355XQR_CQR_RETRY (lab): a refused full-width panel is retried preconditioned (shifted CholeskyQR3) before the leaf chain */
+    int defer_t;                                            /* MI355XQR_DEFER_T (lab): a one-launch panel's Gram matrix + T merge on the update stream in the chain-bound phase */
     int fused_gram;                                         /* the panel's Gram blocks V_prev^T V_l inside the one-launch panel (else one launch after it): constant 0 */
 } qr_knobs;
 static qr_knobs g_knobs;
@@ -182,6 +188,8 @@ static void knobs_init(void)
     k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
     k->tall_nt = lab_env_int("MI355XQR_TALL_NT", 1) != 0;
     k->cqr_park = lab_env_int("MI355XQR_CQR_PARK", 1) != 0;
+    k->defer_t = lab_env_int("MI355XQR_DEFER_T", 1) != 0;
+    k->cqr_retry = lab_env_int("MI355XQR_CQR_RETRY", 1) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -586,6 +594,12 @@ int qr_plan_route_stats(qr_plan* p, long long* out4)
     out4[0] = p->n_cqr; out4[1] = p->n_cqr_refused; out4[2] = p->n_pf_leaf_fallback; out4[3] = p->n_pf_stall;
     return 0;
 }
+int qr_plan_retry_stats(qr_plan* p, long long* out2)
+{
+    if (!p || !out2) return QR_E_ARG;
+    out2[0] = p->n_cqr_retried; out2[1] = p->n_cqr_retry_ok;
+    return 0;
+}
 void* qr_plan_stream(qr_plan* p) { return p ? p->s_main : NULL; }
 
 int qr_plan_info(qr_plan* p, int* nb, int* ib, int* lookahead)
@@ -778,11 +792,23 @@ static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, doub
     if (latch) { p->cq_dirty = 1; return 0; }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    unsigned cur = seq;
+    int retried = 0;
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = __atomic_load_n(p->cq_hword, __ATOMIC_ACQUIRE);
-        if ((v >> 1) == seq) {
-            if (v & 1u) p->n_cqr_refused += 1;
-            return (int) (v & 1u);
+        if ((v >> 1) == cur) {
+            if (!(v & 1u)) { if (retried) p->n_cqr_retry_ok += 1; return 0; }
+            if (!retried) p->n_cqr_refused += 1;
+            /* Refused (cond > ~1e7, or not of full rank).  Once more, PRECONDITIONED (shifted CholeskyQR3, qrd_panel_cqr_retry: R0 from the
+             * shifted Gram matrix this attempt left in the workspace, the same pipeline on A R0^-1) -- queued, like everything here, while
+             * the refused attempt's remaining launches return at once; only a panel refused twice goes to the leaf chain */
+            if (retried || !knobs()->cqr_retry || Qh == Vh || Qh == Ah) return 1;
+            retried = 1;
+            cur = (++p->cq_seq) & 0x3fffffffu;
+            CHECK(qrd_panel_cqr_retry(p->stream, Ah, lda, mkh, wh, tauh, Th, ldt, Vh, ldv, p->cq_ws, p->cq_status, Qh, ldv, p->cq_hword_dev, cur, park));
+            p->n_cqr_retried += 1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            continue;
         }
         cpu_relax();                         /* the verdict is ~0.3 ms away: do not hammer the line the device is about to write */
         if ((spins & 1023u) == 1023u) {
@@ -813,6 +839,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
 {
     const int park_hint = p->park_hint;
     p->park_hint = 0;
+    p->t_deferred = 0;
     CHECK(cq_unpark(p));                                      /* (never pending here: every caller that hints unparks behind its update) */
     const int mk = m - k, ib = p->ib, ldv = p->ldv, ldt = p->ldt, nb = p->nb;
     double* Ak = dA + (size_t) k * lda + k;
@@ -912,6 +939,10 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         if (p->v_ready && nhalf == 1) CHECK(qrd_event_record(p->v_ready, p->stream));   /* V done; what follows only builds T */
         double* Vh = p->Vw + (size_t) c0 * ldv + c0;          /* this half's V: rows from c0 (zero above) */
         double* Thh = p->T + (size_t) c0 * ldt + c0;
+        if (wh > ib && !cqr_done && p->defer_hint && fused_half && nhalf == 1 && !gram_done) {
+            p->t_deferred = 1;                                /* V, tau and the leaves' T blocks are complete: the caller merges (deferred_t_merge) */
+            continue;
+        }
         if (wh > ib && !cqr_done) {
             double* Ghh = p->G + (size_t) c0 * nb + c0;
             if (!gram_done) CHECK(tn(p, wh, wh, mk - c0, Vh, ldv, Vh, ldv, Ghh, nb, NULL));       /* Gram of the half */
@@ -1094,6 +1125,20 @@ static int update_bound(const qr_plan* p, int mk, int wout, int nwide)
     return F * nwide / p->bal_ru > tc;
 }
 
+/* The T merge a one-launch panel left to its caller (factor_panel with defer_hint): G = V^T V and the merge tree, for panel set e, on
+ * `stream`.  In the chain-bound phase of a look-ahead factorisation the critical chain is  panel -> Gram -> merge -> look-ahead update ->
+ * next panel;  on the panel stream's 32 compute units the Gram product of a 4096 x 256 V takes 85-90 us (its 0.4 GFLOP are matrix-core
+ * time there), on the idle update stream's 224 it takes 22, and the hop between the streams in front of the look-ahead update goes too
+ * (profiles/r06_c3_tail_kernels.txt). */
+static int deferred_t_merge(qr_plan* p, void* stream, int e, int mk, int wout, const double* tau_k, double* slabs)
+{
+#ifdef QR_TRACE_DEFER
+    fprintf(stderr, "deferred_t_merge: mk %d wout %d on %s\n", mk, wout, stream == p->stream_u ? "update stream" : "panel stream");
+#endif
+    CHECK(qrd_gemm_tn(stream, wout, wout, mk, 1.0, p->Vw2[e], p->ldv, p->Vw2[e], p->ldv, 0.0, p->G, p->nb, slabs, p->slab_cap, NULL, 0));
+    return qrd_larft(stream, wout, p->ib, p->G, p->nb, tau_k, p->T2[e], p->ldt, NULL, 0, p->X, p->nb);
+}
+
 static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau);
 
 int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
@@ -1170,6 +1215,8 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
     const int nb = p->nb;
     p->cq_parked = 0;             /* (a factorisation that ended in an error may have left a panel parked in ANOTHER array: never restore into that) */
     p->park_hint = 0;
+    p->defer_hint = 0;
+    p->t_deferred = 0;
     if (!p->lookahead) {
         use_set(p, 0);
         for (int k = 0; k < n; k += nb) {
@@ -1195,6 +1242,7 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
      *   P(s+2) overwrites panel set s&1, which W(s) reads: ordered through N(s+1)'s wait on ev_wide[s&1]. */
     int wide_pending[2] = {0, 0}, extra_pending = 0;
     int v_recorded[2] = {0, 0};     /* ev_v[e] was recorded inside factor_panel for the panel now in set e */
+    int t_deferred[2] = {0, 0};     /* the panel now in set e left its T merge to this loop (deferred_t_merge) */
     const int split_t = knobs()->split_t;
     /* Early look-ahead update (update-bound phase, one-level panels): N(s+1) is issued on the panel stream right after P(s+1),
      * ahead of the panel stream's share E(s) of the wide update, instead of on the update stream between W(s) and W(s+1) --
@@ -1236,8 +1284,27 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         if (early_next && extra > nwide - wnext2) { extra = nwide - wnext2; extra -= extra % 128; }
         const int n_on_u = !n_early && p->stream_u != NULL && p->npairs > 0 &&
                            (p->next_on_update == 1 || (p->next_on_update == 2 && !update_bound(p, mk, wout, nwide)));
+        if (t_deferred[e] && !n_on_u) {
+            /* (never with the defaults: the deferral below predicts n_on_u with the same rule.  A knob that moves N(s) elsewhere: merge on
+             * the panel stream now, and let ev_panel say "T complete" again -- nobody has waited for it yet) */
+            CHECK(deferred_t_merge(p, p->stream, e, mk, wout, dtau + k, p->slabs));
+            CHECK(qrd_event_record(p->ev_panel[e], p->stream));
+            t_deferred[e] = 0;
+        }
         if (n_early) {
             /* nothing: N(s) sits on the panel stream behind P(s) */
+        } else if (n_on_u && t_deferred[e]) {
+            /* chain-bound phase, P(s) was one launch: its Gram matrix and T merge run HERE, on the update stream (idle by now), then N(s) */
+            CHECK(qrd_stream_wait_event(p->stream_u, v_recorded[e] ? p->ev_v[e] : p->ev_panel[e]));
+            if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));
+            CHECK(prof_begin_on(p, 3, p->stream_u));          /* (class 3, misc: a class-2 record is "one panel" to the readers of the records) */
+            CHECK(deferred_t_merge(p, p->stream_u, e, mk, wout, dtau + k, p->slabs_u));
+            CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 8.0 * mk * wout));
+            t_deferred[e] = 0;
+            CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout, nfirst, p->Wn, p->Yn, p->slabs_u, 0, 0));
+            CHECK(qrd_event_record(p->ev_next[e], p->stream_u));
+            CHECK(qrd_stream_wait_event(p->stream, p->ev_next[e]));
+            wide_pending[e ^ 1] = 0;
         } else if (n_on_u) {
             /* N(s) on the update stream: behind W(s-1) by stream order, after P(s) (ev_panel) and E(s-1) (ev_extra) */
             if (v_recorded[e]) {        /* V^T A_next may start as soon as V is complete; T^T (.) waits for the T merge */
@@ -1309,7 +1376,21 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
         CHECK(prof_begin(p, 2));
         p->v_ready = (split_t && p->npairs > 0 && wnext <= QR_HALF && nt1 > 0) ? p->ev_v[e ^ 1] : NULL;
         v_recorded[e ^ 1] = p->v_ready != NULL;
+        {
+            /* Leave P(s+1)'s Gram matrix and T merge to the update stream?  Only where that stream will be idle when P(s+1) ends -- W(s),
+             * issued above, shorter than the one-launch panel (0.45 ms per 256 columns; the update's modelled rate is optimistic in the
+             * tail, hence the margin) -- and N(s+1) is going to run there anyway (the n_on_u rule of the next iteration, evaluated now) */
+            const int nwide1 = nt1 - wnext2;
+            const double w_ms = 4.0 * mk * (double) wout * (double) wide_cols * 1e-9 / (p->bal_ru > 0.0 ? p->bal_ru : 50.0);
+            const int n_on_u1 = !early_next && p->stream_u != NULL && p->npairs > 0 &&
+                                (p->next_on_update == 1 || (p->next_on_update == 2 && !update_bound(p, mk1, wnext, nwide1)));
+            p->defer_hint = knobs()->defer_t && n_on_u1 && nt1 > 0 && wnext <= QR_HALF && w_ms < 0.75 * 0.45 * (double) wnext / 256.0 &&
+                            phase_of(p, nt1, n) == phase_now;
+        }
         CHECK(factor_panel(p, dA, m, lda, k1, wnext, dtau, nt1 > 0, nhalf2 > 0 ? p->ev_half[e] : NULL));
+        p->defer_hint = 0;
+        t_deferred[e ^ 1] = p->t_deferred;
+        p->t_deferred = 0;
         p->v_ready = NULL;
         CHECK(prof_end(p, 2.0 * mk1 * (double) wnext * wnext, 16.0 * mk1 * wnext));
         CHECK(qrd_event_record(p->ev_panel[e ^ 1], p->stream));

@@ -49,7 +49,8 @@ constexpr int CQ_SV = 12 * CQ_W * CQ_W;   // S (CQ_W doubles)
 constexpr int CQ_ST = 12 * CQ_W * CQ_W + CQ_W;   // 64 phase stamps of the one-workgroup kernels (CQ_STAMPS builds)
 constexpr int CQ_FO = CQ_ST + 63;                  // 1.0: R2 of this panel is the first-order factor (its inverse is 2 I - R2: nobody stores it)
 constexpr int CQ_SL = CQ_ST + 64;                  // Gram partials of the streaming passes: 256 workgroups x 36 tiles x 256 doubles (19 MB)
-constexpr int CQ_WS = CQ_SL + 256 * 36 * 256;
+constexpr int CQ_R0 = CQ_SL + 256 * 36 * 256;    // R0 = chol(G1 + s I), row-major: the preconditioner of a retried panel (qrd_panel_cqr_retry)
+constexpr int CQ_WS = CQ_R0 + CQ_W * CQ_W;
 
 // Workspace traffic of the one-workgroup kernels: plain stores and loads.  Every workspace matrix is written ONCE per launch and read
 // only after cq_sync_global() (so no line of it can be in this compute unit's cache before it is written); agent-scope atomic stores
@@ -529,7 +530,10 @@ __device__ __forceinline__ void cq_load_upper(const CqLds& L, const double* G, i
 // ---------------------------------------------------------------------------------------------------------------------------------
 // R1 = chol(G1), R1^-1.  G: column-major ld CQ_W, symmetric (read along its rows).  status[0] |= 1 on a non-positive pivot.
 // ---------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* status)
+// shift_scale > 0: the SHIFTED factorisation that opens the retry of a refused panel (qrd_panel_cqr_retry; shifted CholeskyQR3, Fukaya et
+// al.): R0 = chol(G1 + s I), s = shift_scale * trace(G1) with shift_scale = 11 (m n + n (n + 1)) u -- positive definite whatever the
+// condition of the panel -- kept in CQ_R0 as well, and the refusal word of the first attempt is cleared (this launch is the retry's first).
+__global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* status, double shift_scale)
 {
     extern __shared__ double sm[];
     CqLds L = cq_lds(sm);
@@ -539,6 +543,15 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
     const int tid = threadIdx.x;
     // G(i, j) = G(j, i): consecutive lanes read consecutive addresses
     cq_elems(w, tid, [&](int i, int j) { return ws[CQ_G1 + j + CQ_W * i]; }, [&](int i, int j, double v) { if (j < w && j >= i) L.M[i * CQ_LD + j] = v; });
+    if (shift_scale > 0.0) {
+        if (tid == 0) status[0] = 0;
+        __syncthreads();
+        double tr = 0.0;                                      // every thread the same sum, in the same order
+        for (int i = 0; i < w; ++i) tr += L.M[i * CQ_LD + i];
+        __syncthreads();
+        if (tid < w) L.M[tid * CQ_LD + tid] += shift_scale * tr;      // (a NaN / Inf trace ends at the pivot test below like any other bad panel)
+        __syncthreads();
+    }
     CQ_STAMP(0);
     const bool ok = cq_chol_blocked(L, w, tid);
     CQ_STAMP(1);
@@ -546,7 +559,11 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
 #pragma unroll 8
     for (int e = tid; e < w * CQ_W; e += CQ_T) {
         const int i = e >> 7, j = e & (CQ_W - 1);
-        if (j < w) cq_st(ws + CQ_R1 + i * CQ_W + j, (j >= i) ? L.M[i * CQ_LD + j] : 0.0);
+        if (j < w) {
+            const double r = (j >= i) ? L.M[i * CQ_LD + j] : 0.0;
+            cq_st(ws + CQ_R1 + i * CQ_W + j, r);
+            if (shift_scale > 0.0) cq_st(ws + CQ_R0 + i * CQ_W + j, r);
+        }
     }
     CQ_STAMP(2);
     // what pass 2 multiplies by (cqr_stream_body: block back substitution): R1's off-diagonal 32 x 32 blocks and the inverses of its
@@ -559,6 +576,23 @@ __global__ __launch_bounds__(CQ_T) void cqr_chol_kernel(double* ws, int w, int* 
         cq_st(ws + CQ_R1I + i * CQ_W + j, (j < i) ? 0.0 : (((i ^ j) & ~31) == 0 ? L.M[(j + 1) * CQ_LD + i] : L.M[i * CQ_LD + j]));
     }
     CQ_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Retried panel: R1 <- R1 R0 in the workspace (R1: the first Cholesky factor of the PRECONDITIONED panel Q0 = A R0^-1, just written by
+// cqr_chol_kernel; R0 from CQ_R0), so that the rider of the last pass, R = S R2 R1, comes out as the R of A = Q (S R2 R1 R0) with nothing
+// else of the pipeline knowing about the preconditioner.  The mixed matrix the next pass solves with (CQ_R1I) is R1's and stays.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CQ_T) void cqr_rmul_kernel(double* ws, int w, const int* status)
+{
+    extern __shared__ double sm[];
+    CqLds L = cq_lds(sm);
+    const int tid = threadIdx.x;
+    if (status[0]) return;
+    cq_load_upper(L, ws + CQ_R1, w, tid);
+    cq_load_lowerT(L, ws + CQ_R0, w, tid);
+    __syncthreads();
+    cq_upper_product(L, nullptr, w, tid, [&](int i, int j, double v) { cq_st(ws + CQ_R1 + i * CQ_W + j, (j >= i) ? v : 0.0); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1088,10 +1122,13 @@ __global__ __launch_bounds__(CS_THREADS) void cqr_vpass_kernel(double* ws, int w
 // behind the matrix-core instructions of block i (143-145 us: memory time plus matrix-core time again, although the ISA has the waits
 // for the prefetched block behind the MFMAs)
 // (status: the panel's refusal word starts at zero -- cleared here, by the panel's first launch, instead of by a memset node in front of it)
-__global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs, int* status)
+// (reset = 0: the Gram pass of a RETRIED panel -- the shifted Cholesky in front of it has cleared the word, and a failure of that launch
+// must stand: this pass then returns at once like every other launch of the panel)
+__global__ __launch_bounds__(CS_THREADS) void cqr_gram_kernel(int w, int mk, const double* src, int lds_, double* slabs, int* status, int reset)
 {
     extern __shared__ double sm[];
-    if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0;
+    if (reset) { if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0; }
+    else if (status[0]) return;
     cqr_stream_body<false, true, false>(sm, nullptr, w, mk, src, lds_, nullptr, 0, nullptr, 0, slabs, nullptr, blockIdx.x, gridDim.x);
 }
 
@@ -1171,6 +1208,7 @@ int qrd_panel_cqr_init(void)
     hipError_t e = hipFuncSetAttribute((const void*) cqr_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_lu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_rmul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_vpass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CQ_VP_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*) cqr_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) CS_LDS_GRAM);
@@ -1189,7 +1227,7 @@ static int cs_grid(int mk, int cap = CS_NWG) { const int g = (mk + 63) / 64; ret
 // guard refused the panel -- A is then untouched, and so is Vw when Q has a buffer of its own (Qb: mk x w, ld ldq; NULL = Q lives in
 // Vw, whose contents are then garbage after a refusal); [1] counts refused panels (never reset here).  hflag / seq: see cqr_lu_kernel.
 static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
-                          double* Qb, int ldq, unsigned* hflag, unsigned seq, int park);
+                          double* Qb, int ldq, unsigned* hflag, unsigned seq, int park, int retry = 0);
 int qrd_panel_cqr_q(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
                     double* Qb, int ldq, unsigned* hflag, unsigned seq)
 {
@@ -1215,8 +1253,21 @@ int qrd_panel_cqr_r_block(void* stream, const double* ws, int w, double* D, int 
     hipLaunchKernelGGL(cqr_restore_r_kernel, dim3((w * w + 255) / 256), dim3(256), 0, (hipStream_t) stream, ws, w, D, ldd, 1, (const int*) nullptr);
     return (int) hipGetLastError();
 }
+// The retry of a panel the guard has just refused (same arguments as the refused call; Qb a buffer other than A and Vw; the workspace
+// still holds that call's G1): SHIFTED CholeskyQR3.  R0 = chol(G1 + s I) always exists; Q0 = A R0^-1 (one more pass over the panel, into
+// Qb) has condition <= ~1 / sqrt(11 m n u) ~ 5e3 unless the panel is numerically rank deficient; the ordinary pipeline then factors Q0
+// in place of A (Gram pass, Cholesky, Q + G2 pass, reconstruction, last pass -- with its own guard) and R comes out as S R2 R1 R0
+// (cqr_rmul_kernel).  A refused panel thus costs one failed attempt + 1.3 panels instead of four guarded leaf chains (2.2 ms -> ~1.0 ms at
+// 262144 x 128, profiles/r06_guard_price.txt); a panel that is refused AGAIN (rank deficient, cond > ~1e10) goes to the Householder leaf
+// chain as before.  A is untouched until the last pass, as in the first attempt.
+int qrd_panel_cqr_retry(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                        double* Qb, int ldq, unsigned* hflag, unsigned seq, int park)
+{
+    if (!Qb || Qb == A || Qb == Vw) return -7;
+    return panel_cqr_impl(stream, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, Qb, ldq, hflag, seq, park, 1);
+}
 static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
-                          double* Qb, int ldq, unsigned* hflag, unsigned seq, int park)
+                          double* Qb, int ldq, unsigned* hflag, unsigned seq, int park, int retry)
 {
     if (!qrd_panel_cqr_ok(mk, w)) return -7;
     if (!Qb) { Qb = Vw; ldq = ldv; }
@@ -1226,10 +1277,21 @@ static int panel_cqr_impl(void* stream, double* A, int lda, int mk, int w, doubl
     int cap = qrd_stream_cus(stream);
     if (cap <= 0 || cap > CS_NWG) cap = CS_NWG;
     const int grid = cs_grid(mk, cap), ggrid = cs_grid(mk, cap), ntl = (w >> 4) * ((w >> 4) + 1) / 2;
-    hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, (const double*) A, lda, ws + CQ_SL, status);
+    const double* src = A;                                    // what the pipeline factors: the panel, or (retry) its preconditioned image in Qb
+    int lsrc = lda;
+    if (retry) {
+        const double u = 1.1102230246251565e-16;
+        const double shift_scale = 11.0 * ((double) mk * w + (double) w * (w + 1)) * u;
+        hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status, shift_scale);
+        hipLaunchKernelGGL((cqr_stream_kernel<true, false, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, (const double*) A, lda,
+                           Qb, ldq, (double*) nullptr, 0, (double*) nullptr, status);
+        src = Qb; lsrc = ldq;
+    }
+    hipLaunchKernelGGL(cqr_gram_kernel, dim3(ggrid), dim3(CS_THREADS), CS_LDS_GRAM, s, w, mk, src, lsrc, ws + CQ_SL, status, retry ? 0 : 1);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, ggrid, ws + CQ_G1);
-    hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
-    hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Qb, ldq,
+    hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status, 0.0);
+    if (retry) hipLaunchKernelGGL(cqr_rmul_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, (const int*) status);
+    hipLaunchKernelGGL((cqr_stream_kernel<true, true, false>), dim3(grid), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, src, lsrc, Qb, ldq,
                        (double*) nullptr, 0, ws + CQ_SL, status);
     hipLaunchKernelGGL(cqr_gram_reduce_kernel, dim3(ntl, 8), dim3(256), 0, s, ws + CQ_SL, grid, ws + CQ_G2);
     hipLaunchKernelGGL(cqr_lu_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, Qb, ldq, status, hflag, seq);
@@ -1259,7 +1321,7 @@ int qrd_panel_cqr(void* stream, double* A, int lda, int mk, int w, double* tau, 
 int qrd_panel_cqr_stage1(void* stream, const double* A, int lda, int mk, int w, double* Vw, int ldv, double* ws, int* status)
 {
     hipStream_t s = (hipStream_t) stream;
-    hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status);
+    hipLaunchKernelGGL(cqr_chol_kernel, dim3(1), dim3(CQ_T), CQ_LDS_BYTES, s, ws, w, status, 0.0);
     hipLaunchKernelGGL((cqr_stream_kernel<true, false, false>), dim3(cs_grid(mk)), dim3(CS_THREADS), CS_LDS_BYTES, s, ws + CQ_R1I, w, mk, A, lda, Vw, ldv,
                        (double*) nullptr, 0, (double*) nullptr, status);
     return (int) hipGetLastError();

@@ -34,15 +34,19 @@
 #include "qr_factor32.h"
 
 #define PF_THREADS 256            /* four waves, one per SIMD */
-#define PF_ROWS 256               /* rows per workgroup */
-#define PF_LDQ 260                /* row stride of the [column][row] image (doubles) */
-#define PF_MAXWG 32
+// RT = rows per lane (template parameter of everything row-parallel below): 4 -> a workgroup owns 256 rows (round 4/5), 2 -> 128 rows.
+// The streaming work of a leaf (deferred update + in-panel product over the rest of the panel) is matrix-core time on ONE compute unit per
+// row workgroup -- 43 of a 73 us leaf at 256 columns -- so a panel short enough to be dealt out in 128-row pieces over the stream's compute
+// units (mk <= 128 (cus - 1)) is: half the streaming per workgroup, the same hops (round 6).
+#define PF_ROWS_OF(RT) (64 * (RT))        /* rows per workgroup */
+#define PF_LDQ_OF(RT) (64 * (RT) + 4)     /* row stride of the [column][row] image (doubles) */
+#define PF_MAXWG 64
 #define PF_ZCOLS 224              /* columns of Z: wh - 32 <= 224 */
 #define PF_SPIN_LIMIT (1u << 22)
 
 // workspace layout (doubles); the first 2 KB are the epoch words, one per workgroup, 64 bytes apart
 #define PF_FAC_WORD (16 * PF_MAXWG)   /* the factor workgroup's epoch word (unsigned index) */
-#define PF_OFF_X1 512
+#define PF_OFF_X1 1024                    /* (the epoch words: 16 * (PF_MAXWG + 1) unsigned) */
 #define PF_OFF_X2 (PF_OFF_X1 + 2 * PF_MAXWG * 1024)
 #define PF_OFF_QT (PF_OFF_X2 + 2 * PF_MAXWG * 1024)
 #define PF_OFF_X3 (PF_OFF_QT + 2 * 1024)
@@ -71,7 +75,8 @@
 #define PF_SM_FLAGS (PF_SM_SCR + 4 * 128 + 256)  /* ints */
 #define PF_SM_PART (PF_SM_FLAGS + 8)             /* (16 ints) */             /* 4 x 768 per-wave Gram partials; later U'^-1 and T */
 #define PF_SM_IMG (PF_SM_PART + 3072)            /* [column][row] image of the workgroup's rows; later -W */
-#define PF_SM_DOUBLES (PF_SM_IMG + 32 * PF_LDQ)
+#define PF_SM_IMG_DOUBLES(RT) ((32 * PF_LDQ_OF(RT)) > (4 * PF_M33) ? (32 * PF_LDQ_OF(RT)) : (4 * PF_M33))   /* (the factor workgroup keeps four 32 x 32 matrices there) */
+#define PF_SM_DOUBLES(RT) (PF_SM_IMG + PF_SM_IMG_DOUBLES(RT))
 
 struct PfArgs {
     double* A; int lda;          // panel origin: mk rows x wh columns, factored in place
@@ -148,50 +153,61 @@ __device__ __forceinline__ void pf_wait(const unsigned* flags, int n, unsigned v
 }
 
 // this lane's four rows x eight columns of a leaf (L_row layout): a[t][ks] = A(r4 + t, col0 + 4 ks + l4)
-__device__ __forceinline__ void pf_load_rows(double (&a)[4][8], const double* __restrict__ A, int lda, int col0, int r4c, int l4)
+template <int RT>
+__device__ __forceinline__ void pf_load_rows(double (&a)[RT][8], const double* __restrict__ A, int lda, int col0, int r4c, int l4)
 {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         const double* p = A + (size_t) (col0 + 4 * ks + l4) * lda + r4c;
-        const v2d lo = *reinterpret_cast<const v2d*>(p), hi = *reinterpret_cast<const v2d*>(p + 2);
-        a[0][ks] = lo[0]; a[1][ks] = lo[1]; a[2][ks] = hi[0]; a[3][ks] = hi[1];
+#pragma unroll
+        for (int t = 0; t < RT; t += 2) {
+            const v2d lo = *reinterpret_cast<const v2d*>(p + t);
+            a[t][ks] = lo[0]; a[t + 1][ks] = lo[1];
+        }
     }
 }
 
-__device__ __forceinline__ void pf_store_rows(const double (&a)[4][8], double* __restrict__ A, int lda, int col0, int r4, int l4)
+template <int RT>
+__device__ __forceinline__ void pf_store_rows(const double (&a)[RT][8], double* __restrict__ A, int lda, int col0, int r4, int l4)
 {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         double* p = A + (size_t) (col0 + 4 * ks + l4) * lda + r4;
-        *reinterpret_cast<v2d*>(p) = (v2d){a[0][ks], a[1][ks]};
-        *reinterpret_cast<v2d*>(p + 2) = (v2d){a[2][ks], a[3][ks]};
+#pragma unroll
+        for (int t = 0; t < RT; t += 2) *reinterpret_cast<v2d*>(p + t) = (v2d){a[t][ks], a[t + 1][ks]};
     }
 }
 
-// [column][row] image of the workgroup's 256 rows: img[col * PF_LDQ + row - wgrow0]
-__device__ __forceinline__ void pf_image_write(double* img, const double (&a)[4][8], int wave, int l15, int l4)
+// [column][row] image of the workgroup's 64 RT rows: img[col * PF_LDQ_OF(RT) + row - wgrow0]
+template <int RT>
+__device__ __forceinline__ void pf_image_write(double* img, const double (&a)[RT][8], int wave, int l15, int l4)
 {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        double* p = img + (4 * ks + l4) * PF_LDQ + wave * 64 + 4 * l15;
-        *reinterpret_cast<v2d*>(p) = (v2d){a[0][ks], a[1][ks]};
-        *reinterpret_cast<v2d*>(p + 2) = (v2d){a[2][ks], a[3][ks]};
+        double* p = img + (4 * ks + l4) * PF_LDQ_OF(RT) + wave * (16 * RT) + RT * l15;
+#pragma unroll
+        for (int t = 0; t < RT; t += 2) *reinterpret_cast<v2d*>(p + t) = (v2d){a[t][ks], a[t + 1][ks]};
     }
 }
 
-__device__ __forceinline__ void pf_image_read(const double* img, double (&a)[4][8], int wave, int l15, int l4)
+template <int RT>
+__device__ __forceinline__ void pf_image_read(const double* img, double (&a)[RT][8], int wave, int l15, int l4)
 {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const double* p = img + (4 * ks + l4) * PF_LDQ + wave * 64 + 4 * l15;
-        const v2d lo = *reinterpret_cast<const v2d*>(p), hi = *reinterpret_cast<const v2d*>(p + 2);
-        a[0][ks] = lo[0]; a[1][ks] = lo[1]; a[2][ks] = hi[0]; a[3][ks] = hi[1];
+        const double* p = img + (4 * ks + l4) * PF_LDQ_OF(RT) + wave * (16 * RT) + RT * l15;
+#pragma unroll
+        for (int t = 0; t < RT; t += 2) {
+            const v2d lo = *reinterpret_cast<const v2d*>(p + t);
+            a[t][ks] = lo[0]; a[t + 1][ks] = lo[1];
+        }
     }
 }
 
 // x <- x M for the lane's rows, M (32 x 32, upper triangular) in LDS as Mm[k][c]; transposed product, so the result lands in the
 // layout of the input:  D[i = column][j = row] = sum_k M(k, i) x(row, k)
-__device__ __forceinline__ void pf_rows_times_upper(double (&a)[4][8], pf_m33 Mm, int l15, int l4)
+template <int RT>
+__device__ __forceinline__ void pf_rows_times_upper(double (&a)[RT][8], pf_m33 Mm, int l15, int l4)
 {
     double aw[2][8];
 #pragma unroll
@@ -199,7 +215,7 @@ __device__ __forceinline__ void pf_rows_times_upper(double (&a)[4][8], pf_m33 Mm
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) aw[ti][ks] = Mm[4 * ks + l4][16 * ti + l15];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RT; ++t) {
         v4d acc[2];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -217,16 +233,17 @@ __device__ __forceinline__ void pf_rows_times_upper(double (&a)[4][8], pf_m33 Mm
     }
 }
 
-// Gram matrix of this row wave's 64 rows from the image: tiles (0,0), (0,1), (1,1) -> part[wave][(tile * 4 + rr) * 64 + lane]
+// Gram matrix of this row wave's 16 RT rows from the image: tiles (0,0), (0,1), (1,1) -> part[wave][(tile * 4 + rr) * 64 + lane]
+template <int RT>
 __device__ __forceinline__ void pf_gram_wave(const double* img, double* part, int wave, int lane, int l15, int l4)
 {
     v4d acc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int sg = 0; sg < 4; ++sg) {
-        const double* p0 = img + l15 * PF_LDQ + wave * 64 + 16 * sg + 4 * l4;
-        const double* p1 = p0 + 16 * PF_LDQ;
+    for (int sg = 0; sg < RT; ++sg) {
+        const double* p0 = img + l15 * PF_LDQ_OF(RT) + wave * (16 * RT) + 16 * sg + 4 * l4;
+        const double* p1 = p0 + 16 * PF_LDQ_OF(RT);
         const v2d a0 = *reinterpret_cast<const v2d*>(p0), a1 = *reinterpret_cast<const v2d*>(p0 + 2);
         const v2d b0 = *reinterpret_cast<const v2d*>(p1), b1 = *reinterpret_cast<const v2d*>(p1 + 2);
         const double f0[4] = {a0[0], a0[1], a1[0], a1[1]}, f1[4] = {b0[0], b0[1], b1[0], b1[1]};
@@ -424,11 +441,12 @@ struct PfLeaf {                      // per-leaf constants
     double *X1, *X2, *QT, *X3, *X4, *F1, *F2, *XG, *XT;
 };
 
+template <int RT>
 __device__ __forceinline__ PfLeaf pf_leaf(const PfArgs& P, int c)
 {
     PfLeaf f;
     const int li = c >> 5, par = li & 1;
-    f.c = c; f.nrest = P.wh - c - 32; f.ncols = P.G ? P.wh - 32 : f.nrest; f.gown = c / PF_ROWS;
+    f.c = c; f.nrest = P.wh - c - 32; f.ncols = P.G ? P.wh - 32 : f.nrest; f.gown = c / PF_ROWS_OF(RT);
     f.X1 = P.ws + PF_OFF_X1 + (size_t) par * PF_MAXWG * 1024;
     f.X2 = P.ws + PF_OFF_X2 + (size_t) par * PF_MAXWG * 1024;
     f.QT = P.ws + PF_OFF_QT + (size_t) par * 1024;
@@ -480,13 +498,13 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
             double z = 0.0;
             const int zi = pf_zidx(i, j);
             const double corr = nocorr ? 0.0 : pf_ld(f.X3 + (size_t) nwg * PF_ZSLAB + zi);   // the top-block owner's -B^T x_top
-            {
-                double v[PF_MAXWG];
+            for (int u0 = 0; u0 < nwg; u0 += 32) {            // (32 loads in flight per batch; one batch up to 32 row workgroups)
+                double v[32];
 #pragma unroll
-                for (int u = 0; u < PF_MAXWG; ++u) v[u] = pf_ld(f.X3 + (size_t) min(u, nwg - 1) * PF_ZSLAB + zi);
+                for (int u = 0; u < 32; ++u) v[u] = pf_ld(f.X3 + (size_t) min(u0 + u, nwg - 1) * PF_ZSLAB + zi);
 #pragma unroll
-                for (int u = 0; u < PF_MAXWG; ++u)
-                    if (u < nwg) z += v[u];
+                for (int u = 0; u < 32; ++u)
+                    if (u0 + u < nwg) z += v[u];
             }
             s1[h * 32 + i] = z + corr;
         }
@@ -526,12 +544,15 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
     // g, g + nwg, ... of the 768; the factor workgroup turns the sum into the next leaf's G1 without another exchange (pf_factor_wg)
     if (f.nrest > 0) {
         for (int e = g + nwg * (int) threadIdx.x; e < 768; e += nwg * PF_THREADS) {
-            double v[PF_MAXWG], z = 0.0;
+            double z = 0.0;
+            for (int u0 = 0; u0 < nwg; u0 += 32) {
+                double v[32];
 #pragma unroll
-            for (int u = 0; u < PF_MAXWG; ++u) v[u] = pf_ld(f.X3 + (size_t) min(u, nwg - 1) * PF_ZSLAB + 32 * PF_ZCOLS + e);
+                for (int u = 0; u < 32; ++u) v[u] = pf_ld(f.X3 + (size_t) min(u0 + u, nwg - 1) * PF_ZSLAB + 32 * PF_ZCOLS + e);
 #pragma unroll
-            for (int u = 0; u < PF_MAXWG; ++u)
-                if (u < nwg) z += v[u];
+                for (int u = 0; u < 32; ++u)
+                    if (u0 + u < nwg) z += v[u];
+            }
             pf_st(f.XG + e, z);
         }
     }
@@ -540,12 +561,13 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
 // Row waves: A_rest(:, 32 g .. ) -= V W for this lane's rows and the column groups g1 - 1 down to g0 (32 columns each) of the leaf at
 // column c: V in vr (L_row layout), W straight from the gathered slab X4 (sc1 loads, the next group's requested a group ahead, as is
 // the next 64 x 16 piece of A_rest).  keep: the LAST group's result (group g0) is returned in vr instead of V (it is the next leaf's a).
-__device__ __forceinline__ void pf_update_groups(double (&vr)[4][8], const double* __restrict__ X4, double* __restrict__ A, int lda, int c,
+template <int RT>
+__device__ __forceinline__ void pf_update_groups(double (&vr)[RT][8], const double* __restrict__ X4, double* __restrict__ A, int lda, int c,
                                                  int g0, int g1, bool keep, int r4, int r4c, bool act, int l15, int l4)
 {
     if (g1 <= g0) return;
     double aw[2][8], awn[2][8];
-    v4d ca[4], cbn[4];
+    v4d ca[RT], cbn[RT];
     auto wload = [&](double (&w)[2][8], int jg) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -553,27 +575,30 @@ __device__ __forceinline__ void pf_update_groups(double (&vr)[4][8], const doubl
             for (int ks = 0; ks < 8; ++ks) w[ti][ks] = pf_ld(X4 + (32 * jg + 16 * ti + l15) * 32 + 4 * ks + l4);      // X4 holds -W
     };
     auto cptr = [&](int jg, int ti) { return A + (size_t) (c + 32 + 32 * jg + 16 * ti + l4) * lda; };
-    auto cload = [&](v4d (&cc)[4], const double* cp) {
+    auto cload = [&](v4d (&cc)[RT], const double* cp) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const double* q = cp + (size_t) (4 * rr) * lda + r4c;
-            const v2d lo = *reinterpret_cast<const v2d*>(q), hi = *reinterpret_cast<const v2d*>(q + 2);
-            cc[0][rr] = lo[0]; cc[1][rr] = lo[1]; cc[2][rr] = hi[0]; cc[3][rr] = hi[1];
+#pragma unroll
+            for (int t = 0; t < RT; t += 2) {
+                const v2d lo = *reinterpret_cast<const v2d*>(q + t);
+                cc[t][rr] = lo[0]; cc[t + 1][rr] = lo[1];
+            }
         }
     };
-    auto cstore = [&](const v4d (&cc)[4], double* cp) {
+    auto cstore = [&](const v4d (&cc)[RT], double* cp) {
         if (act) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 double* q = cp + (size_t) (4 * rr) * lda + r4;
-                *reinterpret_cast<v2d*>(q) = (v2d){cc[0][rr], cc[1][rr]};
-                *reinterpret_cast<v2d*>(q + 2) = (v2d){cc[2][rr], cc[3][rr]};
+#pragma unroll
+                for (int t = 0; t < RT; t += 2) *reinterpret_cast<v2d*>(q + t) = (v2d){cc[t][rr], cc[t + 1][rr]};
             }
         }
     };
-    auto mma = [&](v4d (&cc)[4], const double (&w)[8]) {
+    auto mma = [&](v4d (&cc)[RT], const double (&w)[8]) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) cc[t] = pf_mfma(w[ks], vr[t][ks], cc[t]);
     };
@@ -604,7 +629,7 @@ __device__ __forceinline__ void pf_update_groups(double (&vr)[4][8], const doubl
         cstore(cbn, cp1);
         if (keep) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) { vr[t][rr] = ca[t][rr]; vr[t][4 + rr] = cbn[t][rr]; }
         }
@@ -612,7 +637,8 @@ __device__ __forceinline__ void pf_update_groups(double (&vr)[4][8], const doubl
 }
 
 // The next leaf's 32 columns (group 0), in two steps around the wait for W: the 64 x 32 piece of A_rest is requested before the wait.
-__device__ __forceinline__ void pf_update0_load(v4d (&ca)[4], v4d (&cb)[4], const double* __restrict__ A, int lda, int c, int r4c, int l4)
+template <int RT>
+__device__ __forceinline__ void pf_update0_load(v4d (&ca)[RT], v4d (&cb)[RT], const double* __restrict__ A, int lda, int c, int r4c, int l4)
 {
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
@@ -620,13 +646,17 @@ __device__ __forceinline__ void pf_update0_load(v4d (&ca)[4], v4d (&cb)[4], cons
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const double* q = cp + (size_t) (4 * rr) * lda + r4c;
-            const v2d lo = *reinterpret_cast<const v2d*>(q), hi = *reinterpret_cast<const v2d*>(q + 2);
-            v4d (&cc)[4] = ti ? cb : ca;
-            cc[0][rr] = lo[0]; cc[1][rr] = lo[1]; cc[2][rr] = hi[0]; cc[3][rr] = hi[1];
+            v4d (&cc)[RT] = ti ? cb : ca;
+#pragma unroll
+            for (int t = 0; t < RT; t += 2) {
+                const v2d lo = *reinterpret_cast<const v2d*>(q + t);
+                cc[t][rr] = lo[0]; cc[t + 1][rr] = lo[1];
+            }
         }
     }
 }
-__device__ __forceinline__ void pf_update0_finish(double (&vr)[4][8], v4d (&ca)[4], v4d (&cb)[4], const double* __restrict__ X4, double* __restrict__ A,
+template <int RT>
+__device__ __forceinline__ void pf_update0_finish(double (&vr)[RT][8], v4d (&ca)[RT], v4d (&cb)[RT], const double* __restrict__ X4, double* __restrict__ A,
                                                   int lda, int c, int r4, bool act, int l15, int l4)
 {
     double aw[2][8];
@@ -635,24 +665,24 @@ __device__ __forceinline__ void pf_update0_finish(double (&vr)[4][8], v4d (&ca)[
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) aw[ti][ks] = pf_ld(X4 + (16 * ti + l15) * 32 + 4 * ks + l4);                 // X4 holds -W
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) { ca[t] = pf_mfma(aw[0][ks], vr[t][ks], ca[t]); cb[t] = pf_mfma(aw[1][ks], vr[t][ks], cb[t]); }
     if (act) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             double* cp = A + (size_t) (c + 32 + 16 * ti + l4) * lda;
-            v4d (&cc)[4] = ti ? cb : ca;
+            v4d (&cc)[RT] = ti ? cb : ca;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 double* q = cp + (size_t) (4 * rr) * lda + r4;
-                *reinterpret_cast<v2d*>(q) = (v2d){cc[0][rr], cc[1][rr]};
-                *reinterpret_cast<v2d*>(q + 2) = (v2d){cc[2][rr], cc[3][rr]};
+#pragma unroll
+                for (int t = 0; t < RT; t += 2) *reinterpret_cast<v2d*>(q + t) = (v2d){cc[t][rr], cc[t + 1][rr]};
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) { vr[t][rr] = ca[t][rr]; vr[t][4 + rr] = cb[t][rr]; }
 }
@@ -668,8 +698,8 @@ __device__ __forceinline__ void pf_update0_finish(double (&vr)[4][8], v4d (&ca)[
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct PfTau { double tau[32]; };
 
-template <int J>
-__device__ __forceinline__ void pf_house_col(double (&a)[4][8], const PfArgs& P, const PfLeaf& f, const PfLds& L, unsigned* flags, unsigned er0,
+template <int RT, int J>
+__device__ __forceinline__ void pf_house_col(double (&a)[RT][8], const PfArgs& P, const PfLeaf& f, const PfLds& L, unsigned* flags, unsigned er0,
                                              int g, int nrow, int r4, int l15, int l4, int wave)
 {
     constexpr int KJ = J >> 2, LJ = J & 3;
@@ -678,14 +708,17 @@ __device__ __forceinline__ void pf_house_col(double (&a)[4][8], const PfArgs& P,
     double* sc = L.part + 128;                // [32] s_c, then [3] tau, beta, 1/u
     double* XF = P.ws + PF_OFF_XF + (size_t) (J & 1) * PF_MAXWG * 128;
     // x_J of this lane's four rows: held by the lanes with l4 == J % 4
-    double xj[4], p[8];
+    double xj[RT], p[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RT; ++t) {
         const double v = __shfl(a[t][KJ], l15 + 16 * LJ);
         xj[t] = (r4 + t > c + J) ? v : 0.0;                 // rows strictly below the pivot row (rows beyond mk hold zeros)
     }
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) p[ks] = (xj[0] * a[0][ks] + xj[1] * a[1][ks]) + (xj[2] * a[2][ks] + xj[3] * a[3][ks]);
+    for (int ks = 0; ks < 8; ++ks) {
+        if constexpr (RT == 4) p[ks] = (xj[0] * a[0][ks] + xj[1] * a[1][ks]) + (xj[2] * a[2][ks] + xj[3] * a[3][ks]);
+        else p[ks] = xj[0] * a[0][ks] + xj[1] * a[1][ks];
+    }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {                        // sum over the 16 lanes of this l4 (the 64 rows of the wave)
         p[ks] += __shfl_xor(p[ks], 1); p[ks] += __shfl_xor(p[ks], 2); p[ks] += __shfl_xor(p[ks], 4); p[ks] += __shfl_xor(p[ks], 8);
@@ -694,9 +727,9 @@ __device__ __forceinline__ void pf_house_col(double (&a)[4][8], const PfArgs& P,
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) red[wave * 32 + 4 * ks + l4] = p[ks];
     }
-    if (g == f.gown && r4 == c + (J & ~3)) {                // the pivot row: row c + J = r4 + LJ of these four lanes
+    if (g == f.gown && r4 == c + (J & ~(RT - 1))) {         // the pivot row: row c + J = r4 + J % RT of these four lanes (one per l4)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) pf_st(XF + (size_t) g * 128 + 32 + 4 * ks + l4, a[LJ][ks]);
+        for (int ks = 0; ks < 8; ++ks) pf_st(XF + (size_t) g * 128 + 32 + 4 * ks + l4, a[J & (RT - 1)][ks]);
     }
     __syncthreads();
     if (tid < 32) pf_st(XF + (size_t) g * 128 + tid, (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]));
@@ -730,7 +763,7 @@ __device__ __forceinline__ void pf_house_col(double (&a)[4][8], const PfArgs& P,
     __syncthreads();
     const double tj = sc[32], beta = sc[33], iu = sc[34];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RT; ++t) {
         const int row = r4 + t;
         const bool below = row > c + J && row < P.mk, piv = row == c + J;
         const double vi = below ? xj[t] * iu : (piv ? 1.0 : 0.0);
@@ -743,23 +776,24 @@ __device__ __forceinline__ void pf_house_col(double (&a)[4][8], const PfArgs& P,
         }
     }
     __syncthreads();                                          // sc / red are rewritten by the next column
-    if constexpr (J + 1 < 32) pf_house_col<J + 1>(a, P, f, L, flags, er0, g, nrow, r4, l15, l4, wave);
+    if constexpr (J + 1 < 32) pf_house_col<RT, J + 1>(a, P, f, L, flags, er0, g, nrow, r4, l15, l4, wave);
 }
 
-__device__ __forceinline__ void pf_householder_leaf(double (&ar)[4][8], const PfArgs& P, const PfLeaf& f, const PfLds& L, unsigned* flags,
+template <int RT>
+__device__ __forceinline__ void pf_householder_leaf(double (&ar)[RT][8], const PfArgs& P, const PfLeaf& f, const PfLds& L, unsigned* flags,
                                                     unsigned er0, int g, int nrow, int r4, int r4c, bool act, bool toprow, int l15, int l4,
                                                     int wave)
 {
     const int tid = threadIdx.x, c = f.c;
-    pf_load_rows(ar, P.A, P.lda, c, r4c, l4);                 // the leaf as the previous update left it
+    pf_load_rows<RT>(ar, P.A, P.lda, c, r4c, l4);             // the leaf as the previous update left it
     if (!act) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) ar[t][ks] = 0.0;
     }
     __syncthreads();
-    pf_house_col<0>(ar, P, f, L, flags, er0, g, nrow, r4, l15, l4, wave);
+    pf_house_col<RT, 0>(ar, P, f, L, flags, er0, g, nrow, r4, l15, l4, wave);
     // T from tau and the Gram columns (row p of T depends on row p only: thread p), U'^-1 := I
     {
         PfTau th;
@@ -780,7 +814,7 @@ __device__ __forceinline__ void pf_householder_leaf(double (&ar)[4][8], const Pf
     }
     if (toprow) {                                             // R on and above the diagonal, reflector tails below it: LAPACK's in-place form
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const int rr_ = r4 + t - c, col = 4 * ks + l4;
@@ -791,8 +825,8 @@ __device__ __forceinline__ void pf_householder_leaf(double (&ar)[4][8], const Pf
                 ar[t][ks] = l1;
             }
     } else if (act) {
-        pf_store_rows(ar, P.Vw, P.ldv, c, r4, l4);
-        pf_store_rows(ar, P.A, P.lda, c, r4, l4);
+        pf_store_rows<RT>(ar, P.Vw, P.ldv, c, r4, l4);
+        pf_store_rows<RT>(ar, P.A, P.lda, c, r4, l4);
     }
 }
 
@@ -804,8 +838,10 @@ __device__ __forceinline__ void pf_householder_leaf(double (&ar)[4][8], const Pf
 // Q_top), + 3 (Z partials; the owner of the top block also its correction, R, L1, T, tau), + 4 (W slices); the factor workgroup
 // publishes + 1 (R1^-1) and + 2 (U'^-1, T, L1 \ U', R, S R2).
 // ---------------------------------------------------------------------------------------------------------------------------------
+template <int RT>
 __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, int nrow)
 {
+    constexpr int PF_ROWS = PF_ROWS_OF(RT), PF_LDQ = PF_LDQ_OF(RT);
     const PfLds L = pf_lds(sm);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: "this wave owns that tile" tests become uniform branches, not exec-mask blocks)
     const int mk = P.mk, wh = P.wh, lda = P.lda, ldv = P.ldv;
@@ -815,19 +851,19 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
     const int wgrow0 = g * PF_ROWS;
     unsigned er = P.epoch0, ef = P.epoch0;                 // epoch values of the row workgroups / the factor workgroup before this leaf
     bool g1_derived = false;                               // the factor workgroup derives this leaf's G1 from the previous leaf's G' and R12
-    double ar[4][8];
+    double ar[RT][8];
     if (tid == 0) L.gflags[4] = 0;
     {
         const int l15 = tid & 15, l4 = (tid & 63) >> 4;
-        pf_load_rows(ar, A, lda, 0, min(wgrow0 + wave * 64 + 4 * l15, mk - 4), l4);
+        pf_load_rows<RT>(ar, A, lda, 0, min(wgrow0 + wave * (16 * RT) + RT * l15, mk - RT), l4);
     }
     for (int c = 0; c < wh; c += 32) {
-        const PfLeaf f = pf_leaf(P, c);
+        const PfLeaf f = pf_leaf<RT>(P, c);
         int lane = tid & 63;                                  // opaque once per leaf: keeps the lane-dependent addresses and selects
         asm volatile("" : "+v"(lane));                        // of the unrolled bodies below from being hoisted out of this loop
         const int l15 = lane & 15, l4 = lane >> 4;
-        const int r4 = wgrow0 + wave * 64 + 4 * l15;         // this lane's four rows r4 .. r4 + 3
-        const int r4c = min(r4, mk - 4);
+        const int r4 = wgrow0 + wave * (16 * RT) + RT * l15; // this lane's RT rows r4 .. r4 + RT - 1
+        const int r4c = min(r4, mk - RT);
         const bool act = r4 >= c && r4 < mk;
         const bool own = g == f.gown;
         const bool toprow = own && r4 >= c && r4 < c + 32;
@@ -835,14 +871,14 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         // ---- G1 = A^T A: image of the leaf's rows, partial Gram per wave, workgroup partial -> X1
         if (!act) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) ar[t][ks] = 0.0;
         }
-        pf_image_write(L.img, ar, wave, l15, l4);
+        pf_image_write<RT>(L.img, ar, wave, l15, l4);
         __syncthreads();
         if (!g1_derived) {                                    // first leaf of the panel, or the one after a Householder-route leaf
-            pf_gram_wave(L.img, L.part, wave, lane, l15, l4);
+            pf_gram_wave<RT>(L.img, L.part, wave, lane, l15, l4);
             __syncthreads();
             pf_gram_publish(L.part, f.X1 + (size_t) g * 1024);
         }
@@ -853,16 +889,16 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         { pf_m33 m1[1] = {L.Ws}; pf_m33_in<1>(m1, f.F1); }    // R1^-1
         __syncthreads();
         // ---- Q = A R1^-1 (registers), its image, the top block of Q -> QT, partial G2 = Q^T Q -> X2
-        pf_rows_times_upper(ar, L.Ws, l15, l4);
-        pf_image_write(L.img, ar, wave, l15, l4);
+        pf_rows_times_upper<RT>(ar, L.Ws, l15, l4);
+        pf_image_write<RT>(L.img, ar, wave, l15, l4);
         if (toprow) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) pf_st(f.QT + (4 * ks + l4) * 32 + (r4 + t - c), ar[t][ks]);
+                for (int t = 0; t < RT; ++t) pf_st(f.QT + (4 * ks + l4) * 32 + (r4 + t - c), ar[t][ks]);
         }
         __syncthreads();
-        pf_gram_wave(L.img, L.part, wave, lane, l15, l4);
+        pf_gram_wave<RT>(L.img, L.part, wave, lane, l15, l4);
         __syncthreads();
         pf_gram_publish(L.part, f.X2 + (size_t) g * 1024);
         pf_publish(flags, 16 * g, er + 2);
@@ -875,16 +911,16 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         if (c > 0 && f.nrest > 0) {
             const int cp_ = c - 32;
             const bool actp = r4 >= cp_ && r4 < mk;
-            pf_load_rows(ar, Vw, ldv, cp_, r4c, l4);
+            pf_load_rows<RT>(ar, Vw, ldv, cp_, r4c, l4);
             if (!actp) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < RT; ++t)
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) ar[t][ks] = 0.0;
             }
-            pf_update_groups(ar, P.ws + PF_OFF_X4 + (size_t) (((cp_ >> 5) & 1)) * 32 * PF_ZCOLS, A, lda, cp_, 1, (wh - cp_ - 32) / 32, false,
+            pf_update_groups<RT>(ar, P.ws + PF_OFF_X4 + (size_t) (((cp_ >> 5) & 1)) * 32 * PF_ZCOLS, A, lda, cp_, 1, (wh - cp_ - 32) / 32, false,
                              r4, r4c, actp, l15, l4);
-            pf_image_read(L.img, ar, wave, l15, l4);
+            pf_image_read<RT>(L.img, ar, wave, l15, l4);
             __syncthreads();                                  // the product's waves read rows other waves have just updated
         }
         PF_STAMP(2);
@@ -940,16 +976,19 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
                     acc0 = pf_mfma(qa1[1], x[s4][3], acc0); acc1 = pf_mfma(qb1[1], x[s4][3], acc1);
                 }
             };
+            static_assert(RT == 2 || RT == 4, "the chunk pipeline below alternates two operand buffers: an even number of 64-row chunks per tile");
             if (nval > 0) xload(xb[0], xptr(0), 0);
             for (int slot = 0; slot < nval; ++slot) {
                 v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
                 const double* xp = xptr(slot);
                 const bool gdiag = want_g && slot == 0 && wave < 2;       // wave-uniform
-                xload(xb[1], xp, 1); mma(xb[0], 0, acc0, acc1); if (gdiag) gmma(xb[0], xb[0], 0);
-                xload(xb[0], xp, 2); mma(xb[1], 1, acc0, acc1); if (gdiag) gmma(xb[1], xb[1], 1);
-                xload(xb[1], xp, 3); mma(xb[0], 2, acc0, acc1); if (gdiag) gmma(xb[0], xb[0], 2);
-                if (slot + 1 < nval) xload(xb[0], xptr(slot + 1), 0);
-                mma(xb[1], 3, acc0, acc1); if (gdiag) gmma(xb[1], xb[1], 3);
+#pragma unroll
+                for (int ch = 0; ch < RT; ++ch) {                        // the next chunk (or the next tile's first) is requested before this chunk's MFMAs
+                    if (ch + 1 < RT) xload(xb[(ch + 1) & 1], xp, ch + 1);
+                    else if (slot + 1 < nval) xload(xb[0], xptr(slot + 1), 0);
+                    mma(xb[ch & 1], ch, acc0, acc1);
+                    if (gdiag) gmma(xb[ch & 1], xb[ch & 1], ch);
+                }
                 double* zp = X3g + (wave + 4 * slot) * 512 + 2 * lane;          // pf_zidx layout
                 pf_st2(zp, acc0[0], acc0[1]); pf_st2(zp + 128, acc0[2], acc0[3]);
                 pf_st2(zp + 256, acc1[0], acc1[1]); pf_st2(zp + 384, acc1[2], acc1[3]);
@@ -959,7 +998,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
                 const double* x0 = A + (size_t) (c + 32 + l15) * lda;
                 const double* x1 = x0 + (size_t) 16 * lda;
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) { xload(xb[0], x0, ch); xload(xc, x1, ch); gmma(xb[0], xc, ch); }
+                for (int ch = 0; ch < RT; ++ch) { xload(xb[0], x0, ch); xload(xc, x1, ch); gmma(xb[0], xc, ch); }
             }
             if (want_g && wave < 3) {                            // accumulator order, as the Gram partials: tile 0, 2, 1 for wave 0, 1, 2
                 const int tile = (wave == 0) ? 0 : (wave == 1 ? 2 : 1);
@@ -989,8 +1028,8 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         PF_STAMP(6);
         const bool fb = pf_ld(f.F2 + 5 * 1024) != 0.0;         // the factor workgroup refused the leaf (workgroup-, launch-uniform)
         if (fb) {
-            pf_householder_leaf(ar, P, f, L, flags, er + 2u, g, nrow, r4, r4c, act, toprow, l15, l4, wave);
-            pf_image_write(L.img, ar, wave, l15, l4);           // the product again, from V (Q never existed)
+            pf_householder_leaf<RT>(ar, P, f, L, flags, er + 2u, g, nrow, r4, r4c, act, toprow, l15, l4, wave);
+            pf_image_write<RT>(L.img, ar, wave, l15, l4);       // the product again, from V (Q never existed)
             __syncthreads();
             product();
         }
@@ -1001,10 +1040,10 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         else { pf_m33 m2[2] = {L.Uinv, L.Ts}; pf_m33_in<2>(m2, f.F2); }
         __syncthreads();
         // ---- V = Q U'^-1; the top block's rows become L1
-        pf_rows_times_upper(ar, L.Uinv, l15, l4);
+        pf_rows_times_upper<RT>(ar, L.Uinv, l15, l4);
         if (toprow) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const int rr_ = r4 + t - c, col = 4 * ks + l4;
@@ -1042,8 +1081,8 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         PF_STAMP(7);
         // V goes to memory behind the publish (nobody else reads these rows; the publish's drain would wait for the 128 KB)
         if (!fb && act && !toprow) {
-            pf_store_rows(ar, Vw, ldv, c, r4, l4);
-            pf_store_rows(ar, A, lda, c, r4, l4);
+            pf_store_rows<RT>(ar, Vw, ldv, c, r4, l4);
+            pf_store_rows<RT>(ar, A, lda, c, r4, l4);
         }
         if (own && !fb) {
             // the top block: R above the diagonal of A, L1 below it and (unit lower) in Vw; T and tau -- behind the publish: nobody
@@ -1064,13 +1103,13 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         pf_fold(P, f, L, g, nrow, wave, lane, fb);
         pf_publish(flags, 16 * g, er + 4 + xe);
         PF_STAMP(9);
-        v4d uca[4], ucb[4];
-        if (f.nrest > 0) pf_update0_load(uca, ucb, A, lda, c, r4c, l4);
+        v4d uca[RT], ucb[RT];
+        if (f.nrest > 0) pf_update0_load<RT>(uca, ucb, A, lda, c, r4c, l4);
         pf_wait(flags, nrow, er + 4 + xe, &L.gflags[4]);
         PF_STAMP(10);
         // the next leaf's 32 columns are updated now (the result stays in registers as its a); the other columns of A_rest wait for
         // the next pass's Cholesky window (above)
-        if (f.nrest > 0) pf_update0_finish(ar, uca, ucb, f.X4, A, lda, c, r4, act, l15, l4);
+        if (f.nrest > 0) pf_update0_finish<RT>(ar, uca, ucb, f.X4, A, lda, c, r4, act, l15, l4);
         PF_STAMP(11);
         er += 4u + (fb ? 32u : 0u);
         ef += 2u;
@@ -1097,7 +1136,7 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
     bool g1_derived = false;
     if (tid == 0) { L.gflags[4] = 0; L.gflags[5] = 0; L.gflags[6] = 0; }
     for (int c = 0; c < P.wh; c += 32) {
-        const PfLeaf f = pf_leaf(P, c);
+        const PfLeaf f = pf_leaf<4>(P, c);                  // (only gown depends on the row split, and this workgroup does not use it)
         // the lane index is made opaque once per leaf: otherwise every lane-dependent constant of the unrolled recurrences below
         // (identity columns, `lane == K` selects, ...) is hoisted out of this loop and kept in registers across it -- ~400 of them
         int lane = tid & 63;
@@ -1134,7 +1173,18 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
         PF_STAMP_S(19);
         pf_wait(flags, nrow, er + 2, &L.gflags[4]);
         PF_STAMP_S(20);
+        // Q_top (published with the G2 partials) is requested NOW and parked in LDS while the partials are summed: the modified LU then
+        // takes its 32 operand values per lane from LDS instead of opening with a round trip to memory (9.5 us in situ against 7.6 alone)
+        pf_m33 Qts = reinterpret_cast<pf_m33>(L.img + PF_M33);          // (At's place: free until this leaf's G1 derivation, far behind the LU)
+        double qtv[1024 / PF_THREADS];
+#pragma unroll
+        for (int q = 0; q < 1024 / PF_THREADS; ++q) qtv[q] = pf_ld(f.QT + tid + q * PF_THREADS);
         pf_gram_sum(f.X2, nrow, L.Gs, L.gflags, true);
+#pragma unroll
+        for (int q = 0; q < 1024 / PF_THREADS; ++q) {
+            const int e = tid + q * PF_THREADS;
+            Qts[e >> 5][e & 31] = qtv[q];                               // Qts[j][i] = Q_top(i, j)
+        }
         __syncthreads();
         PF_STAMP_S(21);
         // R2 = chol(G2) (to first order when G2 - I is tiny) and the modified LU  Q_top - S R2 = L1 U' on wave 0.  Its upper 32 lanes
@@ -1173,7 +1223,7 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
                 // modified LU  Q_top - S R2 = L1 U'  with L1^-1 and U'^-1, all on the matrix cores (qr_factor32.h; round 4: a register
                 // recurrence here, 10 us, and two 16-step recurrences + 8 MFMAs on waves 1 and 2 behind it for U'^-1, 3.5 us).
                 // Ls aliases Gs: G2 is not needed any more
-                lu32_mfma(lane, [&](int i, int j) { return pf_ld(f.QT + j * 32 + i); }, [&](int i, int j) { return L.R2s[i][j]; },
+                lu32_mfma(lane, [&](int i, int j) { return Qts[j][i]; }, [&](int i, int j) { return L.R2s[i][j]; },
                           [&](int i, int j, double v) { L.Bs[i][j] = v; }, [&](int i, double v) { L.Ss[i] = v; },
                           [&](int i, int j, double v) { L.Ls[i][j] = v; }, [&](int i, int j, double v) { L.Uinv[j][i] = v; });
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1328,11 +1378,12 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
     }
 }
 
+template <int RT>
 __global__ __launch_bounds__(PF_THREADS) void panel_fused_kernel(PfArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int nrow = (int) gridDim.x - 1;
-    if ((int) blockIdx.x < nrow) pf_row_wg(P, sm, blockIdx.x, nrow);
+    if ((int) blockIdx.x < nrow) pf_row_wg<RT>(P, sm, blockIdx.x, nrow);
     else pf_factor_wg(P, sm, nrow);
 }
 
@@ -1346,34 +1397,67 @@ size_t qrd_panel_fused_ws_doubles(void) { return (size_t) PF_WS_DOUBLES; }
 
 int qrd_panel_fused_init(void)
 {
-    return (int) hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int) (PF_SM_DOUBLES * sizeof(double)));
+    int rc = (int) hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) (PF_SM_DOUBLES(4) * sizeof(double)));
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(panel_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (PF_SM_DOUBLES(2) * sizeof(double)));
+    return rc;
 }
 
-// 1 when the one-launch panel can take this (half-)panel: whole 32-column leaves, at most 256 columns, at most 32 x 256 rows and as many
-// free compute units on the stream, vector-aligned operands
+// Rows per row workgroup for a panel of mk rows x wh columns on this stream: 128 or 256; 0: the one-launch panel cannot take it (more
+// than 8192 rows, or more row workgroups than the stream has compute units beside the factor workgroup's: all must be co-resident).
+// 128 halves a workgroup's streaming work (deferred update + in-panel product: matrix-core time on its one compute unit) and doubles
+// the partials the hand-offs sum; measured, us per panel, 256 -> 128 rows (profiles/r06_panel_fused_perf.txt): 2048 x 256 477 -> 359,
+// 4096 x 256 443 -> 359, 8192 x 256 440 -> 405, 2048 x 128 181 -> 156, 4096 x 128 175 -> 167, 8192 x 128 185 -> 194, 4096 x 64 86 -> 85,
+// 2048 x 64 86 -> 77.  So: 128 up to 32 row workgroups (4096 rows), and beyond that for panels wider than 128 columns, where the
+// streaming dominates.  want: 0 = this rule, 128 / 256 = that form if it fits (unit tests; MI355XQR_PF_ROWS in the lab build).
+static int pf_rows_for(void* stream, int mk, int wh, int want = 0)
+{
+    static const int env = QRD_LAB_ENV_INT("MI355XQR_PF_ROWS", 0);
+    const int forced = want ? want : env;
+    int cus = qrd_stream_cus(stream) - 1;
+    if (cus > PF_MAXWG) cus = PF_MAXWG;
+    if (mk > 8192) return 0;
+    const int n128 = (mk + 127) / 128, n256 = (mk + 255) / 256;
+    const bool fit128 = n128 <= cus, fit256 = n256 <= cus;
+    if (forced == 128 && fit128) return 128;
+    if (forced == 256 && fit256) return 256;
+    if (fit128 && (n128 <= 32 || wh > 128 || !fit256)) return 128;
+    return fit256 ? 256 : 0;
+}
+
+// 1 when the one-launch panel can take this (half-)panel: whole 32-column leaves, at most 256 columns, at most 8192 rows and a free
+// compute unit per row workgroup on the stream, vector-aligned operands
 int qrd_panel_fused_ok(void* stream, const double* A, int lda, int mk, int wh, const double* Vw, int ldv)
 {
     if (wh < 32 || wh > 256 || wh % 32 || mk < wh || mk % 4) return 0;
     if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(Vw) & 15) || lda % 2 || ldv % 2) return 0;
-    const int nrow = (mk + PF_ROWS - 1) / PF_ROWS;           // row workgroups; one more workgroup (one more compute unit) factors
-    int cus = qrd_stream_cus(stream) - 1;
-    if (cus > PF_MAXWG) cus = PF_MAXWG;
-    return nrow <= cus;
+    return pf_rows_for(stream, mk, wh) != 0;
 }
 
-// *epoch: the caller's epoch counter for this workspace (starts at 0 with a zeroed workspace); advanced by the launch
-int qrd_panel_fused(void* stream, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv,
-                    double* G, int ldg, double* ws, unsigned* epoch, int* status)
+// *epoch: the caller's epoch counter for this workspace (starts at 0 with a zeroed workspace); advanced by the launch.
+// rows: 0 = the library's choice (pf_rows_for); 256 = the 256-row workgroups whatever the stream offers (kernel unit tests)
+int qrd_panel_fused_rows(void* stream, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv,
+                         double* G, int ldg, double* ws, unsigned* epoch, int* status, int want_rows)
 {
+    if (want_rows != 0 && want_rows != 128 && want_rows != 256) return -7;
     if (!qrd_panel_fused_ok(stream, A, lda, mk, wh, Vw, ldv) || !ws || !epoch || !status) return -7;
     PfArgs a;
     a.A = A; a.lda = lda; a.mk = mk; a.wh = wh; a.Vw = Vw; a.ldv = ldv; a.T = T; a.ldt = ldt; a.tau = tau; a.G = G; a.ldg = ldg;
     a.ws = ws; a.epoch0 = *epoch; a.status = status; a.stamps = g_pf_stamps;
     *epoch += 1024u;
-    const int nrow = (mk + PF_ROWS - 1) / PF_ROWS;
-    hipLaunchKernelGGL(panel_fused_kernel, dim3(nrow + 1), dim3(PF_THREADS), PF_SM_DOUBLES * sizeof(double), (hipStream_t) stream, a);
+    const int rows = pf_rows_for(stream, mk, wh, want_rows), nrow = (mk + rows - 1) / rows;
+    if (rows == 128)
+        hipLaunchKernelGGL(panel_fused_kernel<2>, dim3(nrow + 1), dim3(PF_THREADS), PF_SM_DOUBLES(2) * sizeof(double), (hipStream_t) stream, a);
+    else
+        hipLaunchKernelGGL(panel_fused_kernel<4>, dim3(nrow + 1), dim3(PF_THREADS), PF_SM_DOUBLES(4) * sizeof(double), (hipStream_t) stream, a);
     return (int) hipGetLastError();
+}
+
+int qrd_panel_fused(void* stream, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv,
+                    double* G, int ldg, double* ws, unsigned* epoch, int* status)
+{
+    return qrd_panel_fused_rows(stream, A, lda, mk, wh, tau, T, ldt, Vw, ldv, G, ldg, ws, epoch, status, 0);
 }
 
 }   // extern "C"

@@ -1,4 +1,5 @@
-"""time the one-launch panel (qrd_panel_fused) on a few panel shapes: us per launch, us per leaf"""
+"""time the one-launch panel (qrd_panel_fused_rows) on a few panel shapes: us per launch, us per leaf.
+python devtools/tools_panel_fused_perf.py [rows per row workgroup: 0 = library's choice | 128 | 256]   (PF_NO_GRAM=1: without the Gram blocks, as the plans call it)"""
 import ctypes as C
 import sys
 
@@ -10,15 +11,17 @@ import cuda_qr_amd as qr
 
 lib = qr.lib
 qr.check(lib.qrd_init(), "init")
-f = lib.qrd_panel_fused
+f = lib.qrd_panel_fused_rows
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-              C.c_void_p, C.POINTER(C.c_uint), C.c_void_p]
+              C.c_void_p, C.POINTER(C.c_uint), C.c_void_p, C.c_int]
+ROWS = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 lib.qrd_panel_fused_ws_doubles.restype = C.c_size_t
 ws = torch.zeros(int(lib.qrd_panel_fused_ws_doubles()), dtype=torch.float64, device="cuda")
 epoch = C.c_uint(0)
 status = torch.zeros(4, dtype=torch.int32, device="cuda")
-shapes = [(256, 64), (512, 64), (1024, 64), (2048, 64), (3072, 64), (4096, 64), (1024, 128), (2048, 128), (4096, 128), (2048, 256), (4096, 256), (8192, 256)]
+shapes = [(256, 64), (512, 64), (1024, 64), (2048, 64), (3072, 64), (4096, 64), (1024, 128), (2048, 128), (4096, 128), (8192, 128), (2048, 256), (4096, 256), (8192, 256)]
+print(f"rows per row workgroup: {ROWS or 'library choice'}; Gram blocks: {'no' if __import__('os').environ.get('PF_NO_GRAM') else 'yes'}")
 reps = 20
 for mk, wh in shapes:
     rng = np.random.default_rng(1)
@@ -33,7 +36,7 @@ for mk, wh in shapes:
     gp = None if os.environ.get("PF_NO_GRAM") else G.data_ptr()
     def go(b):
         rc = f(None, b.data_ptr(), mk, mk, wh, tau.data_ptr(), T.data_ptr(), wh, V.data_ptr(), mk, gp, wh, ws.data_ptr(),
-               C.byref(epoch), status.data_ptr())
+               C.byref(epoch), status.data_ptr(), ROWS)
         assert rc == 0, rc
     for i in range(3):
         go(bufs[i])

@@ -245,6 +245,10 @@ int qr_plan_set_guard_mode(qr_plan* plan, int latch);
 /* out4: full-width tall panels issued, of them refused, leaves of one-launch panels that took their Householder route, one-launch
  * panels whose hand-off stalled -- since the plan was created (refusals in latch mode and the last two are counted at qr_plan_sync) */
 int qr_plan_route_stats(qr_plan* plan, long long* out4);
+/* out2: refused full-width panels that were retried PRECONDITIONED (shifted CholeskyQR3: R0 = chol(A^T A + s I), the same three-pass pipeline
+ * on A R0^-1; default guard mode only), and how many of those the guard then accepted -- the others (rank deficient, cond > ~1e10) went
+ * to the Householder leaf chain.  No reference counterpart (the reference factors column by column, qr.c:109-235). */
+int qr_plan_retry_stats(qr_plan* plan, long long* out2);
 void* qr_plan_stream(qr_plan* plan);          /* the hipStream_t work is queued on */
 int qr_plan_update_cus(qr_plan* plan);        /* compute units the wide trailing update runs on (its share of the CU partition) */
 

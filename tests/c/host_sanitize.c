@@ -159,6 +159,27 @@ int main(void)
         OK(qr_device_free(dA)); OK(qr_device_free(dtau));
         OK(qr_plan_destroy(p));
     }
+    /* 1b'. the preconditioned retry of a refused panel (poll mode): the stub's guard accepts a retried panel unless bit 7 of its height is
+     *      set -- 69632 rows: panel 0 refused, retried, accepted; panel 1 (69504) accepted at once.  (65408 above: refused twice -> leaf chain) */
+    {
+        qr_plan* p = NULL;
+        double *dA = NULL, *dtau = NULL;
+        long long st[4], rt[2];
+        const int m = 69632, n = 256;
+        OK(qr_plan_create(&p, m, n, 128, 0));
+        OK(qr_device_malloc((void**) &dA, sizeof(double) * (size_t) m * n));
+        OK(qr_device_malloc((void**) &dtau, sizeof(double) * n));
+        OK(qr_geqrf_dev(p, dA, m, n, m, dtau));
+        OK(qr_plan_sync(p));
+        OK(qr_plan_route_stats(p, st));
+        OK(qr_plan_retry_stats(p, rt));
+        if (st[0] != 2 || st[1] != 1 || rt[0] != 1 || rt[1] != 1) {
+            fprintf(stderr, "retry: %lld tall panels, %lld refused, %lld retried, %lld accepted then\n", st[0], st[1], rt[0], rt[1]);
+            return 25;
+        }
+        OK(qr_device_free(dA)); OK(qr_device_free(dtau));
+        OK(qr_plan_destroy(p));
+    }
     /* 1c. a stalled one-launch panel under the host-pointer entry points: mmqr_status and qr_thin must see QR_E_STALL at their plan
      *     sync and factor again with the route off (status 0 for the caller), never return rc = 0 over the stalled result */
     {

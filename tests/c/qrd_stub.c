@@ -231,6 +231,19 @@ int qrd_panel_cqr_p(void* s, double* A, int lda, int mk, int w, double* tau, dou
     if (park && (!Qb || Qb == A)) return -7;
     return qrd_panel_cqr_q(s, A, lda, mk, w, tau, T, ldt, Vw, ldv, ws, status, Qb, ldq, hflag, seq);
 }
+/* the stub's guard accepts a retried panel unless bit 7 of its height is set too (65408 = 0xFF80: refused twice; 61440 + ...: see host_sanitize.c) */
+int qrd_panel_cqr_retry(void* s, double* A, int lda, int mk, int w, double* tau, double* T, int ldt, double* Vw, int ldv, double* ws, int* status,
+                        double* Qb, int ldq, unsigned* hflag, unsigned seq, int park)
+{
+    (void) s; (void) park;
+    if (!Qb || Qb == A || Qb == Vw) return -7;
+    leaf_chk("cqr retry", A, lda, mk, w, tau, T, ldt, Vw, ldv);
+    chk("cqr retry Q", Qb, ldq, mk, w);
+    chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); chkb("cqr status", status, 4 * sizeof(int));
+    status[0] = (mk & 128) ? 1 : 0;
+    if (hflag) __atomic_store_n(hflag, 2u * seq + (unsigned) status[0], __ATOMIC_RELEASE);
+    return 0;
+}
 int qrd_panel_cqr_restore_r(void* s, double* A, int lda, int w, const double* ws, const int* status)
 { (void) s; (void) status; chk("cqr restore A", A, lda, w, w); chkb("cqr ws", ws, sizeof(double) * qrd_panel_cqr_ws_doubles()); return 0; }
 int qrd_panel_cqr_r_block(void* s, const double* ws, int w, double* D, int ldd)
@@ -295,6 +308,9 @@ int qrd_panel_fused(void* s, double* A, int lda, int mk, int wh, double* tau, do
     if (getenv("QRD_STUB_STALL_ONCE")) { status[1] = 1; unsetenv("QRD_STUB_STALL_ONCE"); ++g_stub_stalls; }
     return 0;
 }
+int qrd_panel_fused_rows(void* s, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv, double* G, int ldg,
+                         double* ws, unsigned* epoch, int* status, int rows)
+{ (void) rows; return qrd_panel_fused(s, A, lda, mk, wh, tau, T, ldt, Vw, ldv, G, ldg, ws, epoch, status); }
 long qrd_stub_stalls(void) { return g_stub_stalls; }
 int qrd_slab_reduce(void* s, int M, int N, int ns, const double* slabs, int lds, size_t stride, double* out, int ldo)
 { (void) s; chk("slab_reduce in", slabs, lds, M, N); (void) ns; (void) stride; chk("slab_reduce out", out, ldo, M, N); return 0; }

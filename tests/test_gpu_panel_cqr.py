@@ -338,6 +338,8 @@ def test_bench_cond_input_refuses_every_tall_panel(qr):
     p.sync()
     st = p.route_stats()
     assert st["tall_panels"] == 2 and st["tall_panels_refused"] == 2, st
+    # round 6: a refused panel is retried preconditioned (shifted CholeskyQR3) before the leaf chain; cond 1e9 is well inside its range
+    assert st["tall_panels_retried"] == 2 and st["tall_panels_retry_accepted"] == 2, st
     R = np.triu(host(dA)[:n])
     p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
     p.sync()
@@ -346,3 +348,37 @@ def test_bench_cond_input_refuses_every_tall_panel(qr):
     assert np.isfinite(R).all() and np.isfinite(Q).all()
     assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-12
+
+
+@pytest.mark.parametrize("cond", [1e7, 1e8, 1e9, 1e10, 1e11, 1e13])
+def test_refused_panel_retry_is_householder_grade_across_conditions(qr, cond):
+    """The preconditioned retry of a refused full-width panel (shifted CholeskyQR3: R0 = chol(A^T A + s I), the three-pass pipeline on
+    A R0^-1, R = S R2 R1 R0) on panels whose singular values fall geometrically from 1 to 1 / cond, mixed over all columns: whichever
+    route ends up factoring the panel -- first attempt (cond <~ 1e7), retry (up to ~1e10), Householder leaf chain (beyond) -- the result
+    must be Householder-grade: backward error and orthogonality at round-off, R equal to LAPACK's where R is well determined."""
+    m, n = 32768, 128
+    rng = np.random.default_rng(int(np.log10(cond)))
+    U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+    W, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    A = (U * np.logspace(0, -np.log10(cond), n)) @ W.T
+    p = qr.Plan(m, n, 128, 32)
+    dA, dtau, dQ = dev(A), zeros(n, 1), zeros(m, n)
+    p.geqrf(dA, m, n, m, dtau)
+    p.sync()
+    st = p.route_stats()
+    R = np.triu(host(dA)[:n])
+    p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+    p.sync()
+    Q = host(dQ)
+    p.close()
+    assert st["tall_panels"] == 1, st
+    if cond >= 1e8:
+        assert st["tall_panels_refused"] == 1 and st["tall_panels_retried"] == 1, st
+    if 1e8 <= cond <= 1e9:
+        assert st["tall_panels_retry_accepted"] == 1, st                 # inside the retry's range: no leaf chain
+    assert np.isfinite(R).all() and np.isfinite(Q).all()
+    assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-14 * 4, (cond, st)
+    assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 2e-13, (cond, st)
+    from oracle import oracle as O                                       # the checker: sign normalisation only
+    Rl = O.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert np.linalg.norm(O.sign_normalise(R) - Rl) / np.linalg.norm(Rl) < 1e-11, (cond, st)

@@ -21,6 +21,9 @@ def q(qr):
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                   C.c_void_p, C.POINTER(C.c_uint), C.c_void_p]
+    fr = qr.lib.qrd_panel_fused_rows                         # rows per row workgroup given: 128 (round 6) / 256 (round 4-5) / 0 = the library's choice
+    fr.restype = C.c_int
+    fr.argtypes = f.argtypes + [C.c_int]
     qr.lib.qrd_panel_fused_ws_doubles.restype = C.c_size_t
     return qr
 
@@ -45,7 +48,7 @@ def merged_t(V, Tdiag, wh):
     return T
 
 
-def run_panel(q, ws, P, lda=None, ldv=None):
+def run_panel(q, ws, P, lda=None, ldv=None, rows=0):
     mk, wh = P.shape
     lda = lda or mk
     ldv = ldv or mk
@@ -56,8 +59,8 @@ def run_panel(q, ws, P, lda=None, ldv=None):
     dT, dtau, dG = dev(np.full((wh, wh), np.nan)), zeros(wh, 1), dev(np.full((wh, wh), np.nan))
     ws.status.zero_()
     torch.cuda.synchronize()
-    rc = q.lib.qrd_panel_fused(None, dA.data_ptr(), lda, mk, wh, dtau.data_ptr(), dT.data_ptr(), wh, dV.data_ptr(), ldv, dG.data_ptr(), wh,
-                               ws.buf.data_ptr(), C.byref(ws.epoch), ws.status.data_ptr())
+    rc = q.lib.qrd_panel_fused_rows(None, dA.data_ptr(), lda, mk, wh, dtau.data_ptr(), dT.data_ptr(), wh, dV.data_ptr(), ldv, dG.data_ptr(), wh,
+                                    ws.buf.data_ptr(), C.byref(ws.epoch), ws.status.data_ptr(), rows)
     assert rc == 0, rc
     q.check(q.lib.qrd_device_sync(), "sync")
     st = ws.status.cpu().numpy()
@@ -93,12 +96,13 @@ def check_panel(P, out, V, Tdiag, tau, G, tol=1e-12):
     assert np.linalg.norm(S[:, None] * R - Rref) / np.linalg.norm(Rref) < 1e-12
 
 
+@pytest.mark.parametrize("rows", [128, 256])
 @pytest.mark.parametrize("mk,wh", [(256, 32), (256, 64), (512, 64), (1024, 128), (1000, 256), (2048, 256), (4096, 64), (4096, 256),
-                                   (8192, 256), (8192, 128), (5000, 96), (260, 256)])
-def test_panel_fused_well_conditioned(q, mk, wh):
+                                   (8192, 256), (8192, 128), (5000, 96), (260, 256), (3968, 256), (132, 128)])
+def test_panel_fused_well_conditioned(q, mk, wh, rows):
     ws = Ws(q)
     P = np.random.default_rng(mk + wh).random((mk, wh))
-    out, V, T, tau, G, st = run_panel(q, ws, P, lda=mk + 6, ldv=mk + 2)
+    out, V, T, tau, G, st = run_panel(q, ws, P, lda=mk + 6, ldv=mk + 2, rows=rows)
     assert st[1] == 0, "a wait timed out"
     assert st[0] == 0, "a leaf of a well-conditioned panel took the Householder route"
     check_panel(P, out, V, T, tau, G)
@@ -110,15 +114,15 @@ def test_panel_fused_repeated_launches_share_a_workspace(q):
     rng = np.random.default_rng(5)
     first = {}
     for rep in range(3):
-        for mk, wh in [(2048, 128), (4096, 256), (512, 32)]:
+        for mk, wh, rows in [(2048, 128, 128), (4096, 256, 256), (512, 32, 0), (4096, 256, 128)]:      # both row splits through the same epoch words
             P = np.random.default_rng(mk).random((mk, wh))
-            out, V, T, tau, G, st = run_panel(q, ws, P)
+            out, V, T, tau, G, st = run_panel(q, ws, P, rows=rows)
             assert st[0] == 0 and st[1] == 0
             if rep == 0:
                 check_panel(P, out, V, T, tau, G)
-                first[(mk, wh)] = out
+                first[(mk, wh, rows)] = out
             else:
-                assert np.array_equal(out, first[(mk, wh)])
+                assert np.array_equal(out, first[(mk, wh, rows)])
 
 
 def test_panel_fused_declines_what_it_cannot_take(q):
@@ -126,7 +130,7 @@ def test_panel_fused_declines_what_it_cannot_take(q):
     d = zeros(9000, 64)
     args = lambda mk, wh, lda: (None, d.data_ptr(), lda, mk, wh, d.data_ptr(), d.data_ptr(), wh, d.data_ptr(), lda, d.data_ptr(), wh,
                                 ws.buf.data_ptr(), C.byref(ws.epoch), ws.status.data_ptr())
-    assert q.lib.qrd_panel_fused(*args(8196, 64, 9000)) == -7      # more than 32 x 256 rows
+    assert q.lib.qrd_panel_fused(*args(8196, 64, 9000)) == -7      # more than 8192 rows
     assert q.lib.qrd_panel_fused(*args(1026, 64, 9000)) == -7      # rows not a multiple of 4
     assert q.lib.qrd_panel_fused(*args(1024, 48, 9000)) == -7      # not whole leaves
     assert q.lib.qrd_panel_fused(*args(1024, 64, 8999)) == -7      # odd leading dimension
@@ -149,9 +153,10 @@ def _check_wy_only(P, out, V, Tdiag, tau, tol=1e-11):
         assert np.abs(H.T @ H - np.eye(mk)).max() < 1e-12
 
 
+@pytest.mark.parametrize("rows", [128, 256])
 @pytest.mark.parametrize("kind", ["zero_column", "dependent", "cond1e10", "two_bad_leaves", "all_zero"])
 @pytest.mark.parametrize("mk,wh", [(2048, 128), (512, 64), (4096, 256)])
-def test_panel_fused_householder_route(q, kind, mk, wh):
+def test_panel_fused_householder_route(q, kind, mk, wh, rows):
     """leaves the CholeskyQR2 route must refuse (zero / dependent columns, cond 1e10): the launch switches to its in-kernel Householder
     route for exactly those leaves (status counts them) and the panel is a valid compact-WY panel all the same"""
     ws = Ws(q)
@@ -171,12 +176,12 @@ def test_panel_fused_householder_route(q, kind, mk, wh):
         bad = 2
     else:
         P[:, :32] = 0.0
-    out, V, T, tau, G, st = run_panel(q, ws, P)
+    out, V, T, tau, G, st = run_panel(q, ws, P, rows=rows)
     assert st[1] == 0
     assert st[0] == bad, st
     _check_wy_only(P, out, V, T, tau, tol=1e-10 if kind == "cond1e10" else 1e-11)
     # a second launch through the same workspace (the epoch words moved by the extra exchanges) still works
     P2 = rng.random((mk, wh))
-    out, V, T, tau, G, st = run_panel(q, ws, P2)
+    out, V, T, tau, G, st = run_panel(q, ws, P2, rows=rows)
     assert st[0] == 0 and st[1] == 0
     check_panel(P2, out, V, T, tau, G)

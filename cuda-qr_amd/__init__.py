@@ -17,9 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (`make -C cuda-qr_amd lab`), in which the measurement knobs are environment variables and the development entry points of the 32 x 32
 # factor core exist.  For devtools/ scripts and the tests that force a schedule branch on a small matrix; everything else (bench.py,
 # smoke(), the parity tests) runs the product library.
-LAB = os.environ.get("CUDA_QR_AMD_LIB", "") == "lab"
+_which = os.environ.get("CUDA_QR_AMD_LIB", "")
+LAB = _which == "lab" or _which.endswith(".so")        # (a path: an experimental build of the lab flavour, devtools/ A/Bs of two kernel versions)
 LAB_LIB_PATH = os.path.join(HERE, "libmi355xqr_lab.so")
-LIB_PATH = LAB_LIB_PATH if LAB else os.path.join(HERE, "libmi355xqr.so")
+LIB_PATH = (os.path.join(HERE, _which) if _which.endswith(".so") else LAB_LIB_PATH) if LAB else os.path.join(HERE, "libmi355xqr.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mi355x_qr.h")
 
 if not os.path.exists(LIB_PATH):

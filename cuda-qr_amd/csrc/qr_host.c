@@ -136,6 +136,7 @@ typedef struct qr_knobs {
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
     int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
     int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
+    int tsqr_halves_rows;                                   /* MI355XQR_TSQR_HALVES (lab): stacked matrices shorter than this get their last block column in two halves */
     int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: 128-column panels of at least this many rows at full width (0 = never).  Round 4:
                                                              * 196608 (its one-workgroup kernels cost 274 us per panel); round 5 (181 us, profiles/r05_cqr_crossover.txt): everything
                                                              * the one-launch panel cannot take (> 8192 rows) on single-stream plans -- 32768 x 256 0.73 against 0.82 ms,
@@ -183,7 +184,11 @@ static void knobs_init(void)
     k->plan_cache = env_int("MI355XQR_PLAN_CACHE", 1) != 0;
     k->early_product = lab_env_int("MI355XQR_EP", 1) != 0;
     k->fused_panel = lab_env_int("MI355XQR_FUSED_PANEL", 1) != 0;
-    k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 3072);
+    k->fused_min_rows = env_int("MI355XQR_FUSED_MIN_ROWS", 256);      /* round 4-5: 3072 (below, the launch chain was as fast).  Round 6, with 128-row workgroups: every
+                                                                       * height gains -- 16384^2 118.1 -> 116.4 ms, 8192^2 25.3 -> 24.4, 4096^2 (nb 64) 11.2 -> 10.6, 2048^2 4.55 -> 4.08,
+                                                                       * 1024^2 2.31 -> 2.04; 128 and 32 measure like 256 (profiles/r06_fused_min_rows.txt) */
+    k->tsqr_halves_rows = lab_env_int("MI355XQR_TSQR_HALVES", 0);     /* round 5: 3072 (short stacked matrices went leaf by leaf); with one-launch stacked panels from 256 rows on the
+                                                                       * split costs more than it hides at every size: C4 rank of 4 / of 2 1.12 / 1.44 -> 1.07 / 1.37 ms (profiles/r06_tsqr_rank_step_latency.txt) */
     k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
     k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
     k->tall_nt = lab_env_int("MI355XQR_TALL_NT", 1) != 0;
@@ -338,7 +343,10 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
      * slow each other: 262144 x 512 7.38 vs 7.22 ms, 65536 x 2048 20.5 vs 19.0).  Below that the single-stream schedule
      * is 5-10 % faster (2048^2 5.46 -> 4.93 ms, 3072^2 8.4 -> 7.9, 4096 x 1024 2.90 -> 2.65; equal at 4096^2;
      * profiles/r02_session2_ab_measurements.txt section 12) */
-    p->lookahead = tsqr_local ? 0 : (la ? atoi(la) != 0 : (n >= 2048 && (long long) m * n >= 18000000LL && (long long) m < 16LL * n));
+    /* Round 6 (one-launch panels on 128-row workgroups): 4096^2 now gains too where the block is wide enough for the update to be worth a
+     * stream of its own -- nb 256: 9.26 -> 8.46 ms, nb 128: 9.47 -> 9.15, nb 64: 10.57 -> 10.69 (profiles/r06_lookahead_threshold.txt) */
+    p->lookahead = tsqr_local ? 0 : (la ? atoi(la) != 0 : (n >= 2048 && (long long) m < 16LL * n &&
+                                     ((long long) m * n >= 18000000LL || ((long long) m * n >= 16000000LL && nb >= 128))));
     /* MI355XQR_GRAPH=1: the single-stream schedule captured once per argument set and replayed (no measured gain: the cost of a leaf is
      * the device-side kernel boundary, not the host launch).  Never with look-ahead: capturing the CU-masked two-stream schedule
      * crashes inside the runtime (round 3: segmentation fault in hipStreamEndCapture), so the knob is ignored there. */
@@ -2005,7 +2013,7 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
              * leaf by leaf); from 3072 stacked rows a stacked panel is ONE launch (qr_panel_fused.hip) and two of them with an update in
              * between cost more than they hide (C5 rank, 4096 stacked rows: 0.83 -> 0.65 ms exposed without the split; C4 ranks, 1024 /
              * 512 rows: 0.29 / 0.40 with it against 0.32 / 0.44).  Halves of 32 columns lose (65536 x 256, nb 64: 0.39 against 0.32) */
-            if (pnb >= 128 && (pnb / 2) % t->p->ib == 0 && t->sm < knobs()->fused_min_rows) {
+            if (pnb >= 128 && (pnb / 2) % t->p->ib == 0 && t->sm < knobs()->tsqr_halves_rows) {
                 t->pan_k[t->npan] = n - pnb / 2;
                 t->pan_k[++t->npan] = n;
             }

@@ -55,7 +55,7 @@
 #define PF_OFF_XF (PF_OFF_X4 + 2 * 32 * PF_ZCOLS)
 #define PF_OFF_F1 (PF_OFF_XF + 2 * PF_MAXWG * 128)      /* factor -> rows: R1^-1 (1024) + status (8), per parity */
 #define PF_F1_SZ 1032
-#define PF_OFF_F2 (PF_OFF_F1 + 2 * PF_F1_SZ)              /* factor -> rows: U'^-1, T, L1\\U', R, S R2 (5 x 1024) + status (8) */
+#define PF_OFF_F2 (PF_OFF_F1 + 2 * PF_F1_SZ)              /* factor -> rows, in two hand-offs: U'^-1, L1\\U', S R2 (3 x 1024; + status at 5 x 1024), then T, R (2 x 1024) */
 #define PF_F2_SZ (5 * 1024 + 8)
 #define PF_OFF_XG (PF_OFF_F2 + 2 * PF_F2_SZ)              /* summed Gram matrix of the next leaf's columns before their update (768) */
 #define PF_OFF_XT (PF_OFF_XG + 2 * 1024)                 /* their top 32 rows before the update (32 x 32) */
@@ -411,7 +411,8 @@ struct PfLds {
     pf_m33 Uinv, Ts, Gs, Ls, R1s, Ws, Us, R2s, Bs, Rm;
     double *Ss, *r2inv, *scr;
     int* gflags;     // [0] first Cholesky ok, [1] |G2 - I| > 1/64, [2] > 1e-9, [3] second Cholesky failed, [4] dead (a wait timed out),
-                     // [5] leaves whose LU (B, L1, U') is in LDS, [6] leaves whose inverse of U'(16:32, 16:32) is in LDS
+                     // [5] leaves whose LU (B, L1, U') is in LDS, [6] leaves whose inverse of U'(16:32, 16:32) is in LDS,
+                     // [8 + w] leaves whose first hand-off wave w of the factor workgroup has drained (w = 1 .. 3)
 };
 
 __device__ __forceinline__ PfLds pf_lds(double* sm)
@@ -836,7 +837,8 @@ __device__ __forceinline__ void pf_householder_leaf(double (&ar)[RT][8], const P
 // MFMAs the f64 VALU chain of the LU took 2.5 x as long (24.6 us instead of 9.6: the two share the SIMD's double-precision datapath),
 // so that nothing could be hidden behind anything.  Epoch protocol per leaf (PfLeaf): rows publish + 1 (G1 partial), + 2 (G2 partial,
 // Q_top), + 3 (Z partials; the owner of the top block also its correction, R, L1, T, tau), + 4 (W slices); the factor workgroup
-// publishes + 1 (R1^-1) and + 2 (U'^-1, T, L1 \ U', R, S R2).
+// publishes + 1 (R1^-1), + 2 (U'^-1, L1 \ U', S R2 and the leaf's verdict: as soon as the LU is done) and + 3 (T, R: round 6 -- they
+// used to travel with + 2, 4.8 us later than V needs U'^-1).
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int RT>
 __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, int nrow)
@@ -1036,8 +1038,8 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
       if (!fb) {
         // ---- the factors: U'^-1 and T for everyone (they alias the Gram partials, published long ago); the owner of the top block
         // also takes L1 \ U', R = S R2 R1 and S R2
-        if (own) { pf_m33 m5[5] = {L.Uinv, L.Ts, L.Bs, L.R1s, L.R2s}; pf_m33_in<5>(m5, f.F2); }
-        else { pf_m33 m2[2] = {L.Uinv, L.Ts}; pf_m33_in<2>(m2, f.F2); }
+        if (own) { pf_m33 m3[3] = {L.Uinv, L.Bs, L.R2s}; pf_m33_in<3>(m3, f.F2); }
+        else { pf_m33 m1[1] = {L.Uinv}; pf_m33_in<1>(m1, f.F2); }
         __syncthreads();
         // ---- V = Q U'^-1; the top block's rows become L1
         pf_rows_times_upper<RT>(ar, L.Uinv, l15, l4);
@@ -1084,6 +1086,14 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
             pf_store_rows<RT>(ar, Vw, ldv, c, r4, l4);
             pf_store_rows<RT>(ar, A, lda, c, r4, l4);
         }
+        if (!fb) {
+            // the second hand-off of the factor workgroup (T; the owner also takes R): it left ~6 us behind the first, and the
+            // correction, the publish and the stores above took as long
+            pf_wait(flags, 0, ef + 3, &L.gflags[4]);
+            if (own) { pf_m33 m2[2] = {L.Ts, L.R1s}; pf_m33_in<2>(m2, f.F2 + 3 * 1024); }
+            else { pf_m33 m1[1] = {L.Ts}; pf_m33_in<1>(m1, f.F2 + 3 * 1024); }
+            __syncthreads();
+        }
         if (own && !fb) {
             // the top block: R above the diagonal of A, L1 below it and (unit lower) in Vw; T and tau -- behind the publish: nobody
             // else waits for these.  Written by the workgroup that owns these rows: it reads them back later (x_top of the
@@ -1112,7 +1122,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
         if (f.nrest > 0) pf_update0_finish<RT>(ar, uca, ucb, f.X4, A, lda, c, r4, act, l15, l4);
         PF_STAMP(11);
         er += 4u + (fb ? 32u : 0u);
-        ef += 2u;
+        ef += 3u;
         g1_derived = !fb && f.nrest > 0;
     }
     if (g == 0 && tid == 0 && L.gflags[4]) P.status[1] = 1;
@@ -1134,7 +1144,7 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
     int nfallback = 0;
     unsigned er = P.epoch0, ef = P.epoch0;
     bool g1_derived = false;
-    if (tid == 0) { L.gflags[4] = 0; L.gflags[5] = 0; L.gflags[6] = 0; }
+    if (tid == 0) { L.gflags[4] = 0; L.gflags[5] = 0; L.gflags[6] = 0; L.gflags[8] = 0; L.gflags[9] = 0; L.gflags[10] = 0; L.gflags[11] = 0; }
     for (int c = 0; c < P.wh; c += 32) {
         const PfLeaf f = pf_leaf<4>(P, c);                  // (only gown depends on the row split, and this workgroup does not use it)
         // the lane index is made opaque once per leaf: otherwise every lane-dependent constant of the unrolled recurrences below
@@ -1266,6 +1276,29 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
                     for (int cc = 0; cc < PW; ++cc) L.Us[lane][cc] = (cc >= lane) ? u[cc] : 0.0;
                 }
             }
+        } else {
+            // Round 6: the FIRST hand-off of the leaf's factors -- U'^-1 (V = q U'^-1), L1 \ U' (the top block's rows of V) and S R2 (the
+            // correction of the product), with the leaf's verdict -- goes out from waves 1-3 as soon as the LU is done, while wave 0
+            // goes on to U, T and R: the row workgroups used to wait for those too (4.8 us per leaf), and need T only at the fold, ~6 us
+            // later.  No workgroup barrier here (wave 0 is busy): each wave drains its own stores and raises an LDS word, wave 3 collects
+            // the three and stores the epoch word.
+            pf_lds_await(&L.gflags[5], seq);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int t3 = tid - 64;                             // 0 .. 191
+            for (int e = t3; e < 1024; e += 192) {
+                const int i = e >> 5, cc = e & 31;
+                pf_st(f.F2 + e, L.Uinv[i][cc]);
+                pf_st(f.F2 + 1024 + e, L.Bs[i][cc]);
+                pf_st(f.F2 + 2 * 1024 + e, L.Ss[i] * L.R2s[i][cc]);      // S R2 replaces R2 for the row workgroups' correction
+            }
+            if (t3 == 0) pf_st(f.F2 + 5 * 1024, (L.gflags[0] == 0 || L.gflags[1] != 0 || L.gflags[3] != 0) ? 1.0 : 0.0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pf_lds_signal(&L.gflags[8 + wave], seq);
+            if (wave == 3) {
+                pf_lds_await(&L.gflags[9], seq);
+                pf_lds_await(&L.gflags[10], seq);
+                if (lane == 0) __hip_atomic_store(flags + PF_FAC_WORD, ef + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
         PF_STAMP_S(23);
@@ -1293,19 +1326,12 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
             }
         }
         __syncthreads();
-        // S R2 replaces R2 for the row workgroups' correction
-        for (int e = tid; e < 1024; e += PF_THREADS) {
-            const int i = e >> 5, cc = e & 31;
-            pf_st(f.F2 + 4 * 1024 + e, L.Ss[i] * L.R2s[i][cc]);
-        }
-        pf_m33_out(L.Uinv, f.F2);
-        pf_m33_out(L.Ts, f.F2 + 1024);
-        pf_m33_out(L.Bs, f.F2 + 2 * 1024);
-        pf_m33_out(L.Rm, f.F2 + 3 * 1024);
+        // the SECOND hand-off: T (the fold's W = T^T y; the owner's T block and tau) and R (the owner's top block)
+        pf_m33_out(L.Ts, f.F2 + 3 * 1024);
+        pf_m33_out(L.Rm, f.F2 + 4 * 1024);
         const bool fb = L.gflags[0] == 0 || L.gflags[1] != 0 || L.gflags[3] != 0;
-        if (tid == 0) pf_st(f.F2 + 5 * 1024, fb ? 1.0 : 0.0);
         if (fb) ++nfallback;
-        pf_publish(flags, PF_FAC_WORD, ef + 2);
+        pf_publish(flags, PF_FAC_WORD, ef + 3);
         PF_STAMP_S(24);
         // ---- the next leaf's G1 without an exchange: G1 = G' - R12^T R12 with G' = A_next^T A_next before this leaf's update (summed
         // slice-wise by the row workgroups with their fold) and R12 = A_next(top 32 rows) - L1 W(:, next 32 columns), the rows this
@@ -1370,7 +1396,7 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
             __syncthreads();
         }
         er += 4u + (fb ? 32u : 0u);                          // the Householder route's 32 column exchanges among the row workgroups
-        ef += 2u;
+        ef += 3u;
     }
     if (tid == 0) {
         if (nfallback) atomicAdd(P.status, nfallback);

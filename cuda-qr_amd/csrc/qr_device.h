@@ -95,6 +95,7 @@ int qrd_panel_cqr_stage2(void* stream, double* A, int lda, int mk, int w, double
 /* a whole outer panel (<= 256 columns, <= 8192 rows) in ONE launch (qr_panel_fused.hip) */
 size_t qrd_panel_fused_ws_doubles(void);
 int qrd_panel_fused_init(void);
+int qrd_panel_fused_merges_t(int wh, int with_gram);   /* 1: a launch with these arguments leaves the panel's complete T (no merge tree behind it) */
 int qrd_panel_fused_ok(void* stream, const double* A, int lda, int mk, int wh, const double* Vw, int ldv);
 int qrd_panel_fused(void* stream, double* A, int lda, int mk, int wh, double* tau, double* T, int ldt, double* Vw, int ldv,
                     double* G, int ldg, double* ws, unsigned* epoch, int* status);

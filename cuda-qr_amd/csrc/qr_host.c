@@ -147,7 +147,7 @@ typedef struct qr_knobs {
     int cqr_park;                                           /* MI355XQR_CQR_PARK: full-width panels of tall single-stream plans write V once (into A) */
     int cqr_retry;                                          /* MI355XQR_CQR_RETRY (lab): a refused full-width panel is retried preconditioned (shifted CholeskyQR3) before the leaf chain */
     int defer_t;                                            /* MI355XQR_DEFER_T (lab): a one-launch panel's Gram matrix + T merge on the update stream in the chain-bound phase */
-    int fused_gram;                                         /* the panel's Gram blocks V_prev^T V_l inside the one-launch panel (else one launch after it): constant 0 */
+    int fused_gram;                                         /* MI355XQR_FUSED_GRAM (lab): widest panel whose Gram blocks come out of the one-launch panel itself */
 } qr_knobs;
 static qr_knobs g_knobs;
 static pthread_once_t g_knobs_once = PTHREAD_ONCE_INIT;
@@ -189,7 +189,9 @@ static void knobs_init(void)
                                                                        * 1024^2 2.31 -> 2.04; 128 and 32 measure like 256 (profiles/r06_fused_min_rows.txt) */
     k->tsqr_halves_rows = lab_env_int("MI355XQR_TSQR_HALVES", 0);     /* round 5: 3072 (short stacked matrices went leaf by leaf); with one-launch stacked panels from 256 rows on the
                                                                        * split costs more than it hides at every size: C4 rank of 4 / of 2 1.12 / 1.44 -> 1.07 / 1.37 ms (profiles/r06_tsqr_rank_step_latency.txt) */
-    k->fused_gram = 0;                 /* measured equal either way (profiles/r04_fused_ab.txt): the Gram blocks stay one launch after the panel */
+    k->fused_gram = lab_env_int("MI355XQR_FUSED_GRAM", 128);   /* widest panel whose Gram blocks V_prev^T V_l come out of the one-launch panel itself (its in-panel product
+                                                                * takes the columns of V_prev along) instead of one launch pair behind it.  At 256 columns the extra product
+                                                                * columns cost what the launch pair does (profiles/r04_fused_ab.txt); at 64-128 they are a tile or six */
     k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
     k->tall_nt = lab_env_int("MI355XQR_TALL_NT", 1) != 0;
     k->cqr_park = lab_env_int("MI355XQR_CQR_PARK", 1) != 0;
@@ -878,7 +880,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         }
         /* the whole half in ONE launch (qr_panel_fused.hip: every leaf, its in-panel product and update; leaf T blocks, tau, V and
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
-        int cqr_done = 0;
+        int cqr_done = 0, t_merged = 0;
         if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= plan_cqr_min_rows(p) && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
             /* (2: the last panel -- V once, R in place at once, nothing parked) */
             const int park = (park_hint && kn->cqr_park && nhalf == 1 && !p->lookahead) ? (want_t ? 1 : 2) : 0;
@@ -890,12 +892,16 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         }
         const int fused_half = !cqr_done && p->pf_ws && !p->fused_off && !p->use_graph && ib == 32 && mk - c0 >= kn->fused_min_rows &&
                                qrd_panel_fused_ok(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, p->Vw + (size_t) c0 * ldv + c0, ldv);
+        /* the Gram blocks out of the launch itself: always at 64 columns (one tile of product more, and the launch then merges T as well);
+         * up to MI355XQR_FUSED_GRAM columns from 2048 rows on (1024^2 at nb 128: 1.98 against 2.04 ms with them, profiles/r06_fused_gram.txt) */
+        const int fused_gram_here = wh <= 64 ? kn->fused_gram >= 64 : (wh <= kn->fused_gram && mk - c0 >= 2048);
         if (fused_half) {
             CHECK(qrd_panel_fused(p->stream, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
-                                  p->Vw + (size_t) c0 * ldv + c0, ldv, (need_t && kn->fused_gram) ? p->G + (size_t) c0 * nb + c0 : NULL, nb, p->pf_ws,
+                                  p->Vw + (size_t) c0 * ldv + c0, ldv, (need_t && fused_gram_here) ? p->G + (size_t) c0 * nb + c0 : NULL, nb, p->pf_ws,
                                   &p->pf_epoch, p->pf_status));
             p->pf_dirty = 1;
-            gram_done = need_t && kn->fused_gram;
+            gram_done = need_t && fused_gram_here;
+            t_merged = gram_done && qrd_panel_fused_merges_t(wh, 1);       /* (64-column panels: the launch has merged its two T blocks itself) */
         }
         for (int c = c0; c < cend && !fused_half && !cqr_done; c += ib) {
             const int w = imin(ib, cend - c), mkl = mk - c;
@@ -956,7 +962,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
             if (!gram_done) CHECK(tn(p, wh, wh, mk - c0, Vh, ldv, Vh, ldv, Ghh, nb, NULL));       /* Gram of the half */
             /* V*T is not formed here: the look-ahead update applies T to the small product V^T A_next instead, and the
              * wide update builds V*T itself on its own stream (update_cols), off the critical path */
-            CHECK(qrd_larft(p->stream, wh, ib, Ghh, nb, dtau + k + c0, Thh, ldt, NULL, 0, p->X, nb));
+            if (!t_merged) CHECK(qrd_larft(p->stream, wh, ib, Ghh, nb, dtau + k + c0, Thh, ldt, NULL, 0, p->X, nb));
         }
         if (h > 0) {
             /* T(0:c0, c0:cend) = -T(0:c0, 0:c0) (V(:, 0:c0)^T V(:, c0:cend)) T(c0:cend, c0:cend) */

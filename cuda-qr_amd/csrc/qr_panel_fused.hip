@@ -89,6 +89,8 @@ struct PfArgs {
     double* ws;                  // PF_WS_DOUBLES
     unsigned epoch0;             // epoch words hold values <= epoch0 when the launch starts
     int* status;                 // [0] += leaves that took the Householder route; [1] = 1 when a wait timed out
+    int merge64;                 // wh == 64 with G given: the launch also merges the two leaves' T blocks, T(0:32, 32:64) = -T_0 (V_0^T V_1) T_1
+                                 // (the factor workgroup, behind the last fold: the host's two-launch merge tree is not needed)
     long long* stamps;           // development builds (-DPF_STAMPS): 32 phase stamps per leaf of workgroup 0 (100 MHz clock)
 };
 
@@ -527,7 +529,7 @@ __device__ __forceinline__ void pf_fold(const PfArgs& P, const PfLeaf& f, const 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (have) {
             if (j >= f.nrest) {
-                P.G[(size_t) (f.c + i) * P.ldg + (j - f.nrest)] = y;
+                pf_st(P.G + (size_t) (f.c + i) * P.ldg + (j - f.nrest), y);     // (write-through: with merge64 the factor workgroup reads the block in this launch)
             } else {
                 double wv = 0.0;
                 pf_lds_col32(&L.Ts[0][i], mcol);                                          // T is stored with its zeros
@@ -812,6 +814,7 @@ __device__ __forceinline__ void pf_householder_leaf(double (&ar)[RT][8], const P
             P.T[(size_t) (c + cc) * P.ldt + c + i] = L.Ts[i][cc];
             if (i == cc) P.tau[c + i] = L.Ss[i];
         }
+        if (P.merge64) pf_m33_out(L.Ts, f.F2 + 3 * 1024);    // where the factor workgroup's T would be: it merges the panel's T from there
     }
     if (toprow) {                                             // R on and above the diagonal, reflector tails below it: LAPACK's in-place form
 #pragma unroll
@@ -1093,6 +1096,7 @@ __device__ __forceinline__ void pf_row_wg(const PfArgs& P, double* sm, int g, in
             if (own) { pf_m33 m2[2] = {L.Ts, L.R1s}; pf_m33_in<2>(m2, f.F2 + 3 * 1024); }
             else { pf_m33 m1[1] = {L.Ts}; pf_m33_in<1>(m1, f.F2 + 3 * 1024); }
             __syncthreads();
+            PF_STAMP(12);
         }
         if (own && !fb) {
             // the top block: R above the diagonal of A, L1 below it and (unit lower) in Vw; T and tau -- behind the publish: nobody
@@ -1298,6 +1302,9 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
                 pf_lds_await(&L.gflags[9], seq);
                 pf_lds_await(&L.gflags[10], seq);
                 if (lane == 0) __hip_atomic_store(flags + PF_FAC_WORD, ef + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PF_STAMPS
+                if (lane == 0 && P.stamps) P.stamps[(c >> 5) * 32 + 25] = (long long) __builtin_amdgcn_s_memrealtime();
+#endif
             }
         }
         __syncthreads();
@@ -1327,9 +1334,11 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
         }
         __syncthreads();
         // the SECOND hand-off: T (the fold's W = T^T y; the owner's T block and tau) and R (the owner's top block)
-        pf_m33_out(L.Ts, f.F2 + 3 * 1024);
-        pf_m33_out(L.Rm, f.F2 + 4 * 1024);
         const bool fb = L.gflags[0] == 0 || L.gflags[1] != 0 || L.gflags[3] != 0;
+        if (!fb) {                                               // (a refused leaf: its T comes from the Householder route of the row workgroups)
+            pf_m33_out(L.Ts, f.F2 + 3 * 1024);
+            pf_m33_out(L.Rm, f.F2 + 4 * 1024);
+        }
         if (fb) ++nfallback;
         pf_publish(flags, PF_FAC_WORD, ef + 3);
         PF_STAMP_S(24);
@@ -1395,6 +1404,54 @@ __device__ __forceinline__ void pf_factor_wg(const PfArgs& P, double* sm, int nr
             }
             __syncthreads();
         }
+        if (P.merge64 && c == 32) {
+            // The panel's T in this launch (64-column panels: BASELINE's C2 block size): T(0:32, 32:64) = -T_0 (V_0^T V_1) T_1.  The Gram block
+            // comes from the row workgroups' fold of this leaf (write-through stores, complete with their W slices), the leaves' T blocks
+            // from the two hand-off slabs (leaf parity 0 / 1) -- the factor workgroup's own, or the owner's after a Householder-route leaf
+            pf_wait(flags, nrow, er + 4u + (fb ? 32u : 0u), &L.gflags[4]);
+            pf_m33 T0 = reinterpret_cast<pf_m33>(L.img + PF_M33), T1 = reinterpret_cast<pf_m33>(L.img + 2 * PF_M33),
+                   Gm = reinterpret_cast<pf_m33>(L.img + 3 * PF_M33), Xm = L.Rm;
+            {
+                double t0[4], t1[4], gv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q;
+                    t0[q] = pf_ld(P.ws + PF_OFF_F2 + 3 * 1024 + e);
+                    t1[q] = pf_ld(P.ws + PF_OFF_F2 + PF_F2_SZ + 3 * 1024 + e);
+                    gv[q] = pf_ld(P.G + (size_t) (32 + (e >> 5)) * P.ldg + (e & 31));      // G(j' = e & 31, 32 + i), i = e >> 5
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + 256 * q;
+                    T0[e >> 5][e & 31] = t0[q];
+                    T1[e >> 5][e & 31] = t1[q];
+                    Gm[e & 31][e >> 5] = gv[q];
+                }
+            }
+            __syncthreads();
+            const int l15 = lane & 15, l4 = lane >> 4, ti = wave & 1, tj = wave >> 1;
+            {
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k = 4 * ks + l4;
+                    acc = pf_mfma(Gm[16 * ti + l15][k], T1[k][16 * tj + l15], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xm[16 * ti + l4 + 4 * r][16 * tj + l15] = acc[r];
+            }
+            __syncthreads();
+            {
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k = 4 * ks + l4;
+                    acc = pf_mfma(-T0[16 * ti + l15][k], Xm[k][16 * tj + l15], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P.T[(size_t) (32 + 16 * tj + l15) * P.ldt + 16 * ti + l4 + 4 * r] = acc[r];
+            }
+        }
         er += 4u + (fb ? 32u : 0u);                          // the Householder route's 32 column exchanges among the row workgroups
         ef += 3u;
     }
@@ -1452,6 +1509,10 @@ static int pf_rows_for(void* stream, int mk, int wh, int want = 0)
     return fit256 ? 256 : 0;
 }
 
+// 1 when a launch with these arguments leaves the panel's COMPLETE T behind (the leaves' blocks and the merge): 64-column panels whose Gram
+// block is taken along.  The caller then skips its merge tree (qrd_larft).
+int qrd_panel_fused_merges_t(int wh, int with_gram) { return wh == 64 && with_gram; }
+
 // 1 when the one-launch panel can take this (half-)panel: whole 32-column leaves, at most 256 columns, at most 8192 rows and a free
 // compute unit per row workgroup on the stream, vector-aligned operands
 int qrd_panel_fused_ok(void* stream, const double* A, int lda, int mk, int wh, const double* Vw, int ldv)
@@ -1471,6 +1532,7 @@ int qrd_panel_fused_rows(void* stream, double* A, int lda, int mk, int wh, doubl
     PfArgs a;
     a.A = A; a.lda = lda; a.mk = mk; a.wh = wh; a.Vw = Vw; a.ldv = ldv; a.T = T; a.ldt = ldt; a.tau = tau; a.G = G; a.ldg = ldg;
     a.ws = ws; a.epoch0 = *epoch; a.status = status; a.stamps = g_pf_stamps;
+    a.merge64 = qrd_panel_fused_merges_t(wh, G != nullptr);
     *epoch += 1024u;
     const int rows = pf_rows_for(stream, mk, wh, want_rows), nrow = (mk + rows - 1) / rows;
     if (rows == 128)

@@ -20,13 +20,13 @@ lib.qrd_panel_fused_set_stamps(stamps.data_ptr())
 epoch = C.c_uint(0)
 status = torch.zeros(4, dtype=torch.int32, device="cuda")
 names = {0: "leaf start", 1: "G1 partial published", 2: "deferred update done (behind the G2 publish since round 5)", 3: "R1^-1 seen", 4: "q, G2 partial published", 5: "product done",
-         6: "factors seen", 7: "V, (owner: top block, correction), Z published", 8: "all Z seen", 9: "fold, W published", 10: "all W seen",
+         6: "first hand-off (U'^-1) seen", 7: "V, (owner: correction), Z published", 12: "second hand-off (T) seen", 8: "all Z seen", 9: "fold, W published", 10: "all W seen",
          11: "next columns updated"}
-order = [0, 1, 3, 4, 2, 5, 6, 7, 8, 9, 10, 11]
-fnames = {16: "all G1 seen", 17: "G1 summed", 18: "chol", 19: "R1^-1 published", 20: "all G2 seen", 21: "G2 summed", 22: "LU", 23: "U, U'^-1",
-          24: "T, R, published"}
-forder = [16, 17, 18, 19, 20, 21, 22, 23, 24]
-for mk, wh in [(4096, 64), (8192, 256), (4096, 128)]:
+order = [0, 1, 3, 4, 2, 5, 6, 7, 12, 8, 9, 10, 11]
+fnames = {16: "all G1 seen", 17: "G1 summed", 18: "chol", 19: "R1^-1 published", 20: "all G2 seen", 21: "G2 summed", 22: "LU", 25: "first hand-off published (waves 1-3)",
+          23: "U", 24: "T, R, published"}
+forder = [16, 17, 18, 19, 20, 21, 22, 25, 23, 24]
+for mk, wh in [(2048, 64), (4096, 256), (8192, 256), (4096, 128)]:
     P = torch.from_numpy(np.ascontiguousarray(np.random.default_rng(1).random((wh, mk)))).cuda()
     V = torch.zeros((wh, mk), dtype=torch.float64, device="cuda")
     T = torch.zeros((wh, wh), dtype=torch.float64, device="cuda")

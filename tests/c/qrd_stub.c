@@ -288,6 +288,7 @@ int qrd_panel_cqr_stage2(void* s, double* A, int lda, int mk, int w, double* tau
 size_t qrd_panel_fused_ws_doubles(void) { return 700000; }
 /* same shape rules as the real launch layer (whole leaves, <= 256 columns, <= 32 x 256 rows, rows a multiple of 4, aligned operands);
  * heights with bit 9 set are declined so that both routes of factor_panel are exercised */
+int qrd_panel_fused_merges_t(int wh, int with_gram) { return wh == 64 && with_gram; }
 int qrd_panel_fused_ok(void* s, const double* A, int lda, int mk, int wh, const double* Vw, int ldv)
 {
     (void) s;

@@ -86,6 +86,8 @@ def check_panel(P, out, V, Tdiag, tau, G, tol=1e-12):
             Gref = V[:, :c].T @ Vl
             assert np.abs(G[:c, c:c + 32] - Gref).max() < tol * np.sqrt(mk) * max(1.0, np.abs(Gref).max())
     T = merged_t(V, Tdiag, wh)
+    if wh == 64:            # round 6: a 64-column launch that takes the Gram block along merges its two T blocks itself
+        assert np.abs(Tdiag[:32, 32:] - T[:32, 32:]).max() < 1e-12 * max(1.0, np.abs(T).max()), "in-launch T merge"
     QtP = P - V @ (T.T @ (V.T @ P))
     scale = np.abs(P).max()
     assert np.abs(np.tril(QtP, -1)).max() < 1e-11 * np.sqrt(mk) * scale
@@ -144,6 +146,8 @@ def _check_wy_only(P, out, V, Tdiag, tau, tol=1e-11):
     assert np.array_equal(np.triu(V[:wh], 1), np.zeros((wh, wh))) and np.array_equal(np.diag(V[:wh]), np.ones(wh))
     assert np.array_equal(np.tril(V, -1), np.tril(out, -1))
     T = merged_t(V, Tdiag, wh)
+    if wh == 64:
+        assert np.abs(Tdiag[:32, 32:] - T[:32, 32:]).max() < 1e-11 * max(1.0, np.abs(T).max()), "in-launch T merge (Householder-route leaves included)"
     QtP = P - V @ (T.T @ (V.T @ P))
     cs = np.maximum(np.abs(P).max(axis=0), 1e-300)
     assert (np.abs(np.tril(QtP, -1)) / cs).max() < tol * np.sqrt(mk)

@@ -144,6 +144,7 @@ _sig("qrd_gemm_tn_update_wide", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_dou
      _vp, C.c_int, _vp, C.c_size_t)
 _sig("qrd_gemm_tn_dual", C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int,
      _vp, C.c_size_t)
+_sig("qrd_trsm_gt", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
 _sig("qrd_larft", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
 _sig("qrd_panel_ws_size", C.c_size_t, C.c_int)
 _sig("qrd_panel_tsqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)

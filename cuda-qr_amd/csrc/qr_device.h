@@ -52,6 +52,9 @@ int qrd_gemm_nn_batch(void* stream, int M, int N, int K, double alpha, const dou
 int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const double* tau, double* T, int ldt,
               double* Tt, int build_diag, double* X, int ldx);
 int qrd_zero_block(void* stream, double* A, int ld, int rows, int cols);
+/* W = T^T Y from the panel's Gram matrix G = V^T V and the leaves' 32 x 32 T blocks on the diagonal of T, no merged T needed (forward
+ * substitution over the leaves); -7: shape not taken (kw % 32, nc % 16, kw > 256) */
+int qrd_trsm_gt(void* stream, int kw, int nc, const double* G, int ldg, const double* T, int ldt, const double* Y, int ldy, double* W, int ldw);
 int qrd_transpose(void* stream, int rows, int cols, const double* S, int lds, double* D, int ldd);   /* D (cols x rows) = S^T */
 int qrd_extract_v(void* stream, const double* P, int ld, int mk, int w, double* V, int ldv);
 int qrd_extract_r(void* stream, const double* A, int lda, int m, int n, double* R, int ldr, int rrows);

@@ -146,6 +146,7 @@ typedef struct qr_knobs {
     int tall_nt;                                            /* MI355XQR_TALL_NT: the update of a tall block through gemm_nt (W transposed first) */
     int cqr_park;                                           /* MI355XQR_CQR_PARK: full-width panels of tall single-stream plans write V once (into A) */
     int cqr_retry;                                          /* MI355XQR_CQR_RETRY (lab): a refused full-width panel is retried preconditioned (shifted CholeskyQR3) before the leaf chain */
+    int trsm_next;                                          /* MI355XQR_TRSM (lab): the look-ahead update behind a deferred merge without the merged T (qrd_trsm_gt) */
     int defer_t;                                            /* MI355XQR_DEFER_T (lab): a one-launch panel's Gram matrix + T merge on the update stream in the chain-bound phase */
     int fused_gram;                                         /* MI355XQR_FUSED_GRAM (lab): widest panel whose Gram blocks come out of the one-launch panel itself */
 } qr_knobs;
@@ -197,6 +198,7 @@ static void knobs_init(void)
     k->cqr_park = lab_env_int("MI355XQR_CQR_PARK", 1) != 0;
     k->defer_t = lab_env_int("MI355XQR_DEFER_T", 1) != 0;
     k->cqr_retry = lab_env_int("MI355XQR_CQR_RETRY", 1) != 0;
+    k->trsm_next = lab_env_int("MI355XQR_TRSM", 1) != 0;
 }
 
 static const qr_knobs* knobs(void)
@@ -765,6 +767,7 @@ int qr_gemm_dev(qr_plan* p, char transa, int M, int N, int K, double alpha, cons
  * in p->Vw and the panel's compact-WY T in p->T (only if want_t). */
 static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, const double* T, int ldt, int mk, int kw, double* A2,
                          int lda, int nc, double* Wbuf, double* Ybuf, double* slabs);
+static int apply_vw(qr_plan* p, void* stream, const double* V, int ldv, int mk, int kw, double* A2, int lda, int nc, double* Wbuf, double* Ybuf);
 
 /* One outer panel: columns [k, k+wout) over rows [k, m).  Leaves V (explicit, unit lower trapezoid) in p->Vw and the panel's
  * compact-WY T in p->T (only if want_t).
@@ -998,6 +1001,13 @@ static int apply_small_t(qr_plan* p, void* stream, const double* V, int ldv, con
         if (t_wait) CHECK(qrd_stream_wait_event(stream, t_wait));
         CHECK(qrd_gemm_tn(stream, kw, nc, kw, 1.0, T, ldt, Ybuf, kw, 0.0, Wbuf, kw, NULL, 0, NULL, 0));
     }
+    return apply_vw(p, stream, V, ldv, mk, kw, A2, lda, nc, Wbuf, Ybuf);
+}
+
+/* A2 (mk x nc) -= V (mk x kw) W (kw x nc): the last step of every small-T application.  Ybuf: kw * nc doubles of scratch (free by now) or NULL. */
+static int apply_vw(qr_plan* p, void* stream, const double* V, int ldv, int mk, int kw, double* A2, int lda, int nc, double* Wbuf, double* Ybuf)
+{
+    (void) p;
     /* Round 5: the update of a tall block through the trailing-update kernel of the square case (qr_gemm_nt.hip: four workgroups per CU,
      * operands HBM -> LDS directly, tiles dealt to the XCDs so that the column tiles of a row block share V in one L2): it wants W
      * transposed (nc x kw, row-fast), one more tiny launch.  MI355XQR_TALL_NT=0: the 8-wave NN kernel as before. */
@@ -1144,13 +1154,37 @@ static int update_bound(const qr_plan* p, int mk, int wout, int nwide)
  * next panel;  on the panel stream's 32 compute units the Gram product of a 4096 x 256 V takes 85-90 us (its 0.4 GFLOP are matrix-core
  * time there), on the idle update stream's 224 it takes 22, and the hop between the streams in front of the look-ahead update goes too
  * (profiles/r06_c3_tail_kernels.txt). */
-static int deferred_t_merge(qr_plan* p, void* stream, int e, int mk, int wout, const double* tau_k, double* slabs)
+static int deferred_gram(qr_plan* p, void* stream, int e, int mk, int wout, double* slabs)
 {
 #ifdef QR_TRACE_DEFER
     fprintf(stderr, "deferred_t_merge: mk %d wout %d on %s\n", mk, wout, stream == p->stream_u ? "update stream" : "panel stream");
 #endif
-    CHECK(qrd_gemm_tn(stream, wout, wout, mk, 1.0, p->Vw2[e], p->ldv, p->Vw2[e], p->ldv, 0.0, p->G, p->nb, slabs, p->slab_cap, NULL, 0));
+    return qrd_gemm_tn(stream, wout, wout, mk, 1.0, p->Vw2[e], p->ldv, p->Vw2[e], p->ldv, 0.0, p->G, p->nb, slabs, p->slab_cap, NULL, 0);
+}
+static int deferred_tree(qr_plan* p, void* stream, int e, int wout, const double* tau_k)
+{
     return qrd_larft(stream, wout, p->ib, p->G, p->nb, tau_k, p->T2[e], p->ldt, NULL, 0, p->X, p->nb);
+}
+static int deferred_t_merge(qr_plan* p, void* stream, int e, int mk, int wout, const double* tau_k, double* slabs)
+{
+    CHECK(deferred_gram(p, stream, e, mk, wout, slabs));
+    return deferred_tree(p, stream, e, wout, tau_k);
+}
+
+/* The look-ahead update N(s) of a panel whose T merge was deferred, WITHOUT the merged T (round 6): A_next -= V W with W = T^T (V^T A_next)
+ * from the forward substitution over the leaves (qrd_trsm_gt: the panel's Gram matrix and the leaves' own T blocks suffice), so that the
+ * merge tree -- six dependent launches at 256 columns, 35 us -- runs BEHIND N(s), off the chain P(s) -> N(s) -> P(s+1).  Returns 1
+ * when the shape is not whole leaves x whole 16-column tiles (the caller merges first and applies T as usual). */
+static int lookahead_update_no_t(qr_plan* p, void* stream, int e, double* dA, int lda, int k, int mk, int wout, int nc, double* slabs)
+{
+    double* A2 = dA + (size_t) (k + wout) * lda + k;
+    if (wout % 32 || wout > 256 || nc % 16 || nc < 16 || p->ib != 32) return 1;
+    CHECK(prof_begin_on(p, 4, stream));
+    CHECK(qrd_gemm_tn(stream, wout, nc, mk, 1.0, p->Vw2[e], p->ldv, A2, lda, 0.0, p->Yn, wout, slabs, p->slab_cap, NULL, 0));
+    CHECK(qrd_trsm_gt(stream, wout, nc, p->G, p->nb, p->T2[e], p->ldt, p->Yn, wout, p->Wn, wout));
+    CHECK(apply_vw(p, stream, p->Vw2[e], p->ldv, mk, wout, A2, lda, nc, p->Wn, p->Yn));
+    CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
+    return 0;
 }
 
 static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dtau);
@@ -1312,12 +1346,23 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
             CHECK(qrd_stream_wait_event(p->stream_u, v_recorded[e] ? p->ev_v[e] : p->ev_panel[e]));
             if (extra_pending) CHECK(qrd_stream_wait_event(p->stream_u, p->ev_extra[e ^ 1]));
             CHECK(prof_begin_on(p, 3, p->stream_u));          /* (class 3, misc: a class-2 record is "one panel" to the readers of the records) */
-            CHECK(deferred_t_merge(p, p->stream_u, e, mk, wout, dtau + k, p->slabs_u));
+            CHECK(deferred_gram(p, p->stream_u, e, mk, wout, p->slabs_u));
             CHECK(prof_end(p, 2.0 * mk * (double) wout * wout, 8.0 * mk * wout));
             t_deferred[e] = 0;
-            CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout, nfirst, p->Wn, p->Yn, p->slabs_u, 0, 0));
+            /* N(s) from the Gram matrix and the leaves' T blocks, the merge tree behind it (MI355XQR_TRSM=0 in the lab build: tree first) */
+            int need_tree_first = !knobs()->trsm_next;
+            if (!need_tree_first) {
+                const int rc = lookahead_update_no_t(p, p->stream_u, e, dA, lda, k, mk, wout, nfirst, p->slabs_u);
+                if (rc < 0 || rc > 1) return rc;
+                need_tree_first = rc == 1;
+            }
+            if (need_tree_first) {
+                CHECK(deferred_tree(p, p->stream_u, e, wout, dtau + k));
+                CHECK(update_cols(p, p->stream_u, e, dA, lda, k, mk, wout, k + wout, nfirst, p->Wn, p->Yn, p->slabs_u, 0, 0));
+            }
             CHECK(qrd_event_record(p->ev_next[e], p->stream_u));
             CHECK(qrd_stream_wait_event(p->stream, p->ev_next[e]));
+            if (!need_tree_first) CHECK(deferred_tree(p, p->stream_u, e, wout, dtau + k));      /* W(s), next on this stream, needs the merged T */
             wide_pending[e ^ 1] = 0;
         } else if (n_on_u) {
             /* N(s) on the update stream: behind W(s-1) by stream order, after P(s) (ev_panel) and E(s-1) (ev_extra) */

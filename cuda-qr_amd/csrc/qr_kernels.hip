@@ -685,6 +685,78 @@ static int launch_tn(hipStream_t s, int M, int N, int K, int ksplit, int kchunk,
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// W = T^T Y WITHOUT the merged T (round 6): for a compact-WY panel of nblk leaves of 32 columns, T^-1 = striu(G) + diag(1 / tau) with
+// G = V^T V, so W solves the block lower-triangular system  (T^-T) W = Y  by forward substitution over the leaves,
+//     W_i = T_ii^T (Y_i - sum_{j < i} G_ij W_j),        G_ij = V_i^T V_j (the block BELOW the diagonal), T_ii the leaf's own 32 x 32 T,
+// which needs the panel's Gram matrix and the leaves' T blocks only: the merge tree (qrd_larft: six dependent launches at 256 columns)
+// leaves the critical chain of a look-ahead step.  One workgroup per 16 columns of Y; wave w keeps the running right-hand sides of the
+// leaves i = w, w + 4 in accumulator tiles (register r of a tile IS the B operand of k-step r: nothing moves between lanes); W_j goes
+// round through LDS.  kw a multiple of 32 up to 256, nc a multiple of 16.  W may be Y.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trsm_gt_kernel(int kw, const double* __restrict__ G, int ldg, const double* __restrict__ T, int ldt,
+                                                      const double* Y, int ldy, double* W, int ldw)
+{
+    __shared__ double Ws[2][32][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int nblk = kw >> 5, c0 = blockIdx.x * 16;
+    v4d acc[2][2];                                            // [own leaf slot s: leaf i = wave + 4 s][16-row tile t]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int i = wave + 4 * s;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[s][t][r] = (i < nblk) ? Y[(size_t) (c0 + l15) * ldy + 32 * i + 16 * t + 4 * r + l4] : 0.0;
+    }
+    for (int j = 0; j < nblk; ++j) {
+        const int ow = j & 3, os = j >> 2;                    // the wave / slot that owns leaf j
+        if (wave == ow) {
+            // W_j = T_jj^T acc_j: A operand (T^T)(row 16 t' + l15, k) = T(32 j + k, 32 j + 16 t' + l15), B operand: the accumulator registers
+            v4d o[2];
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                o[tp] = (v4d){0.0, 0.0, 0.0, 0.0};
+                const double* tc = T + (size_t) (32 * j + 16 * tp + l15) * ldt + 32 * j;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k = 4 * ks + l4;
+                    const double a = (k <= 16 * tp + l15) ? tc[k] : 0.0;          // T_jj is upper triangular
+                    const double b = os ? acc[1][ks >> 2][ks & 3] : acc[0][ks >> 2][ks & 3];
+                    o[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, o[tp], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * tp + 4 * r + l4;
+                    Ws[j & 1][row][l15] = o[tp][r];
+                    W[(size_t) (c0 + l15) * ldw + 32 * j + row] = o[tp][r];
+                }
+        }
+        __syncthreads();
+        // every wave: its leaves i > j take  acc_i -= G_ij W_j
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int i = wave + 4 * s;
+            if (i > j && i < nblk) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const double* gr = G + (size_t) (32 * j) * ldg + 32 * i + 16 * t + l15;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const int k = 4 * ks + l4;
+                        acc[s][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-gr[(size_t) k * ldg], Ws[j & 1][k][l15], acc[s][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // (no second barrier: W_{j+1} goes to the other LDS buffer, and buffer j & 1 is rewritten at step j + 2, behind the next barrier)
+    }
+}
+
 template <typename K>
 static int allow_lds(K kern, size_t bytes)
 {
@@ -1036,6 +1108,15 @@ int qrd_larft(void* stream, int nbp, int ib, const double* G, int ldg, const dou
         return (int) hipGetLastError();
     }
     return 0;
+}
+
+// W (kw x nc, ldw) = T^T Y for the panel whose Gram matrix is G and whose leaves' T blocks sit on the diagonal of T (trsm_gt_kernel): -7 when
+// the shape is not whole leaves x whole 16-column tiles (the caller then merges T and multiplies)
+int qrd_trsm_gt(void* stream, int kw, int nc, const double* G, int ldg, const double* T, int ldt, const double* Y, int ldy, double* W, int ldw)
+{
+    if (kw < 32 || kw > 256 || kw % 32 || nc < 16 || nc % 16) return -7;
+    hipLaunchKernelGGL(trsm_gt_kernel, dim3(nc / 16), dim3(256), 0, (hipStream_t) stream, kw, G, ldg, T, ldt, Y, ldy, W, ldw);
+    return (int) hipGetLastError();
 }
 
 int qrd_transpose(void* stream, int rows, int cols, const double* S, int lds, double* D, int ldd)

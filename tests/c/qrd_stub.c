@@ -260,6 +260,13 @@ int qrd_host_word_alloc(unsigned** host, unsigned** dev)
     return 0;
 }
 int qrd_host_word_free(unsigned* host) { free(host); return 0; }
+int qrd_trsm_gt(void* s, int kw, int nc, const double* G, int ldg, const double* T, int ldt, const double* Y, int ldy, double* W, int ldw)
+{
+    (void) s;
+    if (kw < 32 || kw > 256 || kw % 32 || nc < 16 || nc % 16) return -7;
+    chk("trsm G", G, ldg, kw, kw); chk("trsm T", T, ldt, kw, kw); chk("trsm Y", Y, ldy, kw, nc); chk("trsm W", W, ldw, kw, nc);
+    return 0;
+}
 int qrd_transpose(void* s, int rows, int cols, const double* S, int lds, double* D, int ldd)
 {
     (void) s;

@@ -566,3 +566,38 @@ def test_gemm_tn_dual_short_and_tall(q, K, N1, N2):
         assert np.abs(outs[0][1][:N2] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()) * np.sqrt(K)
         assert np.array_equal(outs[0][1][:N2], outs[1][1][:N2])
         assert np.isnan(outs[0][1][N2:]).all()
+
+
+@pytest.mark.parametrize("kw,nc,lds", [(256, 256, (256, 256, 256, 256)), (128, 16, (200, 130, 128, 160)), (64, 48, (64, 64, 70, 64)), (32, 32, (40, 32, 32, 32)),
+                                       (96, 256, (96, 100, 96, 96)), (224, 64, (256, 256, 224, 224))])
+def test_trsm_gt_applies_t_transposed_without_the_merged_t(q, kw, nc, lds):
+    """qrd_trsm_gt (round 6): W = T^T Y from the panel's Gram matrix G = V^T V and the leaves' own 32 x 32 T blocks -- for a compact-WY panel
+    T^-1 = striu(G) + diag(G) / 2, so W is a block forward substitution over the leaves and the merge tree (qrd_larft) is not needed.
+    Checked against T^T Y with the full T formed in numpy; W written over Y as well."""
+    rng = np.random.default_rng(kw + nc)
+    V = np.tril(rng.standard_normal((3 * kw, kw)), -1)[:, :]      # unit lower trapezoidal reflectors, tails of moderate size
+    V[np.arange(kw), np.arange(kw)] = 1.0
+    V[kw:] *= 0.3
+    G = V.T @ V
+    Tinv = np.triu(G, 1) + np.diag(np.diag(G) / 2.0)
+    T = np.linalg.inv(Tinv)
+    Tin = np.full((kw, kw), np.nan)                                # only the leaves' diagonal blocks may be read
+    for c in range(0, kw, 32):
+        Tin[c:c + 32, c:c + 32] = np.triu(T[c:c + 32, c:c + 32])
+    Y = rng.standard_normal((kw, nc))
+    ldg, ldt, ldy, ldw = lds
+    pad = lambda M, ld: np.vstack([M, np.full((ld - M.shape[0], M.shape[1]), np.nan)])
+    dG, dT, dY, dW = dev(pad(G, ldg)), dev(pad(Tin, ldt)), dev(pad(Y, ldy)), dev(np.full((ldw, nc), np.nan))
+    assert q.lib.qrd_trsm_gt(None, kw, nc, dG.data_ptr(), ldg, dT.data_ptr(), ldt, dY.data_ptr(), ldy, dW.data_ptr(), ldw) == 0
+    q.check(q.lib.qrd_device_sync(), "sync")
+    Wref = T.T @ Y
+    W = host(dW)[:kw]
+    assert np.isfinite(W).all()
+    assert rel(W, Wref) < 1e-13
+    if ldy == ldw or True:                                         # in place: W over Y
+        assert q.lib.qrd_trsm_gt(None, kw, nc, dG.data_ptr(), ldg, dT.data_ptr(), ldt, dY.data_ptr(), ldy, dY.data_ptr(), ldy) == 0
+        q.check(q.lib.qrd_device_sync(), "sync")
+        assert rel(host(dY)[:kw], Wref) < 1e-13
+    # shapes it does not take are declined, not mangled
+    assert q.lib.qrd_trsm_gt(None, 48, 16, dG.data_ptr(), ldg, dT.data_ptr(), ldt, dY.data_ptr(), ldy, dW.data_ptr(), ldw) == -7
+    assert q.lib.qrd_trsm_gt(None, 32, 24, dG.data_ptr(), ldg, dT.data_ptr(), ldt, dY.data_ptr(), ldy, dW.data_ptr(), ldw) == -7

@@ -515,9 +515,17 @@ def main():
                 "profiled_steps_in_timed_region": len(range(0, K, stride)),
                 "algorithmic_flops_per_launch": upd["flops"] / upd["launches"],
                 "algorithmic_bytes_per_launch": upd["bytes"] / upd["launches"],
-                "companion_tn": {"kernel": "gemm_tn_kernel<4, 4, true, 1> + slab_reduce_kernel (Wt = A2^T (V T))",
-                                 "achieved": tn["flops"] / (tn["ms"] * 1e-3) / 1e12 if tn["ms"] else None,
-                                 "launches": tn["launches"]},
+                # the OTHER kernel of the update pair in the same shape: Wt = A2^T (V T), from the extra profiled step
+                "companion_tn": (lambda a: {"kernel": "gemm_tn_kernel<4, 4, true, 1> + slab_reduce_kernel (Wt = A2^T (V T); split-K slabs summed in a fixed order)",
+                                            "bound": "mfma", "achieved": a, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": (a / FP64_MATRIX_PEAK_TFLOPS) if a else None,
+                                            "traffic": (tj or {}).get("gemm_tn_kernel<4,4,true,1>", {}).get("hbm_bytes_per_launch") if (tj and wl == "c3" and nb == tj.get("nb")) else None,
+                                            "traffic_ratio_to_algorithmic": (tj or {}).get("gemm_tn_kernel<4,4,true,1>", {}).get("ratio") if (tj and wl == "c3" and nb == tj.get("nb")) else None,
+                                            "traffic_note": "x2.28 of algorithmic: A2 is read once per 128-column tile of V T (N / 128 = 2 times at nb 256); the 128 x 256-tile form "
+                                                            "(x1.25, lab knob MI355XQR_TN_WIDE) was re-measured this round at the final code and LOSES 3 ms at C3 "
+                                                            "(profiles/r06_tn_wide_ab.txt): the product is matrix-core bound, the refetches come from the Infinity Cache",
+                                            "launches": tn["launches"], "avg_launch_ms": tn["ms"] / tn["launches"] if tn["launches"] else None})(
+                                     tn["flops"] / (tn["ms"] * 1e-3) / 1e12 if tn["ms"] else None),
                 "panel_ms_per_step": pan["ms"] / K_pan,
                 "other_classes_note": "wide_product_tn and panel_ms_per_step come from one extra, fully profiled factorisation after "
                                       "the timed region; inside it only the dominant kernel's launches carry HIP events"}

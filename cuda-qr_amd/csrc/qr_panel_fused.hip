@@ -298,7 +298,9 @@ __device__ __forceinline__ void pf_ld2_wait16(v2d (&v)[16])
 }
 
 // all threads: Gs[j][i] = sum over the workgroups (in index order) of their partial G(i, j).  A thread owns the entry pairs 2 tid and
-// (tid < 128) 2 (tid + 256) and has the 16-byte loads of 16 workgroups for both in flight at once
+// (tid < 128) 2 (tid + 256) and has the 16-byte loads of 16 workgroups for both in flight at once.  (NOT 32, round 6: with 64 asm loads in
+// flight the register allocator parks some of their destination registers in AGPRs BEFORE the s_waitcnt -- to the compiler an asm output is
+// defined when the statement ends -- and the sums read registers the loads had not reached yet: every leaf failed its guard.)
 __device__ __forceinline__ void pf_gram_sum(const double* __restrict__ X, int nwg, pf_m33 Gs, int* gflags, bool check)
 {
     const int e0 = 2 * threadIdx.x, e1 = 2 * (threadIdx.x + 256);

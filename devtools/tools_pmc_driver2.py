@@ -1,7 +1,7 @@
 """Workload for the round-2 PMC passes (rocprofv3 --pmc ...), see profiles/README.md.
 
 rocprofv3 counter collection crashes on this pool beyond ~16k dispatches per process and on CU-masked streams, so the counters
-are taken (MI355XQR_PANEL_CUS=0: no CU masks) on (a) calibration kernels with known byte counts and (b) the wide trailing-update
+are taken (MI355XQR_SPLIT=0: no CU masks) on (a) calibration kernels with known byte counts and (b) the wide trailing-update
 GEMM pair at the exact C3 shapes of every 8th outer step (mk = nt + nb = 16384 - k, K = nb), launched through the update's own
 launch helpers: gemm_tn_kernel<4,4,true,1> (+ slab reduce) producing Wt = A2^T (V T) and gemm_nt_kernel<true,0> doing
 A2 -= V Wt^T -- the same kernels, tiles and split-K the factorisation uses."""

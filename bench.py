@@ -450,7 +450,7 @@ def main():
             measured = None
     # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 counter passes cannot share a process with the
     # timed region, and crash on CU-masked streams on this pool).  The committed round-5 PMC pass (profiles/r05_pmc_traffic.json,
-    # devtools/scripts_r5_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
+    # devtools/rounds/r5/scripts_r5_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
     # ITS algorithmic bytes, and `traffic` itself only when that file was made for this block size; otherwise null.
     traffic, traffic_src = None, None
     try:
@@ -546,7 +546,7 @@ def main():
         except Exception:
             pass
         # whole-factorisation HBM bytes of this shape (every dispatch: leaf kernels, in-panel products and updates, outer updates),
-        # PMC passes of devtools/scripts_r4_pmc.sh -- replayed, not measured in this run
+        # PMC passes of devtools/rounds/r4/scripts_r4_pmc.sh -- replayed, not measured in this run
         whole = None
         try:
             wj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_tsqr_total_traffic.json")))

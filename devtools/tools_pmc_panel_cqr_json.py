@@ -1,4 +1,4 @@
-"""profiles/r05_pmc_panel_hbm.json from the two PMC summaries of devtools/scripts_r5_pmc.sh over tools_cqr_perf.py 262144 128 0:
+"""profiles/r05_pmc_panel_hbm.json from the two PMC summaries of devtools/rounds/r5/scripts_r5_pmc.sh over tools_cqr_perf.py 262144 128 0:
 python devtools/tools_pmc_panel_cqr_json.py cqr_FETCH_SIZE_summary.txt cqr_WRITE_SIZE_summary.txt <git head>"""
 import json, re, sys
 
@@ -24,5 +24,5 @@ for name in F:
 alg = 16.0 * mk * w
 print(json.dumps({"mk": mk, "w": w, "hbm_bytes_per_panel": tot, "algorithmic_bytes_16_mk_w": alg, "ratio": tot / alg, "kernels": kern,
                   "covers": "every kernel of one full-width panel (qrd_panel_cqr): Gram pass + reduce, Cholesky, Q + G2 pass + reduce, reconstruction (LU, post), V pass, top block",
-                  "method": "2*FETCH_SIZE + WRITE_SIZE per dispatch (KiB, gfx950 correction), separate rocprofv3 --pmc passes over devtools/tools_cqr_perf.py 262144 128 0; devtools/scripts_r5_pmc.sh",
+                  "method": "2*FETCH_SIZE + WRITE_SIZE per dispatch (KiB, gfx950 correction), separate rocprofv3 --pmc passes over devtools/tools_cqr_perf.py 262144 128 0; devtools/rounds/r5/scripts_r5_pmc.sh",
                   "git_head": sys.argv[3] if len(sys.argv) > 3 else None}, indent=1))

@@ -1,4 +1,4 @@
-"""profiles/r02_pmc_panel_hbm.json from the per-dispatch table of devtools/scripts_r2_pmc_panel.sh (cholqr_hbm_summary.txt):
+"""profiles/r02_pmc_panel_hbm.json from the per-dispatch table of devtools/rounds/r2/scripts_r2_pmc_panel.sh (cholqr_hbm_summary.txt):
 the three streaming kernels of a 262144 x 32 CholeskyQR2 leaf, averaged over the dispatches that read >= 60 MB.
 python devtools/tools_pmc_panel_json.py gpurun_out/pmc_panel_r02/cholqr_hbm_summary.txt <git head>"""
 import sys, json, collections
@@ -29,5 +29,5 @@ out["algorithmic_bytes_per_leaf"] = 2 * 262144 * 32 * 8
 out["note"] = ("inside a factorisation only the first leaf of an outer panel runs gram32_kernel: the others get their Gram matrix from the "
                "previous leaf's in-panel update (leaf_update_gram_kernel), whose bytes are not in this table")
 out["method"] = ("2*FETCH_SIZE + WRITE_SIZE per dispatch (gfx950 correction), duration from a --kernel-trace pass of the same driver; "
-                 "devtools/scripts_r2_pmc_panel.sh")
+                 "devtools/rounds/r2/scripts_r2_pmc_panel.sh")
 print(json.dumps(out, indent=1))

@@ -701,16 +701,38 @@ __global__ __launch_bounds__(256) void trsm_gt_kernel(int kw, const double* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int nblk = kw >> 5, c0 = blockIdx.x * 16;
     v4d acc[2][2];                                            // [own leaf slot s: leaf i = wave + 4 s][16-row tile t]
+    double tf[2][2][8];                                       // the own leaves' T^T fragments (A operands of W_j = T_jj^T acc_j), requested up front
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int i = wave + 4 * s;
+        const int i = wave + 4 * s, ic = i < nblk ? i : 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[s][t][r] = (i < nblk) ? Y[(size_t) (c0 + l15) * ldy + 32 * i + 16 * t + 4 * r + l4] : 0.0;
+            for (int r = 0; r < 4; ++r) acc[s][t][r] = Y[(size_t) (c0 + l15) * ldy + 32 * ic + 16 * t + 4 * r + l4];
+            const double* tc = T + (size_t) (32 * ic + 16 * t + l15) * ldt + 32 * ic;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) tf[s][t][ks] = tc[4 * ks + l4];
+        }
     }
-    for (int j = 0; j < nblk; ++j) {
+    // The Gram blocks G_ij of this wave's leaves i > j are requested ONE STEP AHEAD (they do not depend on W_j), and the barrier of a step is
+    // an LDS-only one: __syncthreads() also drains the vector-memory counter, i.e. waits for the blocks just requested -- a memory latency
+    // per step, 23-28 us per launch of eight steps
+    double gf[2][2][2][8];                                    // [buffer][slot][tile][k-step]
+    auto gload = [&](double (&g)[2][2][8], int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int i = wave + 4 * s, jc = j < nblk ? j : nblk - 1, ic = (i > jc && i < nblk) ? i : jc;   // (clamped: an inactive slot reads a valid block and ignores it)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double* gr = G + (size_t) (32 * jc) * ldg + 32 * ic + 16 * t + l15;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) g[s][t][ks] = gr[(size_t) (4 * ks + l4) * ldg];
+            }
+        }
+    };
+    auto step = [&](const double (&g)[2][2][8], double (&gn)[2][2][8], int j) __attribute__((always_inline)) {
+        gload(gn, j + 1);
+        __builtin_amdgcn_sched_barrier(0);
         const int ow = j & 3, os = j >> 2;                    // the wave / slot that owns leaf j
         if (wave == ow) {
             // W_j = T_jj^T acc_j: A operand (T^T)(row 16 t' + l15, k) = T(32 j + k, 32 j + 16 t' + l15), B operand: the accumulator registers
@@ -718,11 +740,11 @@ __global__ __launch_bounds__(256) void trsm_gt_kernel(int kw, const double* __re
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
                 o[tp] = (v4d){0.0, 0.0, 0.0, 0.0};
-                const double* tc = T + (size_t) (32 * j + 16 * tp + l15) * ldt + 32 * j;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const int k = 4 * ks + l4;
-                    const double a = (k <= 16 * tp + l15) ? tc[k] : 0.0;          // T_jj is upper triangular
+                    const double tv = os ? tf[1][tp][ks] : tf[0][tp][ks];
+                    const double a = (k <= 16 * tp + l15) ? tv : 0.0;             // T_jj is upper triangular
                     const double b = os ? acc[1][ks >> 2][ks & 3] : acc[0][ks >> 2][ks & 3];
                     o[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, o[tp], 0, 0, 0);
                 }
@@ -736,24 +758,25 @@ __global__ __launch_bounds__(256) void trsm_gt_kernel(int kw, const double* __re
                     W[(size_t) (c0 + l15) * ldw + 32 * j + row] = o[tp][r];
                 }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // W_j is in LDS for everybody; nothing waits for global memory here
         // every wave: its leaves i > j take  acc_i -= G_ij W_j
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int i = wave + 4 * s;
             if (i > j && i < nblk) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const double* gr = G + (size_t) (32 * j) * ldg + 32 * i + 16 * t + l15;
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) {
-                        const int k = 4 * ks + l4;
-                        acc[s][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-gr[(size_t) k * ldg], Ws[j & 1][k][l15], acc[s][t], 0, 0, 0);
-                    }
-                }
+                    for (int ks = 0; ks < 8; ++ks)
+                        acc[s][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-g[s][t][ks], Ws[j & 1][4 * ks + l4][l15], acc[s][t], 0, 0, 0);
             }
         }
         // (no second barrier: W_{j+1} goes to the other LDS buffer, and buffer j & 1 is rewritten at step j + 2, behind the next barrier)
+    };
+    gload(gf[0], 0);
+    for (int j = 0; j < nblk; j += 2) {                      // (two steps per trip: the operand buffers alternate by name, not by a run-time index)
+        step(gf[0], gf[1], j);
+        if (j + 1 < nblk) step(gf[1], gf[0], j + 1);
     }
 }
 

@@ -181,7 +181,7 @@ def main():
         desc = f"C3: 16384x16384 square fp64 QR on 1 MI355X, nb={nb}"
     elif wl == "c4":
         m_local, n, nb = 262144 // world, 256, args.nb or 128     # round 5: shards of 131072 / 65536 rows take the full-width panel route at nb 128
-                                                                  # (rank step 1.59 / 1.18 ms against 1.80 / 1.30 at nb 64, profiles/r05_tsqr_rank_step_latency.txt)
+                                                                  # (rank step 1.59 / 1.18 ms against 1.80 / 1.30 at nb 64, profiles/r06_tsqr_rank_step_latency.txt)
         desc = f"C4: tall-skinny 262144x256 fp64 TSQR, row-block sharded over {world} GPU(s)"
     elif wl == "c5":
         m_local, n, nb = 2097152 // world, 512, args.nb or 128
@@ -449,12 +449,12 @@ def main():
         except Exception:
             measured = None
     # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 counter passes cannot share a process with the
-    # timed region, and crash on CU-masked streams on this pool).  The committed round-5 PMC pass (profiles/r05_pmc_traffic.json,
+    # timed region, and crash on CU-masked streams on this pool).  The committed round-6 PMC pass (profiles/r06_pmc_traffic.json,
     # devtools/rounds/r5/scripts_r5_pmc.sh: the same kernel, shapes of every 8th C3 step, no CU masks) is quoted under its own key with
     # ITS algorithmic bytes, and `traffic` itself only when that file was made for this block size; otherwise null.
     traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))
     except Exception:
         tj = None
     gen = 2
@@ -465,7 +465,7 @@ def main():
         if tj and wl == "c3" and nb == tj.get("nb") and gen == 2 and "gemm_nt_kernel" in tj:
             e = tj["gemm_nt_kernel"]                    # (key kept from round 3: the entry is the update kernel of the pass, now gemm_nt4_kernel)
             traffic = e["hbm_bytes_per_launch"]
-            traffic_src = {"file": "profiles/r05_pmc_traffic.json", "git_head_of_pass": tj.get("git_head"),
+            traffic_src = {"file": "profiles/r06_pmc_traffic.json", "git_head_of_pass": tj.get("git_head"),
                            "launch_mix": tj.get("config"),
                            "algorithmic_bytes_per_launch_same_mix": e["algorithmic_bytes_per_launch"],
                            "ratio_traffic_to_algorithmic": e["ratio"],
@@ -479,10 +479,10 @@ def main():
         rocprof_ref = None
         try:
             import csv
-            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_bench_c3_kernel_stats.csv"))):
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_bench_c3_kernel_stats.csv"))):
                 if wl == "c3" and row["Name"].startswith("void gemm_nt4_kernel<true, 0, 8, 3>"):
                     ns = float(row["AverageNs"])
-                    rocprof_ref = {"file": "profiles/r05_bench_c3_kernel_stats.csv", "calls": int(row["Calls"]), "avg_launch_ms": ns * 1e-6,
+                    rocprof_ref = {"file": "profiles/r06_bench_c3_kernel_stats.csv", "calls": int(row["Calls"]), "avg_launch_ms": ns * 1e-6,
                                    "achieved_at_that_duration": (upd["flops"] / upd["launches"]) / (ns * 1e-9) / 1e12,
                                    "note": "same command under rocprofv3 (committed); the launch mix per step is the one timed here"}
         except Exception:
@@ -507,7 +507,7 @@ def main():
                 # chip, as the contract asks): what the kernel itself leaves on the table, apart from the schedule's CU partition
                 "cus": cus_u,
                 "frac_of_cus_used": (ach / (FP64_MATRIX_PEAK_TFLOPS * cus_u / float(qr.device_info()["compute_units"] or 256))) if cus_u else None,
-                "rocprof_pmc": "profiles/r05_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel, whole chip: rocprofv3 --pmc crashes on CU-masked streams on this pool)",
+                "rocprof_pmc": "profiles/r06_pmc_mfma_lds_util.txt (MfmaUtil, LdsUtil, LdsBankConflict of the same kernel, whole chip: rocprofv3 --pmc crashes on CU-masked streams on this pool)",
                 "ceiling": "profiles/r05_nt_ceiling.txt (same launch mix with the C traffic / the operand loads compiled out: 58.9 / 61.4 TFLOP/s in situ bound any K = 256 kernel on 224 CUs)",
                 "measured_probe": measured,
                 "rocprofv3_same_kernel": rocprof_ref,
@@ -539,19 +539,19 @@ def main():
         ptraffic, psrc = None, None
         try:
             # round 4: a 262144-row, 128-column panel takes the full-width route (qr_panel_cqr.hip): PMC passes over one such panel
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_panel_hbm.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_panel_hbm.json")))
             if m_local == pj["mk"] and nb == pj["w"]:
                 ptraffic = pj["hbm_bytes_per_panel"]
-                psrc = {"file": "profiles/r05_pmc_panel_hbm.json", "covers": pj["covers"], "method": pj["method"] + "; replayed from the committed file"}
+                psrc = {"file": "profiles/r06_pmc_panel_hbm.json", "covers": pj["covers"], "method": pj["method"] + "; replayed from the committed file"}
         except Exception:
             pass
         # whole-factorisation HBM bytes of this shape (every dispatch: leaf kernels, in-panel products and updates, outer updates),
         # PMC passes of devtools/rounds/r4/scripts_r4_pmc.sh -- replayed, not measured in this run
         whole = None
         try:
-            wj = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_tsqr_total_traffic.json")))
+            wj = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_tsqr_total_traffic.json")))
             if m_local == wj["m"] and n == wj["n"]:
-                whole = {"file": "profiles/r05_pmc_tsqr_total_traffic.json", "hbm_bytes_per_factorisation": wj["hbm_bytes_per_factorisation"],
+                whole = {"file": "profiles/r06_pmc_tsqr_total_traffic.json", "hbm_bytes_per_factorisation": wj["hbm_bytes_per_factorisation"],
                          "algorithmic_bytes_16mn": wj["algorithmic_bytes_16mn"], "ratio": wj["ratio"],
                          "achieved_GBps_whole_step": wj["hbm_bytes_per_factorisation"] / (dt / K) / 1e9}
         except Exception:

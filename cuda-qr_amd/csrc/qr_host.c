@@ -836,7 +836,8 @@ static int panel_cqr_half(qr_plan* p, double* Ah, int lda, int mkh, int wh, doub
     int st[4] = {0, 0, 0, 0};
     CHECK(qrd_d2h(p->stream, st, p->cq_status, sizeof st));
     CHECK(qrd_stream_sync(p->stream));
-    if (st[0]) p->n_cqr_refused += 1;
+    if (st[0] && !retried) p->n_cqr_refused += 1;          /* (a retried panel's first refusal has been counted) */
+    if (!st[0] && retried) p->n_cqr_retry_ok += 1;
     return st[0] != 0;
 }
 
@@ -2361,13 +2362,17 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
             return QR_E_ARG;                 /* (shards of unequal height are fine: the schedule of the exchange does not depend on them) */
     const int n = tps[0]->n;
     {
-        /* P ranks on ONE device are 2 P streams, each of which may hold a one-launch panel (up to 33 co-resident workgroups, a compute unit
-         * each): beyond the chip's compute units two such launches can each sit on part of the chip and wait for workgroups the other one
+        /* P ranks on ONE device are 2 P streams, each of which may hold a one-launch panel (up to 33 -- 65 between 4097 and 8192 rows --
+         * co-resident workgroups, a compute unit each): beyond the chip's compute units two such launches can each sit on part of the chip and wait for workgroups the other one
          * keeps out -- until the hand-off times out (QR_E_STALL).  A real rank has the chip to itself (2 streams); here the launch chain is
          * used instead once the streams could crowd each other. */
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
-        if (2 * P * 33 > cus)
+        /* (round 6: a one-launch panel of more than 4096 rows may be dealt out in 128-row workgroups: up to 65 of them) */
+        int tallest = tps[0]->sm;
+        for (int r = 0; r < P; ++r) if (tps[r]->m_local > tallest) tallest = tps[r]->m_local;
+        const int per_launch = (tallest > 4096 && tallest <= 8192) ? 65 : 33;
+        if (2 * P * per_launch > cus)
             for (int r = 0; r < P; ++r) { tps[r]->p->fused_off = 1; if (tps[r]->p2) tps[r]->p2->fused_off = 1; }
     }
     for (int pi = 0; pi < tps[0]->npan; ++pi) {

@@ -220,17 +220,39 @@ static void defaults_from_env_locked(void)
     }
 }
 
+/* Does the look-ahead schedule (two streams, CU partition) pay for an m x n problem at block size nb?  Measured rule (round 6, after the
+ * one-launch panel moved to 128-row workgroups: profiles/r06_block_size_lookahead_rule.txt, 40 shapes x 3 block sizes x on / off):
+ *  - there has to be a wide update worth a stream of its own: n >= 2048 and m n >= 8 M (3072^2 6.31 -> 5.95 ms, 4096 x 2048 3.98 -> 3.80;
+ *    2560^2 and below: the single-stream schedule at nb = 64 wins), never for m >= 16 n (panel and update both HBM-bound there);
+ *  - the panel stream has 32 compute units: a panel of <= 8192 rows is one launch that fits them, a taller one is a chain of launches that
+ *    wants the whole chip, and the overlap only pays for it when the update is long enough -- m <= n^2 / 800 at nb = 256 (16384 x 4096
+ *    equal, 24576 x 4096 25.4 -> 24.1 but 23.3 single-stream at nb = 128; 12288 x 2048 6.43 single-stream against 7.14; 65536 x 8192
+ *    168.2 -> 164.3), m <= 2 n at nb = 128 (32768 x 8192: 90.1 single-stream against 94.3);
+ *  - narrow blocks (nb < 128): the round-2 rule, 18 M elements (4096^2 at nb = 64: 9.50 single-stream against 9.67). */
+static int lookahead_pays(long long m, long long n, int nb)
+{
+    if (n < 2048 || m >= 16 * n) return 0;
+    if (nb < 128) return m * n >= 18000000LL;
+    if (m * n < 8000000LL) return 0;
+    if (m <= 8192) return 1;
+    return nb >= 256 ? 800 * m <= n * n : m <= 2 * n;
+}
+
 /* the block sizes a plan for an m x n problem gets when the caller passes nb = 0 / ib = 0 */
 static void default_blocks(int m, int n, int* nb, int* ib)
 {
     pthread_mutex_lock(&g_lock);
     defaults_from_env_locked();
     int b = g_nb;
-    /* large problems are update-bound: K = 256 lifts the update GEMMs (C3: 155 -> 151 ms in round 1).  With the round-2 leaf the
-     * same holds for every square-ish problem from 1024 columns on -- half as many panel tails (T merge, look-ahead update) for
-     * the same leaves: 4096^2 12.1 -> 11.5 ms, 2048^2 5.9 -> 5.6, 12288 x 8192 41.9 -> 39.2 -- while tall shapes keep 128
-     * (16384 x 2048: 9.0 against 9.9 ms; 8192 x 4096: 13.8 against 14.0); profiles/r02_session2_ab_measurements.txt */
-    if (!g_nb_explicit && 256 % g_ib == 0 && (n >= 8192 || (n >= 1024 && 2LL * m <= 3LL * n))) b = 256;
+    /* (same measurement as lookahead_pays.)  Wherever the look-ahead schedule pays it pays most at nb = 256: K = 256 lifts the update
+     * GEMMs and halves the number of panel tails; so do problems of 8192 columns and more whatever their height.  Small square-ish
+     * problems run single-stream and are all panel: 64-column panels are two leaves whose T is merged inside the panel's one launch,
+     * and the update GEMMs are too small for K to matter (2048^2: 3.65 ms at nb 64, 3.91 at 128, 4.04 at 256; 1024^2 1.83 / 1.98 / 2.08;
+     * 2048 x 1024 1.67 / 1.82 / 1.82; from m = 4 n on 128 is as good or better).  Tall shapes keep 128 (16384 x 2048: 6.95 against 7.78). */
+    if (!g_nb_explicit) {
+        if (256 % g_ib == 0 && (n >= 8192 || lookahead_pays(m, n, 256))) b = 256;
+        else if (64 % g_ib == 0 && n >= 512 && (long long) m <= 3LL * n) b = 64;
+    }
     if (nb) *nb = b;
     if (ib) *ib = g_ib;
     pthread_mutex_unlock(&g_lock);
@@ -342,15 +364,9 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
     p->ldv = (m + 15) & ~15;
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
-    /* Look-ahead (two streams, CU partition) pays where there is a wide update worth overlapping: from 2048 columns and ~18 M
-     * elements on, and not for very tall shapes (m >= 16 n: panel and update are both HBM-bound there, side by side they only
-     * slow each other: 262144 x 512 7.38 vs 7.22 ms, 65536 x 2048 20.5 vs 19.0).  Below that the single-stream schedule
-     * is 5-10 % faster (2048^2 5.46 -> 4.93 ms, 3072^2 8.4 -> 7.9, 4096 x 1024 2.90 -> 2.65; equal at 4096^2;
-     * profiles/r02_session2_ab_measurements.txt section 12) */
-    /* Round 6 (one-launch panels on 128-row workgroups): 4096^2 now gains too where the block is wide enough for the update to be worth a
-     * stream of its own -- nb 256: 9.26 -> 8.46 ms, nb 128: 9.47 -> 9.15, nb 64: 10.57 -> 10.69 (profiles/r06_lookahead_threshold.txt) */
-    p->lookahead = tsqr_local ? 0 : (la ? atoi(la) != 0 : (n >= 2048 && (long long) m < 16LL * n &&
-                                     ((long long) m * n >= 18000000LL || ((long long) m * n >= 16000000LL && nb >= 128))));
+    /* Look-ahead (two streams, CU partition): where lookahead_pays() says so; MI355XQR_LOOKAHEAD = 0 / 1 decides instead.  (History of the
+     * rule: profiles/r02_session2_ab_measurements.txt section 12, profiles/r06_lookahead_threshold.txt, profiles/r06_block_size_lookahead_rule.txt) */
+    p->lookahead = tsqr_local ? 0 : (la ? atoi(la) != 0 : lookahead_pays(m, n, nb));
     /* MI355XQR_GRAPH=1: the single-stream schedule captured once per argument set and replayed (no measured gain: the cost of a leaf is
      * the device-side kernel boundary, not the host launch).  Never with look-ahead: capturing the CU-masked two-stream schedule
      * crashes inside the runtime (round 3: segmentation fault in hipStreamEndCapture), so the knob is ignored there. */

@@ -7,6 +7,7 @@ import cuda_qr_amd as q
 
 def run(m, n, nb, ib=32, reps=2):
     p = q.Plan(m, n, nb, ib)
+    if nb == 0: nb = q.default_block_size(m, n)[0]      # MxNx0: the block size (and schedule) the library picks for the shape
     dA = torch.empty((n, m), dtype=torch.float64, device="cuda")
     dtau = torch.empty(n, dtype=torch.float64, device="cuda")
     best = None

@@ -87,8 +87,9 @@ int explicitQR_legacy_status(double* A, double* tau, double* Q, double* R, int m
 const char* qr_strerror(int status);
 
 /* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 512, above 256 a multiple of 256;
- * leaf width ib <= 32).  Defaults 128 / 32 (256 / 32 when nothing was set explicitly and n >= 8192, or n >= 1024 with
- * m <= 1.5 n: square-ish problems -- getPanelDims(m, n, ..) reports the panel grid of the block size that shape will really get);
+ * leaf width ib <= 32).  Defaults 128 / 32; when nothing was set explicitly the outer block follows the shape: 256 where the two-stream
+ * look-ahead schedule is used (n >= 2048, m n >= 8 M, not too tall) and from 8192 columns on, 64 for small square-ish problems
+ * (n >= 512, m <= 3 n) -- qr_default_block_size / getPanelDims(m, n, ..) report what that shape will really get;
  * env MI355XQR_NB / MI355XQR_IB override the defaults.
  * Threading: the library may be used from one host thread per GPU (each thread with its own current device and its own
  * plans; a plan belongs to one thread at a time).  Process-wide state (these defaults, per-device kernel attributes, the

@@ -436,7 +436,7 @@ def test_profile_hooks(qr):
     p.set_profile(True)
     p.geqrf(dA, m, n, m, dtau)
     prof = p.get_profile()
-    nb = qr.get_block_size()[0]
+    nb = qr.default_block_size(m, n)[0]
     assert 1 <= prof["update_nn"]["launches"] <= n // nb - 1 and prof["panel"]["launches"] == n // nb
     assert prof["update_nn"]["ms"] > 0 and prof["update_nn"]["flops"] > 0
     assert prof["update_nn"]["flops"] == prof["vta_tn"]["flops"]
@@ -496,10 +496,10 @@ def test_qr_device_cli_like_reference_harness(qr):
     assert (v and 0.0 < float(v.group(1)) < 5.0) or "rocSOLVER not" in out
 
 
-@pytest.mark.parametrize("m,n", [(1024, 1024), (2048, 2048), (1536, 1100)])
-def test_dropin_roundtrip_where_the_default_block_is_256(qr, oracle, m, n):
-    """mmqr -> explicitQR through the host-pointer ABI on shapes that get nb = 256 by default (square-ish, >= 1024 columns) while
-    the global default stays 128: tau must carry all n scalars (it is sized from the block size the SHAPE gets) or explicitQR
+@pytest.mark.parametrize("m,n", [(1024, 1024), (2048, 2048), (1536, 1100), (3072, 3072)])
+def test_dropin_roundtrip_where_the_default_block_is_not_the_global_one(qr, oracle, m, n):
+    """mmqr -> explicitQR through the host-pointer ABI on shapes that get nb = 64 (small square-ish problems) or 256 (where the look-ahead
+    schedule pays) by default while the global default stays 128: tau must carry all n scalars (it is sized from the block size the SHAPE gets) or explicitQR
     reads past it and returns a wrong Q."""
     rng = np.random.default_rng(m + n)
     A = rng.random((m, n))

@@ -31,9 +31,11 @@ def test_host_only_helpers(qr, capfd):
     assert np.array_equal(I, np.eye(5))
     nb, ib = qr.get_block_size()
     assert qr.get_panel_dims(512, 128) == (1, -(-128 // nb))
-    assert qr.get_panel_dims(8192, 4096) == (1, -(-4096 // nb))              # tall: the default block
-    assert qr.get_panel_dims(4096, 4096) == (1, 4096 // 256)                 # square-ish from 1024 columns on: 256 (what mmqr really uses)
-    assert qr.get_panel_dims(32768, 8192) == (1, 8192 // 256)
+    assert qr.get_panel_dims(16384, 2048) == (1, -(-2048 // nb))             # tall: the default block
+    assert qr.get_panel_dims(4096, 4096) == (1, 4096 // 256)                 # wherever the look-ahead schedule pays: 256 (what mmqr really uses)
+    assert qr.get_panel_dims(8192, 4096) == (1, 4096 // 256)
+    assert qr.get_panel_dims(32768, 8192) == (1, 8192 // 256)                # and from 8192 columns on
+    assert qr.get_panel_dims(2048, 2048) == (1, 2048 // 64)                  # small square-ish problems (single stream, all panel): 64
     A = np.asfortranarray(np.arange(6, dtype=np.float64).reshape(2, 3))
     qr.lib.printMat(A.ctypes.data_as(C.POINTER(C.c_double)), 2, 3)   # qr.c:21-33 format
     C.CDLL(None).fflush(None)
@@ -118,15 +120,17 @@ def test_tsqr_plan_argument_checks(qr):
 
 
 def test_default_block_size_sizes_tau(qr):
-    """mmqr's tau has rowPanels*colPanels*nb entries of the block size THAT SHAPE gets (256 for square-ish problems from 1024
-    columns on), not of the global default: the Python wrapper and C callers size it through qr_default_block_size."""
+    """mmqr's tau has rowPanels*colPanels*nb entries of the block size THAT SHAPE gets (256 where the look-ahead schedule pays, 64 for
+    small square-ish problems), not of the global default: the Python wrapper and C callers size it through qr_default_block_size."""
     # in a fresh process: an earlier qr_set_block_size (test_block_size_validation) pins nb for the rest of this one
     code = ("import sys; sys.path.insert(0, %r); import cuda_qr_amd as qr\n"
             "g = qr.get_block_size()[0]\n"
             "assert qr.default_block_size(512, 128)[0] == g\n"
-            "assert qr.default_block_size(1024, 1024)[0] == 256 and qr.tau_len(1024, 1024) == 1024\n"
+            "assert qr.default_block_size(1024, 1024)[0] == 64 and qr.tau_len(1024, 1024) == 1024\n"
+            "assert qr.default_block_size(4096, 4096)[0] == 256 and qr.default_block_size(3072, 3072)[0] == 256\n"
+            "assert qr.default_block_size(2560, 2560)[0] == 64 and qr.default_block_size(16384, 2048)[0] == g\n"
             "assert qr.default_block_size(8192, 1024)[0] == g\n"
-            "assert qr.tau_len(2048, 2048) == 2048 and qr.tau_len(1300, 1100) == 1280\n"
+            "assert qr.tau_len(2048, 2048) == 2048 and qr.tau_len(1300, 1100) == 1152\n"
             "assert qr.lib.qr_default_block_size(4, 8, None, None) == -101\n"
             "qr.set_block_size(64, 32)\n"
             "assert qr.default_block_size(4096, 4096)[0] == 64 and qr.tau_len(1000, 100) == 128\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -157,6 +157,7 @@ int qrd_device_count(int* n);
 int qrd_set_device(int d);
 int qrd_get_device(int* d);
 int qrd_stream_cus(void* s);
+int qrd_stream_cus_coresident(void* s);   /* ... that a launch of workgroups waiting for each other may count on (whole multiples of 32 of a mask) */
 /* one 32-bit word of pinned host memory mapped into the device (kernels publish small verdicts into it with system scope) */
 int qrd_host_word_alloc(unsigned** host, unsigned** dev);
 int qrd_host_word_free(unsigned* host);

@@ -33,7 +33,8 @@
 /* large square problems are update-bound for most of their flops: 32 CUs for the panel chain, 224 for the wide update, and the
  * look-ahead update N(s) on the update stream in the chain-bound phase (it would crawl on 32 CUs).  Measured at 16384^2: 125.6 ms
  * against 131.8 with 64 / 192 (the update GEMMs run at 50 instead of 43 TFLOP/s per launch); at 8192^2 and below the chain
- * dominates and 64 CUs are faster.  A mask bit i is compute unit i/8 of XCC i%8 (profiles/r02_probe_cumask.txt): a contiguous
+ * dominated and 64 CUs were faster (round 6, with the one-launch panel on 128-row workgroups: 8192^2 23.5 -> 23.0 ms with 32, 6144^2
+ * equal, 16384 x 8192 46.3 against 47.7 and 8192 x 4096 9.4 against 10.1 still want 64: profiles/r06_cu_split_by_shape.txt).  A mask bit i is compute unit i/8 of XCC i%8 (profiles/r02_probe_cumask.txt): a contiguous
  * range of 32 bits = 4 CUs of every XCD, so both streams stay balanced over the XCDs; a 48 / 208 split was measured 15 % slower. */
 #define QR_DEFAULT_SPLIT_BIG "32"
 struct qr_plan {
@@ -252,6 +253,10 @@ static void default_blocks(int m, int n, int* nb, int* ib)
     if (!g_nb_explicit) {
         if (256 % g_ib == 0 && (n >= 8192 || lookahead_pays(m, n, 256))) b = 256;
         else if (64 % g_ib == 0 && n >= 512 && (long long) m <= 3LL * n) b = 64;
+        /* taller than that but still one-launch panels all the way (m <= 8192): fewer, wider panels -- 8192 x 512 0.99 -> 0.95 ms,
+         * 4096 x 512 0.87 -> 0.83, 8192 x 1024 2.20 -> 2.10; beyond 8192 rows the 128-column full-width panel route wants 128
+         * (65536 x 512: 1.89 against 2.59 at 256 and 2.54 at 64) */
+        else if (256 % g_ib == 0 && n >= 512 && m <= 8192) b = 256;
     }
     if (nb) *nb = b;
     if (ib) *ib = g_ib;
@@ -402,7 +407,7 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         const char* sp = getenv("MI355XQR_SPLIT");
         char spec[128];
         if (sp) snprintf(spec, sizeof spec, "%s", sp);
-        else snprintf(spec, sizeof spec, "%s", n >= 2048 ? ((m >= 10240 && n >= 10240) ? QR_DEFAULT_SPLIT_BIG : QR_DEFAULT_SPLIT) : "0");
+        else snprintf(spec, sizeof spec, "%s", n >= 2048 ? (((m >= 10240 && n >= 10240) || (n >= 8192 && 4LL * m <= 5LL * n)) ? QR_DEFAULT_SPLIT_BIG : QR_DEFAULT_SPLIT) : "0");
         int cus = 256;
         qrd_device_info(NULL, 0, &cus, NULL, NULL);
         char* save = NULL;
@@ -1078,6 +1083,8 @@ static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int ld
         CHECK(prof_end(p, 4.0 * mk * (double) nc * wout, 24.0 * mk * (double) nc + 16.0 * mk * wout));
         return 0;
     }
+    /* (round 6: small wide updates -- 512^2 ... 4096^2 at nb 64 / 128 -- through the T-folded reduction instead, three launches and no V*T:
+     * within 0.5 % at every threshold; these updates are not launch-bound.  profiles/NOTES.md) */
     if (profile == 1 && qrd_gemm_nt_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda)) {
         /* second-generation wide update: W kept transposed (Wt = A2^T (V T), nc x wout), so that both operands of
          * A2 -= V Wt^T are row-fast and go HBM -> LDS directly (qr_gemm_nt.hip) */
@@ -2059,7 +2066,7 @@ static int tsqr_plan_build(qr_tsqr_plan** out, void* comm, int own_comm, int nra
     if (!rc) rc = qrd_malloc((void**) &t->dtau, sizeof(double) * n);
     if (!rc) rc = qrd_malloc((void**) &t->dRp, sizeof(double) * nn);
     if (!rc && nranks > 1) {
-        rc = qr_plan_create(&t->p2, t->sm, n, nb, 0);
+        rc = qr_plan_create(&t->p2, t->sm, n, t->p->nb, t->p->ib);     /* the local plan's blocks: the pipelined exchange walks both panel by panel */
         if (!rc) rc = qrd_malloc((void**) &t->dtau2, sizeof(double) * n);
         if (!rc) rc = qrd_malloc((void**) &t->dRall, sizeof(double) * nn * nranks);
         if (!rc) rc = qrd_malloc((void**) &t->dS, sizeof(double) * (size_t) t->sm * n);

@@ -1500,7 +1500,7 @@ static int pf_rows_for(void* stream, int mk, int wh, int want = 0)
 {
     static const int env = QRD_LAB_ENV_INT("MI355XQR_PF_ROWS", 0);
     const int forced = want ? want : env;
-    int cus = qrd_stream_cus(stream) - 1;
+    int cus = qrd_stream_cus_coresident(stream) - 1;
     if (cus > PF_MAXWG) cus = PF_MAXWG;
     if (mk > 8192) return 0;
     const int n128 = (mk + 127) / 128, n256 = (mk + 255) / 256;

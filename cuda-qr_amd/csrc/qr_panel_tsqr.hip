@@ -1903,14 +1903,14 @@ static int panel_tsqr_impl(void* stream, double* P, int ld, int mk, int w, doubl
             // participants: the launch is a no-op nearly always, and what a no-op costs is dispatching its workgroups (140 KB of LDS
             // each) -- 64 are gone in ~5 us; on the guard route they walk their blocks grid-stride
             static const int gcap = 64;
-            int G = qrd_stream_cus(stream);
+            int G = qrd_stream_cus_coresident(stream);
             if (G > gcap) G = gcap;
             if (G > t.nblk0) G = t.nblk0;
             if (G < 1) G = 1;
             const int fblocks = (mk + PT - 1) / PT;
             // (final3 as its own launch measured equal within noise at 65536 / 131072 rows: 1.04 / 1.46 ms against 1.03 / 1.43 fused)
             static const int fuse_tall = 1;
-            if (fuse_tall && fblocks <= qrd_stream_cus(stream))
+            if (fuse_tall && fblocks <= qrd_stream_cus_coresident(stream))
                 hipLaunchKernelGGL(final3_coop_tall_kernel, dim3(fblocks > G ? fblocks : G), dim3(PT), ep_shm, s, final3_u, t, G, mk, w, Vloc1, Vup,
                                    taus, Ts, stacks, Cup, Rt, Umat, P, ld, tau, T, ldt, Vw, ldv, bar, guard, ep ? 1 : 0, epw, ep0);
             else {

@@ -89,7 +89,7 @@ const char* qr_strerror(int status);
 /* Block sizes used by the drop-in entry points (outer compact-WY block nb: multiple of ib, <= 512, above 256 a multiple of 256;
  * leaf width ib <= 32).  Defaults 128 / 32; when nothing was set explicitly the outer block follows the shape: 256 where the two-stream
  * look-ahead schedule is used (n >= 2048, m n >= 8 M, not too tall) and from 8192 columns on, 64 for small square-ish problems
- * (n >= 512, m <= 3 n) -- qr_default_block_size / getPanelDims(m, n, ..) report what that shape will really get;
+ * (n >= 512, m <= 3 n), 256 for taller ones of at most 8192 rows -- qr_default_block_size / getPanelDims(m, n, ..) report what that shape will really get;
  * env MI355XQR_NB / MI355XQR_IB override the defaults.
  * Threading: the library may be used from one host thread per GPU (each thread with its own current device and its own
  * plans; a plan belongs to one thread at a time).  Process-wide state (these defaults, per-device kernel attributes, the

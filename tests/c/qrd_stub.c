@@ -104,6 +104,7 @@ int qrd_stream_create(void** s, int hp) { (void) hp; stub_stream* x = calloc(1, 
 int qrd_stream_create_cumask(void** s, int first, int count) { (void) first; stub_stream* x = calloc(1, sizeof *x); if (!x) return 2; x->cus = count; *s = x; return 0; }
 int qrd_stream_destroy(void* s) { free(s); return 0; }
 int qrd_stream_cus(void* s) { return s ? ((stub_stream*) s)->cus : 256; }
+int qrd_stream_cus_coresident(void* s) { const int c = qrd_stream_cus(s); return c >= 32 ? c / 32 * 32 : c / 2; }
 int qrd_stream_sync(void* s) { (void) s; return 0; }
 int qrd_device_sync(void) { return 0; }
 int qrd_capture_begin(void* s) { (void) s; return 0; }

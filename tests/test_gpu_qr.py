@@ -315,6 +315,23 @@ def test_lookahead_matches_sequential_schedule(qr, oracle):
     assert rel(oracle.sign_normalise(outs[0]), oracle.sign_normalise(outs[1])) < 1e-13
 
 
+def test_cu_split_that_is_not_a_multiple_of_32(qr, oracle):
+    """MI355XQR_SPLIT=48: the dispatcher deals workgroups evenly over the shader engines whatever the mask says, so the one-launch panel
+    (workgroups waiting for each other) may only count on whole multiples of 32 of a mask (qrd_stream_cus_coresident); before, its hand-off
+    timed out on a 6144-row panel (status -105).  Same R as the single-stream schedule."""
+    import subprocess, sys, os
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import cuda_qr_amd as q;"
+            "m,n=6144,2048; p=q.Plan(m,n,256,32); A=torch.empty((n,m),dtype=torch.float64,device='cuda');"
+            "t=torch.empty(n,dtype=torch.float64,device='cuda'); p.fill_uniform(A,m,m,n,seed=5); p.geqrf(A,m,n,m,t); p.sync();"
+            "R=np.triu(A.cpu().numpy().T[:n]); np.save(sys.argv[1], R)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_add in ({"MI355XQR_LOOKAHEAD": "1", "MI355XQR_SPLIT": "48"}, {"MI355XQR_LOOKAHEAD": "0"}):
+        path = "/tmp/split48_%d.npy" % len(outs)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env_add), timeout=300)
+        outs.append(np.load(path))
+    assert rel(oracle.sign_normalise(outs[0]), oracle.sign_normalise(outs[1])) < 1e-13
+
+
 def test_tsqr_backend_pipelined_stack_factor(qr, oracle):
     """HipBackend.stack_factor(wait=False) leaves the stacked QR queued on its own plan while the next local QR runs
     (bench.py's pipelined TSQR steps): same R as the synchronous call."""

@@ -129,7 +129,7 @@ def test_default_block_size_sizes_tau(qr):
             "assert qr.default_block_size(1024, 1024)[0] == 64 and qr.tau_len(1024, 1024) == 1024\n"
             "assert qr.default_block_size(4096, 4096)[0] == 256 and qr.default_block_size(3072, 3072)[0] == 256\n"
             "assert qr.default_block_size(2560, 2560)[0] == 64 and qr.default_block_size(16384, 2048)[0] == g\n"
-            "assert qr.default_block_size(8192, 1024)[0] == g\n"
+            "assert qr.default_block_size(8192, 1024)[0] == 256 and qr.default_block_size(16384, 1024)[0] == g\n"
             "assert qr.tau_len(2048, 2048) == 2048 and qr.tau_len(1300, 1100) == 1152\n"
             "assert qr.lib.qr_default_block_size(4, 8, None, None) == -101\n"
             "qr.set_block_size(64, 32)\n"

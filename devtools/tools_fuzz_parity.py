@@ -15,6 +15,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "ragged":        # odd sizes: ragged til
 if len(sys.argv) > 2 and sys.argv[2] == "edges":         # shapes next to the thresholds of the default rules (block size, look-ahead, partition)
     shapes = [(1536, 1024, 0), (1537, 1024, 0), (1024, 1023, 0), (4243, 4243, 0), (4242, 4242, 0), (32768, 2048, 0), (32767, 2048, 0),
               (10240, 10240, 0), (10239, 10239, 0), (16385, 16384, 0), (8192, 8192, 0), (16384, 1024, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "edges6":        # ... of the round-6 rules (qr_host.c: lookahead_pays, default_blocks, the 32-CU split from 8192^2)
+    shapes = [(2828, 2828, 0), (2829, 2829, 0), (3072, 1024, 0), (3073, 1024, 0), (8192, 2048, 0), (8193, 2048, 0), (8193, 4097, 0),
+              (20480, 4096, 0), (21000, 4096, 0), (1024, 512, 0), (1024, 511, 0), (1537, 512, 0), (8192, 8191, 0), (10241, 8192, 0),
+              (8192, 512, 0), (8193, 512, 0), (4001, 2000, 0), (6143, 2049, 0), (2047, 2047, 0), (777, 555, 0)]
 worst = 0.0
 for (m, n, nb) in shapes:
     kind = rng.integers(0, 3)

@@ -315,6 +315,24 @@ def test_lookahead_matches_sequential_schedule(qr, oracle):
     assert rel(oracle.sign_normalise(outs[0]), oracle.sign_normalise(outs[1])) < 1e-13
 
 
+@pytest.mark.parametrize("m,n", [(2829, 2829), (2828, 2828), (3073, 1024), (8193, 2048), (8192, 2048), (1024, 511), (8192, 512), (777, 555)])
+def test_shapes_next_to_the_block_size_and_schedule_thresholds(qr, oracle, m, n):
+    """The library's own choice of block size and schedule (nb = 0: qr_host.c lookahead_pays / default_blocks, measured rule of round 6) on
+    shapes either side of its thresholds -- 8 M elements, m = 3 n, 8192 rows, 512 columns -- and ragged ones: sign-normalised R against
+    LAPACK, residual through the device API (more shapes: devtools/tools_fuzz_parity.py 6 edges6)."""
+    rng = np.random.default_rng(m * 31 + n)
+    A = rng.random((m, n))
+    p = qr.Plan(m, n, 0, 0)
+    dA, dtau, dR = dev(A), zeros(n, 1), zeros(n, n)
+    p.geqrf(dA, m, n, m, dtau); p.extract_r(dA, m, n, m, dR, n, n); p.sync()
+    assert rel(oracle.sign_normalise(host(dR)), oracle.sign_normalise(np.linalg.qr(A, mode="r"))) < 1e-13
+    dQ, dQR = zeros(m, n), zeros(m, n)
+    p.applyq(dA, m, n, m, dtau, dQ, n, m, True)
+    p.gemm("N", m, n, n, 1.0, dQ, m, dR, n, 0.0, dQR, m); p.sync()
+    assert np.linalg.norm(host(dQR) - A) / np.linalg.norm(A) < 1e-13
+    p.close()
+
+
 def test_cu_split_that_is_not_a_multiple_of_32(qr, oracle):
     """MI355XQR_SPLIT=48: the dispatcher deals workgroups evenly over the shader engines whatever the mask says, so the one-launch panel
     (workgroups waiting for each other) may only count on whole multiples of 32 of a mask (qrd_stream_cus_coresident); before, its hand-off

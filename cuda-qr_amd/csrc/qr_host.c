@@ -146,6 +146,7 @@ typedef struct qr_knobs {
                                                              * against 8.7): there the round-4 threshold stays */
     int tall_nt;                                            /* MI355XQR_TALL_NT: the update of a tall block through gemm_nt (W transposed first) */
     int cqr_park;                                           /* MI355XQR_CQR_PARK: full-width panels of tall single-stream plans write V once (into A) */
+    int cqr_min_rows_la;                                    /* MI355XQR_CQR_MIN_ROWS_LA (lab): the same threshold on look-ahead plans (QR_CQR_MIN_ROWS_LOOKAHEAD) */
     int cqr_retry;                                          /* MI355XQR_CQR_RETRY (lab): a refused full-width panel is retried preconditioned (shifted CholeskyQR3) before the leaf chain */
     int trsm_next;                                          /* MI355XQR_TRSM (lab): the look-ahead update behind a deferred merge without the merged T (qrd_trsm_gt) */
     int defer_t;                                            /* MI355XQR_DEFER_T (lab): a one-launch panel's Gram matrix + T merge on the update stream in the chain-bound phase */
@@ -195,6 +196,7 @@ static void knobs_init(void)
                                                                 * takes the columns of V_prev along) instead of one launch pair behind it.  At 256 columns the extra product
                                                                 * columns cost what the launch pair does (profiles/r04_fused_ab.txt); at 64-128 they are a tile or six */
     k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
+    k->cqr_min_rows_la = lab_env_int("MI355XQR_CQR_MIN_ROWS_LA", 196608);   /* = QR_CQR_MIN_ROWS_LOOKAHEAD: see plan_cqr_min_rows */
     k->tall_nt = lab_env_int("MI355XQR_TALL_NT", 1) != 0;
     k->cqr_park = lab_env_int("MI355XQR_CQR_PARK", 1) != 0;
     k->defer_t = lab_env_int("MI355XQR_DEFER_T", 1) != 0;
@@ -335,12 +337,17 @@ static inline void cpu_relax(void)
 #endif
 }
 
-/* rows from which a 128-column panel of this plan takes the full-width route (knob comment above) */
+/* rows from which a 128-column panel of this plan takes the full-width route (knob comment above).  On look-ahead plans: round 4's
+ * threshold.  Re-measured in round 6 (profiles/NOTES.md, r6_run27.sh): at nb 128 the full-width route on the 32 / 64-CU panel stream is
+ * 25-30 % faster per tall panel than the leaf chain (16384 x 8192 51.3 -> 48.5 ms, 16384^2 128.3 -> 127.2) -- but those shapes run at
+ * nb 256 (45.9 / 114-116 ms), whose 256-column panels the 128-column route does not take; factoring them as two 128-column halves is
+ * worth an estimated 0.7 ms at C3 (the update-bound phase returns 12 % of what a panel saves) and was not built. */
 #define QR_CQR_MIN_ROWS_LOOKAHEAD 196608
 static int plan_cqr_min_rows(const qr_plan* p)
 {
     const int r = knobs()->cqr_min_rows;
-    return (p->lookahead && r > 0 && r < QR_CQR_MIN_ROWS_LOOKAHEAD) ? QR_CQR_MIN_ROWS_LOOKAHEAD : r;
+    const int la = knobs()->cqr_min_rows_la;
+    return (p->lookahead && r > 0 && r < la) ? la : r;
 }
 
 /* ---------------------------------------------------------------------------------------------- */

@@ -135,12 +135,13 @@ typedef struct qr_knobs {
     int early_next;                                         /* MI355XQR_EARLY_NEXT */
     int plan_cache;                                         /* MI355XQR_PLAN_CACHE */
     int early_product;                                      /* MI355XQR_EP: the leaf's in-panel product in the launch of its reconstruction */
-    int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 8192 rows) in one launch */
+    int fused_panel;                                        /* MI355XQR_FUSED_PANEL: a whole outer panel (<= 16384 rows) in one launch */
     int fused_min_rows;                                     /* MI355XQR_FUSED_MIN_ROWS: ... from this many rows on */
     int tsqr_halves_rows;                                   /* MI355XQR_TSQR_HALVES (lab): stacked matrices shorter than this get their last block column in two halves */
     int cqr_min_rows;                                       /* MI355XQR_CQR_MIN_ROWS: 128-column panels of at least this many rows at full width (0 = never).  Round 4:
                                                              * 196608 (its one-workgroup kernels cost 274 us per panel); round 5 (181 us, profiles/r05_cqr_crossover.txt): everything
-                                                             * the one-launch panel cannot take (> 8192 rows) on single-stream plans -- 32768 x 256 0.73 against 0.82 ms,
+                                                             * the one-launch panel cannot take (> 8192 rows then; end of round 6: > 16384 rows, where it wins again -- 16384 x 512
+                                                             * 1.24 -> 1.14 ms, 12288 x 2048 5.89 -> 5.66 single-stream) on single-stream plans -- 32768 x 256 0.73 against 0.82 ms,
                                                              * 65536 x 256 0.93 against 0.99, 131072 x 256 1.28 against 1.35; below 8192 rows the one-launch panel wins (4096 x 512
                                                              * 1.04 against 1.20), and on the CU-masked panel stream of a look-ahead plan the leaf chain does (16384 x 2048 8.0
                                                              * against 8.7): there the round-4 threshold stays */
@@ -195,7 +196,7 @@ static void knobs_init(void)
     k->fused_gram = lab_env_int("MI355XQR_FUSED_GRAM", 128);   /* widest panel whose Gram blocks V_prev^T V_l come out of the one-launch panel itself (its in-panel product
                                                                 * takes the columns of V_prev along) instead of one launch pair behind it.  At 256 columns the extra product
                                                                 * columns cost what the launch pair does (profiles/r04_fused_ab.txt); at 64-128 they are a tile or six */
-    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 8193);
+    k->cqr_min_rows = env_int("MI355XQR_CQR_MIN_ROWS", 16385);          /* = everything the one-launch panel cannot take, see the struct comment */
     k->cqr_min_rows_la = lab_env_int("MI355XQR_CQR_MIN_ROWS_LA", 196608);   /* = QR_CQR_MIN_ROWS_LOOKAHEAD: see plan_cqr_min_rows */
     k->tall_nt = lab_env_int("MI355XQR_TALL_NT", 1) != 0;
     k->cqr_park = lab_env_int("MI355XQR_CQR_PARK", 1) != 0;
@@ -227,17 +228,19 @@ static void defaults_from_env_locked(void)
  * one-launch panel moved to 128-row workgroups: profiles/r06_block_size_lookahead_rule.txt, 40 shapes x 3 block sizes x on / off):
  *  - there has to be a wide update worth a stream of its own: n >= 2048 and m n >= 8 M (3072^2 6.31 -> 5.95 ms, 4096 x 2048 3.98 -> 3.80;
  *    2560^2 and below: the single-stream schedule at nb = 64 wins), never for m >= 16 n (panel and update both HBM-bound there);
- *  - the panel stream has 32 compute units: a panel of <= 8192 rows is one launch that fits them, a taller one is a chain of launches that
- *    wants the whole chip, and the overlap only pays for it when the update is long enough -- m <= n^2 / 800 at nb = 256 (16384 x 4096
- *    equal, 24576 x 4096 25.4 -> 24.1 but 23.3 single-stream at nb = 128; 12288 x 2048 6.43 single-stream against 7.14; 65536 x 8192
- *    168.2 -> 164.3), m <= 2 n at nb = 128 (32768 x 8192: 90.1 single-stream against 94.3);
+ *  - the panel stream has 32 or 64 compute units: a panel the one-launch kernel takes (<= 16384 rows; on 32 CUs <= 7936) fits them, a
+ *    taller one is a chain of launches that wants the whole chip, and the overlap only pays for it when the update is long enough --
+ *    m <= n^2 / 800 at nb = 256 (24576 x 4096 25.4 -> 24.1 but 23.3 single-stream at nb = 128; 65536 x 8192 168.2 -> 164.3), m <= 2 n at
+ *    nb = 128 (32768 x 8192: 90.1 single-stream against 94.3).  (The one-launch panel stopped at 8192 rows when this rule was first
+ *    measured, and so did its first clause; with 16384: 12288 x 2048 6.43 single-stream -> 5.25 two-stream, 16384 x 2048 6.95 -> 5.89,
+ *    12288 x 4096 14.8 -> 12.45, 16384 x 4096 18.1 -> 15.1: profiles/r06_panel_fused_16384_rows.txt);
  *  - narrow blocks (nb < 128): the round-2 rule, 18 M elements (4096^2 at nb = 64: 9.50 single-stream against 9.67). */
 static int lookahead_pays(long long m, long long n, int nb)
 {
     if (n < 2048 || m >= 16 * n) return 0;
     if (nb < 128) return m * n >= 18000000LL;
     if (m * n < 8000000LL) return 0;
-    if (m <= 8192) return 1;
+    if (m <= 16384) return 1;
     return nb >= 256 ? 800 * m <= n * n : m <= 2 * n;
 }
 
@@ -253,7 +256,8 @@ static void default_blocks(int m, int n, int* nb, int* ib)
      * and the update GEMMs are too small for K to matter (2048^2: 3.65 ms at nb 64, 3.91 at 128, 4.04 at 256; 1024^2 1.83 / 1.98 / 2.08;
      * 2048 x 1024 1.67 / 1.82 / 1.82; from m = 4 n on 128 is as good or better).  Tall shapes keep 128 (16384 x 2048: 6.95 against 7.78). */
     if (!g_nb_explicit) {
-        if (256 % g_ib == 0 && (n >= 8192 || lookahead_pays(m, n, 256))) b = 256;
+        /* (two-stream shapes of more than 8192 rows and fewer than 3072 columns: 128 is 2-4 % ahead -- 12288 x 2048 5.25 against 5.40 ms) */
+        if (256 % g_ib == 0 && (n >= 8192 || lookahead_pays(m, n, 256))) b = (n < 3072 && m > 8192 && lookahead_pays(m, n, 128)) ? g_nb : 256;
         else if (64 % g_ib == 0 && n >= 512 && (long long) m <= 3LL * n) b = 64;
         /* taller than that but still one-launch panels all the way (m <= 8192): fewer, wider panels -- 8192 x 512 0.99 -> 0.95 ms,
          * 4096 x 512 0.87 -> 0.83, 8192 x 1024 2.20 -> 2.10; beyond 8192 rows the 128-column full-width panel route wants 128
@@ -2394,7 +2398,7 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
             return QR_E_ARG;                 /* (shards of unequal height are fine: the schedule of the exchange does not depend on them) */
     const int n = tps[0]->n;
     {
-        /* P ranks on ONE device are 2 P streams, each of which may hold a one-launch panel (up to 33 -- 65 between 4097 and 8192 rows --
+        /* P ranks on ONE device are 2 P streams, each of which may hold a one-launch panel (up to 33 -- 65 between 4097 and 16384 rows --
          * co-resident workgroups, a compute unit each): beyond the chip's compute units two such launches can each sit on part of the chip and wait for workgroups the other one
          * keeps out -- until the hand-off times out (QR_E_STALL).  A real rank has the chip to itself (2 streams); here the launch chain is
          * used instead once the streams could crowd each other. */
@@ -2403,7 +2407,7 @@ int qr_tsqr_factor_virtual_dev(qr_tsqr_plan** tps, int P, double** dA, int lda, 
         /* (round 6: a one-launch panel of more than 4096 rows may be dealt out in 128-row workgroups: up to 65 of them) */
         int tallest = tps[0]->sm;
         for (int r = 0; r < P; ++r) if (tps[r]->m_local > tallest) tallest = tps[r]->m_local;
-        const int per_launch = (tallest > 4096 && tallest <= 8192) ? 65 : 33;
+        const int per_launch = (tallest > 4096 && tallest <= 16384) ? 65 : 33;
         if (2 * P * per_launch > cus)
             for (int r = 0; r < P; ++r) { tps[r]->p->fused_off = 1; if (tps[r]->p2) tps[r]->p2->fused_off = 1; }
     }

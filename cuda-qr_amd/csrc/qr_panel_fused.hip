@@ -1,6 +1,6 @@
 // qr_panel_fused.hip -- a whole outer panel (up to 256 columns = 8 leaves of 32) in ONE launch.
 //
-// Replaces, for panels of up to 8192 rows, the per-leaf launch sequence of qr_panel_tsqr.hip (gram32 -> cholq3 -> hr3_ep -> final4 ->
+// Replaces, for panels of up to 16384 rows (8192 until the end of round 6), the per-leaf launch sequence of qr_panel_tsqr.hip (gram32 -> cholq3 -> hr3_ep -> final4 ->
 // reduce' -> update: six dependent launches per 32 columns, each starting cold from L2 / HBM) -- the role of the reference's serial
 // one-block panel kernel (panelHouseholderKernel, qr.cu:60-333, launched at qr.cu:518; host form qr.c:109-235) plus its in-panel apply
 // (qr.c:215-235).  Same mathematics per leaf (CholeskyQR2 + Householder reconstruction, qr_leaf_math.h), different execution:
@@ -1490,7 +1490,7 @@ int qrd_panel_fused_init(void)
 }
 
 // Rows per row workgroup for a panel of mk rows x wh columns on this stream: 128 or 256; 0: the one-launch panel cannot take it (more
-// than 8192 rows, or more row workgroups than the stream has compute units beside the factor workgroup's: all must be co-resident).
+// than 16384 rows, or more row workgroups than the stream has compute units beside the factor workgroup's: all must be co-resident).
 // 128 halves a workgroup's streaming work (deferred update + in-panel product: matrix-core time on its one compute unit) and doubles
 // the partials the hand-offs sum; measured, us per panel, 256 -> 128 rows (profiles/r06_panel_fused_perf.txt): 2048 x 256 477 -> 359,
 // 4096 x 256 443 -> 359, 8192 x 256 440 -> 405, 2048 x 128 181 -> 156, 4096 x 128 175 -> 167, 8192 x 128 185 -> 194, 4096 x 64 86 -> 85,
@@ -1502,7 +1502,11 @@ static int pf_rows_for(void* stream, int mk, int wh, int want = 0)
     const int forced = want ? want : env;
     int cus = qrd_stream_cus_coresident(stream) - 1;
     if (cus > PF_MAXWG) cus = PF_MAXWG;
-    if (mk > 8192) return 0;
+    // up to PF_MAXWG row workgroups of 256 rows: 16384 rows where the stream has 65 compute units (rounds 4-6: 8192, the 32 x 256 rows of round
+    // 4's workspace -- the limit outlived it by a round; 16384 x 256 is 473 us in one launch where the leaf chain took 1.0-1.4 ms:
+    // profiles/r06_panel_fused_16384_rows.txt).  MI355XQR_PF_MAX_ROWS (lab build): the old limit for A/B runs
+    static const int max_rows = QRD_LAB_ENV_INT("MI355XQR_PF_MAX_ROWS", PF_MAXWG * 256);
+    if (mk > max_rows || mk > PF_MAXWG * 256) return 0;
     const int n128 = (mk + 127) / 128, n256 = (mk + 255) / 256;
     const bool fit128 = n128 <= cus, fit256 = n256 <= cus;
     if (forced == 128 && fit128) return 128;
@@ -1515,7 +1519,7 @@ static int pf_rows_for(void* stream, int mk, int wh, int want = 0)
 // block is taken along.  The caller then skips its merge tree (qrd_larft).
 int qrd_panel_fused_merges_t(int wh, int with_gram) { return wh == 64 && with_gram; }
 
-// 1 when the one-launch panel can take this (half-)panel: whole 32-column leaves, at most 256 columns, at most 8192 rows and a free
+// 1 when the one-launch panel can take this (half-)panel: whole 32-column leaves, at most 256 columns, at most 16384 rows and a free
 // compute unit per row workgroup on the stream, vector-aligned operands
 int qrd_panel_fused_ok(void* stream, const double* A, int lda, int mk, int wh, const double* Vw, int ldv)
 {

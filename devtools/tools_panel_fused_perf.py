@@ -21,6 +21,8 @@ ws = torch.zeros(int(lib.qrd_panel_fused_ws_doubles()), dtype=torch.float64, dev
 epoch = C.c_uint(0)
 status = torch.zeros(4, dtype=torch.int32, device="cuda")
 shapes = [(256, 64), (512, 64), (1024, 64), (2048, 64), (3072, 64), (4096, 64), (1024, 128), (2048, 128), (4096, 128), (8192, 128), (2048, 256), (4096, 256), (8192, 256)]
+if __import__('os').environ.get("PF_TALL"):       # panels of more than 8192 rows (MI355XQR_PF_MAX_ROWS in the lab build)
+    shapes = [(8192, 128), (12288, 128), (16384, 128), (8192, 256), (12288, 256), (16128, 256), (16384, 256), (12288, 64), (16384, 64)]
 print(f"rows per row workgroup: {ROWS or 'library choice'}; Gram blocks: {'no' if __import__('os').environ.get('PF_NO_GRAM') else 'yes'}")
 reps = 20
 for mk, wh in shapes:

@@ -123,7 +123,7 @@ int qr_thin_mgpu(const double* A, int m, int n, double* Q, double* R, int nb, in
  *                                                               redundant QR of the stacked (nranks n) x n matrix -> dR (n x n, ld n)
  *                qr_tsqr_formq_dev(tp, dA_shard, lda, dQ, ldq)  optional: this rank's m_local x n rows of the thin Q
  * Stream-ordered: no stream is drained inside a step; in the default guard mode (qr_plan_set_guard_mode below) the host thread waits
- * once per full-width panel of a shard above 8192 rows for that panel's verdict word while its last pass still runs -- latch mode on
+ * once per full-width panel of a shard above 16384 rows for that panel's verdict word while its last pass still runs -- latch mode on
  * qr_tsqr_local_plan(tp) removes even that.  The stacked factorisation of one call overlaps the local factorisation
  * of the next (independent matrices).  qr_tsqr_sync() before results are read on another stream.  librccl.so is dlopen()ed
  * on first use.  nranks = 1 needs no id (NULL) and no communicator.  qr_tsqr_plan_create_comm takes an ncclComm_t the caller

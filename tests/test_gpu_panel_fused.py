@@ -110,6 +110,21 @@ def test_panel_fused_well_conditioned(q, mk, wh, rows):
     check_panel(P, out, V, T, tau, G)
 
 
+@pytest.mark.parametrize("mk,wh", [(12288, 256), (16384, 256), (16384, 128), (16380, 64), (10000, 96), (8196, 256)])
+def test_panel_fused_beyond_8192_rows(q, mk, wh):
+    """End of round 6: up to 64 row workgroups of 256 rows = 16384 rows in one launch (the limit of 8192 was round 4's workspace)."""
+    ws = Ws(q)
+    P = np.random.default_rng(mk + wh).random((mk, wh))
+    out, V, T, tau, G, st = run_panel(q, ws, P, lda=mk + 6, ldv=mk + 2, rows=0)
+    assert st[1] == 0, "a wait timed out"
+    assert st[0] == 0, "a leaf of a well-conditioned panel took the Householder route"
+    check_panel(P, out, V, T, tau, G)
+    P2 = P.copy(); P2[:, 40] = P2[:, 3]                     # a dependent column: the Householder-route leaf at this height
+    out, V, T, tau, G, st = run_panel(q, ws, P2, rows=0)
+    assert st[1] == 0 and st[0] >= 1
+    _check_wy_only(P2, out, V, T, tau)
+
+
 def test_panel_fused_repeated_launches_share_a_workspace(q):
     """the epoch words are never reset: several panels of different heights through one workspace, results bitwise reproducible"""
     ws = Ws(q)
@@ -129,13 +144,13 @@ def test_panel_fused_repeated_launches_share_a_workspace(q):
 
 def test_panel_fused_declines_what_it_cannot_take(q):
     ws = Ws(q)
-    d = zeros(9000, 64)
+    d = zeros(17000, 64)
     args = lambda mk, wh, lda: (None, d.data_ptr(), lda, mk, wh, d.data_ptr(), d.data_ptr(), wh, d.data_ptr(), lda, d.data_ptr(), wh,
                                 ws.buf.data_ptr(), C.byref(ws.epoch), ws.status.data_ptr())
-    assert q.lib.qrd_panel_fused(*args(8196, 64, 9000)) == -7      # more than 8192 rows
-    assert q.lib.qrd_panel_fused(*args(1026, 64, 9000)) == -7      # rows not a multiple of 4
-    assert q.lib.qrd_panel_fused(*args(1024, 48, 9000)) == -7      # not whole leaves
-    assert q.lib.qrd_panel_fused(*args(1024, 64, 8999)) == -7      # odd leading dimension
+    assert q.lib.qrd_panel_fused(*args(16388, 64, 17000)) == -7    # more than 16384 rows
+    assert q.lib.qrd_panel_fused(*args(1026, 64, 17000)) == -7      # rows not a multiple of 4
+    assert q.lib.qrd_panel_fused(*args(1024, 48, 17000)) == -7      # not whole leaves
+    assert q.lib.qrd_panel_fused(*args(1024, 64, 16999)) == -7      # odd leading dimension
 
 
 def _check_wy_only(P, out, V, Tdiag, tau, tol=1e-11):

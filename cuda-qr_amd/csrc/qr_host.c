@@ -1164,6 +1164,8 @@ static int balance_cols(const qr_plan* p, int mk, int wout, int nwide)
 {
     if (!p->npairs || p->bal_rp <= 0.0 || nwide <= 0) return 0;
     const double F = 4.0 * mk * (double) wout * 1e-9;                  /* GFLOP per column */
+    /* (round 6, run 32: a chain time of its own for this decision -- the 64-CU panel stream idles 0.4-0.85 ms per step once its tall panels are
+     * one launch -- gains nothing: a larger share costs the update stream what it saves; profiles/NOTES.md) */
     const double tc = chain_ms(p, mk, wout);                           /* ms */
     const double x = (F * nwide / p->bal_ru - tc) / (F * (1.0 / p->bal_rp + 1.0 / p->bal_ru));   /* rates in GFLOP/ms = TFLOP/s */
     int xi = (int) x;

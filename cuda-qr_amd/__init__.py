@@ -151,6 +151,8 @@ _sig("qrd_panel_tsqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C
 _sig("qrd_panel_cholqr", C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_size_t, C.c_int)
 _sig("qrd_leaf_update_gram", C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_int))
 _sig("qrd_gemm_nt", C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp)
+if hasattr(lib, "qrd_gemm_nt4_ok"):        # (absent from libraries of earlier commits loaded for A/B runs through CUDA_QR_AMD_LIB)
+    _sig("qrd_gemm_nt4_ok", C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int)
 _sig("qrd_copy_block", C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int)
 _sig("qrd_init", C.c_int)
 _sig("qrd_device_sync", C.c_int)

@@ -27,6 +27,8 @@ int qrd_gemm_tn_update_wide(void* stream, int M, int N, int K, double alpha, con
 /* second-generation wide update (qr_gemm_nt.hip): W kept transposed, direct-to-LDS tile loads */
 int qrd_gemm2_init(void);
 int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc);
+/* ... to the four-workgroup kernel of the trailing update: also N = 64 (mod 128), and M = 64 (mod 128) where A is readable to the next multiple of 128 rows */
+int qrd_gemm_nt4_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc);
 int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt,
                 double* C, int ldc, int gm, unsigned long long* stamps);
 size_t qrd_panel_ws_size(int m);

@@ -265,7 +265,12 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
 // Measured (profiles/r05_nt_ceiling.txt): 60.8 against 59.0 TFLOP/s isolated, 51.2 against 49.8 in situ at 16384^2 (117.6 against 118.5 ms):
 // the default since round 5; MI355XQR_NT4=0 restores the 8-wave kernel, =2 is a 3-per-CU form with 16-deep k-tiles (no gain).
 // ------------------------------------------------------------------------------------------------
-template <bool NEG, int CEIL, int BK4, int NS>
+// RAG (round 6): M = 64 (mod 128) -- the bottom row tile is half a tile.  The two waves that own its lower 64 rows (wi = 1) neither load
+// nor store C; the tile loader still brings 128 rows of A, so the caller guarantees that A's columns are readable up to the next multiple
+// of 128 (qrd_gemm_nt4_ok: that fits A's leading dimension -- the rows are whatever the buffer holds and only reach accumulators that
+// are never stored).  What it is for: outer blocks of 64 columns, where every other trailing matrix starts 64 rows into a tile and the
+// update went to the generic kernels (4096^2 at nb 64: 0.20 against 0.15 ms per step).
+template <bool NEG, int CEIL, int BK4, int NS, bool RAG = false>
 __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M, int N, int K, const double* __restrict__ A, int lda,
                                                           const double* __restrict__ Bt, int ldbt,
                                                           double* __restrict__ C, int ldc, int gx, int gy, int gm)
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M
     __builtin_amdgcn_sched_barrier(0);
     v4d acc[2][4];
     double* cp[2];
+    const bool cval = !RAG || i0 + 64 * wi < M;          // (wave-uniform) this wave's 64 rows of C exist
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         cp[a] = C + (size_t) (j0 + 32 * wj + 2 * l15 + a) * ldc + i0 + 64 * wi + 2 * l4;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const v2d v = CEIL ? (v2d){1.0, 2.0} : *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
+                const v2d v = (CEIL || !cval) ? (v2d){1.0, 2.0} : *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
                 acc[a][2 * c][r] = v[0];
                 acc[a][2 * c + 1][r] = v[1];
             }
@@ -403,6 +409,7 @@ __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
+    if (!cval) return;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -457,6 +464,7 @@ int qrd_gemm2_init(void)
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT_STAGE * 8);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 0, 8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
+    rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<true, 0, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 8 * 192 * 8);
 #ifdef QR_LAB
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     rc |= (int) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<true, 0, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -475,10 +483,32 @@ int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* 
     return M >= 128 && N >= 128 && M % 128 == 0 && N % 128 == 0 && K >= 16 && K % 16 == 0 && al16(A, lda) && al16(Bt, ldbt) && al16(C, ldc);
 }
 
+// 1 if C -= A Bt^T can go to the four-workgroup kernel (the trailing update's default): as above, or N a multiple of 64 only (its tiles are
+// 128 x 64), or M = 64 (mod 128) with A readable to the next multiple of 128 rows (gemm_nt4_kernel<.., RAG>)
+int qrd_gemm_nt4_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc)
+{
+    if (nt4() != 1) return qrd_gemm_nt_ok(M, N, K, A, lda, Bt, ldbt, C, ldc);
+    if (M < 128 || N < 64 || N % 64 || K < 32 || K % 16 || !al16(A, lda) || !al16(Bt, ldbt) || !al16(C, ldc)) return 0;
+    if (M % 128 == 0) return 1;
+    return M % 64 == 0 && (M + 127) / 128 * 128 <= lda;
+}
+
 // C -= A Bt^T (sign < 0) or C += A Bt^T (sign > 0) on the tile-aligned problem; gm < 0: library default
 int qrd_gemm_nt(void* stream, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt,
                 double* C, int ldc, int gm, unsigned long long* stamps)
 {
+    if (!stamps && sign < 0 && nt4() == 1 && !qrd_gemm_nt_ok(M, N, K, A, lda, Bt, ldbt, C, ldc) && qrd_gemm_nt4_ok(M, N, K, A, lda, Bt, ldbt, C, ldc)) {
+        // N = 64 (mod 128) and / or M = 64 (mod 128): the four-workgroup kernel alone
+        const int gx4 = (M + 127) / 128, gy4 = N / 64;
+        if (gm < 0) gm = nt_gm();
+        if (M % 128)
+            hipLaunchKernelGGL((gemm_nt4_kernel<true, 0, 8, 3, true>), dim3(gx4 * gy4), dim3(256), 3 * (8 * 192) * sizeof(double), (hipStream_t) stream,
+                               M, N, K, A, lda, Bt, ldbt, C, ldc, gx4, gy4, gm);
+        else
+            hipLaunchKernelGGL((gemm_nt4_kernel<true, 0, 8, 3>), dim3(gx4 * gy4), dim3(256), 3 * (8 * 192) * sizeof(double), (hipStream_t) stream,
+                               M, N, K, A, lda, Bt, ldbt, C, ldc, gx4, gy4, gm);
+        return (int) hipGetLastError();
+    }
     if (!qrd_gemm_nt_ok(M, N, K, A, lda, Bt, ldbt, C, ldc)) return -7;
     const int gx = M / 128, gy = N / 128;
     if (gm < 0) gm = nt_gm();

@@ -177,7 +177,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nn_w8_kernel(int M, int N, int K,
 // K is the long dimension (panel height): gridDim.z K-slices each write their own slab
 // (slab z at C + z*slab_stride, ld = ldc) and slab_reduce_kernel sums them in a fixed order
 // (deterministic; no float atomics).  Used for W = (V T)^T A2, Gram = V^T V, Q^T Q.
-template <int TI, int TJ, bool FAST, int TAG = 0>
+// MIXED (round 6; with FAST): launched over the WHOLE ragged problem, ceil(M / BM) x ceil(N / BN) tiles -- interior tiles take the fast K
+// loop, edge tiles (a workgroup-uniform test) the guarded one.  Before, the ragged strips were launches of their own behind the interior:
+// a row of a few edge tiles, each walking a K slice as long as the interior's, with the chip idle around them (the wide product of a
+// 16448^2 factorisation: 37 TFLOP/s against 55 on the aligned 16384^2).
+template <int TI, int TJ, bool FAST, int TAG = 0, bool MIXED = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, int kchunk, double alpha,
                                                          const double* __restrict__ A, int lda,
                                                          const double* __restrict__ B, int ldb,
@@ -216,7 +220,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(int M, int N, int K, in
 
     // TAG 0 / 1 (1: the wide product of the trailing update under its own profiler name): K loop with the issue order spelled out where
     // the instantiation allows it (whole 128 x 128 tiles); TAG 3 / 4: the same two with the plain double-buffered loop (MI355XQR_KPIPE=0)
-    if constexpr (TAG <= 1 && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+    if constexpr (MIXED) {
+        if (i0 + BM > M || j0 + BN > N) gemm_kloop<TI, TJ, false, false>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+        else if constexpr (TAG <= 1 && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+        else gemm_kloop<TI, TJ, false, true>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
+    }
+    else if constexpr (TAG <= 1 && FAST && TI == 4 && TJ == 4) gemm_kloop_il<TI, TJ>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
     else gemm_kloop<TI, TJ, false, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, kbeg, kend, As, Bs, tid, wi, wj, l15, l4);
 
     if (beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
@@ -675,6 +684,15 @@ static int launch_tn(hipStream_t s, int M, int N, int K, int ksplit, int kchunk,
     const int Mi = al ? (M / BM) * BM : 0, Ni = al ? (N / BN) * BN : 0;
     if (!(Mi > 0 && Ni > 0))
         return launch_tn1<TI, TJ, false>(s, M, N, K, ksplit, kchunk, alpha, A, lda, B, ldb, beta, C, ldc, slab_stride);
+    if constexpr (TI == 4 && TJ == 4 && TAG <= 1) {
+        if (Mi < M || Ni < N) {         // ragged: one launch over all tiles, the edge tiles guarded (gemm_tn_kernel<.., MIXED>)
+            const size_t shm = sizeof(double) * (2 * BM * LDKF + 2 * BN * LDKF);
+            dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, ksplit);
+            hipLaunchKernelGGL((gemm_tn_kernel<TI, TJ, true, TAG, true>), grid, dim3(256), shm, s, M, N, K, kchunk, alpha, A, lda, B, ldb,
+                               beta, C, ldc, slab_stride);
+            return (int) hipGetLastError();
+        }
+    }
     int rc = launch_tn1<TI, TJ, true, TAG>(s, Mi, Ni, K, ksplit, kchunk, alpha, A, lda, B, ldb, beta, C, ldc, slab_stride);
     if (!rc && Ni < N)
         rc = launch_tn1<TI, TJ, false>(s, M, N - Ni, K, ksplit, kchunk, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta,
@@ -802,6 +820,8 @@ int qrd_init(void)
     rc |= allow_lds(gemm_tn_wide_kernel<1>, sizeof(double) * (2 * (128 + 256) * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 0, true>, sizeof(double) * (4 * 128 * LDKF));
+    rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1, true>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, false>, sizeof(double) * (4 * 128 * LDKF));
     rc |= qrd_gemm2_init();
     rc |= qrd_panel_tsqr_init();

@@ -57,6 +57,31 @@ def test_gemm_nt_update(q, M, N, K, lda, ldbt, ldc, sign):
         assert rel(out[:M], ref[:M]) < 1e-13 and np.array_equal(out[M:], C0[M:]), (gm,)
 
 
+@pytest.mark.parametrize("M,N,K,lda", [(192, 64, 64, 256), (4032, 3968, 64, 4096), (4032, 4032, 64, 4096), (1984, 192, 256, 2048), (2048, 192, 64, 2050),
+                                       (320, 320, 32, 384)])
+def test_gemm_nt4_half_tiles(q, M, N, K, lda):
+    """Round 6: the four-workgroup update kernel on M = 64 (mod 128) (bottom row tile half full: gemm_nt4_kernel<.., RAG>) and N = 64 (mod 128):
+    the trailing matrices of every other 64-column outer step.  A's rows beyond M (read by the tile loader, never used) are NaN; C's rows beyond M
+    are never written."""
+    rng = np.random.default_rng(M + N + K)
+    ldbt, ldc = N + 2, lda + 2
+    A, Bt, C0 = rng.standard_normal((lda, K)), rng.standard_normal((ldbt, K)), rng.standard_normal((ldc, N))
+    A[M:] = np.nan
+    ref = C0.copy()
+    ref[:M] -= A[:M] @ Bt[:N].T
+    assert q.lib.qrd_gemm_nt4_ok(M, N, K, None, lda, None, ldbt, None, ldc) == 1
+    for gm in (0, 8):
+        dA, dB, dC = dev(A), dev(Bt), dev(C0)
+        torch.cuda.synchronize()
+        q.check(q.lib.qrd_gemm_nt(None, M, N, K, -1, dA.data_ptr(), lda, dB.data_ptr(), ldbt, dC.data_ptr(), ldc, gm, None))
+        _sync(q)
+        out = host(dC)
+        assert rel(out[:M], ref[:M]) < 1e-13 and np.array_equal(out[M:], C0[M:]), (gm,)
+    # a half tile whose 128 rows do not fit A's leading dimension is declined
+    assert q.lib.qrd_gemm_nt4_ok(192, 64, 64, None, 192, None, ldbt, None, ldc) == 0
+    assert q.lib.qrd_gemm_nt(None, 192, 64, 64, -1, dA.data_ptr(), 192, dB.data_ptr(), ldbt, dC.data_ptr(), ldc, 0, None) != 0
+
+
 def test_gemm_nt_rejects_ragged_shapes(q):
     d = zeros(256, 256)
     assert q.lib.qrd_gemm_nt(None, 200, 128, 16, -1, d.data_ptr(), 256, d.data_ptr(), 256, d.data_ptr(), 256, 0, None) != 0

@@ -1099,9 +1099,10 @@ static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int ld
     /* (half tiles -- mk or nc = 64 mod 128: every other step at nb 64, every step of a matrix whose height is 64 mod 128 -- go to the
      * four-workgroup kernel too (round 6): always at K >= 128 (4032^2 at nb 128 23.8 -> 19.4 ms, 4160^2 at nb 256 18.0 -> 15.9), at K = 64 from
      * 8 M elements of trailing matrix on (4096^2 at nb 64 9.59 -> 9.09, 8192^2 73.7 -> 68.5; below, the generic kernels' 64 x 64 tiles fill
-     * the chip better on a product that is HBM-bound anyway: 2048^2 3.68 against 3.82 through this route).  profiles/r06_nt4_half_tiles.txt) */
+     * the chip better on a product that is HBM-bound anyway: 2048^2 3.68 against 3.82 through this route; not at K = 32, where the generic
+     * kernels win outright: 16384^2 at nb 32 296 against 324 ms).  profiles/r06_nt4_half_tiles.txt) */
     if (profile == 1 && (qrd_gemm_nt_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda) ||
-                         ((wout >= 128 || (long long) mk * nc >= 8388608LL) && qrd_gemm_nt4_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda)))) {
+                         ((wout >= 128 || (wout >= 64 && (long long) mk * nc >= 8388608LL)) && qrd_gemm_nt4_ok(mk, nc, wout, p->Vw2[e], ldv, Wbuf, nc, A2, lda)))) {
         /* second-generation wide update: W kept transposed (Wt = A2^T (V T), nc x wout), so that both operands of
          * A2 -= V Wt^T are row-fast and go HBM -> LDS directly (qr_gemm_nt.hip) */
         if (form_vt || !p->vt_formed[e]) {     /* on demand: an earlier slice of this update may have taken the tall-skinny shortcut above */

@@ -265,11 +265,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_kernel(int M, int N, int K, co
 // Measured (profiles/r05_nt_ceiling.txt): 60.8 against 59.0 TFLOP/s isolated, 51.2 against 49.8 in situ at 16384^2 (117.6 against 118.5 ms):
 // the default since round 5; MI355XQR_NT4=0 restores the 8-wave kernel, =2 is a 3-per-CU form with 16-deep k-tiles (no gain).
 // ------------------------------------------------------------------------------------------------
-// RAG (round 6): M = 64 (mod 128) -- the bottom row tile is half a tile.  The two waves that own its lower 64 rows (wi = 1) neither load
-// nor store C; the tile loader still brings 128 rows of A, so the caller guarantees that A's columns are readable up to the next multiple
+// RAG (round 6): M not a multiple of 128 (any even M) -- the bottom row tile is ragged.  Lanes neither load nor store the row pairs of C
+// beyond M; the tile loader still brings 128 rows of A, so the caller guarantees that A's columns are readable up to the next multiple
 // of 128 (qrd_gemm_nt4_ok: that fits A's leading dimension -- the rows are whatever the buffer holds and only reach accumulators that
 // are never stored).  What it is for: outer blocks of 64 columns, where every other trailing matrix starts 64 rows into a tile and the
-// update went to the generic kernels (4096^2 at nb 64: 0.20 against 0.15 ms per step).
+// update went to the generic kernels (4096^2 at nb 64: 0.20 against 0.15 ms per step), and matrices whose height is not a multiple of 128.
 template <bool NEG, int CEIL, int BK4, int NS, bool RAG = false>
 __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M, int N, int K, const double* __restrict__ A, int lda,
                                                           const double* __restrict__ Bt, int ldbt,
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M
     __builtin_amdgcn_sched_barrier(0);
     v4d acc[2][4];
     double* cp[2];
-    const bool cval = !RAG || i0 + 64 * wi < M;          // (wave-uniform) this wave's 64 rows of C exist
+    const int rlim = RAG ? M - (i0 + 64 * wi + 2 * l4) : 0;   // RAG: this lane's row pair 32 c + 8 r exists while 32 c + 8 r < rlim (M is even)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         cp[a] = C + (size_t) (j0 + 32 * wj + 2 * l15 + a) * ldc + i0 + 64 * wi + 2 * l4;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const v2d v = (CEIL || !cval) ? (v2d){1.0, 2.0} : *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
+                const v2d v = (CEIL || (RAG && 32 * c + 8 * r >= rlim)) ? (v2d){1.0, 2.0} : *reinterpret_cast<const v2d*>(cp[a] + 32 * c + 8 * r);
                 acc[a][2 * c][r] = v[0];
                 acc[a][2 * c + 1][r] = v[1];
             }
@@ -409,13 +409,13 @@ __global__ __launch_bounds__(256, (BK4 == 8 ? 4 : 3)) void gemm_nt4_kernel(int M
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
-    if (!cval) return;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (RAG && 32 * c + 8 * r >= rlim) continue;
                 if (CEIL) { if (acc[a][2 * c][r] == 0.12345678) *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]}; }
                 else *reinterpret_cast<v2d*>(cp[a] + 32 * c + 8 * r) = (v2d){acc[a][2 * c][r], acc[a][2 * c + 1][r]};
             }
@@ -484,13 +484,13 @@ int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* 
 }
 
 // 1 if C -= A Bt^T can go to the four-workgroup kernel (the trailing update's default): as above, or N a multiple of 64 only (its tiles are
-// 128 x 64), or M = 64 (mod 128) with A readable to the next multiple of 128 rows (gemm_nt4_kernel<.., RAG>)
+// 128 x 64), or any even M with A readable to the next multiple of 128 rows (gemm_nt4_kernel<.., RAG>)
 int qrd_gemm_nt4_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc)
 {
     if (nt4() != 1) return qrd_gemm_nt_ok(M, N, K, A, lda, Bt, ldbt, C, ldc);
     if (M < 128 || N < 64 || N % 64 || K < 32 || K % 16 || !al16(A, lda) || !al16(Bt, ldbt) || !al16(C, ldc)) return 0;
     if (M % 128 == 0) return 1;
-    return M % 64 == 0 && (M + 127) / 128 * 128 <= lda;
+    return M % 2 == 0 && (M + 127) / 128 * 128 <= lda;
 }
 
 // C -= A Bt^T (sign < 0) or C += A Bt^T (sign > 0) on the tile-aligned problem; gm < 0: library default

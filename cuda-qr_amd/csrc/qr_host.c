@@ -377,7 +377,7 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
     qr_plan* p = (qr_plan*) calloc(1, sizeof(qr_plan));
     if (!p) return QR_E_ALLOC;
     p->m = m; p->n = n; p->nb = nb; p->ib = ib;
-    p->ldv = (m + 15) & ~15;
+    p->ldv = (m + 127) & ~127;       /* (a multiple of 128: the update kernel's tile loader reads V to the end of the last row tile, gemm_nt4_kernel<.., RAG>) */
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
     /* Look-ahead (two streams, CU partition): where lookahead_pays() says so; MI355XQR_LOOKAHEAD = 0 / 1 decides instead.  (History of the
@@ -1096,6 +1096,15 @@ static int update_cols_inner(qr_plan* p, void* stream, int e, double* dA, int ld
     }
     /* (round 6: small wide updates -- 512^2 ... 4096^2 at nb 64 / 128 -- through the T-folded reduction instead, three launches and no V*T:
      * within 0.5 % at every threshold; these updates are not launch-bound.  profiles/NOTES.md) */
+    if (profile == 1 && nc % 64 != 0 && nc >= 192 && wout >= 64) {
+        /* ragged width: the last nc % 64 columns through the generic kernels, the rest as whole 64-column tiles of the update kernel
+         * (whose bottom row tile may be ragged: gemm_nt4_kernel<.., RAG>) -- where that part would take the kernel at all */
+        const int r = nc % 64, ni = nc - r;
+        if ((wout >= 128 || (long long) mk * ni >= 8388608LL) && qrd_gemm_nt4_ok(mk, ni, wout, p->Vw2[e], ldv, Wbuf, ni, A2, lda)) {
+            CHECK(update_cols_inner(p, stream, e, dA, lda, k, mk, wout, c0 + ni, r, Wbuf, Ybuf, slabs, profile, form_vt));
+            return update_cols_inner(p, stream, e, dA, lda, k, mk, wout, c0, ni, Wbuf, Ybuf, slabs, profile, 0);
+        }
+    }
     /* (half tiles -- mk or nc = 64 mod 128: every other step at nb 64, every step of a matrix whose height is 64 mod 128 -- go to the
      * four-workgroup kernel too (round 6): always at K >= 128 (4032^2 at nb 128 23.8 -> 19.4 ms, 4160^2 at nb 256 18.0 -> 15.9), at K = 64 from
      * 8 M elements of trailing matrix on (4096^2 at nb 64 9.59 -> 9.09, 8192^2 73.7 -> 68.5; below, the generic kernels' 64 x 64 tiles fill

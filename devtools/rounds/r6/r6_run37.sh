@@ -11,11 +11,11 @@ for l in sys.stdin:
     except Exception: print(l.strip()[-300:]); continue
     print(d['m'], d['n'], d['nb'], 'ms %.3f' % d['ms'], 'resid', d.get('resid'), {k: (v['ms'], v['tflops']) for k, v in d.items() if isinstance(v, dict)})
 "; }
-S="8200x8200x256 4100x4100x256 12300x4100x0 5000x5000x0 3000x3000x0 16400x16400x256 10000x10000x0 100000x500x0 8200x2056x0"
+S="8200x8200x256 4100x4100x256 12300x4100x0 5000x5000x0 3000x3000x0 16400x16400x256 10000x10000x0 16384x16384x256 4096x4096x64 20000x3000x0 8200x2056x0 6000x6000x0"
 ( for i in 1 2; do
   echo "== previous commit"; CHECK=1 CUDA_QR_AMD_LIB=libmi355xqr_exp_prev.so python3 devtools/tools_perf.py $S 2>&1 | fmt
   echo "== this tree"; CHECK=1 python3 devtools/tools_perf.py $S 2>&1 | fmt
   done ) > $O/offgrid_ab.txt 2>&1
 cut -c1-230 $O/offgrid_ab.txt
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -4 $O/tests.log
-timeout -k 5 300 python3 devtools/tools_fuzz_parity.py 3 ragged 2>&1 | grep -v amdgpu.ids > $O/fuzz_ragged.txt; tail -4 $O/fuzz_ragged.txt
+( timeout -k 5 300 python3 devtools/tools_fuzz_parity.py 3 ragged; timeout -k 5 300 python3 devtools/tools_fuzz_parity.py 6 edges6; timeout -k 5 300 python3 devtools/tools_fuzz_parity.py 1 ) 2>&1 | grep -v amdgpu.ids > $O/fuzz_ragged.txt; grep -c " x " $O/fuzz_ragged.txt; grep "^ok\|Error\|assert" $O/fuzz_ragged.txt

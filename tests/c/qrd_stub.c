@@ -183,7 +183,7 @@ int qrd_gemm_tn_dual(void* s, int N1, int N2, int K, const double* A, int lda, c
 int qrd_gemm_nt_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc)
 { (void) A; (void) Bt; (void) C; (void) lda; (void) ldbt; (void) ldc; return M % 128 == 0 && N % 128 == 0 && K % 16 == 0; }
 int qrd_gemm_nt4_ok(int M, int N, int K, const double* A, int lda, const double* Bt, int ldbt, const double* C, int ldc)
-{ (void) A; (void) Bt; (void) C; (void) ldbt; (void) ldc; return M >= 128 && N >= 64 && N % 64 == 0 && K >= 32 && K % 16 == 0 && (M % 128 == 0 || (M % 64 == 0 && (M + 127) / 128 * 128 <= lda)); }
+{ (void) A; (void) Bt; (void) C; (void) ldbt; (void) ldc; return M >= 128 && N >= 64 && N % 64 == 0 && K >= 32 && K % 16 == 0 && (M % 128 == 0 || (M % 2 == 0 && (M + 127) / 128 * 128 <= lda)); }
 int qrd_gemm_nt(void* s, int M, int N, int K, int sign, const double* A, int lda, const double* Bt, int ldbt, double* C, int ldc, int gm,
                 unsigned long long* st)
 { (void) s; (void) sign; (void) gm; (void) st; chk("gemm_nt A", A, lda, M, K); chk("gemm_nt Bt", Bt, ldbt, N, K); chk("gemm_nt C", C, ldc, M, N); return 0; }

@@ -58,10 +58,10 @@ def test_gemm_nt_update(q, M, N, K, lda, ldbt, ldc, sign):
 
 
 @pytest.mark.parametrize("M,N,K,lda", [(192, 64, 64, 256), (4032, 3968, 64, 4096), (4032, 4032, 64, 4096), (1984, 192, 256, 2048), (2048, 192, 64, 2050),
-                                       (320, 320, 32, 384)])
+                                       (320, 320, 32, 384), (200, 128, 64, 256), (4030, 1984, 256, 4096), (130, 64, 128, 256), (3850, 3840, 256, 3968)])
 def test_gemm_nt4_half_tiles(q, M, N, K, lda):
-    """Round 6: the four-workgroup update kernel on M = 64 (mod 128) (bottom row tile half full: gemm_nt4_kernel<.., RAG>) and N = 64 (mod 128):
-    the trailing matrices of every other 64-column outer step.  A's rows beyond M (read by the tile loader, never used) are NaN; C's rows beyond M
+    """Round 6: the four-workgroup update kernel on any even M (ragged bottom row tile: gemm_nt4_kernel<.., RAG>) and N = 64 (mod 128):
+    the trailing matrices of every other 64-column outer step, matrices whose height is not a multiple of 128.  A's rows beyond M (read by the tile loader, never used) are NaN; C's rows beyond M
     are never written."""
     rng = np.random.default_rng(M + N + K)
     ldbt, ldc = N + 2, lda + 2

@@ -28,10 +28,7 @@
 // C = beta*C + alpha*A*B     A: M x K (lda), B: K x N (ldb), C: M x N (ldc), all column-major.
 // Used for: trailing update A2 -= V*W (K = nb), VT = V*T, T merges, Q*R products, Q_local*Q_tree.
 // TAG only gives the wide trailing-update launches their own kernel name in profiler output (TAG = 1).
-// MIXED (round 6; with FAST): the launch covers a ragged problem, ceil(M / BM) x ceil(N / BN) tiles; interior tiles take the fast K loop, edge
-// tiles (workgroup-uniform) the guarded one.  Replaces both the strips-as-separate-launches form and the "small ragged products go
-// guarded as a whole" rule, whose threshold (0.4 GFLOP) put V*T of a 6000-row panel on a 3 TFLOP/s kernel (6000^2: 9.7 ms of 26.8).
-template <int TI, int TJ, bool FAST, bool MIXED = false>
+template <int TI, int TJ, bool FAST>
 __device__ __forceinline__ void gemm_nn_body(int M, int N, int K, double alpha, const double* __restrict__ A, int lda,
                                              const double* __restrict__ B, int ldb, double beta,
                                              double* __restrict__ C, int ldc)
@@ -72,23 +69,19 @@ __device__ __forceinline__ void gemm_nn_body(int M, int N, int K, double alpha, 
     }
 
     // FAST (host-checked): every tile of this launch is fully in range, K % BK == 0, operands 16-B aligned
-    if constexpr (MIXED) {
-        if (i0 + BM > M || j0 + BN > N) gemm_kloop<TI, TJ, true, false>(acc, A, lda, B, ldb, i0, j0, M, N, 0, K, As, Bs, tid, wi, wj, l15, l4);
-        else gemm_kloop<TI, TJ, true, true>(acc, A, lda, B, ldb, i0, j0, M, N, 0, K, As, Bs, tid, wi, wj, l15, l4);
-    }
-    else gemm_kloop<TI, TJ, true, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, 0, K, As, Bs, tid, wi, wj, l15, l4);
+    gemm_kloop<TI, TJ, true, FAST>(acc, A, lda, B, ldb, i0, j0, M, N, 0, K, As, Bs, tid, wi, wj, l15, l4);
 
     if (cinit || beta == 0.0) gemm_epilogue<TI, TJ, true>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
     else gemm_epilogue<TI, TJ, false>(acc, C, ldc, M, N, i0, j0, alpha, beta, wi, wj, l15, l4);
 }
 
-template <int TI, int TJ, bool FAST, int TAG = 0, bool MIXED = false>
+template <int TI, int TJ, bool FAST, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(int M, int N, int K, double alpha,
                                                          const double* __restrict__ A, int lda,
                                                          const double* __restrict__ B, int ldb,
                                                          double beta, double* __restrict__ C, int ldc)
 {
-    gemm_nn_body<TI, TJ, FAST, MIXED>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    gemm_nn_body<TI, TJ, FAST>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
 // blockIdx.z = batch index: the same small product on operands a fixed stride apart (the T-merge tree)
@@ -657,12 +650,11 @@ static int launch_nn(hipStream_t s, int M, int N, int K, double alpha, const dou
     const bool al = vec_ok(A, lda) && vec_ok(B, ldb) && (K % BK) == 0;
     const int Mi = al ? (M / BM) * BM : 0, Ni = al ? (N / BN) * BN : 0;
     if (!(Mi > 0 && Ni > 0)) return launch_nn1<TI, TJ, false>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-    if (Mi < M || Ni < N) {     // ragged: ONE launch over all tiles, the edge tiles on the guarded loop (gemm_nn_kernel<.., MIXED>)
-        const size_t shm = sizeof(double) * (2 * BK * (BM + 16) + 2 * BN * LDKF);
-        dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-        hipLaunchKernelGGL((gemm_nn_kernel<TI, TJ, true, TAG, true>), grid, dim3(256), shm, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
-        return (int) hipGetLastError();
-    }
+    // small ragged products sit on the panel's critical path, where a second (edge) launch costs more than guarded loads
+    // (round 6 re-measured the 0.4 GFLOP threshold: at 0.06 GFLOP 2000^2 loses 8 %, 4096^2 at nb 64 3 %; and an edge-tiles-inside-the-fast-grid
+    // form like gemm_tn_kernel<.., MIXED> spills here -- 158 VGPRs -- and loses to both.  profiles/NOTES.md)
+    if ((Mi < M || Ni < N) && (double) M * N * K < 4e8)
+        return launch_nn1<TI, TJ, false>(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
     int rc = launch_nn1<TI, TJ, true, TAG>(s, Mi, Ni, K, alpha, A, lda, B, ldb, beta, C, ldc);
     if (!rc && Ni < N)      /* right strip: all rows, columns [Ni, N) */
         rc = launch_nn1<TI, TJ, false>(s, M, N - Ni, K, alpha, A, lda, B + (size_t) Ni * ldb, ldb, beta,
@@ -829,8 +821,6 @@ int qrd_init(void)
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 4>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_wide_kernel<1>, sizeof(double) * (2 * (128 + 256) * LDKF));
     rc |= allow_lds(gemm_nn_kernel<4, 4, false>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
-    rc |= allow_lds(gemm_nn_kernel<4, 4, true, 0, true>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
-    rc |= allow_lds(gemm_nn_kernel<4, 4, true, 1, true>, sizeof(double) * (2 * BK * (128 + 16) + 2 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 0, true>, sizeof(double) * (4 * 128 * LDKF));
     rc |= allow_lds(gemm_tn_kernel<4, 4, true, 1, true>, sizeof(double) * (4 * 128 * LDKF));

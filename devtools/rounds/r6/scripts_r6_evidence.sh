@@ -27,7 +27,7 @@ for n in ("bench_c3", "bench_tsqr", "bench_tsqr_cond1e9", "bench_c2", "bench_c3_
     except Exception as e:
         print(n, "parse failed", e)
 PY
-grep "gemm_nt4_kernel\|gemm_tn_kernel<4, 4, true, 1>\|panel_fused\|trsm_gt" $R/c3/bench_kernel_stats.csv | cut -c1-170
+grep "gemm_nt4_kernel\|gemm_tn_kernel<4, 4, true, 1\|panel_fused\|trsm_gt" $R/c3/bench_kernel_stats.csv | cut -c1-170
 python3 devtools/tools_perf.py 4096x4096x64 4096x4096x128 4096x4096x256 8192x8192x256 16384x16384x32 16384x16384x64 16384x16384x128 16384x16384x256 16384x16384x512 131072x256x128 65536x256x128 262144x256x128 262144x512x128 2097152x512x128 4096x512x128 2048x2048x128 1024x1024x128 2>&1 | grep -v amdgpu.ids | python3 -c "
 import sys, json
 for l in sys.stdin:

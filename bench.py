@@ -480,7 +480,7 @@ def main():
         try:
             import csv
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_bench_c3_kernel_stats.csv"))):
-                if wl == "c3" and row["Name"].startswith("void gemm_nt4_kernel<true, 0, 8, 3")      # (<.., RAG = false>: the aligned instantiation, the only one C3 launches):
+                if wl == "c3" and row["Name"].startswith("void gemm_nt4_kernel<true, 0, 8, 3"):      # (<.., RAG = false>: the aligned instantiation, the only one C3 launches)
                     ns = float(row["AverageNs"])
                     rocprof_ref = {"file": "profiles/r06_bench_c3_kernel_stats.csv", "calls": int(row["Calls"]), "avg_launch_ms": ns * 1e-6,
                                    "achieved_at_that_duration": (upd["flops"] / upd["launches"]) / (ns * 1e-9) / 1e12,

@@ -213,3 +213,13 @@ def test_integration_md_documents_exactly_the_public_knobs():
     sec = sec[:sec.index("\n## ", 5)] if "\n## " in sec[5:] else sec
     table = {m for m in re.findall(r"^\| `(MI355XQR_[A-Z0-9_]+)`", sec, flags=re.M)}
     assert table == PUBLIC_KNOBS, sorted(table ^ PUBLIC_KNOBS)
+
+
+def test_entry_scripts_compile():
+    """bench.py, __graft_entry__.py and the measurement helpers are what the driver and the evidence scripts execute: a syntax error there is
+    only seen on the GPU box otherwise."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(root, "devtools", "*.py"))):
+        py_compile.compile(f, doraise=True)

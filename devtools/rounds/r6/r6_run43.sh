@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6, run 43: the one-launch panel with up to 128 row workgroups (PF_MAXWG 128): parity of the kernel tests, then the launch on 8192-32768 rows
+# (a record: PF_MAXWG 128, MI355XQR_PF_MAX128 and PF_TALL=2 existed only in the tree of this experiment -- profiles/NOTES.md, profiles/r06_panel_fused_128_workgroups_negative.txt)
 # (128 x 128 rows against 64 x 256 rows up to 16384; 256-row workgroups beyond), then whole factorisations of 16385-32768 rows against the full-width route
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r6_run43; mkdir -p $O

@@ -106,7 +106,8 @@ def test_gemm_nn_with_leading_dimensions(q):
 
 TN_SHAPES = [(16, 16, 64), (128, 128, 4096), (128, 1000, 5000), (32, 96, 16384), (32, 224, 777), (64, 64, 100),
              (128, 16384, 1024), (5, 3, 11), (256, 256, 3000), (130, 67, 129), (1, 1, 1), (32, 20, 100000),
-             (512, 300, 50000), (300, 512, 40000), (257, 33, 9000)]
+             (512, 300, 50000), (300, 512, 40000), (257, 33, 9000),
+             (512, 1024, 8200), (384, 1000, 10248)]     # K % 16 != 0 above 4 GFLOP: whole k-tiles on the fast path + an accumulated guarded remainder (round 6)
 
 
 @pytest.mark.parametrize("M,N,K", TN_SHAPES)

@@ -315,7 +315,8 @@ def test_lookahead_matches_sequential_schedule(qr, oracle):
     assert rel(oracle.sign_normalise(outs[0]), oracle.sign_normalise(outs[1])) < 1e-13
 
 
-@pytest.mark.parametrize("m,n", [(2829, 2829), (2828, 2828), (3073, 1024), (8193, 2048), (8192, 2048), (1024, 511), (8192, 512), (777, 555)])
+@pytest.mark.parametrize("m,n", [(2829, 2829), (2828, 2828), (3073, 1024), (8193, 2048), (8192, 2048), (1024, 511), (8192, 512), (777, 555),
+                                 (6000, 4100), (4100, 4100), (4160, 2112)])    # (the last three: ragged bottom tile / ragged width of the update kernel, half tiles)
 def test_shapes_next_to_the_block_size_and_schedule_thresholds(qr, oracle, m, n):
     """The library's own choice of block size and schedule (nb = 0: qr_host.c lookahead_pays / default_blocks, measured rule of round 6) on
     shapes either side of its thresholds -- 8 M elements, m = 3 n, 8192 rows, 512 columns -- and ragged ones: sign-normalised R against

@@ -1732,10 +1732,18 @@ int qr_release_cached_plans(void)
 int mmqr_status(double* mat, double** tau, int m, int n)
 {
     if (!mat || !tau || n < 1 || m < n) return QR_E_ARG;
+    /* Heights that are not multiples of 16 are factored with zero rows appended, in a device buffer of its own leading dimension: the
+     * reflectors get zeros there and R, tau and the first m rows of V are those of the unpadded matrix (in exact arithmetic: the same
+     * sums with zeros added), while an odd height or leading dimension keeps every kernel off its aligned path -- the one-launch panel
+     * wants mk % 4 == 0, vector loads an even leading dimension: 5001^2 34.0 ms against 10.9 for 5000^2, 8191^2 60.9 against 22.9
+     * (profiles/r06_odd_sizes.txt).  Callers of the device API own their buffers and pad (or not) themselves. */
+    const int mp = (m >= 512 && m % 16 != 0) ? (int) (((long long) m + 15) & ~15LL) : m;
     host_slot priv, *sl = NULL;
-    CHECK(slot_acquire(m, n, &priv, &sl));
+    CHECK(slot_acquire(mp, n, &priv, &sl));
     qr_plan* p = sl->p;
-    const size_t ntau = (size_t) ((n + p->nb - 1) / p->nb) * p->nb;           /* rowPanels * colPanels * nb, qr.c:61 sizing rule */
+    int nb_u = p->nb;
+    if (mp != m) default_blocks(m, n, &nb_u, NULL);                           /* tau is sized by the block size the CALLER's shape gets (getPanelDims) */
+    const size_t ntau = (size_t) ((n + nb_u - 1) / nb_u) * nb_u;              /* rowPanels * colPanels * nb, qr.c:61 sizing rule */
     double* htau = (double*) calloc(ntau, sizeof(double));                    /* zero-filled like qr.c:61-62 */
     if (!htau) { slot_release(sl); return QR_E_ALLOC; }
     const size_t bytes = sizeof(double) * (size_t) m * n;
@@ -1745,8 +1753,12 @@ int mmqr_status(double* mat, double** tau, int m, int n)
     const int latch0 = p->guard_latch;
     p->guard_latch = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        rc = qrd_h2d(p->stream, sl->dA, mat, bytes);
-        if (!rc) rc = qr_geqrf_dev(p, sl->dA, m, n, m, sl->dtau);
+        if (mp == m) rc = qrd_h2d(p->stream, sl->dA, mat, bytes);
+        else {
+            rc = qrd_memset(p->stream, sl->dA, 0, sizeof(double) * (size_t) mp * n);
+            if (!rc) rc = qrd_h2d_2d(p->stream, sl->dA, sizeof(double) * mp, mat, sizeof(double) * m, sizeof(double) * m, n);
+        }
+        if (!rc) rc = qr_geqrf_dev(p, sl->dA, mp, n, mp, sl->dtau);
         /* the status words of the panel kernels, before the result replaces the caller's matrix: after a stalled one-launch panel the
          * matrix is factored again from the host copy with that route off */
         const int rs = qr_plan_sync(p);
@@ -1755,7 +1767,8 @@ int mmqr_status(double* mat, double** tau, int m, int n)
         break;
     }
     p->guard_latch = latch0;
-    if (!rc) rc = qrd_d2h(p->stream, mat, sl->dA, bytes);
+    if (!rc) rc = mp == m ? qrd_d2h(p->stream, mat, sl->dA, bytes)
+                          : qrd_d2h_2d(p->stream, mat, sizeof(double) * m, sl->dA, sizeof(double) * mp, sizeof(double) * m, n);
     if (!rc) rc = qrd_d2h(p->stream, htau, sl->dtau, sizeof(double) * n);
     if (!rc) rc = qrd_stream_sync(p->stream);
     else qr_plan_sync(p);
@@ -1970,9 +1983,11 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
     if (nshards > 1 && (m - (nshards - 1) * ms) < n) return QR_E_ARG;   /* every shard needs >= n rows */
     qr_plan *p = NULL, *p2 = NULL;
     double *dA = NULL, *dQ = NULL, *dtau = NULL, *dR = NULL, *dS = NULL, *dQt = NULL, *dtau2 = NULL;
-    const size_t abytes = sizeof(double) * (size_t) m * n;
+    /* one shard: heights that are not multiples of 16 get zero rows appended on the device (see mmqr_status); md = the device-side height */
+    const int md = (nshards == 1 && m >= 512 && m % 16 != 0) ? (int) (((long long) m + 15) & ~15LL) : m;
+    const size_t abytes = sizeof(double) * (size_t) md * n;
     const int sm = nshards * n;
-    int rc = qr_plan_create(&p, nshards > 1 ? ms : m, n, nb, 0);
+    int rc = qr_plan_create(&p, nshards > 1 ? ms : md, n, nb, 0);
     if (!rc) rc = qrd_malloc((void**) &dA, abytes);
     if (!rc) rc = qrd_malloc((void**) &dQ, abytes);
     if (!rc) rc = qrd_malloc((void**) &dtau, sizeof(double) * (size_t) n * nshards);
@@ -1989,11 +2004,15 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
     if (p) p->guard_latch = 0;
     if (p2) p2->guard_latch = 0;
     for (int attempt = 0; attempt < 2 && !rc; ++attempt) {
-        rc = qrd_h2d(p->stream, dA, A, abytes);
+        if (md == m) rc = qrd_h2d(p->stream, dA, A, abytes);
+        else {
+            rc = qrd_memset(p->stream, dA, 0, abytes);
+            if (!rc) rc = qrd_h2d_2d(p->stream, dA, sizeof(double) * md, A, sizeof(double) * m, sizeof(double) * m, n);
+        }
         if (!rc && nshards == 1) {
-            rc = qr_geqrf_dev(p, dA, m, n, m, dtau);
-            if (!rc) rc = qr_extract_r_dev(p, dA, m, n, m, dR, n, n);
-            if (!rc) rc = qr_applyq_dev(p, dA, m, n, m, dtau, dQ, n, m, 1);
+            rc = qr_geqrf_dev(p, dA, md, n, md, dtau);
+            if (!rc) rc = qr_extract_r_dev(p, dA, md, n, md, dR, n, n);
+            if (!rc) rc = qr_applyq_dev(p, dA, md, n, md, dtau, dQ, n, md, 1);      /* the appended rows of the thin Q are zero */
         } else if (!rc) {
             for (int s = 0; s < nshards && !rc; ++s) {            /* step 1: independent local QRs */
                 const int r0 = s * ms, rows = imin(ms, m - r0);
@@ -2026,7 +2045,8 @@ int qr_thin(const double* A, int m, int n, double* Q, double* R, int nb, int nsh
         }
         break;
     }
-    if (!rc) rc = qrd_d2h(p->stream, Q, dQ, abytes);
+    if (!rc) rc = md == m ? qrd_d2h(p->stream, Q, dQ, abytes)
+                          : qrd_d2h_2d(p->stream, Q, sizeof(double) * m, dQ, sizeof(double) * md, sizeof(double) * m, n);
     if (!rc) rc = qrd_d2h(p->stream, R, dR, sizeof(double) * (size_t) n * n);
     if (!rc) rc = qrd_stream_sync(p->stream);
     qrd_free(dA); qrd_free(dQ); qrd_free(dtau); qrd_free(dR); qrd_free(dS); qrd_free(dQt); qrd_free(dtau2);

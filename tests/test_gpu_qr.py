@@ -185,6 +185,27 @@ def test_qr_thin_tsqr_shard_invariance(qr, oracle, m, n, P):
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 1e-13 * n
 
 
+@pytest.mark.parametrize("m,n", [(1541, 1100), (777, 555), (5001, 300), (2050, 2049)])
+def test_host_pointer_entry_points_pad_odd_heights(qr, oracle, m, n):
+    """mmqr / qr_thin on heights that are not multiples of 16: factored with zero rows appended on the device (an odd height keeps every
+    kernel off its aligned path: 5001^2 took three times as long as 5000^2); what comes back is the m x n factored form / the thin
+    factors of the caller's matrix -- R against LAPACK, explicitQR on the returned factors, rows beyond m never touched."""
+    rng = np.random.default_rng(m + n)
+    A = rng.random((m, n))
+    F, tau = qr.mmqr(A)
+    assert F.shape == (m, n) and tau.shape[0] == qr.tau_len(m, n) >= n
+    ref = oracle.sign_normalise(np.linalg.qr(A, mode="r"))
+    assert rel(oracle.sign_normalise(F), ref) < 1e-13
+    if m <= 2100:
+        Q, R = qr.explicit_qr(F, tau)                       # the factors are an ordinary compact-WY form of the UNPADDED matrix
+        assert np.linalg.norm(A - Q @ R) / np.linalg.norm(A) < 1e-13
+        assert np.linalg.norm(Q.T @ Q - np.eye(m)) < 1e-12
+    Qt, Rt = qr.qr_thin(A, nb=128, nshards=1)
+    assert Qt.shape == (m, n)
+    assert rel(oracle.sign_normalise(Rt), ref) < 1e-13
+    assert np.linalg.norm(A - Qt @ Rt) / np.linalg.norm(A) < 1e-13 and np.linalg.norm(Qt.T @ Qt - np.eye(n)) < 1e-13 * n
+
+
 @pytest.mark.parametrize("m,n", [(4096, 256), (999, 40)])
 def test_qr_thin_mgpu_single_device_matches_qr_thin(qr, oracle, m, n):
     """C-level TSQR entry with ngpu = 1 (no communicator): same factors as qr_thin; ngpu beyond the visible devices is refused."""

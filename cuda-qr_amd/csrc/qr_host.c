@@ -57,6 +57,8 @@ struct qr_plan {
     void* ev_extra[2];          /* panel-stream share of wide update s finished */
     double *We, *Ye;            /* its W buffer and raw V^T A2 */
     double *Ye2;                /* raw V^T A2 of a wide update that applies T to the small product (tall-skinny plans) */
+    int m_user;                 /* the height the plan was asked for; m (>= m_user) is what it factors: see padA */
+    double* padA;               /* (m x n, ld m) heights that are not multiples of 16: qr_geqrf_dev factors a copy with zero rows appended */
     double *Yn;                 /* raw V^T A_next of the look-ahead update */
     double bal_rp, bal_ru, bal_tc0, bal_tc1;   /* load-balance model (TFLOP/s, ms); bal_rp = 0: off */
     double bal_tail_tc;         /* chain time where the next panel is ONE launch (see chain_ms); 0: the linear model everywhere */
@@ -367,6 +369,12 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
 {
     if (!out || m < 1 || n < 1 || m < n) return QR_E_ARG;
     CHECK(ensure_device());
+    /* Heights that are not multiples of 16: the plan is built for the next multiple, and qr_geqrf_dev on the full height factors a copy
+     * of the caller's matrix with zero rows appended (R, tau and the first m rows of V are the caller's matrix's -- see mmqr_status;
+     * 5001^2 through the caller's own buffer: 34 ms, 5000^2: 11).  Costs one more m x n buffer; not for the local plans of a multi-GPU
+     * step (their shards are the caller's to size) and not above 4 GiB of matrix. */
+    const int m_user = m;
+    if (!tsqr_local && m >= 512 && m % 16 != 0 && (double) m * n * 8.0 <= 4294967296.0 && m <= 2147483647 - 16) m = (m + 15) & ~15;
     {
         int dnb, dib;
         default_blocks(tsqr_local ? (1 << 30) : m, n, &dnb, &dib);
@@ -376,7 +384,7 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
     if (ib > QRD_LEAFW || nb < ib || nb > QR_MAX_NB || nb % ib || (nb > QR_HALF && nb % QR_HALF)) return QR_E_ARG;
     qr_plan* p = (qr_plan*) calloc(1, sizeof(qr_plan));
     if (!p) return QR_E_ALLOC;
-    p->m = m; p->n = n; p->nb = nb; p->ib = ib;
+    p->m = m; p->n = n; p->nb = nb; p->ib = ib; p->m_user = m_user;
     p->ldv = (m + 127) & ~127;       /* (a multiple of 128: the update kernel's tile loader reads V to the end of the last row tile, gemm_nt4_kernel<.., RAG>) */
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
@@ -539,6 +547,7 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         if (!rc) rc = qrd_malloc((void**) &p->pf_status, 4 * sizeof(int));
         if (!rc) rc = qrd_memset(p->stream, p->pf_status, 0, 4 * sizeof(int));
     }
+    if (!rc && p->m != p->m_user) rc = qrd_malloc((void**) &p->padA, sizeof(double) * (size_t) p->m * n);
     if (rc) { qr_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -571,7 +580,7 @@ int qr_plan_destroy(qr_plan* p)
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
     qrd_free(p->slabs); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
-    qrd_free(p->pf_ws); qrd_free(p->pf_status); qrd_free(p->cq_ws); qrd_free(p->cq_status);
+    qrd_free(p->pf_ws); qrd_free(p->pf_status); qrd_free(p->cq_ws); qrd_free(p->cq_status); qrd_free(p->padA);
     qrd_host_word_free(p->cq_hword);
     if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
@@ -1244,6 +1253,14 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
 int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     if (!p || !dA || !dtau || n < 1 || m < n || m > p->m || n > p->n || lda < m) return QR_E_ARG;
+    if (p->padA && m == p->m_user && !p->use_graph) {
+        /* zero rows appended (plan_create_impl): copy in, factor at the padded height, copy the caller's m rows back -- all on the plan's stream */
+        const int mp = p->m;
+        CHECK(qrd_memset(p->stream, p->padA, 0, sizeof(double) * (size_t) mp * n));
+        CHECK(qrd_copy_block(p->stream, dA, lda, p->padA, mp, m, n));
+        CHECK(geqrf_issue(p, p->padA, mp, n, mp, dtau));
+        return qrd_copy_block(p->stream, p->padA, mp, dA, lda, m, n);
+    }
     if (!p->use_graph || p->prof_on) return geqrf_issue(p, dA, m, n, lda, dtau);
     if (!(p->graph_exec && p->g_dA == dA && p->g_dtau == dtau && p->g_m == m && p->g_n == n && p->g_lda == lda)) {
         CHECK(qr_plan_sync(p));

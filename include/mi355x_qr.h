@@ -178,7 +178,9 @@ int qr_release_cached_plans(void);
 typedef struct qr_plan qr_plan;
 
 /* Workspace + streams for factoring matrices up to m x n with outer block nb and leaf width ib
- * (nb = 0 / ib = 0 select the library defaults). */
+ * (nb = 0 / ib = 0 select the library defaults).  A plan whose height is not a multiple of 16 (from 512 rows on, up to 4 GiB of
+ * matrix) also holds an m x n buffer: qr_geqrf_dev at the plan's full height factors a copy of the caller's matrix with zero rows
+ * appended -- same R, tau and V -- because an odd height or leading dimension keeps every kernel off its aligned path (x3). */
 int qr_plan_create(qr_plan** plan, int m, int n, int nb, int ib);
 int qr_plan_destroy(qr_plan* plan);
 

@@ -16,6 +16,7 @@
 #define _POSIX_C_SOURCE 200809L      /* strtok_r, pthread under -std=c99 */
 #include <pthread.h>
 #include <sched.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -58,6 +59,7 @@ struct qr_plan {
     double *We, *Ye;            /* its W buffer and raw V^T A2 */
     double *Ye2;                /* raw V^T A2 of a wide update that applies T to the small product (tall-skinny plans) */
     int m_user;                 /* the height the plan was asked for; m (>= m_user) is what it factors: see padA */
+    int pad_failed;             /* the lazy allocation of padA failed once: do not try again */
     double* padA;               /* (m x n, ld m) heights that are not multiples of 16: qr_geqrf_dev factors a copy with zero rows appended */
     double *Yn;                 /* raw V^T A_next of the look-ahead update */
     double bal_rp, bal_ru, bal_tc0, bal_tc1;   /* load-balance model (TFLOP/s, ms); bal_rp = 0: off */
@@ -1253,6 +1255,11 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
 int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     if (!p || !dA || !dtau || n < 1 || m < n || m > p->m || n > p->n || lda < m) return QR_E_ARG;
+    if (!p->padA && m == p->m_user && m >= 512 && !p->use_graph && !p->pad_failed && ((lda & 1) || ((uintptr_t) dA & 15)) &&
+        (double) p->m * p->n * 8.0 <= 4294967296.0) {
+        /* an odd leading dimension or a misaligned array under an otherwise aligned height: the same copy, allocated on first need */
+        if (qrd_malloc((void**) &p->padA, sizeof(double) * (size_t) p->m * p->n)) { p->padA = NULL; p->pad_failed = 1; }
+    }
     if (p->padA && m == p->m_user && !p->use_graph) {
         /* zero rows appended (plan_create_impl): copy in, factor at the padded height, copy the caller's m rows back -- all on the plan's stream */
         const int mp = p->m;

@@ -355,6 +355,31 @@ def test_shapes_next_to_the_block_size_and_schedule_thresholds(qr, oracle, m, n)
     p.close()
 
 
+@pytest.mark.parametrize("m,n,lda,off", [(4096, 1024, 4097, 0), (4096, 1024, 4100, 1), (2049, 700, 2051, 0), (5001, 640, 5001, 0)])
+def test_geqrf_dev_on_odd_leading_dimensions_and_misaligned_arrays(qr, oracle, m, n, lda, off):
+    """qr_geqrf_dev on the caller's own array when its height is not a multiple of 16, its leading dimension odd or its first element not 16-byte
+    aligned: the plan factors a re-pitched, zero-padded copy and copies the m rows back -- R against LAPACK, the rows between m and lda and the
+    elements in front of the array never written."""
+    rng = np.random.default_rng(m + n + lda)
+    A = rng.random((m, n))
+    buf = np.full(lda * n + off, 7.25)
+    buf[off:].reshape(n, lda)[:, :m] = A.T                         # column-major with leading dimension lda, `off` doubles into the allocation
+    d = torch.from_numpy(buf).cuda()
+    dtau = zeros(n, 1)
+    torch.cuda.synchronize()
+    p = qr.Plan(m, n, 0, 0)
+    p.geqrf(d[off:], m, n, lda, dtau)
+    p.sync()
+    out = d.cpu().numpy()
+    p.close()
+    assert np.array_equal(out[:off], buf[:off])
+    F = out[off:].reshape(n, lda)
+    assert np.array_equal(F[:, m:], np.full((n, lda - m), 7.25)), "rows beyond m are the caller's"
+    R = np.triu(F[:, :m].T[:n])
+    assert rel(oracle.sign_normalise(R), oracle.sign_normalise(np.linalg.qr(A, mode="r"))) < 1e-13
+    assert np.all(np.isfinite(F[:, :m]))
+
+
 def test_cu_split_that_is_not_a_multiple_of_32(qr, oracle):
     """MI355XQR_SPLIT=48: the dispatcher deals workgroups evenly over the shader engines whatever the mask says, so the one-launch panel
     (workgroups waiting for each other) may only count on whole multiples of 32 of a mask (qrd_stream_cus_coresident); before, its hand-off

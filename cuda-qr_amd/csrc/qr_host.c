@@ -58,7 +58,8 @@ struct qr_plan {
     void* ev_extra[2];          /* panel-stream share of wide update s finished */
     double *We, *Ye;            /* its W buffer and raw V^T A2 */
     double *Ye2;                /* raw V^T A2 of a wide update that applies T to the small product (tall-skinny plans) */
-    int m_user;                 /* the height the plan was asked for; m (>= m_user) is what it factors: see padA */
+    int m_user, n_user;         /* the shape the plan was asked for; m x n (>= it) is what it factors: see padA */
+    double* pad_tau;            /* n scalars of the padded factorisation (the caller's dtau has n_user) */
     int pad_failed;             /* the lazy allocation of padA failed once: do not try again */
     double* padA;               /* (m x n, ld m) heights that are not multiples of 16: qr_geqrf_dev factors a copy with zero rows appended */
     double *Yn;                 /* raw V^T A_next of the look-ahead update */
@@ -375,8 +376,20 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
      * of the caller's matrix with zero rows appended (R, tau and the first m rows of V are the caller's matrix's -- see mmqr_status;
      * 5001^2 through the caller's own buffer: 34 ms, 5000^2: 11).  Costs one more m x n buffer; not for the local plans of a multi-GPU
      * step (their shards are the caller's to size) and not above 4 GiB of matrix. */
-    const int m_user = m;
-    if (!tsqr_local && m >= 512 && m % 16 != 0 && (double) m * n * 8.0 <= 4294967296.0 && m <= 2147483647 - 16) m = (m + 15) & ~15;
+    const int m_user = m, n_user = n;
+    /* ... and widths that are not whole 32-column leaves get columns appended: unit vectors e_{m_user + j}, in zero rows appended for them.
+     * Column j of R, V and tau depends on columns 0 .. j only (Cholesky, the triangular solves and the reconstruction are all
+     * column-recursive), so the caller's n columns come out as without them -- and the appended ones stay exactly orthogonal to them
+     * (every reflector has zeros in their rows) -- while the last panel, ragged otherwise (leaf by leaf, its updates on the generic
+     * kernels), takes the whole-leaf routes (262144 x 500: 5.8 ms against 4.6 for 262144 x 512; profiles/r06_odd_sizes.txt) */
+    /* (not for tall-skinny shapes, m >= 16 n: the two copies of the matrix cost what the ragged panel does -- 100000 x 300 1.55 -> 1.68 ms
+     * with them, 262144 x 500 5.8 -> 5.6; from 10000 x 1000 (2.79 -> 2.65) to 1000^2 (2.05 -> 1.85) and 8192 x 8191 (25.3 -> 24.2) they pay) */
+    if (!tsqr_local && m >= 512 && n >= 64 && n % 32 != 0 && (long long) m < 16LL * n && m <= 2147483647 - 64 &&
+        ((double) m + 48.0) * ((n + 31) & ~31) * 8.0 <= 4294967296.0) {
+        n = (n + 31) & ~31;
+        m = (m + (n - n_user) + 15) & ~15;
+    }
+    else if (!tsqr_local && m >= 512 && m % 16 != 0 && (double) m * n * 8.0 <= 4294967296.0 && m <= 2147483647 - 16) m = (m + 15) & ~15;
     {
         int dnb, dib;
         default_blocks(tsqr_local ? (1 << 30) : m, n, &dnb, &dib);
@@ -386,7 +399,7 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
     if (ib > QRD_LEAFW || nb < ib || nb > QR_MAX_NB || nb % ib || (nb > QR_HALF && nb % QR_HALF)) return QR_E_ARG;
     qr_plan* p = (qr_plan*) calloc(1, sizeof(qr_plan));
     if (!p) return QR_E_ALLOC;
-    p->m = m; p->n = n; p->nb = nb; p->ib = ib; p->m_user = m_user;
+    p->m = m; p->n = n; p->nb = nb; p->ib = ib; p->m_user = m_user; p->n_user = n_user;
     p->ldv = (m + 127) & ~127;       /* (a multiple of 128: the update kernel's tile loader reads V to the end of the last row tile, gemm_nt4_kernel<.., RAG>) */
     p->ldt = nb;
     const char* la = getenv("MI355XQR_LOOKAHEAD");
@@ -549,7 +562,8 @@ static int plan_create_impl(qr_plan** out, int m, int n, int nb, int ib, int tsq
         if (!rc) rc = qrd_malloc((void**) &p->pf_status, 4 * sizeof(int));
         if (!rc) rc = qrd_memset(p->stream, p->pf_status, 0, 4 * sizeof(int));
     }
-    if (!rc && p->m != p->m_user) rc = qrd_malloc((void**) &p->padA, sizeof(double) * (size_t) p->m * n);
+    if (!rc && (p->m != p->m_user || p->n != p->n_user)) rc = qrd_malloc((void**) &p->padA, sizeof(double) * (size_t) p->m * p->n);
+    if (!rc && p->n != p->n_user) rc = qrd_malloc((void**) &p->pad_tau, sizeof(double) * (size_t) p->n);
     if (rc) { qr_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -582,7 +596,7 @@ int qr_plan_destroy(qr_plan* p)
     free(p->prof_ev); free(p->prof_cls); free(p->prof_flops); free(p->prof_bytes);
     qrd_free(p->W); qrd_free(p->Tt); qrd_free(p->G); qrd_free(p->X);
     qrd_free(p->slabs); qrd_free(p->panel_ws); qrd_free(p->chol_ws); qrd_free(p->slabs_ep);
-    qrd_free(p->pf_ws); qrd_free(p->pf_status); qrd_free(p->cq_ws); qrd_free(p->cq_status); qrd_free(p->padA);
+    qrd_free(p->pf_ws); qrd_free(p->pf_status); qrd_free(p->cq_ws); qrd_free(p->cq_status); qrd_free(p->padA); qrd_free(p->pad_tau);
     qrd_host_word_free(p->cq_hword);
     if (p->s_main) qrd_stream_destroy(p->s_main);
     free(p);
@@ -928,7 +942,7 @@ static int factor_panel_inner(qr_plan* p, double* dA, int m, int lda, int k, int
         /* the whole half in ONE launch (qr_panel_fused.hip: every leaf, its in-panel product and update; leaf T blocks, tau, V and
          * the Gram blocks for the merge below come out exactly as from the leaf loop) where the panel is short enough */
         int cqr_done = 0, t_merged = 0;
-        if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= plan_cqr_min_rows(p) && wh == 128 && qrd_panel_cqr_ok(mk - c0, wh)) {
+        if (p->cq_ws && !p->use_graph && ib == 32 && kn->cqr_min_rows > 0 && mk - c0 >= plan_cqr_min_rows(p) && (wh == 128 || (wh == wout && wh == 96 && nhalf == 1)) && qrd_panel_cqr_ok(mk - c0, wh)) {   /* (96: the whole leaves of a ragged last panel; at 32 the route's one-workgroup kernels cost more than the leaf: 100000 x 300 1.55 -> 1.64 ms) */
             /* (2: the last panel -- V once, R in place at once, nothing parked) */
             const int park = (park_hint && kn->cqr_park && nhalf == 1 && !p->lookahead) ? (want_t ? 1 : 2) : 0;
             const int rc = panel_cqr_half(p, Ak + (size_t) c0 * lda + c0, lda, mk - c0, wh, dtau + k + c0, p->T + (size_t) c0 * ldt + c0, ldt,
@@ -1055,10 +1069,15 @@ static int apply_vw(qr_plan* p, void* stream, const double* V, int ldv, int mk, 
     /* Round 5: the update of a tall block through the trailing-update kernel of the square case (qr_gemm_nt.hip: four workgroups per CU,
      * operands HBM -> LDS directly, tiles dealt to the XCDs so that the column tiles of a row block share V in one L2): it wants W
      * transposed (nc x kw, row-fast), one more tiny launch.  MI355XQR_TALL_NT=0: the 8-wave NN kernel as before. */
-    if (knobs()->tall_nt && Ybuf && mk >= 16384 && kw >= 32 && kw % 16 == 0 && nc >= 128 && nc % 128 == 0 && mk % 128 == 0 &&
-        qrd_gemm_nt_ok(mk, nc, kw, V, ldv, Ybuf, nc, A2, lda)) {
-        CHECK(qrd_transpose(stream, kw, nc, Wbuf, kw, Ybuf, nc));          /* Ybuf (free by now) <- W^T */
-        return qrd_gemm_nt(stream, mk, nc, kw, -1, V, ldv, Ybuf, nc, A2, lda, -1, NULL);
+    if (knobs()->tall_nt && Ybuf && mk >= 16384 && kw >= 32 && kw % 16 == 0 && nc >= 128) {
+        /* (round 6: any width -- whole 64-column tiles through the kernel, the last nc % 64 columns through the generic one -- and any even
+         * height, gemm_nt4_kernel<.., RAG>: 262144 x 500 took 5.75 ms where 262144 x 512 takes 4.53, nearly all of it here) */
+        const int r = nc % 64, ni = nc - r;
+        if (ni >= 128 && qrd_gemm_nt4_ok(mk, ni, kw, V, ldv, Ybuf, ni, A2, lda)) {
+            if (r > 0) CHECK(qrd_gemm_nn(stream, mk, r, kw, -1.0, V, ldv, Wbuf + (size_t) ni * kw, kw, 1.0, A2 + (size_t) ni * lda, lda));
+            CHECK(qrd_transpose(stream, kw, ni, Wbuf, kw, Ybuf, ni));      /* Ybuf (free by now) <- W^T */
+            return qrd_gemm_nt(stream, mk, ni, kw, -1, V, ldv, Ybuf, ni, A2, lda, -1, NULL);
+        }
     }
     /* tall products go to the 8-wave kernel (4 waves per SIMD keep the C traffic of a K <= 256 update flowing);
      * it hands anything it cannot take (ragged, unaligned) to the generic path itself */
@@ -1255,17 +1274,19 @@ static int geqrf_issue(qr_plan* p, double* dA, int m, int n, int lda, double* dt
 int qr_geqrf_dev(qr_plan* p, double* dA, int m, int n, int lda, double* dtau)
 {
     if (!p || !dA || !dtau || n < 1 || m < n || m > p->m || n > p->n || lda < m) return QR_E_ARG;
-    if (!p->padA && m == p->m_user && m >= 512 && !p->use_graph && !p->pad_failed && ((lda & 1) || ((uintptr_t) dA & 15)) &&
+    if (!p->padA && m == p->m_user && n == p->n_user && m >= 512 && !p->use_graph && !p->pad_failed && ((lda & 1) || ((uintptr_t) dA & 15)) &&
         (double) p->m * p->n * 8.0 <= 4294967296.0) {
         /* an odd leading dimension or a misaligned array under an otherwise aligned height: the same copy, allocated on first need */
         if (qrd_malloc((void**) &p->padA, sizeof(double) * (size_t) p->m * p->n)) { p->padA = NULL; p->pad_failed = 1; }
     }
-    if (p->padA && m == p->m_user && !p->use_graph) {
-        /* zero rows appended (plan_create_impl): copy in, factor at the padded height, copy the caller's m rows back -- all on the plan's stream */
-        const int mp = p->m;
-        CHECK(qrd_memset(p->stream, p->padA, 0, sizeof(double) * (size_t) mp * n));
+    if (p->padA && m == p->m_user && n == p->n_user && !p->use_graph) {
+        /* zero rows / unit columns appended (plan_create_impl): copy in, factor the padded shape, copy the caller's m x n back -- all on the plan's stream */
+        const int mp = p->m, np = p->n;
+        CHECK(qrd_memset(p->stream, p->padA, 0, sizeof(double) * (size_t) mp * np));
         CHECK(qrd_copy_block(p->stream, dA, lda, p->padA, mp, m, n));
-        CHECK(geqrf_issue(p, p->padA, mp, n, mp, dtau));
+        if (np > n) CHECK(qrd_set_identity(p->stream, p->padA + (size_t) n * mp + m, mp, np - n, np - n, 0));   /* e_{m + j} in appended column j (rows m .. are zero everywhere else) */
+        CHECK(geqrf_issue(p, p->padA, mp, np, mp, np > n ? p->pad_tau : dtau));
+        if (np > n) CHECK(qrd_d2d(p->stream, dtau, p->pad_tau, sizeof(double) * (size_t) n));
         return qrd_copy_block(p->stream, p->padA, mp, dA, lda, m, n);
     }
     if (!p->use_graph || p->prof_on) return geqrf_issue(p, dA, m, n, lda, dtau);
@@ -1343,8 +1364,13 @@ static int geqrf_issue_inner(qr_plan* p, double* dA, int m, int n, int lda, doub
     p->t_deferred = 0;
     if (!p->lookahead) {
         use_set(p, 0);
-        for (int k = 0; k < n; k += nb) {
-            const int wout = imin(nb, n - k), mk = m - k, nt = n - (k + wout);
+        for (int k = 0, wout = 0; k < n; k += wout) {
+            wout = imin(nb, n - k);
+            /* a ragged last panel (width not a multiple of the leaf width): its whole leaves first, as a panel of their own -- they keep the
+             * one-launch / full-width routes, which take whole leaves only -- and the few columns left over as one more (65536 x 500: the
+             * 116-column last panel went leaf by leaf, 2.34 ms against 1.92 for 65536 x 512; profiles/r06_odd_sizes.txt) */
+            if (p->ib == 32 && wout > 32 && wout % 32 != 0) wout -= wout % 32;
+            const int mk = m - k, nt = n - (k + wout);
             CHECK(prof_begin(p, 2));
             /* (what follows decides whether a full-width panel may park its R: only the update that applies T to the small product reads V
              * through a pointer of its own -- and behind the last panel nothing reads V at all: R goes back at once) */
